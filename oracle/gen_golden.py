@@ -1,0 +1,234 @@
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference (test infrastructure).
+
+    python -m oracle.gen_golden            # needs /root/reference; writes tests/golden/
+
+The reference ships no tests/golden vectors, so these vectors -- the
+reference's own outputs on seeded tiny models with injected noise -- are what pins the oracle.
+Two regimes are recorded:
+  *_fp32 : the reference exactly as it runs on CPU (autocast("cuda") inert, fp32 weights)
+  *_amp  : the reference under the CUDA bf16-autocast policy emulated on CPU
+           (oracle/ref_harness.py CudaAutocastOnCpu), LLM weights in bf16 as from_pretrained(bf16)
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import ref_harness as rh
+from . import tiny_models as tm
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def save(name, **arrs):
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().to(torch.float32).cpu().numpy() if v.is_floating_point() else v.cpu().numpy()
+        conv[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **conv)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def check_shapes(module, shapes, what):
+    sd = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    want = {k: tuple(v) for k, v in shapes.items()}
+    assert sd == want, f"{what}: state_dict mismatch: {set(sd) ^ set(want)}"
+
+
+def build_head():
+    from modeling.vision_head.flow_head_parallel_x import DiffHead
+    head = DiffHead(**tm.TINY_HEAD).eval()
+    shapes = tm.head_shapes(tm.TINY_HEAD)
+    check_shapes(head, shapes, "DiffHead")
+    head.load_state_dict(tm.seeded_state(shapes, seed=11))
+    return head
+
+
+def build_llm(dtype):
+    from transformers import Qwen3Config, Qwen3ForCausalLM
+    c = tm.TINY_LLM
+    cfg = Qwen3Config(vocab_size=c["vocab_size"], hidden_size=c["hidden_size"],
+                      intermediate_size=c["intermediate_size"], num_hidden_layers=c["num_hidden_layers"],
+                      num_attention_heads=c["num_attention_heads"], num_key_value_heads=c["num_key_value_heads"],
+                      head_dim=c["head_dim"], rms_norm_eps=c["rms_norm_eps"], max_position_embeddings=8192,
+                      rope_parameters={"rope_type": "default", "rope_theta": c["rope_theta"]},
+                      tie_word_embeddings=False, attention_bias=False)
+    m = Qwen3ForCausalLM(cfg).eval()
+    shapes = tm.llm_shapes(c)
+    sd = tm.seeded_state(shapes, seed=22)
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items() if k != "lm_head.weight"}
+    assert got == {k: tuple(v) for k, v in shapes.items()}, set(got) ^ set(shapes)
+    sd["lm_head.weight"] = torch.zeros(c["vocab_size"], c["hidden_size"])
+    m.load_state_dict(sd)
+    m = m.to(dtype)
+    rh.add_mask_slice_hook(m.model)
+    return m
+
+
+def build_projector():
+    from modeling.utils import MLPconnector
+    p = MLPconnector(32, tm.TINY_LLM["hidden_size"], "gelu_pytorch_tanh").eval()
+    shapes = tm.proj_shapes(32, tm.TINY_LLM["hidden_size"])
+    check_shapes(p, shapes, "MLPconnector")
+    p.load_state_dict(tm.seeded_state(shapes, seed=33))
+    return p
+
+
+def build_ae():
+    from modeling.vision_encoder.autoencoder import VQModel
+    ae = VQModel(**tm.TINY_AE).eval()
+    shapes = {k: tuple(v.shape) for k, v in ae.state_dict().items()}
+    ae.load_state_dict(tm.seeded_state(shapes, seed=44, gain=1.4))
+    return ae, shapes
+
+
+def build_pipeline(dtype):
+    from modeling.t2i_pipeline import BitDanceT2IPipeline
+    pipe = object.__new__(BitDanceT2IPipeline)
+    pipe.device = "cpu"
+    pipe.tokenizer = tm.FakeTokenizer()
+    pipe.llm_model = build_llm(dtype)
+    pipe.hidden_size = tm.TINY_LLM["hidden_size"]
+    pipe.ae, _ = build_ae()
+    pipe.vae_patch_size = 16
+    pipe.vision_head = build_head()
+    pipe.parallel_num = tm.TINY_HEAD["parallel_num"]
+    pipe.ps = int(pipe.parallel_num ** 0.5)
+    pipe.embed_vision_mlp = build_projector()
+    pipe.build_pos_embed()
+    return pipe
+
+
+def gen_sampler():
+    from modeling.vision_head import sampling_x as sx
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(4, 4, generator=g)
+    Cm = torch.randn(6, 4, generator=g) * 0.3
+    c = torch.randn(4, 8, 6, generator=g)
+
+    def toy(x, t, cc):
+        return torch.tanh(x @ A + cc @ Cm + t.view(-1, 1, 1))
+
+    for tag, cfg, cc in (("cfg", 3.0, c), ("nocfg", 1.0, c[:2])):
+        with rh.ReplayNoise(seed=7) as rn:
+            out = sx.euler_maruyama(4, toy, cc, cfg, num_sampling_steps=6)
+        save(f"sampler_{tag}", A=A, Cm=Cm, c=cc, cfg=np.float32(cfg), n_steps=6, out=out,
+             noise=torch.stack(rn.record), calls=rn.calls)
+
+
+def gen_head():
+    head = build_head()
+    g = torch.Generator().manual_seed(101)
+    x = torch.randn(4, 64, 32, generator=g)
+    t = torch.tensor([0.0, 0.3, 0.62, 0.95])
+    c = torch.randn(4, 64, 256, generator=g)
+    z = torch.randn(4, 64, 256, generator=g)
+    for tag in ("fp32", "amp"):
+        ctx = rh.CudaAutocastOnCpu() if tag == "amp" else torch.no_grad()
+        grab = {}
+        hk = head.net.res_blocks[0].register_forward_hook(lambda m, i, o: grab.__setitem__("x1", o.detach().clone()))
+        with torch.no_grad(), ctx:
+            y = head.net(x, t, c)
+            hk.remove()
+            with rh.ReplayNoise(seed=9) as rn:
+                s = head.sample(z, cfg=2.5, num_sampling_steps=3)
+        save(f"head_{tag}", x=x, t=t, c=c, y=y, x1=grab["x1"], z=z, sample=s, noise=torch.stack(rn.record),
+             cfg=np.float32(2.5), n_steps=3)
+
+
+def gen_llm():
+    g = torch.Generator().manual_seed(202)
+    ids = torch.randint(0, 256, (2, 11), generator=g)
+    blk = torch.randn(2, 64, 256, generator=g) * 0.5
+    dec = torch.randn(2, 64, 256, generator=g) * 0.5
+    for tag, dtype in (("fp32", torch.float32), ("amp", torch.bfloat16)):
+        m = build_llm(dtype)
+        model = m.model
+        ctx = rh.CudaAutocastOnCpu() if tag == "amp" else torch.no_grad()
+        with torch.no_grad(), ctx:
+            emb = model.embed_tokens(ids)
+            o1 = model(inputs_embeds=emb, use_cache=True)
+            pkv = o1.past_key_values
+            past = pkv[0][0].shape[2]
+            ones = torch.ones(2, 1, 64, 64 + past + 5, dtype=torch.bool)     # oversize on purpose (shim 3)
+            o2 = model(inputs_embeds=blk.to(dtype), past_key_values=pkv, use_cache=True, attention_mask=ones)
+            pkv = o2.past_key_values
+            ones = torch.ones(2, 1, 64, 64 + pkv[0][0].shape[2], dtype=torch.bool)
+            o3 = model(inputs_embeds=dec, past_key_values=pkv, use_cache=True, attention_mask=ones)
+            k0 = o3.past_key_values[0][0]
+        save(f"llm_{tag}", ids=ids, blk=blk, dec=dec, h1=o1.last_hidden_state, h2=o2.last_hidden_state,
+             h3=o3.last_hidden_state, k0=k0)
+
+
+def gen_pipeline():
+    for tag, dtype in (("fp32", torch.float32), ("amp", torch.bfloat16)):
+        pipe = build_pipeline(dtype)
+        ctx = rh.CudaAutocastOnCpu() if tag == "amp" else torch.no_grad()
+        captured = {}
+        orig_decode = pipe.decode_image
+
+        def spy(lat, image_size=None, ps=1):
+            captured["tokens"] = lat.clone()
+            return orig_decode(lat, image_size, ps)
+
+        pipe.decode_image = spy
+        preds = []
+        orig_sample = pipe.vision_head.sample
+
+        def rec_sample(*a, **k):
+            o = orig_sample(*a, **k)
+            preds.append(o.detach().clone())
+            return o
+
+        pipe.vision_head.sample = rec_sample
+        with torch.no_grad(), ctx, rh.ReplayNoise(seed=13) as rn:
+            img = pipe.gen_image(cond_prompt="a red fox", uncond_prompt="<|", guidance_scale=4.0,
+                                 num_sampling_steps=4, max_length=256, num_images=1, image_size=[256, 256])
+        save(f"gen_{tag}", tokens=captured["tokens"], preds=torch.stack(preds), image=img, noise=torch.stack(rn.record),
+             calls=rn.calls, cfg=np.float32(4.0), n_steps=4)
+
+
+def gen_misc():
+    pipe = build_pipeline(torch.float32)
+    save("posembed", table=pipe.pos_embed_1d, e_4_6_2=pipe.get_2d_embed(4, 6, ps=2),
+         e_16_16_8=pipe.get_2d_embed(16, 16, ps=8))
+    ae, shapes = build_ae()
+    g = torch.Generator().manual_seed(303)
+    img = torch.rand(1, 3, 64, 64, generator=g) * 2 - 1
+    with torch.no_grad():
+        q = ae.encode(img)
+        dec = ae.decode(q)
+        henc = ae.encoder(img)
+    save("ae_roundtrip", image=img, henc=henc, quant=q, dec=dec,
+         keys=np.array(sorted(shapes)), shapes=np.array([str(shapes[k]) for k in sorted(shapes)]))
+    # GFQ bit/index math, exhaustive over one 8-bit codebook + random multi-codebook tokens
+    sys.path.insert(0, os.path.join(rh.REF_ROOT, "imagenet_gen"))
+    from src.gfq import GFQ
+    q = GFQ(dim=32, num_codebooks=4)
+    idx = torch.arange(256)
+    bits = q.indices_to_bits(idx)
+    back = q.bits_to_indices(bits)
+    g = torch.Generator().manual_seed(404)
+    z = torch.randn(2, 32, 3, 5, generator=g)
+    quant, _, indices, _ = q(z, return_loss=False) if False else (None, None, None, None)
+    save("gfq", idx=idx, bits=bits, back=back, codebook=q.codebook)
+
+
+def main():
+    rh.install()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    gen_sampler()
+    gen_head()
+    gen_llm()
+    gen_pipeline()
+    gen_misc()
+
+
+if __name__ == "__main__":
+    main()

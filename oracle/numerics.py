@@ -1,0 +1,72 @@
+"""Dtype policies for the oracle (test infrastructure, see oracle/__init__.py).
+
+The reference runs its hot loop under ``torch.amp.autocast("cuda", dtype=bfloat16)``
+(t2i_pipeline.py:130).  The oracle restates that flow with *explicit* casts so the
+rounding points are visible and run identically on any CPU:
+
+  * ``Policy("fp32")``     -- no casts at all: what the reference computes when it is
+                              executed on CPU with fp32 weights (autocast("cuda") is
+                              inert there).  Used to pin the restatement against the
+                              reference bit-for-bit / to 1e-5.
+  * ``Policy("autocast")`` -- the CUDA/HIP autocast policy: ``F.linear`` / ``matmul``
+                              inputs are cast to bf16, accumulate in fp32, round the
+                              result once to bf16; ``layer_norm`` and ``softmax`` run
+                              in fp32 (autocast's fp32 list); everything else follows
+                              normal type promotion of its operands.
+
+Elementwise bf16 ops on CPU tensors (compute in fp32, round to bf16) follow the same
+eager semantics as on the GPU, so the oracle keeps real ``torch.bfloat16`` tensors
+where the reference would and lets torch's type promotion do the rest.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+class Policy:
+    def __init__(self, name: str = "autocast"):
+        if name not in ("fp32", "autocast"):
+            raise ValueError(f"unknown policy {name!r}")
+        self.name = name
+
+    @property
+    def amp(self) -> bool:
+        return self.name == "autocast"
+
+    # -- F.linear under the policy -------------------------------------------------
+    def linear(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None = None) -> torch.Tensor:
+        if not self.amp:
+            return F.linear(x, w, b)
+        xb = x.to(BF16).to(F32)
+        wb = w.to(BF16).to(F32)
+        acc = xb @ wb.t()
+        if b is not None:
+            acc = acc + b.to(BF16).to(F32)
+        return acc.to(BF16)
+
+    # -- torch.matmul under the policy ---------------------------------------------
+    def matmul(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        if not self.amp:
+            return a @ b
+        return (a.to(BF16).to(F32) @ b.to(BF16).to(F32)).to(BF16)
+
+    # -- F.layer_norm: autocast runs it in fp32 and returns fp32 --------------------
+    def layer_norm(self, x, weight, bias, eps: float) -> torch.Tensor:
+        if not self.amp:
+            return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
+        w = None if weight is None else weight.to(F32)
+        b = None if bias is None else bias.to(F32)
+        return F.layer_norm(x.to(F32), (x.shape[-1],), w, b, eps)
+
+    def cast_in(self, x: torch.Tensor) -> torch.Tensor:
+        """What an autocast op does to a floating input."""
+        return x.to(BF16) if self.amp else x
+
+
+def bf16_round(x: torch.Tensor) -> torch.Tensor:
+    """Round-to-nearest-even to bf16, returned as fp32 (value-preserving)."""
+    return x.to(BF16).to(F32)

@@ -1,0 +1,107 @@
+"""Oracle: next-patch-diffusion AR loop -- test infrastructure only.
+
+Restates /root/reference/modeling/t2i_pipeline.py:
+  _get_1d_sincos_pos_embed :85-96     get_2d_embed :98-107
+  gen_image                :157-272   decode_image (un-raster only) :274-283
+and /root/reference/modeling/utils.py MLPconnector :9-20.
+
+Tokenisation is outside the arithmetic path: the loop takes token-id lists where the
+reference calls ``tokenizer.encode`` / ``convert_tokens_to_ids`` (:175-194).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from .numerics import F32, Policy
+from . import diff_head, qwen3
+
+
+def sincos_1d(dim: int, max_len: int) -> torch.Tensor:
+    """:85-96 -> [max_len, dim] = cat(sin, cos)."""
+    omega = torch.arange(dim // 2, dtype=F32)
+    omega /= dim / 2.0
+    omega = 1.0 / 10000 ** omega
+    out = torch.einsum("m,d->md", torch.arange(max_len, dtype=F32), omega)
+    return torch.cat([torch.sin(out), torch.cos(out)], dim=1)
+
+
+def pos_embed_2d(table: torch.Tensor, h: int, w: int, ps: int) -> torch.Tensor:
+    """:98-107 -> [h*w, D]; channel order (emb_h | emb_v), token order '(h w p1 p2)'."""
+    half = table.shape[1]
+    gv = table[:h].view(h, 1, half).expand(h, w, half)
+    gh = table[:w].view(1, w, half).expand(h, w, half)
+    pe = torch.cat([gh, gv], dim=-1)
+    pe = pe.reshape(h // ps, ps, w // ps, ps, 2 * half).permute(0, 2, 1, 3, 4)
+    return pe.reshape(h * w, 2 * half)
+
+
+def projector(w: dict, x: torch.Tensor, pol: Policy) -> torch.Tensor:
+    """MLPconnector.forward utils.py:16-20 with ``gelu_pytorch_tanh``."""
+    h = pol.linear(x, w["fc1.weight"], w["fc1.bias"])
+    h = F.gelu(h, approximate="tanh")
+    return pol.linear(h, w["fc2.weight"], w["fc2.bias"])
+
+
+def unraster(tokens: torch.Tensor, h: int, w: int, ps: int) -> torch.Tensor:
+    """decode_image :274-280: 'b (h w p1 p2) c -> b c (h p1) (w p2)'."""
+    b, _, c = tokens.shape
+    x = tokens.view(b, h // ps, w // ps, ps, ps, c).permute(0, 5, 1, 3, 2, 4)
+    return x.reshape(b, c, h, w)
+
+
+def gen_tokens(llm_w: dict, llm_cfg: dict, head_w: dict, proj_w: dict, embed: torch.Tensor,
+               cond_ids, uncond_ids, start_ids, query_ids, *, h: int, w: int, parallel_num: int,
+               guidance_scale: float, num_sampling_steps: int, num_images: int, noise, pol: Policy,
+               max_patch: int = 256, trace: dict | None = None,
+               force_tokens: torch.Tensor | None = None) -> torch.Tensor:
+    """gen_image :157-270 up to (not including) the AE decode.  Returns [num_images, h*w, C] in {-1,0,+1}.
+
+    embed      : the LLM input-embedding matrix [V, D]
+    start_ids  : [<|vision_start|>, <|res_h|>, <|res_w|>]            (:181-184)
+    query_ids  : [<|query_1|> .. <|query_{P-1}|>]                    (:190-194)
+    noise      : iterator over the RNG draws in reference call order  (sampling_x.py:60,40)
+    force_tokens: teacher forcing for tolerance tests -- [num_images, h*w, C] tokens fed back to the
+                 LLM instead of the loop's own sign(pred) (the returned tokens are still the loop's own)
+    """
+    P = parallel_num
+    ps = int(P ** 0.5)
+    D = embed.shape[1]
+    cfg_on = guidance_scale > 1.0
+    noise = iter(noise)
+    pos = pos_embed_2d(sincos_1d(D // 2, max_patch), h, w, ps).unsqueeze(0)          # fp32
+    tail = F.embedding(torch.tensor(list(start_ids) + list(query_ids)), embed)
+
+    def prefill(ids):
+        x = torch.cat([F.embedding(torch.tensor(list(ids)), embed), tail], dim=0)
+        x = x.unsqueeze(0).repeat(num_images, 1, 1)
+        _, cache = qwen3.model_forward(llm_w, llm_cfg, x[:, :-P], None, None, pol)
+        past = cache[0][0].shape[2]
+        ones = torch.ones(num_images, 1, P, P + past, dtype=torch.bool)
+        hid, cache = qwen3.model_forward(llm_w, llm_cfg, x[:, -P:], cache, ones, pol)
+        return hid[:, -P:], cache
+
+    hid_c, cache_c = prefill(cond_ids)
+    if cfg_on:
+        hid_u, cache_u = prefill(uncond_ids)
+    out = []
+    for step in range((h * w) // P):
+        sl = slice(step * P, (step + 1) * P)
+        hf = torch.cat([hid_c, hid_u], dim=0) if cfg_on else hid_c
+        hf = hf + pos[:, sl]
+        pred = diff_head.sample(head_w, hf, guidance_scale, num_sampling_steps, noise, pol)
+        tok = torch.sign(pred)                                                     # :248 (sign(0)=0)
+        if trace is not None:
+            trace.setdefault("pred", []).append(pred[:num_images].clone())
+            trace.setdefault("cond", []).append(hf.clone())
+        out.append(tok[:num_images])
+        if force_tokens is not None:
+            tok = torch.cat([force_tokens[:, sl]] * (2 if cfg_on else 1), dim=0)
+        x = projector(proj_w, tok, pol) + pos[:, sl]
+        ones = torch.ones(x.shape[0], 1, P, P + cache_c[0][0].shape[2], dtype=torch.bool)
+        hid_c, cache_c = qwen3.model_forward(llm_w, llm_cfg, x[:num_images], cache_c, ones[:num_images], pol)
+        hid_c = hid_c[:, -P:]
+        if cfg_on:
+            hid_u, cache_u = qwen3.model_forward(llm_w, llm_cfg, x[num_images:], cache_u, ones[num_images:], pol)
+            hid_u = hid_u[:, -P:]
+    return torch.cat(out, dim=1)

@@ -1,0 +1,109 @@
+"""Seeded tiny model definitions shared by oracle/gen_golden.py and tests (test infrastructure).
+
+Shapes/key names follow the reference checkpoints; gen_golden.py
+asserts them against the state_dicts of the instantiated reference modules.
+All values are bf16-representable so fp32 and bf16 runs see identical weights.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+TINY_LLM = dict(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                head_dim=128, intermediate_size=512, vocab_size=512, rms_norm_eps=1e-6,
+                rope_theta=1000000.0)
+TINY_HEAD = dict(ch_target=32, ch_cond=256, ch_latent=256, depth_latent=4, depth_adanln=2,
+                 parallel_num=64, use_swiglu=True, time_shift=1.0)
+TINY_AE = dict(ddconfig=dict(double_z=False, z_channels=32, in_channels=3, out_ch=3, ch=32,
+                             ch_mult=[1, 1, 2, 2, 4], num_res_blocks=1))
+
+VISION_START, RES_BASE, QUERY_BASE = 300, 301, 430
+
+
+def llm_shapes(cfg: dict) -> dict:
+    D, nh, nkv, hd, ff = (cfg["hidden_size"], cfg["num_attention_heads"], cfg["num_key_value_heads"],
+                          cfg["head_dim"], cfg["intermediate_size"])
+    s = {"model.embed_tokens.weight": (cfg["vocab_size"], D), "model.norm.weight": (D,)}
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"model.layers.{i}."
+        s[p + "self_attn.q_proj.weight"] = (nh * hd, D)
+        s[p + "self_attn.k_proj.weight"] = (nkv * hd, D)
+        s[p + "self_attn.v_proj.weight"] = (nkv * hd, D)
+        s[p + "self_attn.o_proj.weight"] = (D, nh * hd)
+        s[p + "self_attn.q_norm.weight"] = (hd,)
+        s[p + "self_attn.k_norm.weight"] = (hd,)
+        s[p + "mlp.gate_proj.weight"] = (ff, D)
+        s[p + "mlp.up_proj.weight"] = (ff, D)
+        s[p + "mlp.down_proj.weight"] = (D, ff)
+        s[p + "input_layernorm.weight"] = (D,)
+        s[p + "post_attention_layernorm.weight"] = (D,)
+    return s
+
+
+def head_shapes(cfg: dict) -> dict:
+    D, C, Z = cfg["ch_latent"], cfg["ch_target"], cfg["ch_cond"]
+    H = int(D * 1.5)
+    s = {}
+
+    def lin(name, n, k):
+        s[name + ".weight"] = (n, k)
+        s[name + ".bias"] = (n,)
+
+    lin("net.time_embed.mlp.0", D, 256)
+    lin("net.time_embed.mlp.2", D, D)
+    lin("net.cond_embed", D, Z)
+    lin("net.input_proj", D, C)
+    for i in range(cfg["depth_latent"]):
+        p = f"net.res_blocks.{i}."
+        for n in ("norm1", "norm2"):
+            s[p + n + ".weight"] = (D,)
+            s[p + n + ".bias"] = (D,)
+        lin(p + "attn.wqkv", 3 * D, D)
+        lin(p + "attn.wo", D, D)
+        lin(p + "w1", 2 * H, D)
+        lin(p + "w2", D, H)
+    for j in range(cfg["depth_adanln"]):
+        lin(f"net.ada_ln_blocks.{j}", 6 * D, D)
+    lin("net.final_layer.ada_ln_modulation", 2 * D, D)
+    lin("net.final_layer.linear", C, D)
+    return s
+
+
+def proj_shapes(c: int, d: int) -> dict:
+    return {"fc1.weight": (d, c), "fc1.bias": (d,), "fc2.weight": (d, d), "fc2.bias": (d,)}
+
+
+def seeded_state(shapes: dict, seed: int, gain: float = 1.0) -> dict:
+    """Deterministic weights: matrices ~ N(0, gain/sqrt(fan_in)), norm scales ~ 1+0.1N, biases ~ 0.1N.
+    Iterates names in sorted order from one CPU generator; values rounded to bf16."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name in sorted(shapes):
+        shp = tuple(shapes[name])
+        x = torch.empty(shp, dtype=torch.float32).normal_(generator=g)
+        if len(shp) >= 2:
+            fan_in = math.prod(shp[1:])
+            x = x * (gain / math.sqrt(fan_in))
+        elif name.endswith("bias"):
+            x = x * 0.1
+        else:                               # 1-D scale of a norm layer
+            x = 1.0 + 0.1 * x
+        out[name] = x.to(torch.bfloat16).to(torch.float32)
+    return out
+
+
+class FakeTokenizer:
+    """Stands in for the HF tokenizer (t2i_pipeline.py:175-194): deterministic char -> id map."""
+
+    def encode(self, text: str):
+        return [ord(ch) % 256 for ch in text]
+
+    def convert_tokens_to_ids(self, tok: str) -> int:
+        if tok == "<|vision_start|>":
+            return VISION_START
+        if tok.startswith("<|res_"):
+            return RES_BASE + int(tok[6:-2])
+        if tok.startswith("<|query_"):
+            return QUERY_BASE + int(tok[8:-2])
+        raise KeyError(tok)

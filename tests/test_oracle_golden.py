@@ -1,0 +1,148 @@
+"""The oracle (CPU restatement) against the reference's own outputs (tests/golden, made by
+oracle/gen_golden.py from the unmodified reference).  CPU only; no /root/reference needed."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import diff_head, gfq, pipeline, qwen3, sampler
+from oracle import tiny_models as tm
+from oracle.numerics import Policy
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+    return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fiub" and z[k].ndim > 0 else z[k]) for k in z.files}
+
+
+@pytest.mark.parametrize("tag", ["cfg", "nocfg"])
+def test_sampler_bit_exact(golden_dir, tag):
+    g = load(golden_dir, "sampler_" + tag)
+    A, Cm = g["A"], g["Cm"]
+    toy = lambda x, t, c: torch.tanh(x @ A + c @ Cm + t.view(-1, 1, 1))
+    out = sampler.euler_maruyama(4, toy, g["c"], float(g["cfg"]), int(g["n_steps"]), list(g["noise"]))
+    assert int(g["calls"]) == int(g["n_steps"]) + 1            # RNG draws: 1 + N (SURVEY 8c vii)
+    assert torch.equal(out, g["out"])                           # fp32, op-for-op: bit exact
+
+
+def head_weights():
+    return tm.seeded_state(tm.head_shapes(tm.TINY_HEAD), seed=11)
+
+
+def test_head_forward_fp32(golden_dir):
+    g = load(golden_dir, "head_fp32")
+    y = diff_head.net_forward(head_weights(), g["x"], g["t"], g["c"], Policy("fp32"))
+    torch.testing.assert_close(y, g["y"], atol=2e-5, rtol=1e-4)
+
+
+def test_head_sample_fp32(golden_dir):
+    g = load(golden_dir, "head_fp32")
+    s = diff_head.sample(head_weights(), g["z"], float(g["cfg"]), int(g["n_steps"]), list(g["noise"]), Policy("fp32"))
+    torch.testing.assert_close(s, g["sample"], atol=1e-4, rtol=1e-4)
+
+
+def test_head_forward_amp(golden_dir):
+    """bf16-autocast flow: identical rounding points => only accumulation-order noise (<= 1-2 bf16 ulp)."""
+    g = load(golden_dir, "head_amp")
+    tr = {}
+    y = diff_head.net_forward(head_weights(), g["x"], g["t"], g["c"], Policy("autocast"), trace=tr).float()
+    # after ONE block only accumulation-order noise may differ: a misplaced rounding point would flip ~half
+    x1 = tr["x1"].float()
+    assert (x1 != g["x1"]).float().mean() <= 0.2 and (x1 - g["x1"]).abs().mean() <= 1.5e-3
+    err = (y - g["y"]).abs()                     # 4 blocks of chained bf16 roundings: a few bf16 ulp
+    assert err.max() <= 5e-2 and err.mean() <= 6e-3, (err.max(), err.mean())
+
+
+def test_head_sample_amp(golden_dir):
+    g = load(golden_dir, "head_amp")
+    s = diff_head.sample(head_weights(), g["z"], float(g["cfg"]), int(g["n_steps"]), list(g["noise"]), Policy("autocast"))
+    err = (s - g["sample"]).abs()
+    # CFG (x2.5) and the 1/(1-t) velocity scaling amplify the per-eval bf16 noise of the 4 chained evals
+    assert err.max() <= 0.4 and err.mean() <= 6e-2, (err.max(), err.mean())
+
+
+def llm_weights(dtype=torch.float32):
+    return {k: v.to(dtype) for k, v in tm.seeded_state(tm.llm_shapes(tm.TINY_LLM), seed=22).items()}
+
+
+def run_llm(g, pol, dtype):
+    w = llm_weights(dtype)
+    emb = torch.nn.functional.embedding(g["ids"].long(), w["model.embed_tokens.weight"])
+    h1, cache = qwen3.model_forward(w, tm.TINY_LLM, emb, None, None, pol)
+    past = cache[0][0].shape[2]
+    ones = torch.ones(2, 1, 64, 64 + past + 5, dtype=torch.bool)
+    h2, cache = qwen3.model_forward(w, tm.TINY_LLM, g["blk"].to(dtype), cache, ones, pol)
+    ones = torch.ones(2, 1, 64, 64 + cache[0][0].shape[2], dtype=torch.bool)
+    h3, cache = qwen3.model_forward(w, tm.TINY_LLM, g["dec"], cache, ones, pol)
+    return h1, h2, h3, cache[0][0]
+
+
+def test_llm_fp32(golden_dir):
+    g = load(golden_dir, "llm_fp32")
+    h1, h2, h3, k0 = run_llm(g, Policy("fp32"), torch.float32)
+    for a, b in ((h1, g["h1"]), (h2, g["h2"]), (h3, g["h3"]), (k0, g["k0"])):
+        torch.testing.assert_close(a, b, atol=3e-5, rtol=1e-4)
+
+
+def test_llm_amp(golden_dir):
+    g = load(golden_dir, "llm_amp")
+    h1, h2, h3, k0 = run_llm(g, Policy("autocast"), torch.bfloat16)
+    assert h1.dtype == torch.bfloat16 and h2.dtype == torch.bfloat16 and h3.dtype == torch.float32
+    assert k0.dtype == torch.float32            # K promoted by the decode-time cat
+    for a, b in ((h1, g["h1"]), (h2, g["h2"]), (h3, g["h3"])):
+        err = (a.float() - b).abs()
+        assert err.max() <= 0.12 and err.mean() <= 1e-2, (err.max(), err.mean())
+
+
+def run_gen(g, pol, dtype, force=None, trace=None):
+    lw = llm_weights(dtype)
+    tok = tm.FakeTokenizer()
+    return pipeline.gen_tokens(
+        lw, tm.TINY_LLM, head_weights(), tm.seeded_state(tm.proj_shapes(32, 256), seed=33),
+        lw["model.embed_tokens.weight"], tok.encode("a red fox"), tok.encode("<|"),
+        [tm.VISION_START, tm.RES_BASE + 16, tm.RES_BASE + 16], [tm.QUERY_BASE + i for i in range(1, 64)],
+        h=16, w=16, parallel_num=64, guidance_scale=float(g["cfg"]), num_sampling_steps=int(g["n_steps"]),
+        num_images=1, noise=list(g["noise"]), pol=Policy(pol), force_tokens=force, trace=trace)
+
+
+def test_gen_tokens_fp32(golden_dir):
+    """Whole AR loop, fp32: every binary token equals the reference's (bit-exact index work)."""
+    g = load(golden_dir, "gen_fp32")
+    assert int(g["calls"]) == 4 * (int(g["n_steps"]) + 1)       # AR_steps * (1 + N) draws, SURVEY 8c(vii)
+    tr = {}
+    out = run_gen(g, "fp32", torch.float32, trace=tr)
+    assert torch.equal(out, g["tokens"])                        # [B, h*w, C], patch-raster order
+    torch.testing.assert_close(torch.stack(tr["pred"]), g["preds"][:, :1], atol=2e-4, rtol=1e-3)
+
+
+def test_gen_tokens_amp_teacher_forced(golden_dir):
+    """bf16 flow: a flipped near-zero latent changes every later token (SURVEY 7 'Hard parts'), so the
+    loop is teacher-forced with the reference's tokens and the pre-sign latents are compared per step."""
+    g = load(golden_dir, "gen_amp")
+    tr = {}
+    out = run_gen(g, "autocast", torch.bfloat16, force=g["tokens"], trace=tr)
+    pred, ref = torch.stack(tr["pred"]), g["preds"][:, :1]
+    err = (pred - ref).abs()
+    # CFG mixes x_hat_u + cfg (x_hat_c - x_hat_u): bf16 noise of the evals is amplified ~(2 cfg - 1) = 7x
+    assert err.mean() <= 0.2, err.mean()
+    firm = ref.abs() > 0.5                                      # tokens that are not coin flips
+    assert (torch.sign(pred)[firm] == torch.sign(ref)[firm]).float().mean() >= 0.97
+    assert (out == g["tokens"]).float().mean() >= 0.85
+
+
+def test_posembed(golden_dir):
+    g = load(golden_dir, "posembed")
+    table = pipeline.sincos_1d(128, 256)
+    assert torch.equal(table, g["table"])
+    assert torch.equal(pipeline.pos_embed_2d(table, 4, 6, 2), g["e_4_6_2"])
+    assert torch.equal(pipeline.pos_embed_2d(table, 16, 16, 8), g["e_16_16_8"])
+
+
+def test_gfq_index_math(golden_dir):
+    g = load(golden_dir, "gfq")
+    idx = g["idx"].numpy()
+    bits = gfq.indices_to_bits(idx, 8)
+    assert np.array_equal(bits, g["bits"].numpy().astype(bool))
+    assert np.array_equal(gfq.bits_to_indices(bits), g["back"].numpy())
+    assert np.array_equal(gfq.codes_from_indices(idx, 8), g["codebook"].numpy())
