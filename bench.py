@@ -1,0 +1,288 @@
+#!/usr/bin/env python
+"""Benchmark: images/sec at 1024 px, BitDance-14B-64x shapes, on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A "step" is one whole pass of the hot path: one ``gen_image`` call (prefill, 64 AR steps x [51 diffusion-head
+evaluations + sign + projector + cond/uncond LLM forward], AE decode) for ``--num-images`` images on synthetic
+(random-weight, true-shape) models with inputs resident in HBM.  N > 1 runs one replica per GPU over disjoint
+images (what the reference's own multi-GPU evaluation does, eval/eval_dpg.py:25-29): weak scaling, no data-path
+collective; value = images of all ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  "roofline"     : achieved HBM GB/s of the dominant kernel family (the weight-streaming GEMM), measured live
+                   with HIP events on the pipeline's stream, vs the 8 TB/s HBM3E peak
+  "cpu_baseline" : the CPU oracle (a port of the reference algorithm) timed on this box's host cores on a bounded
+                   sample (one head evaluation + one LLM layer step at true shapes), extrapolated to one image
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", default="14b-64x", choices=["14b-64x", "tiny"])
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--num-images", type=int, default=1)
+    ap.add_argument("--sampling-steps", type=int, default=50)
+    ap.add_argument("--guidance", type=float, default=7.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--tune", default="", help="comma list name.S=4,name.nw=2 overriding GEMM launch configs")
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------------
+def gemm_roofline(pipe, reps: int = 20) -> dict:
+    """Time every distinct weight-streaming GEMM launch of one AR step in isolation (HIP events on the pipeline's
+    stream), weight by its launch count per image, and report algorithmic weight bytes / time."""
+    from bitdance_amd._lib import check, lib
+    eng = next(iter(pipe._engines.values()))
+    hw, lw, pw = pipe.head_w, pipe.llm_w, pipe.proj_w
+    L = lw.cfg["num_hidden_layers"]
+    D, F_, nh, nkv = lw.cfg["hidden_size"], lw.cfg["intermediate_size"], lw.cfg["num_attention_heads"], lw.cfg["num_key_value_heads"]
+    n_ev = eng.n_steps + 1
+    # (name, A frag ws, W ptr name, N, K, swiglu?, out ws, launches per AR step)
+    shapes = [
+        ("head.ada", "head.y_frag", "head.ada_w", hw.nada * 6 * hw.D + 2 * hw.D, hw.D, False, "head.ada_part", n_ev),
+        ("head.qkv", "head.h_frag", "head.blk0.wqkv", 3 * hw.D, hw.D, False, "head.qkv_part", n_ev * hw.nblocks),
+        ("head.wo", "head.attn_frag", "head.blk0.wo", hw.D, hw.D, False, "head.br_part", n_ev * hw.nblocks),
+        ("head.w1", "head.h_frag", "head.blk0.w1", 2 * hw.H, hw.D, True, "head.act_frag", n_ev * hw.nblocks),
+        ("head.w2", "head.act_frag", "head.blk0.w2", hw.D, hw.H, False, "head.br_part", n_ev * hw.nblocks),
+        ("llm.qkv", "llm.a_frag", "llm.l0.wqkv", (nh + 2 * nkv) * 128, D, False, "llm.qkv_part", L),
+        ("llm.o", "llm.attn_frag", "llm.l0.wo", D, nh * 128, False, "llm.br_part", L),
+        ("llm.gu", "llm.a_frag", "llm.l0.wgu", 2 * F_, D, True, "llm.act_frag", L),
+        ("llm.down", "llm.act_frag", "llm.l0.wdown", D, F_, False, "llm.br_part", L),
+    ]
+    cfgs = json.loads(os.environ.get("BD_GEMM_CFG", "{}"))
+    st = pipe._stream
+    rows = []
+    rb = eng.Mpad // 32
+    with torch.cuda.stream(st):
+        for name, a_ws, wname, N, K, swiglu, out_ws, count in shapes:
+            wt = eng._keep[wname]
+            S, nw = gemm_cfg(eng, name, N, K, swiglu)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+            def launch():
+                if swiglu:
+                    check(lib().bd_gemm_swiglu(eng.ws[a_ws].data_ptr(), rb, wt.data_ptr(), None, N, K, nw,
+                                               eng.ws[out_ws].data_ptr(), st.cuda_stream))
+                else:
+                    check(lib().bd_gemm_partial(eng.ws[a_ws].data_ptr(), rb, wt.data_ptr(), N, K, S, nw,
+                                                eng.ws[out_ws].data_ptr(), st.cuda_stream))
+            for _ in range(3):
+                launch()
+            ev0.record(st)
+            for _ in range(reps):
+                launch()
+            ev1.record(st)
+            ev1.synchronize()
+            us = ev0.elapsed_time(ev1) * 1e3 / reps
+            wbytes = N * K * 2
+            rows.append(dict(name=name, N=N, K=K, S=S, nw=nw, us=round(us, 2), GBs=round(wbytes / us / 1e3, 1),
+                             count=count, bytes=wbytes))
+    tot_b = sum(r["bytes"] * r["count"] for r in rows)
+    tot_us = sum(r["us"] * r["count"] for r in rows)
+    n_launch = sum(r["count"] for r in rows)
+    ach = tot_b / tot_us / 1e3
+    return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": "gemm_kernel<NW,MB,EPI> (weight-streaming skinny GEMM, all shapes of one AR step)",
+            "bytes_per_launch": int(tot_b / n_launch), "avg_launch_us": round(tot_us / n_launch, 2),
+            "per_shape": [{k: r[k] for k in ("name", "N", "K", "S", "nw", "us", "GBs", "count")} for r in rows]}
+
+
+def gemm_cfg(eng, name, N, K, swiglu):
+    """Mirror of choose_cfg in bd_api.hip (the launch config the engine itself uses)."""
+    tune = getattr(eng, "_tune", {}) or {}
+    nw = 4 if N % 128 == 0 else 2
+    nst = K // 64
+    if swiglu:
+        S = 1
+        if N // (32 * nw) < 200 and N % 64 == 0:
+            nw = 2
+    else:
+        S = max(1, min(nst, round(320.0 / (N // (32 * nw)))))
+    S = tune.get(name + ".S", S)
+    nw = tune.get(name + ".nw", nw)
+    S = min(S, nst)
+    while S > 1 and (S - 1) * ((nst + S - 1) // S) >= nst:
+        S -= 1
+    return S, nw
+
+
+# ---------------------------------------------------------------------------------------------------------
+def cpu_baseline(args) -> dict:
+    """The CPU oracle (port of the reference algorithm, oracle/) on the host cores: one head evaluation at M=128
+    rows and one LLM decoder layer over a 64-token block with ~2k cached tokens, both at true 14B shapes, timed
+    and extrapolated to one image: T = 64*(N+1)*t_head + 63*L*t_layer (AE decode and prefill not included)."""
+    from oracle import diff_head, qwen3
+    from oracle.numerics import Policy
+    from bitdance_amd import synthetic as syn
+    torch.set_num_threads(os.cpu_count() or 1)
+    big = args.size == "14b-64x"
+    hc, lc = (syn.HEAD_14B_64X, syn.QWEN3_14B) if big else (syn.TINY_HEAD, syn.TINY_LLM)
+    pol = Policy("autocast")
+    D, C, Z = hc["ch_latent"], hc["ch_target"], hc["ch_cond"]
+    H = int(D * 1.5)
+    bf = torch.bfloat16
+    cw = lambda *s: torch.full(s, 0.01, dtype=bf)
+    w = {}
+    for nme, n, k in [("net.time_embed.mlp.0", D, 256), ("net.time_embed.mlp.2", D, D), ("net.cond_embed", D, Z),
+                      ("net.input_proj", D, C), ("net.final_layer.ada_ln_modulation", 2 * D, D),
+                      ("net.final_layer.linear", C, D)]:
+        w[nme + ".weight"], w[nme + ".bias"] = cw(n, k), cw(n)
+    for j in range(hc["depth_adanln"]):
+        w[f"net.ada_ln_blocks.{j}.weight"], w[f"net.ada_ln_blocks.{j}.bias"] = cw(6 * D, D), cw(6 * D)
+    for i in range(hc["depth_latent"]):
+        p = f"net.res_blocks.{i}."
+        for nn_ in ("norm1", "norm2"):
+            w[p + nn_ + ".weight"], w[p + nn_ + ".bias"] = torch.ones(D), torch.zeros(D)
+        for nme, n, k in [("attn.wqkv", 3 * D, D), ("attn.wo", D, D), ("w1", 2 * H, D), ("w2", D, H)]:
+            w[p + nme + ".weight"], w[p + nme + ".bias"] = cw(n, k), cw(n)
+    M = 128
+    x, t, c = torch.randn(M // 64, 64, C), torch.full((M // 64,), 0.3), torch.randn(M // 64, 64, Z)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        diff_head.net_forward(w, x, t, c, pol)
+    t_head = time.perf_counter() - t0
+    del w
+    one = dict(lc, num_hidden_layers=1)
+    Dl, nh, nkv, hd, ff = lc["hidden_size"], lc["num_attention_heads"], lc["num_key_value_heads"], lc["head_dim"], lc["intermediate_size"]
+    lw = {"model.norm.weight": torch.ones(Dl, dtype=bf)}
+    p = "model.layers.0."
+    for nme, n, k in [("self_attn.q_proj", nh * hd, Dl), ("self_attn.k_proj", nkv * hd, Dl), ("self_attn.v_proj", nkv * hd, Dl),
+                      ("self_attn.o_proj", Dl, nh * hd), ("mlp.gate_proj", ff, Dl), ("mlp.up_proj", ff, Dl), ("mlp.down_proj", Dl, ff)]:
+        lw[p + nme + ".weight"] = cw(n, k)
+    for nme, n in [("self_attn.q_norm", hd), ("self_attn.k_norm", hd), ("input_layernorm", Dl), ("post_attention_layernorm", Dl)]:
+        lw[p + nme + ".weight"] = torch.ones(n, dtype=bf)
+    past = 2048 if big else 128
+    cache = [[torch.randn(2, nkv, past, hd).to(bf), torch.randn(2, nkv, past, hd).to(bf)]]
+    xin = torch.randn(2, 64, Dl)
+    ones = torch.ones(2, 1, 64, past + 64, dtype=torch.bool)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        qwen3.model_forward(lw, one, xin, cache, ones, pol)
+    t_layer = time.perf_counter() - t0
+    ar = (args.height // 16) * (args.width // 16) // 64
+    n_ev = args.sampling_steps + 1
+    L = lc["num_hidden_layers"]
+    t_img = ar * n_ev * t_head + (ar - 1) * L * t_layer
+    return {"value": round(1.0 / t_img, 8), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (CPU port): 1 head eval M=128 ({t_head:.2f} s) + 1 LLM layer step, 2x64 tokens, "
+                      f"{past} cached ({t_layer:.2f} s), extrapolated x{ar * n_ev} / x{(ar - 1) * L}; excludes prefill+AE"}
+
+
+# ---------------------------------------------------------------------------------------------------------
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    dev = f"cuda:{local if world > 1 else 0}"
+
+    from bitdance_amd import synthetic as syn
+    from bitdance_amd.build import build
+    build(verbose=False)
+    t0 = time.perf_counter()
+    pipe = syn.build_pipeline(args.size, dev, with_ae=True)
+    tune = {}
+    for kv in filter(None, args.tune.split(",")):
+        k, v = kv.split("=")
+        tune[k] = int(v)
+    pipe.tune = tune or None
+    pipe.use_graph = not args.no_graph
+    if rank == 0:
+        print(f"[bench] model built in {time.perf_counter() - t0:.1f} s", file=sys.stderr)
+    if args.size == "tiny":
+        args.height, args.width = min(args.height, 256), min(args.width, 256)
+    prompt = "A close-up portrait in a cinematic photography style, capturing a girl-next-door look on a sunny daytime urban street."
+    kw = dict(cond_prompt=f"<|im_start|>user\n{prompt}<|im_end|>\n<|im_start|>assistant\n",
+              uncond_prompt="<|im_start|>assistant\n", guidance_scale=args.guidance,
+              num_sampling_steps=args.sampling_steps, num_images=args.num_images,
+              image_size=[args.height, args.width], max_length=(args.height // 16) * (args.width // 16))
+
+    def one_pass(i):
+        torch.manual_seed(1234 + 977 * rank + i)
+        with torch.amp.autocast("cuda", enabled=True, dtype=torch.bfloat16):
+            img = pipe.gen_image(**kw)
+        return img
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_pass(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        img = one_pass(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(img).all()
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    out = None
+    if rank == 0:
+        n = world
+        images = n * args.num_images * args.steps
+        eng = next(iter(pipe._engines.values()))
+        eng._tune = tune
+        out = {
+            "metric": "images/sec @1024px BitDance-14B-64x" if args.size == "14b-64x" else "images/sec (tiny smoke config)",
+            "value": round(images / dt, 5), "unit": "images/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random weights at true shapes, fixed token ids)",
+            "config": {"workload": f"BitDance-14B-64x T2I {args.height}x{args.width}, {args.sampling_steps} sampling steps, "
+                                   f"cfg {args.guidance}, num_images={args.num_images} per GPU"
+                                   if args.size == "14b-64x" else "tiny",
+                       "ar_steps": kw["max_length"] // 64, "parallelism": f"replicas x{n}" if n > 1 else "single GPU",
+                       "hipgraph": pipe.use_graph},
+        }
+        if not args.no_roofline:
+            out["roofline"] = gemm_roofline(pipe)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

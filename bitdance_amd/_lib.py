@@ -1,0 +1,75 @@
+"""ctypes binding of libbitdance_hip.so (C ABI in include/bitdance_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails this raises, loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbitdance_hip.so")
+
+_lib = None
+
+
+class BitDanceHipError(RuntimeError):
+    pass
+
+
+_PROTOS = {
+    "bd_version": (C.c_int, []),
+    "bd_last_error": (C.c_char_p, []),
+    "bd_pack_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "bd_pack_weight_swiglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "bd_rows_to_frag": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "bd_gemm_partial": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bd_gemm_swiglu": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bd_ctx_create": (C.c_void_p, []),
+    "bd_ctx_destroy": (None, [C.c_void_p]),
+    "bd_ctx_set_int": (C.c_int, [C.c_void_p, C.c_char_p, C.c_longlong]),
+    "bd_ctx_set_float": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
+    "bd_ctx_set_ptr": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
+    "bd_ctx_finalize": (C.c_int, [C.c_void_p]),
+    "bd_ctx_ws_count": (C.c_int, [C.c_void_p]),
+    "bd_ctx_ws_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "bd_ctx_ws_bytes": (C.c_longlong, [C.c_void_p, C.c_int]),
+    "bd_ctx_bind": (C.c_int, [C.c_void_p]),
+    "bd_head_set_schedule": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_float]),
+    "bd_head_sample": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bd_head_cond": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bd_head_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "bd_projector": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bd_llm_step": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bd_graph_capture": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "bd_graph_launch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "bd_step_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the native library; raise if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BitDanceHipError(
+                f"{LIB_PATH} not found: build it with `python -m bitdance_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the hot path.")
+        try:
+            l = C.CDLL(LIB_PATH)
+        except OSError as e:  # missing libamdhip64 etc.
+            raise BitDanceHipError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().bd_last_error()
+        raise BitDanceHipError(f"{what or 'libbitdance_hip'} failed ({rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,176 @@
+"""Binary tokenizer (conv autoencoder + sign quantiser), kept on MIOpen/rocBLAS through torch.nn as the north star
+asks.  Module/parameter names mirror the reference checkpoint
+(``ae.safetensors``: ``encoder.*`` / ``decoder.*``, modeling/vision_encoder/autoencoder.py) so that
+``load_state_dict(strict=True)`` works on the released files; the implementation itself is written against the
+checkpoint layout, not copied.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _act(x):
+    return x * torch.sigmoid(x)
+
+
+def _gn(ch):
+    return nn.GroupNorm(32, ch, eps=1e-6)
+
+
+class ResBlock(nn.Module):
+    """GN -> swish -> conv3 -> GN -> swish -> conv3 (+ 1x1 shortcut on channel change).  autoencoder.py:13-57"""
+
+    def __init__(self, cin: int, cout: int):
+        super().__init__()
+        self.cin, self.cout = cin, cout
+        self.norm1 = _gn(cin)
+        self.norm2 = _gn(cout)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1, bias=False)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1, bias=False)
+        if cin != cout:
+            self.nin_shortcut = nn.Conv2d(cin, cout, 1, bias=False)
+
+    def forward(self, x):
+        h = self.conv1(_act(self.norm1(x)))
+        h = self.conv2(_act(self.norm2(h)))
+        return h + (self.nin_shortcut(x) if self.cin != self.cout else x)
+
+
+class _Level(nn.Module):
+    pass
+
+
+class Encoder(nn.Module):
+    """autoencoder.py:59-127"""
+
+    def __init__(self, *, ch, out_ch, in_channels, num_res_blocks, z_channels, ch_mult=(1, 2, 2, 4),
+                 resolution=None, double_z=False):
+        super().__init__()
+        self.nlev, self.nres = len(ch_mult), num_res_blocks
+        self.conv_in = nn.Conv2d(in_channels, ch, 3, padding=1, bias=False)
+        self.down = nn.ModuleList()
+        mults = (1,) + tuple(ch_mult)
+        cin = ch
+        for lv in range(self.nlev):
+            cin, cout = ch * mults[lv], ch * ch_mult[lv]
+            level = _Level()
+            level.block = nn.ModuleList()
+            for _ in range(num_res_blocks):
+                level.block.append(ResBlock(cin, cout))
+                cin = cout
+            if lv < self.nlev - 1:
+                level.downsample = nn.Conv2d(cout, cout, 3, stride=2, padding=1)
+            self.down.append(level)
+        self.mid_block = nn.ModuleList([ResBlock(cin, cin) for _ in range(num_res_blocks)])
+        self.norm_out = _gn(cin)
+        self.conv_out = nn.Conv2d(cin, z_channels, 1)
+
+    def forward(self, x):
+        x = self.conv_in(x)
+        for lv, level in enumerate(self.down):
+            for blk in level.block:
+                x = blk(x)
+            if lv < self.nlev - 1:
+                x = level.downsample(x)
+        for blk in self.mid_block:
+            x = blk(x)
+        return self.conv_out(_act(self.norm_out(x)))
+
+
+def depth_to_space(x: torch.Tensor, r: int) -> torch.Tensor:
+    """DCR depth-to-space: channel index = (dy, dx, c).  autoencoder.py:198-230"""
+    b, c, h, w = x.shape
+    x = x.view(b, r, r, c // (r * r), h, w).permute(0, 3, 4, 1, 5, 2)
+    return x.reshape(b, c // (r * r), h * r, w * r)
+
+
+class Upsampler(nn.Module):
+    def __init__(self, dim: int):
+        super().__init__()
+        self.conv1 = nn.Conv2d(dim, dim * 4, 3, padding=1)
+
+    def forward(self, x):
+        return depth_to_space(self.conv1(x), 2)
+
+
+class AdaptiveGroupNorm(nn.Module):
+    """GroupNorm whose scale/bias come from per-channel std / mean of the token map.  autoencoder.py:251-277"""
+
+    def __init__(self, z_channel: int, ch: int, eps: float = 1e-6):
+        super().__init__()
+        self.gn = nn.GroupNorm(32, ch, eps=eps, affine=False)
+        self.gamma = nn.Linear(z_channel, ch)
+        self.beta = nn.Linear(z_channel, ch)
+        self.eps = eps
+
+    def forward(self, x, tokens):
+        b, c = x.shape[:2]
+        flat = tokens.flatten(2)
+        scale = self.gamma((flat.var(dim=-1) + self.eps).sqrt()).view(b, c, 1, 1)
+        bias = self.beta(flat.mean(dim=-1)).view(b, c, 1, 1)
+        return scale * self.gn(x) + bias
+
+
+class Decoder(nn.Module):
+    """autoencoder.py:129-196"""
+
+    def __init__(self, *, ch, out_ch, in_channels, num_res_blocks, z_channels, ch_mult=(1, 2, 2, 4),
+                 resolution=None, double_z=False):
+        super().__init__()
+        self.nlev, self.nres = len(ch_mult), num_res_blocks
+        cin = ch * ch_mult[-1]
+        self.conv_in = nn.Conv2d(z_channels, cin, 3, padding=1, bias=True)
+        self.mid_block = nn.ModuleList([ResBlock(cin, cin) for _ in range(num_res_blocks)])
+        self.up = nn.ModuleList()
+        self.adaptive = nn.ModuleList()
+        for lv in reversed(range(self.nlev)):
+            cout = ch * ch_mult[lv]
+            self.adaptive.insert(0, AdaptiveGroupNorm(z_channels, cin))
+            level = _Level()
+            level.block = nn.ModuleList()
+            for _ in range(num_res_blocks):
+                level.block.append(ResBlock(cin, cout))
+                cin = cout
+            if lv > 0:
+                level.upsample = Upsampler(cin)
+            self.up.insert(0, level)
+        self.norm_out = _gn(cin)
+        self.conv_out = nn.Conv2d(cin, out_ch, 3, padding=1)
+
+    def forward(self, z):
+        tokens = z
+        z = self.conv_in(z)
+        for blk in self.mid_block:
+            z = blk(z)
+        for lv in reversed(range(self.nlev)):
+            z = self.adaptive[lv](z, tokens)
+            for blk in self.up[lv].block:
+                z = blk(z)
+            if lv > 0:
+                z = self.up[lv].upsample(z)
+        return self.conv_out(_act(self.norm_out(z)))
+
+
+class VQModel(nn.Module):
+    """encode -> where(h>0,+1,-1) ; decode.  autoencoder.py:354-521 (the ``gan_decoder`` variant is not supported)."""
+
+    def __init__(self, ddconfig, checkpoint=None, gan_decoder=False):
+        super().__init__()
+        if gan_decoder:
+            raise NotImplementedError("gan_decoder=True tokenizers are outside the T2I hot path")
+        self.encoder = Encoder(**ddconfig)
+        self.decoder = Decoder(**ddconfig)
+
+    def encode(self, x):
+        h = self.encoder(x)
+        one = torch.ones((), dtype=h.dtype, device=h.device)
+        return torch.where(h > 0, one, -one)
+
+    def decode(self, quant):
+        return self.decoder(quant)
+
+    def forward(self, x):
+        q = self.encode(x)
+        return self.decode(q), q

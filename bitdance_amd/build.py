@@ -1,0 +1,62 @@
+"""Build libbitdance_hip.so (gfx950) in-tree with hipcc.  `python -m bitdance_amd.build`"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libbitdance_hip.so")
+SOURCES = ["bd_gemm.hip", "bd_rows.hip", "bd_attn.hip", "bd_api.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found (ROCm toolchain required)")
+    return exe
+
+
+def _newer(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "bitdance_hip.h"))
+    hipcc = _hipcc()
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or not _newer(o, [s] + headers):
+            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
+        return r
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if jobs or not os.path.exists(LIB):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,457 @@
+// C ABI + native orchestration of the BitDance AR step (see include/bitdance_hip.h).
+// Everything here is host code: it sequences the kernels of bd_gemm/bd_rows/bd_attn on the caller's stream and
+// captures the two phases of an AR step into hipGraphs.  No allocation, no sync inside the step.
+#include <map>
+#include <string>
+#include <vector>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+
+#include "bd_common.h"
+#include "bd_kernels.h"
+#include "../../include/bitdance_hip.h"
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) { g_err = m; return -1; }
+
+#define BD_TRY(expr)                                                                     \
+    do {                                                                                 \
+        int _r = (expr);                                                                 \
+        if (_r != 0) return fail(std::string(#expr) + " failed with " + std::to_string(_r)); \
+    } while (0)
+
+struct GemmCfg { int S = 1, nw = 4; };
+
+struct bd_ctx {
+    std::map<std::string, long long> I;
+    std::map<std::string, double> F;
+    std::map<std::string, const void*> P;
+    std::vector<std::pair<std::string, long long>> ws;
+    std::map<std::string, GemmCfg> g;
+    std::vector<SamplerScalars> sched;
+    bool finalized = false, bound = false;
+    hipGraphExec_t gexec[2] = {nullptr, nullptr};
+    hipGraph_t graph[2] = {nullptr, nullptr};
+
+    // derived
+    int B = 1, branches = 2, Pn = 64, BP = 64, M = 128, RB = 4, RBp = 2, Mpad = 128, BPpad = 64;
+    int hD = 0, hC = 0, hDz = 0, hH = 0, hNB = 0, hNA = 0, hNada = 0, hT = 0;
+    int lD = 0, lL = 0, lnh = 0, lnkv = 0, lF = 0, lLmax = 0, lsplits = 8, lNqkv = 0;
+    bool has_head = false, has_llm = false, has_proj = false;
+
+    long long geti(const std::string& k) const {
+        auto it = I.find(k);
+        if (it == I.end()) throw std::runtime_error("missing int '" + k + "'");
+        return it->second;
+    }
+    long long geti(const std::string& k, long long d) const { auto it = I.find(k); return it == I.end() ? d : it->second; }
+    double getf(const std::string& k, double d) const { auto it = F.find(k); return it == F.end() ? d : it->second; }
+    const void* ptr(const std::string& k) const {
+        auto it = P.find(k);
+        if (it == P.end() || it->second == nullptr) throw std::runtime_error("missing pointer '" + k + "'");
+        return it->second;
+    }
+    void* wptr(const std::string& k) const { return const_cast<void*>(ptr(k)); }
+    const void* optr(const std::string& k) const { auto it = P.find(k); return it == P.end() ? nullptr : it->second; }
+};
+
+static int pad_rows(int m) { return m <= 32 ? 32 : (m <= 64 ? 64 : ((m + 127) / 128) * 128); }
+
+static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K, bool swiglu) {
+    GemmCfg g;
+    g.nw = (N % 128 == 0) ? 4 : 2;
+    const int nst = K / 64;
+    if (swiglu) {
+        g.S = 1;
+        if (N / (32 * g.nw) < 200 && N % 64 == 0) g.nw = 2;
+    } else {
+        const int ntiles = N / (32 * g.nw);
+        int S = (int)std::lround(320.0 / ntiles);
+        if (S < 1) S = 1;
+        if (S > nst) S = nst;
+        g.S = S;
+    }
+    g.S = (int)c->geti("tune." + name + ".S", g.S);
+    g.nw = (int)c->geti("tune." + name + ".nw", g.nw);
+    if (g.S > nst) g.S = nst;
+    while (g.S > 1 && (g.S - 1) * ((nst + g.S - 1) / g.S) >= nst) --g.S;      // no empty split
+    return g;
+}
+
+extern "C" {
+
+int bd_version(void) { return 1; }
+const char* bd_last_error(void) { return g_err.c_str(); }
+
+int bd_pack_weight(void* dst, const void* src, int rows, int K, int dst_row0, void* stream) {
+    if (rows % 32 || dst_row0 % 32) return fail("bd_pack_weight: rows and dst_row0 must be multiples of 32");
+    BD_TRY(bdk_pack_w(dst, src, nullptr, rows / 32, K, dst_row0 / 32, 0, (hipStream_t)stream));
+    return 0;
+}
+int bd_pack_weight_swiglu(void* dst, const void* gate, const void* up, int F, int K, void* stream) {
+    if (F % 16) return fail("bd_pack_weight_swiglu: F must be a multiple of 16");
+    BD_TRY(bdk_pack_w(dst, gate, up, F / 16, K, 0, 1, (hipStream_t)stream));
+    return 0;
+}
+int bd_rows_to_frag(void* dst, const void* src, int src_is_fp32, int M, int K, int RB, void* stream) {
+    BD_TRY(bdk_rows_to_afrag(dst, src_is_fp32 ? (const float*)src : nullptr, src_is_fp32 ? nullptr : src, M, K, RB,
+                             (hipStream_t)stream));
+    return 0;
+}
+int bd_gemm_partial(const void* a, int RB, const void* w, int N, int K, int S, int nw, float* out, void* stream) {
+    BD_TRY(bdk_gemm(a, RB, w, N, K, S, nw, BD_EPI_PARTIAL, out, nullptr, nullptr, (hipStream_t)stream));
+    return 0;
+}
+int bd_gemm_swiglu(const void* a, int RB, const void* w, const void* bias, int N2, int K, int nw, void* act, void* stream) {
+    BD_TRY(bdk_gemm(a, RB, w, N2, K, 1, nw, BD_EPI_SWIGLU, nullptr, act, bias, (hipStream_t)stream));
+    return 0;
+}
+
+bd_ctx* bd_ctx_create(void) { return new bd_ctx(); }
+void bd_ctx_destroy(bd_ctx* c) {
+    if (!c) return;
+    for (int i = 0; i < 2; ++i) {
+        if (c->gexec[i]) hipGraphExecDestroy(c->gexec[i]);
+        if (c->graph[i]) hipGraphDestroy(c->graph[i]);
+    }
+    delete c;
+}
+int bd_ctx_set_int(bd_ctx* c, const char* k, long long v) { c->I[k] = v; return 0; }
+int bd_ctx_set_float(bd_ctx* c, const char* k, double v) { c->F[k] = v; return 0; }
+int bd_ctx_set_ptr(bd_ctx* c, const char* k, const void* p) { c->P[k] = p; return 0; }
+
+int bd_ctx_finalize(bd_ctx* c) {
+    try {
+        c->B = (int)c->geti("B");
+        c->branches = (int)c->geti("branches");
+        c->Pn = (int)c->geti("P");
+        if (c->Pn != 64) return fail("only parallel_num = 64 (64x models) is supported by the native path");
+        c->BP = c->B * c->Pn;
+        c->M = c->branches * c->BP;
+        c->Mpad = pad_rows(c->M);
+        c->BPpad = pad_rows(c->BP);
+        c->RB = c->Mpad / 32;
+        c->RBp = c->BPpad / 32;
+        if (c->branches * c->B > 16) return fail("too many sequences (max 16)");
+        c->has_head = c->I.count("head.D") > 0;
+        c->has_llm = c->I.count("llm.D") > 0;
+        c->has_proj = c->I.count("proj.D") > 0;
+        c->ws.clear();
+        auto add = [&](const std::string& n, long long bytes) { c->ws.push_back({n, bytes}); };
+        add("state", sizeof(BdStepState));
+        const long long Mp = c->Mpad;
+        if (c->has_head) {
+            c->hD = (int)c->geti("head.D"); c->hC = (int)c->geti("head.C"); c->hDz = (int)c->geti("head.Dz");
+            c->hH = (int)c->geti("head.H"); c->hNB = (int)c->geti("head.nblocks"); c->hNA = (int)c->geti("head.nada");
+            c->hT = (int)c->geti("head.T", c->Pn);
+            if (c->hD % 128 || c->hH % 64 || c->hDz % 64) return fail("head dims must be multiples of 128/64");
+            if (c->hNB % c->hNA) return fail("head.nblocks must be divisible by head.nada");
+            c->hNada = c->hNA * 6 * c->hD + 2 * c->hD;
+            c->g["head.cond"] = choose_cfg(c, "head.cond", c->hD, c->hDz, false);
+            c->g["head.ada"] = choose_cfg(c, "head.ada", c->hNada, c->hD, false);
+            c->g["head.qkv"] = choose_cfg(c, "head.qkv", 3 * c->hD, c->hD, false);
+            c->g["head.wo"] = choose_cfg(c, "head.wo", c->hD, c->hD, false);
+            c->g["head.w1"] = choose_cfg(c, "head.w1", 2 * c->hH, c->hD, true);
+            c->g["head.w2"] = choose_cfg(c, "head.w2", c->hD, c->hH, false);
+            const int sbr = std::max(c->g["head.wo"].S, c->g["head.w2"].S);
+            add("head.cond_frag", Mp * c->hDz * 2);
+            add("head.cond_part", (long long)c->g["head.cond"].S * Mp * c->hD * 4);
+            add("head.xt", (long long)c->BP * c->hC * 4);
+            add("head.y_frag", Mp * c->hD * 2);
+            add("head.X", Mp * c->hD * 2);
+            add("head.ada_part", (long long)c->g["head.ada"].S * Mp * c->hNada * 4);
+            add("head.h_frag", Mp * c->hD * 2);
+            add("head.qkv_part", (long long)c->g["head.qkv"].S * Mp * 3 * c->hD * 4);
+            add("head.attn_frag", Mp * c->hD * 2);
+            add("head.br_part", (long long)sbr * Mp * c->hD * 4);
+            add("head.act_frag", Mp * c->hH * 2);
+            add("head.pred", (long long)c->BP * c->hC * 4);
+            add("head.tok_cur", (long long)c->BP * c->hC * 4);
+            add("head.xhat", Mp * c->hC * 4);
+        }
+        if (c->has_proj) {
+            const int D = (int)c->geti("proj.D");
+            c->g["proj.fc2"] = choose_cfg(c, "proj.fc2", D, D, false);
+            add("proj.h_frag", (long long)c->BPpad * D * 2);
+            add("proj.part", (long long)c->g["proj.fc2"].S * c->BPpad * D * 4);
+        }
+        if (c->has_llm) {
+            c->lD = (int)c->geti("llm.D"); c->lL = (int)c->geti("llm.L"); c->lnh = (int)c->geti("llm.nh");
+            c->lnkv = (int)c->geti("llm.nkv"); c->lF = (int)c->geti("llm.F"); c->lLmax = (int)c->geti("llm.Lmax");
+            c->lsplits = (int)c->geti("llm.splits", 8);
+            if (c->geti("llm.head_dim", 128) != 128) return fail("llm.head_dim must be 128");
+            if (c->lLmax % 64) return fail("llm.Lmax must be a multiple of 64");
+            c->lNqkv = (c->lnh + 2 * c->lnkv) * 128;
+            if (c->lD % 64 || c->lF % 64) return fail("llm dims must be multiples of 64");
+            c->g["llm.qkv"] = choose_cfg(c, "llm.qkv", c->lNqkv, c->lD, false);
+            c->g["llm.o"] = choose_cfg(c, "llm.o", c->lD, c->lnh * 128, false);
+            c->g["llm.gu"] = choose_cfg(c, "llm.gu", 2 * c->lF, c->lD, true);
+            c->g["llm.down"] = choose_cfg(c, "llm.down", c->lD, c->lF, false);
+            const int nseq = c->branches * c->B, G = c->lnh / c->lnkv;
+            const int sbr = std::max(c->g["llm.o"].S, c->g["llm.down"].S);
+            add("llm.R", Mp * c->lD * 4);
+            add("llm.a_frag", Mp * c->lD * 2);
+            add("llm.qkv_part", (long long)c->g["llm.qkv"].S * Mp * c->lNqkv * 4);
+            add("llm.q", Mp * c->lnh * 128 * 2);
+            add("llm.k_cache", (long long)c->lL * nseq * c->lnkv * c->lLmax * 128 * 2);
+            add("llm.vt_cache", (long long)c->lL * nseq * c->lnkv * c->lLmax * 128 * 2);
+            add("llm.attn_opart", (long long)nseq * c->lnkv * c->lsplits * G * c->Pn * 128 * 4);
+            add("llm.attn_ml", (long long)nseq * c->lnkv * c->lsplits * G * c->Pn * 2 * 4);
+            add("llm.attn_frag", Mp * c->lnh * 128 * 2);
+            add("llm.br_part", (long long)sbr * Mp * c->lD * 4);
+            add("llm.act_frag", Mp * c->lF * 2);
+            add("llm.hidden", Mp * c->lD * 4);
+        }
+        c->finalized = true;
+        return 0;
+    } catch (const std::exception& e) { return fail(e.what()); }
+}
+int bd_ctx_ws_count(bd_ctx* c) { return (int)c->ws.size(); }
+const char* bd_ctx_ws_name(bd_ctx* c, int i) { return c->ws[i].first.c_str(); }
+long long bd_ctx_ws_bytes(bd_ctx* c, int i) { return c->ws[i].second; }
+int bd_ctx_bind(bd_ctx* c) {
+    if (!c->finalized) return fail("bd_ctx_bind before bd_ctx_finalize");
+    for (auto& w : c->ws)
+        if (!c->optr(w.first)) return fail("workspace '" + w.first + "' not set");
+    c->bound = true;
+    return 0;
+}
+
+int bd_head_set_schedule(bd_ctx* c, int n_steps, const float* s, float cfg) {
+    c->sched.clear();
+    for (int i = 0; i <= n_steps; ++i) {
+        SamplerScalars q;
+        q.t = s[i * 6 + 0]; q.dt = s[i * 6 + 1]; q.den = s[i * 6 + 2]; q.var = s[i * 6 + 3];
+        q.omt = s[i * 6 + 4]; q.noise_scale = s[i * 6 + 5]; q.cfg = cfg;
+        q.is_final = (i == n_steps); q.cfg_mult = c->branches;
+        c->sched.push_back(q);
+    }
+    return 0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+static Partial part(const bd_ctx* c, const std::string& ws, const void* bias, int S, int N, int Mpad) {
+    return Partial{(const float*)c->ptr(ws), bias, S, N, Mpad};
+}
+
+static int head_cond(bd_ctx* c, hipStream_t st) {
+    const GemmCfg& g = c->g["head.cond"];
+    BD_TRY(bdk_gemm(c->ptr("head.cond_frag"), c->RB, c->ptr("head.cond_w"), c->hD, c->hDz, g.S, g.nw, BD_EPI_PARTIAL,
+                    (float*)c->wptr("head.cond_part"), nullptr, nullptr, st));
+    return 0;
+}
+
+static int head_eval(bd_ctx* c, int i, hipStream_t st) {
+    if (i < 0 || i >= (int)c->sched.size()) return fail("bd_head_eval: eval index outside the schedule");
+    const int D = c->hD, H = c->hH, Mp = c->Mpad, RB = c->RB, M = c->M;
+    const int n_steps = (int)c->sched.size() - 1;
+    const BdStepState* state = (const BdStepState*)c->ptr("state");
+    HeadPrologueArgs pa;
+    pa.cond = part(c, "head.cond_part", c->ptr("head.cond_b"), c->g["head.cond"].S, D, Mp);
+    pa.temb = (const bf16_t*)c->ptr("head.temb") + (size_t)i * D;
+    pa.xt = (const float*)c->ptr("head.xt");
+    pa.in_w = c->ptr("head.in_w"); pa.in_b = c->ptr("head.in_b");
+    pa.y_frag = c->wptr("head.y_frag"); pa.X = c->wptr("head.X");
+    pa.M = M; pa.BP = c->BP; pa.D = D; pa.C = c->hC; pa.RB = RB;
+    BD_TRY(bdk_head_prologue(pa, st));
+
+    const GemmCfg& ga = c->g["head.ada"];
+    BD_TRY(bdk_gemm(c->ptr("head.y_frag"), RB, c->ptr("head.ada_w"), c->hNada, D, ga.S, ga.nw, BD_EPI_PARTIAL,
+                    (float*)c->wptr("head.ada_part"), nullptr, nullptr, st));
+    const Partial ada = part(c, "head.ada_part", c->ptr("head.ada_b"), ga.S, c->hNada, Mp);
+    const int sw = c->hNB / c->hNA;
+    const GemmCfg &gq = c->g["head.qkv"], &go = c->g["head.wo"], &g1 = c->g["head.w1"], &g2 = c->g["head.w2"];
+    for (int b = 0; b < c->hNB; ++b) {
+        const std::string pre = "head.blk" + std::to_string(b) + ".";
+        const int base = (b / sw) * 6 * D;
+        LnModArgs l1;
+        l1.X = c->wptr("head.X");
+        if (b == 0) l1.pend = Partial{nullptr, nullptr, 0, 0, 0};
+        else l1.pend = part(c, "head.br_part", c->ptr("head.blk" + std::to_string(b - 1) + ".b2"), g2.S, D, Mp);
+        l1.ada = ada;
+        l1.gate_off = ((b - 1 < 0 ? 0 : b - 1) / sw) * 6 * D + 5 * D;
+        l1.scale_off = base; l1.shift_off = base + D;
+        l1.ln_w = (const float*)c->ptr(pre + "ln1_w"); l1.ln_b = (const float*)c->ptr(pre + "ln1_b");
+        l1.h_frag = c->wptr("head.h_frag"); l1.M = M; l1.D = D; l1.RB = RB; l1.eps = 1e-6f;
+        BD_TRY(bdk_ln_mod(l1, st));
+        BD_TRY(bdk_gemm(c->ptr("head.h_frag"), RB, c->ptr(pre + "wqkv"), 3 * D, D, gq.S, gq.nw, BD_EPI_PARTIAL,
+                        (float*)c->wptr("head.qkv_part"), nullptr, nullptr, st));
+        HeadAttnArgs at;
+        at.qkv = part(c, "head.qkv_part", c->ptr(pre + "bqkv"), gq.S, 3 * D, Mp);
+        at.o_frag = c->wptr("head.attn_frag"); at.nseq = M / 64; at.nhead = D / 128; at.D = D; at.RB = RB;
+        BD_TRY(bdk_head_attn(at, st));
+        BD_TRY(bdk_gemm(c->ptr("head.attn_frag"), RB, c->ptr(pre + "wo"), D, D, go.S, go.nw, BD_EPI_PARTIAL,
+                        (float*)c->wptr("head.br_part"), nullptr, nullptr, st));
+        LnModArgs l2 = l1;
+        l2.pend = part(c, "head.br_part", c->ptr(pre + "bo"), go.S, D, Mp);
+        l2.gate_off = base + 2 * D; l2.scale_off = base + 3 * D; l2.shift_off = base + 4 * D;
+        l2.ln_w = (const float*)c->ptr(pre + "ln2_w"); l2.ln_b = (const float*)c->ptr(pre + "ln2_b");
+        BD_TRY(bdk_ln_mod(l2, st));
+        BD_TRY(bdk_gemm(c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * H, D, 1, g1.nw, BD_EPI_SWIGLU, nullptr,
+                        c->wptr("head.act_frag"), c->ptr(pre + "b1"), st));
+        BD_TRY(bdk_gemm(c->ptr("head.act_frag"), RB, c->ptr(pre + "w2"), D, H, g2.S, g2.nw, BD_EPI_PARTIAL,
+                        (float*)c->wptr("head.br_part"), nullptr, nullptr, st));
+    }
+    HeadFinalArgs fa;
+    fa.X = c->ptr("head.X");
+    fa.pend = part(c, "head.br_part", c->ptr("head.blk" + std::to_string(c->hNB - 1) + ".b2"), g2.S, D, Mp);
+    fa.ada = ada;
+    fa.gate_off = ((c->hNB - 1) / sw) * 6 * D + 5 * D;
+    fa.scale_off = c->hNA * 6 * D; fa.shift_off = c->hNA * 6 * D + D;
+    fa.lin_w = c->ptr("head.lin_w"); fa.lin_b = c->ptr("head.lin_b");
+    fa.xt = (float*)c->wptr("head.xt");
+    fa.noise = (const float*)c->ptr("head.noise");
+    fa.noise_step_stride = (long long)(n_steps + 1) * c->BP * c->hC;
+    fa.eval_index = i; fa.state = state;
+    fa.pred_out = (float*)c->wptr("head.pred"); fa.tok_cur = (float*)c->wptr("head.tok_cur");
+    fa.tok_all = (float*)const_cast<void*>(c->optr("head.tok_all"));
+    fa.T = c->hT; fa.P = c->Pn;
+    fa.xhat_out = c->geti("rt.dump_xhat", 0) ? (float*)c->wptr("head.xhat") : nullptr;
+    fa.sc = c->sched[i];
+    fa.BP = c->BP; fa.D = D; fa.C = c->hC; fa.M = M; fa.eps_ln = 1e-6f;
+    BD_TRY(bdk_head_final(fa, st));
+    return 0;
+}
+
+static int head_sample(bd_ctx* c, hipStream_t st) {
+    if (c->sched.empty()) return fail("bd_head_sample: no schedule set");
+    const int n_steps = (int)c->sched.size() - 1;
+    InitLatentArgs ia{(float*)c->wptr("head.xt"), (const float*)c->ptr("head.noise"),
+                      (long long)(n_steps + 1) * c->BP * c->hC, (const BdStepState*)c->ptr("state"), c->BP * c->hC};
+    BD_TRY(bdk_init_latent(ia, st));
+    BD_TRY(head_cond(c, st));
+    for (int i = 0; i <= n_steps; ++i) BD_TRY(head_eval(c, i, st));
+    return 0;
+}
+
+static int projector(bd_ctx* c, hipStream_t st) {
+    const int D = (int)c->geti("proj.D");
+    ProjFc1Args f1{(const float*)c->ptr("head.tok_cur"), c->ptr("proj.w1"), c->ptr("proj.b1"), c->wptr("proj.h_frag"),
+                   c->BP, D, (int)c->geti("proj.C"), c->RBp};
+    BD_TRY(bdk_proj_fc1(f1, st));
+    const GemmCfg& g = c->g["proj.fc2"];
+    BD_TRY(bdk_gemm(c->ptr("proj.h_frag"), c->RBp, c->ptr("proj.w2"), D, D, g.S, g.nw, BD_EPI_PARTIAL,
+                    (float*)c->wptr("proj.part"), nullptr, nullptr, st));
+    EmbedFinalizeArgs ef;
+    ef.fc2 = Partial{(const float*)c->ptr("proj.part"), c->ptr("proj.b2"), g.S, D, c->BPpad};
+    ef.pos = (const float*)c->ptr("pos"); ef.R = (float*)c->wptr("llm.R");
+    ef.state = (const BdStepState*)c->ptr("state"); ef.BP = c->BP; ef.P = c->Pn; ef.D = D; ef.branches = c->branches;
+    BD_TRY(bdk_embed_finalize(ef, st));
+    return 0;
+}
+
+static int llm_step(bd_ctx* c, hipStream_t st) {
+    const int D = c->lD, F = c->lF, Mp = c->Mpad, RB = c->RB, M = c->M, nh = c->lnh, nkv = c->lnkv;
+    const int nseq = c->branches * c->B;
+    const float eps = (float)c->getf("llm.eps", 1e-6);
+    BdStepState* state = (BdStepState*)c->wptr("state");
+    const GemmCfg &gq = c->g["llm.qkv"], &go = c->g["llm.o"], &gg = c->g["llm.gu"], &gd = c->g["llm.down"];
+    const size_t layer_elems = (size_t)nseq * nkv * c->lLmax * 128;
+    for (int l = 0; l < c->lL; ++l) {
+        const std::string pre = "llm.l" + std::to_string(l) + ".";
+        RmsArgs r1;
+        r1.R = (float*)c->wptr("llm.R");
+        r1.pend = (l == 0) ? Partial{nullptr, nullptr, 0, 0, 0} : part(c, "llm.br_part", nullptr, gd.S, D, Mp);
+        r1.w = c->ptr(pre + "in_norm"); r1.a_frag = c->wptr("llm.a_frag");
+        r1.hidden_out = nullptr; r1.cond_frag = nullptr; r1.pos = nullptr; r1.state = state;
+        r1.M = M; r1.D = D; r1.RB = RB; r1.P = c->Pn; r1.eps = eps;
+        BD_TRY(bdk_rms(r1, st));
+        BD_TRY(bdk_gemm(c->ptr("llm.a_frag"), RB, c->ptr(pre + "wqkv"), c->lNqkv, D, gq.S, gq.nw, BD_EPI_PARTIAL,
+                        (float*)c->wptr("llm.qkv_part"), nullptr, nullptr, st));
+        QkvPostArgs qa;
+        qa.qkv = part(c, "llm.qkv_part", nullptr, gq.S, c->lNqkv, Mp);
+        qa.qn_w = c->ptr(pre + "q_norm"); qa.kn_w = c->ptr(pre + "k_norm");
+        qa.cos = (const float*)c->ptr("llm.cos"); qa.sin = (const float*)c->ptr("llm.sin");
+        qa.q_out = c->wptr("llm.q");
+        qa.k_cache = (bf16_t*)c->wptr("llm.k_cache") + l * layer_elems;
+        qa.vt_cache = (bf16_t*)c->wptr("llm.vt_cache") + l * layer_elems;
+        qa.state = state; qa.M = M; qa.P = c->Pn; qa.nh = nh; qa.nkv = nkv; qa.Lmax = c->lLmax; qa.eps = eps;
+        BD_TRY(bdk_qkv_post(qa, st));
+        LlmAttnArgs aa;
+        aa.q = c->ptr("llm.q"); aa.k_cache = qa.k_cache; aa.vt_cache = qa.vt_cache;
+        aa.o_part = (float*)c->wptr("llm.attn_opart"); aa.ml_part = (float*)c->wptr("llm.attn_ml");
+        aa.o_frag = c->wptr("llm.attn_frag"); aa.state = state;
+        aa.nseq = nseq; aa.P = c->Pn; aa.nh = nh; aa.nkv = nkv; aa.Lmax = c->lLmax; aa.splits = c->lsplits; aa.RB = RB;
+        BD_TRY(bdk_llm_attn(aa, st));
+        BD_TRY(bdk_gemm(c->ptr("llm.attn_frag"), RB, c->ptr(pre + "wo"), D, nh * 128, go.S, go.nw, BD_EPI_PARTIAL,
+                        (float*)c->wptr("llm.br_part"), nullptr, nullptr, st));
+        RmsArgs r2 = r1;
+        r2.pend = part(c, "llm.br_part", nullptr, go.S, D, Mp);
+        r2.w = c->ptr(pre + "post_norm");
+        BD_TRY(bdk_rms(r2, st));
+        BD_TRY(bdk_gemm(c->ptr("llm.a_frag"), RB, c->ptr(pre + "wgu"), 2 * F, D, 1, gg.nw, BD_EPI_SWIGLU, nullptr,
+                        c->wptr("llm.act_frag"), nullptr, st));
+        BD_TRY(bdk_gemm(c->ptr("llm.act_frag"), RB, c->ptr(pre + "wdown"), D, F, gd.S, gd.nw, BD_EPI_PARTIAL,
+                        (float*)c->wptr("llm.br_part"), nullptr, nullptr, st));
+    }
+    StepAdvanceArgs sa{state, nseq, c->Pn};
+    BD_TRY(bdk_step_advance(sa, st));                       // step+1 / kv_len += P: the next patch's position
+    RmsArgs rf;
+    rf.R = (float*)c->wptr("llm.R");
+    rf.pend = part(c, "llm.br_part", nullptr, gd.S, D, Mp);
+    rf.w = c->ptr("llm.final_norm"); rf.a_frag = nullptr;
+    rf.hidden_out = (float*)c->wptr("llm.hidden");
+    const bool emit = c->geti("rt.emit_cond", 1) != 0 && c->has_head;
+    rf.cond_frag = emit ? c->wptr("head.cond_frag") : nullptr;
+    rf.pos = emit ? (const float*)c->ptr("pos") : nullptr;
+    rf.state = state; rf.M = M; rf.D = D; rf.RB = RB; rf.P = c->Pn; rf.eps = eps;
+    BD_TRY(bdk_rms(rf, st));
+    return 0;
+}
+
+struct ResetArgs { BdStepState* state; int kv[16]; int nseq; };
+__global__ void step_reset_kernel(ResetArgs a) {
+    if (threadIdx.x == 0) a.state->step = 0;
+    if ((int)threadIdx.x < 16) a.state->kv_len[threadIdx.x] = ((int)threadIdx.x < a.nseq) ? a.kv[threadIdx.x] : 0;
+}
+
+extern "C" {
+
+#define BD_GUARD(...)                                                        \
+    if (!c->bound) return fail("context not bound (bd_ctx_bind)");           \
+    try { __VA_ARGS__ } catch (const std::exception& e) { return fail(e.what()); }
+
+int bd_head_cond(bd_ctx* c, void* s) { BD_GUARD(return head_cond(c, (hipStream_t)s);) }
+int bd_head_eval(bd_ctx* c, int i, void* s) { BD_GUARD(return head_eval(c, i, (hipStream_t)s);) }
+int bd_head_sample(bd_ctx* c, void* s) { BD_GUARD(return head_sample(c, (hipStream_t)s);) }
+int bd_projector(bd_ctx* c, void* s) { BD_GUARD(return projector(c, (hipStream_t)s);) }
+int bd_llm_step(bd_ctx* c, void* s) { BD_GUARD(return llm_step(c, (hipStream_t)s);) }
+
+int bd_step_reset(bd_ctx* c, const int* kv_len, int nseq, void* s) {
+    BD_GUARD(
+        if (nseq > 16) return fail("bd_step_reset: nseq > 16");
+        ResetArgs a; a.state = (BdStepState*)c->wptr("state"); a.nseq = nseq;
+        for (int i = 0; i < 16; ++i) a.kv[i] = i < nseq ? kv_len[i] : 0;
+        hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, a);
+        return hipGetLastError() == hipSuccess ? 0 : fail("step_reset launch failed");)
+}
+
+int bd_graph_capture(bd_ctx* c, int phase, void* s) {
+    BD_GUARD(
+        if (phase < 0 || phase > 1) return fail("bd_graph_capture: phase must be 0 or 1");
+        hipStream_t st = (hipStream_t)s;
+        if (c->gexec[phase]) { hipGraphExecDestroy(c->gexec[phase]); c->gexec[phase] = nullptr; }
+        if (c->graph[phase]) { hipGraphDestroy(c->graph[phase]); c->graph[phase] = nullptr; }
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) return fail("hipStreamBeginCapture failed");
+        int r = (phase == 0) ? head_sample(c, st) : (projector(c, st) || llm_step(c, st));
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(st, &g);
+        if (r != 0) { if (g) hipGraphDestroy(g); return -1; }
+        if (e != hipSuccess || !g) return fail(std::string("hipStreamEndCapture failed: ") + hipGetErrorString(e));
+        e = hipGraphInstantiate(&c->gexec[phase], g, nullptr, nullptr, 0);
+        if (e != hipSuccess) { hipGraphDestroy(g); return fail(std::string("hipGraphInstantiate failed: ") + hipGetErrorString(e)); }
+        c->graph[phase] = g;
+        return 0;)
+}
+int bd_graph_launch(bd_ctx* c, int phase, void* s) {
+    BD_GUARD(
+        if (phase < 0 || phase > 1 || !c->gexec[phase]) return fail("bd_graph_launch: phase not captured");
+        hipError_t e = hipGraphLaunch(c->gexec[phase], (hipStream_t)s);
+        return e == hipSuccess ? 0 : fail(std::string("hipGraphLaunch failed: ") + hipGetErrorString(e));)
+}
+
+}  // extern "C"

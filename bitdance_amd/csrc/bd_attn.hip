@@ -1,0 +1,306 @@
+// Attention kernels of the BitDance hot path (gfx950, wave64, v_mfma_f32_32x32x16_bf16).
+//
+//  * head_attn   : the DiT block's non-causal attention over one 64-token patch (flow_head:192-220, the
+//                  flash_attn_func branch).  One workgroup per (sequence, head); K and V^T of the patch are
+//                  staged once in LDS, each wave owns 32 query rows.
+//  * llm_attn    : block-bidirectional decode attention (t2i_pipeline.py:256-268: an all-True mask, i.e. every
+//                  one of the P new queries sees all past+P keys) over a static, pre-allocated KV cache --
+//                  K as [seq][kvh][pos][128], V TRANSPOSED as [seq][kvh][128][pos] so that both MFMA operands are
+//                  16-byte contiguous reads.  GQA-aware: one workgroup = one KV head x all G query heads x 64
+//                  queries (G*2 waves share every LDS-staged K/V tile), split over the key range (flash-decode),
+//                  merged by llm_attn_combine.
+//
+// Both use the "swapped" score product S^T = K Q^T so that a lane owns one query row's scores in registers
+// (row max / sum are register reductions plus one lane^32 exchange), softmax statistics in fp32, the
+// un-normalised P rounded to bf16 for P.V, fp32 output accumulation, one normalisation + rounding at the end
+// (the FlashAttention-2 schedule the reference's kernels follow).
+#include "bd_common.h"
+#include "bd_kernels.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+BD_DEV f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                   __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
+}
+
+#define KSTR 136   // K tile row stride (bf16): 128 + 8 -> conflict-free ds_read_b128 across 16 rows
+#define VSTR 72    // V^T tile row stride (bf16): 64 + 8
+
+BD_DEV int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// P (fp32, this lane's 16 scores of a 32-key block: rows mfma_row(r)) -> the two bf16 A operands
+// (keys 0..15 and 16..31 of the block) for O += P V.
+BD_DEV void p_to_afrags(const float* p, int lane, u32x4& a_lo, u32x4& a_hi) {
+    const bool up = lane >= 32;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int r0 = hf * 8;
+        const unsigned X0 = pack2(p[r0 + 0], p[r0 + 1]), X1 = pack2(p[r0 + 2], p[r0 + 3]);
+        const unsigned Y0 = pack2(p[r0 + 4], p[r0 + 5]), Y1 = pack2(p[r0 + 6], p[r0 + 7]);
+        const unsigned tX0 = __shfl_xor(X0, 32), tX1 = __shfl_xor(X1, 32);
+        const unsigned tY0 = __shfl_xor(Y0, 32), tY1 = __shfl_xor(Y1, 32);
+        // lanes <32 need keys base+0..7 = own(0-3) | partner(4-7); lanes >=32 need base+8..15 = partner(8-11) | own(12-15)
+        const u32x4 f = up ? (u32x4){tY0, tY1, Y0, Y1} : (u32x4){X0, X1, tX0, tX1};
+        if (hf == 0) a_lo = f; else a_hi = f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DiT head attention: seq = 64
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void head_attn_kernel(HeadAttnArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * KSTR];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[128 * VSTR];
+    const int seq = blockIdx.x / a.nhead, h = blockIdx.x % a.nhead;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = a.D;
+    const Partial& q = a.qkv;
+    const bf16_t* bias = (const bf16_t*)q.bias;
+    const size_t slab = (size_t)q.Mpad * q.N;
+
+    auto load8 = [&](int row, int col, float* v) {          // Linear output (sum of slabs + bias), bf16-rounded
+        const float* p = q.p + (size_t)row * q.N + col;
+        f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+        for (int s = 1; s < q.S; ++s) {
+            lo += *reinterpret_cast<const f32x4*>(p + s * slab);
+            hi += *reinterpret_cast<const f32x4*>(p + s * slab + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = bfr(lo[j] + (bias ? bf2f(bias[col + j]) : 0.f));
+            v[4 + j] = bfr(hi[j] + (bias ? bf2f(bias[col + 4 + j]) : 0.f));
+        }
+    };
+
+    // stage K [key][d] and V^T [d][key] of this (seq, head)
+    for (int u = tid; u < 1024; u += 128) {
+        const int key = u >> 4, dp = (u & 15) * 8;
+        float v[8];
+        load8(seq * 64 + key, D + h * 128 + dp, v);
+        *reinterpret_cast<u32x4*>(&Ks[key * KSTR + dp]) =
+            (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+        load8(seq * 64 + key, 2 * D + h * 128 + dp, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Vs[(dp + j) * VSTR + key] = f2bf(v[j]);
+    }
+    // Q operand fragments (B of S^T = K Q^T): lane -> query (lane&31), 8 consecutive d
+    u32x4 qf[8];
+    const int qrow = seq * 64 + wave * 32 + (lane & 31);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        float v[8];
+        load8(qrow, h * 128 + ks * 16 + (lane >> 5) * 8, v);
+        qf[ks] = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+    }
+    __syncthreads();
+
+    f32x16 sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const u32x4 kf = *reinterpret_cast<const u32x4*>(&Ks[(kb * 32 + (lane & 31)) * KSTR + ks * 16 + (lane >> 5) * 8]);
+            sacc[kb] = mfma32(kf, qf[ks], sacc[kb]);
+        }
+    }
+    const float scale = 0.08838834764831845f;                // 128^-0.5
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float p[2][16], lsum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { p[kb][r] = __expf((sacc[kb][r] - mx) * scale); lsum += p[kb][r]; }
+    lsum += __shfl_xor(lsum, 32);
+
+    f32x16 oacc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[nb][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        u32x4 pa[2];
+        p_to_afrags(p[kb], lane, pa[0], pa[1]);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int key0 = kb * 32 + hf * 16 + (lane >> 5) * 8;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const u32x4 vf = *reinterpret_cast<const u32x4*>(&Vs[(nb * 32 + (lane & 31)) * VSTR + key0]);
+                oacc[nb] = mfma32(pa[hf], vf, oacc[nb]);
+            }
+        }
+    }
+    bf16_t* O = (bf16_t*)a.o_frag;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qr = mfma_row(r, lane);
+        const float l = __shfl(lsum, qr);
+        const int row = seq * 64 + wave * 32 + qr;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+            O[afrag_off(row, h * 128 + nb * 32 + (lane & 31), a.RB)] = f2bf(oacc[nb][r] / l);
+    }
+}
+
+int bdk_head_attn(const HeadAttnArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(head_attn_kernel, dim3(a.nseq * a.nhead), dim3(128), 0, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LLM decode attention (flash-decode over the static KV cache) + combine
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(640) void llm_attn_kernel(LlmAttnArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * KSTR];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[128 * VSTR];
+    const int split = blockIdx.x, kvh = blockIdx.y, seq = blockIdx.z;
+    const int G = a.nh / a.nkv;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = blockDim.x;
+    const int qh = wave >> 1, half = wave & 1;
+    const int head = kvh * G + qh;
+    const int L = a.state->kv_len[seq] + a.P;                // keys visible to this block of queries
+    const int ntiles = (L + 63) >> 6;
+    const int per = (ntiles + a.splits - 1) / a.splits;
+    const int t_beg = split * per, t_end = min(ntiles, t_beg + per);
+
+    const bf16_t* Kc = (const bf16_t*)a.k_cache + ((size_t)seq * a.nkv + kvh) * a.Lmax * 128;
+    const bf16_t* Vc = (const bf16_t*)a.vt_cache + ((size_t)seq * a.nkv + kvh) * 128 * a.Lmax;
+
+    u32x4 qf[8];
+    {
+        const bf16_t* qp = (const bf16_t*)a.q + ((size_t)(seq * a.P + half * 32 + (lane & 31)) * a.nh + head) * 128 + (lane >> 5) * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qp + ks * 16);
+    }
+    const float scale = 0.08838834764831845f;
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 oacc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[nb][r] = 0.f;
+
+    for (int t = t_beg; t < t_end; ++t) {
+        const int key_base = t * 64;
+        __syncthreads();
+        for (int u = tid; u < 1024; u += NT) {               // K tile: 64 keys x 16 pieces of 8 d
+            const int key = u >> 4, dp = (u & 15) * 8;
+            *reinterpret_cast<u32x4*>(&Ks[key * KSTR + dp]) =
+                *reinterpret_cast<const u32x4*>(Kc + (size_t)(key_base + key) * 128 + dp);
+        }
+        for (int u = tid; u < 1024; u += NT) {               // V^T tile: 128 d x 8 pieces of 8 keys
+            const int d = u >> 3, kp = (u & 7) * 8;
+            *reinterpret_cast<u32x4*>(&Vs[d * VSTR + kp]) =
+                *reinterpret_cast<const u32x4*>(Vc + (size_t)d * a.Lmax + key_base + kp);
+        }
+        __syncthreads();
+        f32x16 sacc[2];
+        float p[2][16];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const u32x4 kf = *reinterpret_cast<const u32x4*>(&Ks[(kb * 32 + (lane & 31)) * KSTR + ks * 16 + (lane >> 5) * 8]);
+                sacc[kb] = mfma32(kf, qf[ks], sacc[kb]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key_base + kb * 32 + mfma_row(r, lane);
+                const float s = (key < L) ? sacc[kb][r] : -INFINITY;
+                p[kb][r] = s;
+                tmax = fmaxf(tmax, s);
+            }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run, tmax);               // finite: every processed tile has a valid key
+        const float alpha = __expf((m_run - m_new) * scale);
+        float tsum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { p[kb][r] = __expf((p[kb][r] - m_new) * scale); tsum += p[kb][r]; }
+        tsum += __shfl_xor(tsum, 32);
+        l_run = l_run * alpha + tsum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float al = __shfl(alpha, mfma_row(r, lane));
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) oacc[nb][r] *= al;
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            u32x4 pa[2];
+            p_to_afrags(p[kb], lane, pa[0], pa[1]);
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int key0 = kb * 32 + hf * 16 + (lane >> 5) * 8;
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const u32x4 vf = *reinterpret_cast<const u32x4*>(&Vs[(nb * 32 + (lane & 31)) * VSTR + key0]);
+                    oacc[nb] = mfma32(pa[hf], vf, oacc[nb]);
+                }
+            }
+        }
+    }
+    // partial results: [seq][kvh][split][G*P rows][128] and (m, l) per row
+    const size_t blk = ((size_t)seq * a.nkv + kvh) * a.splits + split;
+    const int rows = G * a.P;
+    float* op = a.o_part + blk * rows * 128;
+    float* ml = a.ml_part + blk * rows * 2;
+    const int rbase = qh * a.P + half * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = rbase + mfma_row(r, lane);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) op[(size_t)row * 128 + nb * 32 + (lane & 31)] = oacc[nb][r];
+    }
+    if (lane < 32) { ml[(rbase + lane) * 2] = m_run; ml[(rbase + lane) * 2 + 1] = l_run; }
+}
+
+__global__ __launch_bounds__(256) void llm_attn_combine_kernel(LlmAttnArgs a) {
+    const int m = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int G = a.nh / a.nkv;
+    const int seq = m / a.P, pq = m % a.P;
+    const float scale = 0.08838834764831845f;
+    bf16_t* O = (bf16_t*)a.o_frag;
+    for (int head = blockIdx.y * 4 + (threadIdx.x >> 6); head < a.nh; head += gridDim.y * 4) {
+        const int kvh = head / G, qh = head % G;
+        const int rows = G * a.P, row = qh * a.P + pq;
+        const size_t blk0 = ((size_t)seq * a.nkv + kvh) * a.splits;
+        float M = -INFINITY;
+        for (int j = 0; j < a.splits; ++j) M = fmaxf(M, a.ml_part[((blk0 + j) * rows + row) * 2]);
+        float l = 0.f, o0 = 0.f, o1 = 0.f;
+        for (int j = 0; j < a.splits; ++j) {
+            const float mj = a.ml_part[((blk0 + j) * rows + row) * 2];
+            if (mj == -INFINITY) continue;                     // split without keys
+            const float w = __expf((mj - M) * scale);
+            l += w * a.ml_part[((blk0 + j) * rows + row) * 2 + 1];
+            const float* op = a.o_part + ((blk0 + j) * rows + row) * 128;
+            o0 += w * op[lane];
+            o1 += w * op[lane + 64];
+        }
+        O[afrag_off(m, head * 128 + lane, a.RB)] = f2bf(o0 / l);
+        O[afrag_off(m, head * 128 + lane + 64, a.RB)] = f2bf(o1 / l);
+    }
+}
+
+int bdk_llm_attn(const LlmAttnArgs& a, hipStream_t st) {
+    const int G = a.nh / a.nkv;
+    if (a.P != 64 || G * 2 * 64 > 640 || a.nh % a.nkv) return -2;   // G <= 5 (Qwen3-14B: 40/8)
+    hipLaunchKernelGGL(llm_attn_kernel, dim3(a.splits, a.nkv, a.nseq), dim3(G * 2 * 64), 0, st, a);
+    hipLaunchKernelGGL(llm_attn_combine_kernel, dim3(a.nseq * a.P, (a.nh + 3) / 4), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

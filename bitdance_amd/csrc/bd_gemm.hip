@@ -1,0 +1,247 @@
+// Weight-streaming skinny-M GEMM for gfx950:  out[M<=128*j, N] = A[M, K] (bf16) x W[N, K]^T (bf16), fp32 accumulate.
+//
+// This is the kernel that bounds the whole generation loop: at M = 128 rows (one 64-token patch, cond+uncond)
+// every Linear of the diffusion head (flow_head_parallel_x.py:325-342) and of the Qwen3 decode step
+// (HF modeling_qwen3.py:81-83,252-279) is HBM weight-streaming bound.
+//
+// Design (MI355X-first, not a tiled-GEMM port):
+//  * W is re-packed ONCE at load time into MFMA-operand order: for every 32-row panel nb and k-step ks a
+//    1 KiB chunk whose 64 lanes' 16 B are exactly the v_mfma_f32_32x32x16_bf16 B operand.  A wave streams its
+//    panel with perfectly coalesced 1 KiB non-temporal loads straight into VGPRs -- W never touches LDS,
+//    nothing is shared between waves, no bank conflicts, no transposes.
+//  * A (the 128 activation rows) is produced by the upstream kernels directly in the same fragment-major
+//    layout (bd_common.h afrag_off), so a 64-deep K stage is one contiguous 16 KiB copy into LDS and every
+//    ds_read_b128 is lane-linear (conflict free).
+//  * each wave owns 32 output columns x all rows of the tile (MB x 32x32 fp32 accumulators); NW waves per
+//    block share the A stage.  Split-K over the grid fills 256 CUs for the N = 5120 shapes; partial sums go
+//    to fp32 slabs that the consumer row-kernels reduce in their prologue (bd_rows.hip) -- no extra launch.
+//  * fused SwiGLU epilogue (gate/up rows interleaved 16/16 inside each packed panel so the partner value is
+//    one cross-lane exchange away) writes the bf16 activation in fragment-major order for the next GEMM.
+#include "bd_common.h"
+#include "bd_kernels.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+
+BD_DEV f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
+                                                   __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// weight packing: src [rows][K] bf16 row-major  ->  dst panels [nb0 + rows/32][K/16][64 lanes][8 bf16]
+// mode 0: packed row r <- src row r.   mode 1 (SwiGLU pair): panel p, row i<16 <- gate[p*16+i], i>=16 <- up[p*16+i-16]
+// ---------------------------------------------------------------------------------------------------
+__global__ void pack_w_kernel(u32x4* __restrict__ dst, const bf16_t* __restrict__ src, const bf16_t* __restrict__ src2,
+                              int panels, int K, int nb0, int mode) {
+    const int KS = K >> 4;
+    const size_t total = (size_t)panels * KS * 64;
+    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(u & 63);
+        const size_t c = u >> 6;
+        const int ks = (int)(c % KS);
+        const int pn = (int)(c / KS);
+        const int i = l & 31;
+        const bf16_t* row;
+        if (mode == 0) row = src + ((size_t)pn * 32 + i) * K;
+        else row = (i < 16) ? src + ((size_t)pn * 16 + i) * K : src2 + ((size_t)pn * 16 + (i - 16)) * K;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(row + ks * 16 + (l >> 5) * 8);
+        dst[((size_t)(nb0 + pn) * KS + ks) * 64 + l] = v;
+    }
+}
+
+// rows fp32/bf16 row-major [M][K] -> bf16 fragment-major (pad rows untouched)
+__global__ void rows_to_afrag_kernel(bf16_t* __restrict__ dst, const float* __restrict__ src32,
+                                     const bf16_t* __restrict__ src16, int M, int K, int RB) {
+    const size_t total = (size_t)M * (K >> 3);
+    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(u / (K >> 3));
+        const int k0 = (int)(u % (K >> 3)) * 8;
+        unsigned w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (src32) w[j] = pack2(src32[(size_t)m * K + k0 + 2 * j], src32[(size_t)m * K + k0 + 2 * j + 1]);
+            else w[j] = (unsigned)src16[(size_t)m * K + k0 + 2 * j] | ((unsigned)src16[(size_t)m * K + k0 + 2 * j + 1] << 16);
+        }
+        *reinterpret_cast<u32x4*>(dst + afrag_off(m, k0, RB)) = (u32x4){w[0], w[1], w[2], w[3]};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the GEMM
+// ---------------------------------------------------------------------------------------------------
+struct GemmP {
+    const u32x4* A;      // fragment-major activations, RB row-blocks
+    const u32x4* W;      // packed weights
+    float* out;          // EPI_PARTIAL: [S][Mpad][N] fp32
+    bf16_t* act;         // EPI_SWIGLU : fragment-major bf16 [Mpad][N/2]
+    const bf16_t* bias;  // EPI_SWIGLU : [N] in PACKED row order (or null)
+    int RB, N, K, S, Mpad;
+};
+
+template <int NW, int MB, int EPI>
+__global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
+    constexpr int NT = NW * 64;
+    constexpr int UNITS = MB * 256;                       // 16 B units per 64-deep A stage
+    constexpr int XL = (UNITS + NT - 1) / NT;             // A loads per thread per stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4* buf0 = reinterpret_cast<u32x4*>(smem);
+    u32x4* buf1 = buf0 + UNITS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int S = p.S;
+    const int s = blockIdx.x % S, nt = blockIdx.x / S, mt = blockIdx.y;
+    const int nb = nt * NW + wave;
+    const int KS = p.K >> 4;
+    const int nst_total = p.K >> 6;
+    const int q = (nst_total + S - 1) / S;
+    const int st0 = s * q;
+    const int nst = min(q, nst_total - st0);
+
+    const u32x4* Wp = p.W + ((size_t)nb * KS + (size_t)st0 * 4) * 64 + lane;
+    // A: unit u of a stage = chunk (ksl = (u>>6)/MB, mb = (u>>6)%MB), lane u&63
+    size_t a_off[XL];
+#pragma unroll
+    for (int j = 0; j < XL; ++j) {
+        const int u = tid + j * NT;
+        const int c = u >> 6;
+        a_off[j] = (((size_t)(st0 * 4 + c / MB) * p.RB) + mt * MB + (c % MB)) * 64 + (u & 63);
+    }
+    const size_t a_stage = (size_t)4 * p.RB * 64;
+
+    u32x4 w0[4], w1[4], xr[XL];
+    f32x16 acc[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    auto load_w = [&](u32x4(&w)[4], int i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = __builtin_nontemporal_load(Wp + ((size_t)i * 4 + j) * 64);
+    };
+    auto load_x = [&](int i) {
+#pragma unroll
+        for (int j = 0; j < XL; ++j)
+            if (UNITS % NT == 0 || tid + j * NT < UNITS) xr[j] = p.A[a_off[j] + (size_t)i * a_stage];
+    };
+    auto store_x = [&](u32x4* buf) {
+#pragma unroll
+        for (int j = 0; j < XL; ++j)
+            if (UNITS % NT == 0 || tid + j * NT < UNITS) buf[tid + j * NT] = xr[j];
+    };
+    auto compute = [&](const u32x4* buf, const u32x4(&w)[4]) {
+#pragma unroll
+        for (int ksl = 0; ksl < 4; ++ksl) {
+            u32x4 xf[MB];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) xf[m] = buf[(ksl * MB + m) * 64 + lane];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) acc[m] = mfma32(xf[m], w[ksl], acc[m]);
+        }
+    };
+
+    if (nst > 0) {
+        load_x(0);
+        load_w(w0, 0);
+        if (nst > 1) load_w(w1, 1);
+        store_x(buf0);
+        if (nst > 1) load_x(1);
+        __syncthreads();
+        int i = 0;
+        for (; i + 3 < nst; i += 2) {
+            compute(buf0, w0); store_x(buf1); load_x(i + 2); load_w(w0, i + 2); __syncthreads();
+            compute(buf1, w1); store_x(buf0); load_x(i + 3); load_w(w1, i + 3); __syncthreads();
+        }
+        const int rem = nst - i;                         // 1, 2 or 3 stages left
+        compute(buf0, w0);
+        if (rem >= 2) {
+            store_x(buf1);
+            if (rem == 3) { load_x(i + 2); load_w(w0, i + 2); }
+            __syncthreads();
+            compute(buf1, w1);
+            if (rem == 3) {
+                store_x(buf0);
+                __syncthreads();
+                compute(buf0, w0);
+            }
+        }
+    }
+
+    // ---- epilogue.  D layout of the 32x32 MFMA: lane -> column (lane&31), reg r -> row (r&3)+8(r>>2)+4(lane>>5)
+    const int col = nb * 32 + (lane & 31);
+    if (EPI == BD_EPI_PARTIAL) {
+        float* o = p.out + ((size_t)s * p.Mpad + (size_t)mt * MB * 32) * p.N + col;
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                o[(size_t)row * p.N] = acc[m][r];
+            }
+    } else {  // BD_EPI_SWIGLU: lanes (l&16)==0 hold gate feature f, lanes (l&16)!=0 the matching up feature
+        const float b = p.bias ? bf2f(p.bias[col]) : 0.f;
+        const int f = nb * 16 + (lane & 15);
+        const int F = p.N >> 1;
+        (void)F;
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = bfr(acc[m][r] + b);               // Linear output rounded to bf16
+                const float other = __shfl_xor(v, 16);
+                if ((lane & 16) == 0) {
+                    const int row = (mt * MB + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float a = bfr(silu_bf(v) * other);        // silu -> bf16, product -> bf16
+                    p.act[afrag_off(row, f, p.RB)] = f2bf(a);
+                }
+            }
+    }
+}
+
+template <int NW, int MB>
+static int launch_gemm(const GemmP& p, int epi, hipStream_t st) {
+    const int ntiles = p.N / (32 * NW);
+    dim3 grid(ntiles * p.S, p.RB / MB);
+    const size_t lds = (size_t)2 * MB * 256 * 16;
+    if (epi == BD_EPI_PARTIAL)
+        hipLaunchKernelGGL((gemm_kernel<NW, MB, BD_EPI_PARTIAL>), grid, dim3(NW * 64), lds, st, p);
+    else
+        hipLaunchKernelGGL((gemm_kernel<NW, MB, BD_EPI_SWIGLU>), grid, dim3(NW * 64), lds, st, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// A: fragment-major bf16, RB row blocks (RB must be 1, 2 or a multiple of 4).  W: packed.  N % (32*nw) == 0, K % 64 == 0.
+int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw, int epi,
+             float* out_partial, void* out_act, const void* bias, hipStream_t st) {
+    if (K % 64 || N % (32 * nw) || S < 1) return -2;
+    const int nst_total = K / 64, q = (nst_total + S - 1) / S;
+    if ((S - 1) * q >= nst_total) return -3;                       // an empty split
+    if (epi == BD_EPI_SWIGLU && S != 1) return -4;
+    GemmP p{(const u32x4*)A, (const u32x4*)W, out_partial, (bf16_t*)out_act, (const bf16_t*)bias, RB, N, K, S, RB * 32};
+    const int MB = (RB % 4 == 0) ? 4 : RB;
+    if (MB != 4 && MB != 2 && MB != 1) return -5;
+#define BD_CASE(NWV, MBV) if (nw == NWV && MB == MBV) return launch_gemm<NWV, MBV>(p, epi, st);
+    BD_CASE(2, 4) BD_CASE(4, 4) BD_CASE(8, 4)
+    BD_CASE(2, 2) BD_CASE(4, 2) BD_CASE(8, 2)
+    BD_CASE(2, 1) BD_CASE(4, 1) BD_CASE(8, 1)
+#undef BD_CASE
+    return -6;
+}
+
+int bdk_pack_w(void* dst, const void* src, const void* src2, int panels, int K, int nb0, int mode, hipStream_t st) {
+    if (K % 16) return -2;
+    const size_t total = (size_t)panels * (K / 16) * 64;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(256), 0, st, (u32x4*)dst, (const bf16_t*)src,
+                       (const bf16_t*)src2, panels, K, nb0, mode);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int bdk_rows_to_afrag(void* dst, const float* src32, const void* src16, int M, int K, int RB, hipStream_t st) {
+    if (K % 8) return -2;
+    const size_t total = (size_t)M * (K / 8);
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(rows_to_afrag_kernel, dim3(blocks), dim3(256), 0, st, (bf16_t*)dst, src32,
+                       (const bf16_t*)src16, M, K, RB);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

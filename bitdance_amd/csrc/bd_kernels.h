@@ -1,0 +1,157 @@
+// Internal launcher declarations (C++ side of libbitdance_hip.so). Public C ABI: include/bitdance_hip.h
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BD_EPI_PARTIAL 0
+#define BD_EPI_SWIGLU 1
+
+struct BdStepState;
+
+// ---- bd_gemm.hip
+int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw, int epi,
+             float* out_partial, void* out_act, const void* bias, hipStream_t st);
+int bdk_pack_w(void* dst, const void* src, const void* src2, int panels, int K, int nb0, int mode, hipStream_t st);
+int bdk_rows_to_afrag(void* dst, const float* src32, const void* src16, int M, int K, int RB, hipStream_t st);
+
+// ---- bd_rows.hip : row-wise kernels (one workgroup per activation row)
+struct Partial {            // split-K slabs of a GEMM output: [S][Mpad][N] fp32 (+ optional bf16 bias[N])
+    const float* p;
+    const void* bias;
+    int S, N, Mpad;
+};
+
+// diffusion head
+struct HeadPrologueArgs {   // y = silu(t_emb + cond_embed(c)) ; x0 = input_proj(x_t)      flow_head:326-330
+    Partial cond;           // cond_embed GEMM slabs (+bias) [.,Mpad,D]
+    const void* temb;       // [D] bf16: time_embed(t_i) for this eval
+    const float* xt;        // [B*P][C] fp32 latent
+    const void* in_w;       // [D][C] bf16
+    const void* in_b;       // [D] bf16
+    void* y_frag;           // out: fragment-major bf16 [Mpad][D]
+    void* X;                // out: bf16 row-major [Mpad][D]
+    int M, BP, D, C, RB;
+};
+int bdk_head_prologue(const HeadPrologueArgs& a, hipStream_t st);
+
+struct LnModArgs {          // x (+= pending branch * gate) ; h = LN(x)*(1+scale)+shift        flow_head:242-252
+    void* X;                // in/out bf16 row-major [Mpad][D]
+    Partial pend;           // pending branch output (wo / w2 slabs + bias); p == nullptr -> none
+    Partial ada;            // adaLN GEMM slabs + bias, row-major [Mpad][Nada]
+    int gate_off, scale_off, shift_off;   // column offsets inside the adaLN output
+    const float* ln_w;      // [D] fp32 or null (no affine)
+    const float* ln_b;
+    void* h_frag;           // out: fragment-major bf16
+    int M, D, RB;
+    float eps;
+};
+int bdk_ln_mod(const LnModArgs& a, hipStream_t st);
+
+struct SamplerScalars {     // data-independent scalars of one sampling step (sampling_x.py:33-41,77-95)
+    float t, dt, den, var, omt, noise_scale, cfg;
+    int is_final, cfg_mult;
+};
+struct HeadFinalArgs {      // pending update, final LN-mod, Linear(D->C), 2*sigmoid-1, SDE/ODE step, sign
+    const void* X;          // bf16 row-major
+    Partial pend;           // w2 slabs of the last block (+bias)
+    Partial ada;
+    int gate_off, scale_off, shift_off;
+    const void* lin_w;      // [C][D] bf16
+    const void* lin_b;      // [C] bf16
+    float* xt;              // in/out latent [B*P][C] fp32
+    const float* noise;     // pre-drawn normals [AR steps][N+1][B*P][C] in the reference's RNG call order
+    long long noise_step_stride;   // (N+1)*B*P*C
+    int eval_index;         // i: this eval consumes noise[step][i+1] (ignored on the final step)
+    const BdStepState* state;
+    float* pred_out;        // final step: sampled latent x [B*P][C] (pre-sign), may be null
+    float* tok_cur;         // final step: sign(x) [B*P][C] fp32 for the projector, may be null
+    float* tok_all;         // final step: sign(x) scattered to [B][T][C] at token step*P+p, may be null
+    int T, P;
+    float* xhat_out;        // debug: x_hat rows [M][C] fp32, may be null
+    SamplerScalars sc;
+    int BP, D, C, M;
+    float eps_ln;
+};
+int bdk_head_final(const HeadFinalArgs& a, hipStream_t st);
+
+struct InitLatentArgs { float* xt; const float* noise; long long noise_step_stride; const BdStepState* state; int n; };
+int bdk_init_latent(const InitLatentArgs& a, hipStream_t st);    // x_0 = first draw of this AR step (sampling_x.py:60)
+
+struct SwigluArgs {         // split-K fallback of the fused epilogue: act = silu(h1)*h2 from slabs
+    Partial up;             // [.,Mpad,2F] standard (un-interleaved) column order
+    void* act_frag;
+    int M, F, RB;
+};
+int bdk_swiglu_rows(const SwigluArgs& a, hipStream_t st);
+
+// projector (modeling/utils.py:16-20)
+struct ProjFc1Args {
+    const float* tok;       // [BP][C] fp32 in {-1,0,1}
+    const void* w;          // [D][C] bf16
+    const void* b;          // [D]
+    void* h_frag;           // out fragment-major bf16 [BPpad][D]
+    int BP, D, C, RB;
+};
+int bdk_proj_fc1(const ProjFc1Args& a, hipStream_t st);
+
+struct EmbedFinalizeArgs {  // model_input = fc2(h)+b (bf16) + pos (fp32), replicated to both CFG branches
+    Partial fc2;            // [.,BPpad,D]
+    const float* pos;       // [tokens][D] fp32 2-D sincos table in patch-raster order
+    float* R;               // out: residual stream fp32 [Mpad][D]
+    const BdStepState* state;
+    int BP, P, D, branches;
+};
+int bdk_embed_finalize(const EmbedFinalizeArgs& a, hipStream_t st);
+
+// LLM
+struct RmsArgs {            // R (+= bf16(pending)) ; a = bf16(w * R*rsqrt(mean(R^2)+eps))          HF:59-64,294-323
+    float* R;               // in/out fp32 [Mpad][D]
+    Partial pend;           // p == nullptr -> none
+    const void* w;          // [D] bf16
+    void* a_frag;           // out fragment-major bf16 (may be null)
+    float* hidden_out;      // final norm: w * normed, fp32 [M][D] (may be null)
+    void* cond_frag;        // final norm: bf16(hidden + pos[step]) fragment-major (may be null)
+    const float* pos;
+    const BdStepState* state;
+    int M, D, RB, P;
+    float eps;
+};
+int bdk_rms(const RmsArgs& a, hipStream_t st);
+
+struct QkvPostArgs {        // q/k RMS-norm + RoPE + KV-cache append                               HF:241-262
+    Partial qkv;            // [.,Mpad,(nh+2nkv)*128]
+    const void* qn_w;       // [128] bf16
+    const void* kn_w;
+    const float* cos;       // [maxpos][128] fp32
+    const float* sin;
+    void* q_out;            // bf16 [Mpad][nh*128]
+    void* k_cache;          // bf16 [nseq][nkv][Lmax][128]
+    void* vt_cache;         // bf16 [nseq][nkv][128][Lmax]
+    const BdStepState* state;
+    int M, P, nh, nkv, Lmax;
+    float eps;
+};
+int bdk_qkv_post(const QkvPostArgs& a, hipStream_t st);
+
+struct StepAdvanceArgs { BdStepState* state; int nseq, P; };
+int bdk_step_advance(const StepAdvanceArgs& a, hipStream_t st);
+
+// ---- bd_attn.hip
+struct HeadAttnArgs {       // DiT attention, seq = P = 64, non-causal                           flow_head:192-220
+    Partial qkv;            // [.,Mpad,3D]
+    void* o_frag;           // out fragment-major bf16 [Mpad][D]
+    int nseq, nhead, D, RB;
+};
+int bdk_head_attn(const HeadAttnArgs& a, hipStream_t st);
+
+struct LlmAttnArgs {        // block-bidirectional decode attention over the static KV cache
+    const void* q;          // bf16 [Mpad][nh*128]
+    const void* k_cache;
+    const void* vt_cache;
+    float* o_part;          // [nseq][nkv][splits][G*P][128] fp32 (un-normalised)
+    float* ml_part;         // [nseq][nkv][splits][G*P][2]
+    void* o_frag;           // out fragment-major bf16 [Mpad][nh*128]
+    const BdStepState* state;
+    int nseq, P, nh, nkv, Lmax, splits, RB;
+};
+int bdk_llm_attn(const LlmAttnArgs& a, hipStream_t st);

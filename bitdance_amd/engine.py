@@ -1,0 +1,394 @@
+"""Host side of the native AR step: weight packing, context/workspace management, graph replay.
+
+This module is plumbing around libbitdance_hip.so (device memory via torch tensors, streams, ctypes);
+all arithmetic of the hot path runs in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+
+import torch
+
+from ._lib import BitDanceHipError, check, lib
+
+BF16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _bf16(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=BF16).contiguous()
+
+
+def pack_linear(ws: list[torch.Tensor], device) -> torch.Tensor:
+    """Stack nn.Linear weights [n_i, K] along N and re-pack them into MFMA-operand order (bd_gemm.hip)."""
+    K = ws[0].shape[1]
+    n = sum(w.shape[0] for w in ws)
+    if K % 64 or any(w.shape[0] % 32 for w in ws):
+        raise BitDanceHipError(f"pack_linear: unsupported shape N={[w.shape[0] for w in ws]} K={K}")
+    out = torch.empty(n * K, dtype=BF16, device=device)
+    row = 0
+    for w in ws:
+        src = _bf16(w, device)
+        check(lib().bd_pack_weight(out.data_ptr(), src.data_ptr(), src.shape[0], K, row, _stream()), "bd_pack_weight")
+        row += src.shape[0]
+    torch.cuda.current_stream().synchronize()
+    return out
+
+
+def pack_swiglu(gate: torch.Tensor, up: torch.Tensor, device) -> torch.Tensor:
+    F_, K = gate.shape
+    if K % 64 or F_ % 32:
+        raise BitDanceHipError(f"pack_swiglu: unsupported shape F={F_} K={K}")
+    g, u = _bf16(gate, device), _bf16(up, device)
+    out = torch.empty(2 * F_ * K, dtype=BF16, device=device)
+    check(lib().bd_pack_weight_swiglu(out.data_ptr(), g.data_ptr(), u.data_ptr(), F_, K, _stream()), "bd_pack_weight_swiglu")
+    torch.cuda.current_stream().synchronize()
+    return out
+
+
+def pack_swiglu_bias(bg: torch.Tensor, bu: torch.Tensor, device) -> torch.Tensor:
+    return torch.stack([_bf16(bg, device).view(-1, 16), _bf16(bu, device).view(-1, 16)], dim=1).reshape(-1).contiguous()
+
+
+def row_blocks(m: int) -> int:
+    return 1 if m <= 32 else (2 if m <= 64 else 4 * ((m + 127) // 128))
+
+
+# ---------------------------------------------------------------------------------------------------
+@dataclass
+class HeadWeights:
+    """vision_head.safetensors (keys ``net.*``) packed for the native head."""
+    D: int
+    C: int
+    Dz: int
+    H: int
+    nblocks: int
+    nada: int
+    ptrs: dict = field(default_factory=dict)        # name -> tensor (kept alive)
+    time_w0: torch.Tensor = None
+    time_b0: torch.Tensor = None
+    time_w2: torch.Tensor = None
+    time_b2: torch.Tensor = None
+
+    @staticmethod
+    def from_state_dict(sd: dict, device) -> "HeadWeights":
+        g = lambda k: sd[k]
+        D, C = g("net.input_proj.weight").shape
+        Dz = g("net.cond_embed.weight").shape[1]
+        nb = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("net.res_blocks."))
+        na = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("net.ada_ln_blocks."))
+        if "net.res_blocks.0.w1.weight" not in sd:
+            raise BitDanceHipError("native head requires the SwiGLU variant (use_swiglu=True)")
+        H = g("net.res_blocks.0.w2.weight").shape[1]
+        hw = HeadWeights(D=D, C=C, Dz=Dz, H=H, nblocks=nb, nada=na)
+        p = hw.ptrs
+        p["head.cond_w"] = pack_linear([g("net.cond_embed.weight")], device)
+        p["head.cond_b"] = _bf16(g("net.cond_embed.bias"), device)
+        p["head.in_w"] = _bf16(g("net.input_proj.weight"), device)
+        p["head.in_b"] = _bf16(g("net.input_proj.bias"), device)
+        ada_w = [g(f"net.ada_ln_blocks.{j}.weight") for j in range(na)] + [g("net.final_layer.ada_ln_modulation.weight")]
+        ada_b = [g(f"net.ada_ln_blocks.{j}.bias") for j in range(na)] + [g("net.final_layer.ada_ln_modulation.bias")]
+        p["head.ada_w"] = pack_linear(ada_w, device)
+        p["head.ada_b"] = torch.cat([_bf16(b, device) for b in ada_b]).contiguous()
+        for i in range(nb):
+            s, d = f"net.res_blocks.{i}.", f"head.blk{i}."
+            for n in ("1", "2"):
+                p[d + f"ln{n}_w"] = g(s + f"norm{n}.weight").detach().to(device, torch.float32).contiguous()
+                p[d + f"ln{n}_b"] = g(s + f"norm{n}.bias").detach().to(device, torch.float32).contiguous()
+            p[d + "wqkv"] = pack_linear([g(s + "attn.wqkv.weight")], device)
+            p[d + "bqkv"] = _bf16(g(s + "attn.wqkv.bias"), device)
+            p[d + "wo"] = pack_linear([g(s + "attn.wo.weight")], device)
+            p[d + "bo"] = _bf16(g(s + "attn.wo.bias"), device)
+            w1, b1 = g(s + "w1.weight"), g(s + "w1.bias")
+            p[d + "w1"] = pack_swiglu(w1[:H], w1[H:], device)
+            p[d + "b1"] = pack_swiglu_bias(b1[:H], b1[H:], device)
+            p[d + "w2"] = pack_linear([g(s + "w2.weight")], device)
+            p[d + "b2"] = _bf16(g(s + "w2.bias"), device)
+        p["head.lin_w"] = _bf16(g("net.final_layer.linear.weight"), device)
+        p["head.lin_b"] = _bf16(g("net.final_layer.linear.bias"), device)
+        hw.time_w0 = _bf16(g("net.time_embed.mlp.0.weight"), device)
+        hw.time_b0 = _bf16(g("net.time_embed.mlp.0.bias"), device)
+        hw.time_w2 = _bf16(g("net.time_embed.mlp.2.weight"), device)
+        hw.time_b2 = _bf16(g("net.time_embed.mlp.2.bias"), device)
+        return hw
+
+    def ints(self) -> dict:
+        return {"head.D": self.D, "head.C": self.C, "head.Dz": self.Dz, "head.H": self.H,
+                "head.nblocks": self.nblocks, "head.nada": self.nada}
+
+    def time_table(self, ts: torch.Tensor) -> torch.Tensor:
+        """time_embed(t_i) for every eval of the schedule, bf16 [N+1, D]  (flow_head_parallel_x.py:12-27,140-143).
+        Data independent, so it is computed once per schedule (torch ops, bf16 Linear flow) instead of per eval."""
+        half = self.time_w0.shape[1] // 2
+        dev = ts.device
+        t = 1000.0 * ts.float()
+        freqs = torch.exp(-math.log(10000.0) * torch.arange(0, half, dtype=torch.float32, device=dev) / half)
+        args = t[:, None] * freqs[None]
+        f = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+        h = torch.nn.functional.linear(f.to(BF16), self.time_w0, self.time_b0)
+        h = torch.nn.functional.silu(h)
+        return torch.nn.functional.linear(h, self.time_w2, self.time_b2).contiguous()
+
+
+@dataclass
+class ProjWeights:
+    """projector.safetensors: fc1 [D,C], fc2 [D,D] (modeling/utils.py:9-20)."""
+    D: int
+    C: int
+    ptrs: dict = field(default_factory=dict)
+
+    @staticmethod
+    def from_state_dict(sd: dict, device) -> "ProjWeights":
+        D, C_ = sd["fc1.weight"].shape
+        pw = ProjWeights(D=D, C=C_)
+        pw.ptrs["proj.w1"] = _bf16(sd["fc1.weight"], device)
+        pw.ptrs["proj.b1"] = _bf16(sd["fc1.bias"], device)
+        pw.ptrs["proj.w2"] = pack_linear([sd["fc2.weight"]], device)
+        pw.ptrs["proj.b2"] = _bf16(sd["fc2.bias"], device)
+        return pw
+
+    def ints(self) -> dict:
+        return {"proj.D": self.D, "proj.C": self.C}
+
+
+@dataclass
+class LlmWeights:
+    """HF Qwen3 checkpoint (``model.layers.*``) packed for the native decode step; the original bf16
+    tensors are kept for the (once-per-image) prefill, which runs on hipBLASLt/SDPA."""
+    cfg: dict
+    ptrs: dict = field(default_factory=dict)
+    sd: dict = field(default_factory=dict)          # original-layout bf16 tensors on device (prefill)
+
+    @staticmethod
+    def from_state_dict(sd: dict, cfg: dict, device, keep_for_prefill: bool = True) -> "LlmWeights":
+        lw = LlmWeights(cfg=dict(cfg))
+        p = lw.ptrs
+        if cfg["head_dim"] != 128:
+            raise BitDanceHipError("native LLM path requires head_dim == 128 (Qwen3)")
+        for i in range(cfg["num_hidden_layers"]):
+            s, d = f"model.layers.{i}.", f"llm.l{i}."
+            q, k, v = (sd[s + f"self_attn.{n}_proj.weight"] for n in "qkv")
+            p[d + "wqkv"] = pack_linear([q, k, v], device)
+            p[d + "wo"] = pack_linear([sd[s + "self_attn.o_proj.weight"]], device)
+            p[d + "wgu"] = pack_swiglu(sd[s + "mlp.gate_proj.weight"], sd[s + "mlp.up_proj.weight"], device)
+            p[d + "wdown"] = pack_linear([sd[s + "mlp.down_proj.weight"]], device)
+            p[d + "in_norm"] = _bf16(sd[s + "input_layernorm.weight"], device)
+            p[d + "post_norm"] = _bf16(sd[s + "post_attention_layernorm.weight"], device)
+            p[d + "q_norm"] = _bf16(sd[s + "self_attn.q_norm.weight"], device)
+            p[d + "k_norm"] = _bf16(sd[s + "self_attn.k_norm.weight"], device)
+        p["llm.final_norm"] = _bf16(sd["model.norm.weight"], device)
+        if keep_for_prefill:
+            lw.sd = {k: _bf16(v, device) for k, v in sd.items() if k != "lm_head.weight"}
+        else:
+            lw.sd = {"model.embed_tokens.weight": _bf16(sd["model.embed_tokens.weight"], device)}
+        return lw
+
+    def ints(self, Lmax: int, splits: int) -> dict:
+        c = self.cfg
+        return {"llm.D": c["hidden_size"], "llm.L": c["num_hidden_layers"], "llm.nh": c["num_attention_heads"],
+                "llm.nkv": c["num_key_value_heads"], "llm.F": c["intermediate_size"], "llm.head_dim": c["head_dim"],
+                "llm.Lmax": Lmax, "llm.splits": splits}
+
+    def rope_tables(self, max_pos: int, device):
+        """fp32 cos/sin [max_pos, 128] as Qwen3RotaryEmbedding computes them (HF:124-137)."""
+        hd = self.cfg["head_dim"]
+        inv = 1.0 / (self.cfg["rope_theta"] ** (torch.arange(0, hd, 2, dtype=torch.float, device=device) / hd))
+        fr = torch.arange(max_pos, device=device).float()[:, None] * inv[None, :]
+        emb = torch.cat((fr, fr), dim=-1)
+        return emb.cos().contiguous(), emb.sin().contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------
+def sampler_scalars(n_steps: int, device, last_step: float = 0.05, time_shift: float = 1.0):
+    """The data-independent scalars of DiffHead.sample, computed with the same torch ops on the same device as
+    the reference's 0-dim tensors (sampling_x.py:3-4,33-41,62-95).  Returns (fp32 [N+1, 6] on CPU, ts [N+1])."""
+    t_all = torch.linspace(0, 1 - last_step, n_steps + 1, device=device, dtype=torch.float32)
+    inv = 1 / time_shift
+    t_all = inv / (inv + (1 / t_all - 1) ** 1.0)
+    dt = t_all[1:] - t_all[:-1]
+    t = torch.tensor(0.0, device=device, dtype=torch.float32)
+    rows, ts = [], []
+    for i in range(n_steps):
+        sigma = 1 - t
+        var = sigma ** 2 - (t / 1) * -1 * sigma
+        den = (1 - t).clamp_min(0.05)
+        ns = (2.0 * (1.0 - t) * dt[i]) ** 0.5
+        rows.append(torch.stack([t, dt[i], den, var, 1 - t, ns]))
+        ts.append(t.clone())
+        t = t + dt[i]
+    tf = torch.full((), 1 - last_step, device=device, dtype=torch.float32)
+    zero = torch.zeros((), device=device)
+    rows.append(torch.stack([tf, torch.full((), last_step, device=device, dtype=torch.float32),
+                             (1 - tf).clamp_min(0.05), zero, 1 - tf, zero]))
+    ts.append(tf)
+    return torch.stack(rows).float().cpu().contiguous(), torch.stack(ts)
+
+
+class Engine:
+    """One native context for a fixed (num_images, CFG on/off): head + projector + LLM step, workspaces,
+    and the two hipGraphs of an AR step."""
+
+    def __init__(self, head: HeadWeights | None, proj: ProjWeights | None, llm: LlmWeights | None, *,
+                 num_images: int, branches: int, device, max_tokens: int = 64, max_kv: int = 256,
+                 attn_splits: int = 8, tune: dict | None = None):
+        self.l = lib()
+        self.device = torch.device(device)
+        self.head, self.proj, self.llm = head, proj, llm
+        self.B, self.branches, self.P = num_images, branches, 64
+        self.BP = self.B * self.P
+        self.M = self.branches * self.BP
+        self.max_tokens = max_tokens
+        self.Lmax = ((max_kv + 63) // 64) * 64
+        self._keep: dict[str, torch.Tensor] = {}
+        self._sched_key = None
+        self._captured: set = set()
+        self.ctx = self.l.bd_ctx_create()
+        ints = {"B": self.B, "branches": self.branches, "P": self.P}
+        if head is not None:
+            ints.update(head.ints())
+            ints["head.T"] = max_tokens
+        if proj is not None:
+            ints.update(proj.ints())
+        if llm is not None:
+            ints.update(llm.ints(self.Lmax, attn_splits))
+        for k, v in (tune or {}).items():
+            ints["tune." + k] = v
+        for k, v in ints.items():
+            check(self.l.bd_ctx_set_int(self.ctx, k.encode(), int(v)))
+        if llm is not None:
+            check(self.l.bd_ctx_set_float(self.ctx, b"llm.eps", float(llm.cfg["rms_norm_eps"])))
+        for w in (head, proj, llm):
+            if w is not None:
+                for k, t in w.ptrs.items():
+                    self.set_ptr(k, t)
+        check(self.l.bd_ctx_finalize(self.ctx), "bd_ctx_finalize")
+        self.ws: dict[str, torch.Tensor] = {}
+        for i in range(self.l.bd_ctx_ws_count(self.ctx)):
+            name = self.l.bd_ctx_ws_name(self.ctx, i).decode()
+            nbytes = self.l.bd_ctx_ws_bytes(self.ctx, i)
+            t = torch.zeros(max(int(nbytes), 16), dtype=torch.uint8, device=self.device)
+            self.ws[name] = t
+            self.set_ptr(name, t)
+        if head is not None:
+            self.tok_all = torch.zeros(self.B, max_tokens, head.C, dtype=torch.float32, device=self.device)
+            self.set_ptr("head.tok_all", self.tok_all)
+        if llm is not None:
+            self.cos, self.sin = llm.rope_tables(self.Lmax, self.device)
+            self.set_ptr("llm.cos", self.cos)
+            self.set_ptr("llm.sin", self.sin)
+        if proj is not None or llm is not None:
+            D = proj.D if proj is not None else llm.cfg["hidden_size"]
+            self.pos = torch.zeros(max_tokens + self.P, D, dtype=torch.float32, device=self.device)
+            self.set_ptr("pos", self.pos)
+        self.noise = None
+        check(self.l.bd_ctx_bind(self.ctx), "bd_ctx_bind")
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.l.bd_ctx_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    # -- plumbing ---------------------------------------------------------------------------------
+    def set_ptr(self, key: str, t: torch.Tensor) -> None:
+        self._keep[key] = t
+        check(self.l.bd_ctx_set_ptr(self.ctx, key.encode(), t.data_ptr()))
+
+    def set_int(self, key: str, v: int) -> None:
+        check(self.l.bd_ctx_set_int(self.ctx, key.encode(), int(v)))
+
+    def view(self, name: str, dtype, shape) -> torch.Tensor:
+        n = math.prod(shape)
+        return self.ws[name].view(dtype)[:n].view(*shape)
+
+    @property
+    def Mpad(self) -> int:
+        return row_blocks(self.M) * 32
+
+    # -- schedule / noise ---------------------------------------------------------------------------
+    def set_schedule(self, n_steps: int, cfg: float, ar_steps: int) -> None:
+        key = (n_steps, float(cfg), ar_steps)
+        if self._sched_key == key:
+            return
+        sc, ts = sampler_scalars(n_steps, self.device)
+        self._sc = sc
+        check(self.l.bd_head_set_schedule(self.ctx, n_steps, sc.data_ptr(), float(cfg)), "bd_head_set_schedule")
+        self.temb = self.head.time_table(ts)
+        self.set_ptr("head.temb", self.temb)
+        self.noise = torch.zeros(ar_steps, n_steps + 1, self.BP, self.head.C, dtype=torch.float32, device=self.device)
+        self.set_ptr("head.noise", self.noise)
+        self.n_steps = n_steps
+        self._sched_key = key
+        self._captured.clear()                       # pointers / scalars are baked into the graphs
+
+    def draw_noise(self, ar_steps: int) -> None:
+        """Draw every normal the reference would draw, with the same calls in the same order, from the global
+        device generator (sampling_x.py:60 randn, :40 randn_like) -- identical values for an identical seed."""
+        shp = (self.B, self.P, self.head.C)
+        for s in range(ar_steps):
+            x = torch.randn(shp, device=self.device)
+            self.noise[s, 0] = x.view(self.BP, -1)
+            for i in range(self.n_steps):
+                self.noise[s, i + 1] = torch.randn_like(x).view(self.BP, -1)
+
+    def load_noise(self, noise: torch.Tensor) -> None:
+        """Injected noise [ar_steps, N+1, B, P, C] (tests / CPU-vs-GPU parity)."""
+        self.noise[: noise.shape[0]].copy_(noise.reshape(noise.shape[0], noise.shape[1], self.BP, -1))
+
+    def reset(self, kv_len: list[int]) -> None:
+        arr = (C.c_int * len(kv_len))(*kv_len)
+        check(self.l.bd_step_reset(self.ctx, arr, len(kv_len), _stream()), "bd_step_reset")
+
+    # -- operators ------------------------------------------------------------------------------------
+    def set_cond(self, z: torch.Tensor) -> None:
+        """z [M, Dz] fp32 -> head.cond_frag (what cond_embed's autocast cast does, in operand layout)."""
+        z = z.reshape(self.M, -1).to(torch.float32).contiguous()
+        check(self.l.bd_rows_to_frag(self.ws["head.cond_frag"].data_ptr(), z.data_ptr(), 1, self.M, z.shape[1],
+                                     row_blocks(self.M), _stream()), "bd_rows_to_frag")
+
+    def head_sample(self) -> None:
+        check(self.l.bd_head_sample(self.ctx, _stream()), "bd_head_sample")
+
+    def head_cond(self) -> None:
+        check(self.l.bd_head_cond(self.ctx, _stream()), "bd_head_cond")
+
+    def head_eval(self, i: int) -> None:
+        check(self.l.bd_head_eval(self.ctx, i, _stream()), "bd_head_eval")
+
+    def projector(self) -> None:
+        check(self.l.bd_projector(self.ctx, _stream()), "bd_projector")
+
+    def llm_step(self) -> None:
+        check(self.l.bd_llm_step(self.ctx, _stream()), "bd_llm_step")
+
+    def capture(self, phase: int) -> None:
+        if phase in self._captured:
+            return
+        torch.cuda.current_stream().synchronize()
+        check(self.l.bd_graph_capture(self.ctx, phase, _stream()), "bd_graph_capture")
+        self._captured.add(phase)
+
+    def launch(self, phase: int) -> None:
+        check(self.l.bd_graph_launch(self.ctx, phase, _stream()), "bd_graph_launch")
+
+    # convenient typed views of outputs
+    def pred(self) -> torch.Tensor:
+        return self.view("head.pred", torch.float32, (self.B, self.P, self.head.C))
+
+    def tok_cur(self) -> torch.Tensor:
+        return self.view("head.tok_cur", torch.float32, (self.B, self.P, self.head.C))
+
+    def hidden(self) -> torch.Tensor:
+        D = self.llm.cfg["hidden_size"]
+        return self.view("llm.hidden", torch.float32, (self.Mpad, D))[: self.M]
+
+    def residual(self) -> torch.Tensor:
+        D = self.llm.cfg["hidden_size"]
+        return self.view("llm.R", torch.float32, (self.Mpad, D))

@@ -1,0 +1,148 @@
+"""Random-weight models at true (or tiny) shapes, generated directly on the device.
+
+There is no network in the build/bench environment, hence no real checkpoints: benchmarks and smoke tests use
+random weights of the released architectures (SURVEY.md section 8d "Concrete synthetic inputs").  The head's
+zero-initialised tensors (adaLN, output layer: flow_head_parallel_x.py:315-323) are drawn N(0, 0.02) like the rest,
+otherwise a random-weight head would be degenerate.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+BF16 = torch.bfloat16
+
+QWEN3_14B = dict(hidden_size=5120, num_hidden_layers=40, num_attention_heads=40, num_key_value_heads=8, head_dim=128,
+                 intermediate_size=17408, vocab_size=151936 + 320, rms_norm_eps=1e-6, rope_theta=1000000.0)
+HEAD_14B_64X = dict(ch_target=32, ch_cond=5120, ch_latent=5120, depth_latent=6, depth_adanln=2, parallel_num=64,
+                    use_swiglu=True, time_shift=1.0, time_schedule="logit_normal", P_mean=-0.8, P_std=0.8,
+                    diff_batch_mul=1)                      # train/configs/bitdance_14b_64x.yaml:22-33
+AE_D16C32 = dict(ddconfig=dict(double_z=False, z_channels=32, in_channels=3, out_ch=3, ch=256, ch_mult=[1, 1, 2, 2, 4],
+                               num_res_blocks=4), gan_decoder=False)      # bitdance_14b_64x.yaml:9-16
+
+TINY_LLM = dict(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, head_dim=128,
+                intermediate_size=512, vocab_size=512, rms_norm_eps=1e-6, rope_theta=1000000.0)
+TINY_HEAD = dict(ch_target=32, ch_cond=256, ch_latent=256, depth_latent=4, depth_adanln=2, parallel_num=64,
+                 use_swiglu=True, time_shift=1.0)
+TINY_AE = dict(ddconfig=dict(double_z=False, z_channels=32, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 1, 2, 2, 4],
+                             num_res_blocks=1))
+
+
+def _normal(shape, std, gen, device, dtype=BF16):
+    return (torch.randn(shape, generator=gen, device=device, dtype=torch.float32) * std).to(dtype)
+
+
+def random_llm_state(cfg: dict, device, seed: int = 0, std: float = 0.02) -> dict:
+    g = torch.Generator(device=device).manual_seed(seed)
+    D, nh, nkv, hd, ff = (cfg["hidden_size"], cfg["num_attention_heads"], cfg["num_key_value_heads"],
+                          cfg["head_dim"], cfg["intermediate_size"])
+    sd = {"model.embed_tokens.weight": _normal((cfg["vocab_size"], D), std, g, device),
+          "model.norm.weight": torch.ones(D, dtype=BF16, device=device)}
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"model.layers.{i}."
+        sd[p + "self_attn.q_proj.weight"] = _normal((nh * hd, D), std, g, device)
+        sd[p + "self_attn.k_proj.weight"] = _normal((nkv * hd, D), std, g, device)
+        sd[p + "self_attn.v_proj.weight"] = _normal((nkv * hd, D), std, g, device)
+        sd[p + "self_attn.o_proj.weight"] = _normal((D, nh * hd), std, g, device)
+        sd[p + "mlp.gate_proj.weight"] = _normal((ff, D), std, g, device)
+        sd[p + "mlp.up_proj.weight"] = _normal((ff, D), std, g, device)
+        sd[p + "mlp.down_proj.weight"] = _normal((D, ff), std, g, device)
+        for n in ("self_attn.q_norm", "self_attn.k_norm"):
+            sd[p + n + ".weight"] = torch.ones(hd, dtype=BF16, device=device)
+        for n in ("input_layernorm", "post_attention_layernorm"):
+            sd[p + n + ".weight"] = torch.ones(D, dtype=BF16, device=device)
+    return sd
+
+
+def random_head_state(cfg: dict, device, seed: int = 1, std: float = 0.02) -> dict:
+    g = torch.Generator(device=device).manual_seed(seed)
+    D, C, Z = cfg["ch_latent"], cfg["ch_target"], cfg["ch_cond"]
+    H = int(D * 1.5)
+    sd = {}
+
+    def lin(name, n, k):
+        sd[name + ".weight"] = _normal((n, k), std, g, device)
+        sd[name + ".bias"] = _normal((n,), std, g, device)
+
+    lin("net.time_embed.mlp.0", D, 256)
+    lin("net.time_embed.mlp.2", D, D)
+    lin("net.cond_embed", D, Z)
+    lin("net.input_proj", D, C)
+    for i in range(cfg["depth_latent"]):
+        p = f"net.res_blocks.{i}."
+        for n in ("norm1", "norm2"):
+            sd[p + n + ".weight"] = torch.ones(D, dtype=torch.float32, device=device)
+            sd[p + n + ".bias"] = torch.zeros(D, dtype=torch.float32, device=device)
+        lin(p + "attn.wqkv", 3 * D, D)
+        lin(p + "attn.wo", D, D)
+        lin(p + "w1", 2 * H, D)
+        lin(p + "w2", D, H)
+    for j in range(cfg["depth_adanln"]):
+        lin(f"net.ada_ln_blocks.{j}", 6 * D, D)
+    lin("net.final_layer.ada_ln_modulation", 2 * D, D)
+    lin("net.final_layer.linear", C, D)
+    return sd
+
+
+def random_proj_state(c: int, d: int, device, seed: int = 2, std: float = 0.02) -> dict:
+    g = torch.Generator(device=device).manual_seed(seed)
+    return {"fc1.weight": _normal((d, c), 1.0 / math.sqrt(c), g, device), "fc1.bias": _normal((d,), std, g, device),
+            "fc2.weight": _normal((d, d), std, g, device), "fc2.bias": _normal((d,), std, g, device)}
+
+
+def random_ae_state(ae_config: dict, device, seed: int = 3) -> dict:
+    from .autoencoder import VQModel
+    with torch.device("meta"):
+        m = VQModel(**ae_config)
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for k, v in m.state_dict().items():
+        if v.dim() >= 2:
+            fan_in = math.prod(v.shape[1:])
+            sd[k] = _normal(tuple(v.shape), 1.0 / math.sqrt(fan_in), g, device, torch.float32)
+        elif k.endswith("bias"):
+            sd[k] = torch.zeros(v.shape, device=device)
+        else:
+            sd[k] = torch.ones(v.shape, device=device)
+    return sd
+
+
+class SyntheticTokenizer:
+    """Fixed-length stand-in for the HF tokenizer: no tokenizer files exist offline.  ``encode`` maps a prompt to
+    a deterministic id list (77 ids for a user prompt, 3 for the bare assistant prefix)."""
+
+    def __init__(self, vocab_size: int):
+        self.special0 = vocab_size - 320
+
+    def encode(self, text: str):
+        n = 3 if len(text) < 32 else 77
+        base = sum(map(ord, text))
+        return [(base + 13 * i) % self.special0 for i in range(n)]
+
+    def convert_tokens_to_ids(self, tok: str) -> int:
+        if tok == "<|vision_start|>":
+            return self.special0
+        if tok.startswith("<|res_"):
+            return self.special0 + 1 + int(tok[6:-2])
+        if tok.startswith("<|query_"):
+            return self.special0 + 130 + int(tok[8:-2])
+        raise KeyError(tok)
+
+
+def build_pipeline(size: str = "14b-64x", device: str = "cuda", with_ae: bool = True):
+    """A BitDanceT2IPipeline on random weights: ``14b-64x`` (BitDance-14B-64x shapes) or ``tiny``."""
+    from .t2i_pipeline import BitDanceT2IPipeline
+    if size == "14b-64x":
+        lc, hc, ac = QWEN3_14B, HEAD_14B_64X, AE_D16C32
+    elif size == "tiny":
+        lc, hc, ac = TINY_LLM, TINY_HEAD, TINY_AE
+    else:
+        raise ValueError(size)
+    head_cfg = dict(hc)
+    pipe = BitDanceT2IPipeline.from_components(
+        tokenizer=SyntheticTokenizer(lc["vocab_size"]), llm_cfg=lc, llm_sd=random_llm_state(lc, device),
+        ae_config=ac, ae_sd=random_ae_state(ac, device) if with_ae else None, head_config=head_cfg,
+        head_sd=random_head_state(hc, device), proj_sd=random_proj_state(hc["ch_target"], lc["hidden_size"], device),
+        device=device)
+    return pipe

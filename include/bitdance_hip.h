@@ -1,0 +1,71 @@
+/* libbitdance_hip.so -- C ABI of the MI355X-native BitDance generation hot path.
+ *
+ * The reference (shallowdream204/BitDance) is pure Python/PyTorch and has no FFI; its "operator API" for the
+ * hot path is the set of Python seams that BitDanceT2IPipeline.gen_image calls
+ * (modeling/t2i_pipeline.py:170,246,249,261-268).  Each entry point below names the reference interface it
+ * replaces.  Conventions: plain C, device pointers owned by the caller (torch tensors kept alive by the
+ * Python wrapper), stream-ordered and asynchronous, no allocation and no host sync inside a call (so every
+ * call is hipGraph-capturable), int return 0 = ok / negative = error with text in bd_last_error(), not
+ * thread-safe per context.  `stream` is a hipStream_t passed as void*.
+ */
+#ifndef BITDANCE_HIP_H
+#define BITDANCE_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bd_ctx bd_ctx;
+
+int bd_version(void);
+const char* bd_last_error(void);
+
+/* ---- weight / activation layout conversion (load time; replaces nothing in the reference: the reference
+ *      keeps nn.Linear weights [N][K] row-major, t2i_pipeline.py:50-74 -- we re-pack once into MFMA order) */
+int bd_pack_weight(void* dst_packed, const void* src_bf16, int rows, int K, int dst_row0, void* stream);
+int bd_pack_weight_swiglu(void* dst_packed, const void* gate_bf16, const void* up_bf16, int F, int K, void* stream);
+int bd_rows_to_frag(void* dst_frag, const void* src, int src_is_fp32, int M, int K, int row_blocks, void* stream);
+
+/* ---- F.linear under bf16 autocast (flow_head_parallel_x.py:326-339, HF modeling_qwen3.py:81-83,252-279).
+ *      out_partial: [splitk][row_blocks*32][N] fp32 slabs, summed (+bias, bf16 rounding) by the consumer. */
+int bd_gemm_partial(const void* a_frag, int row_blocks, const void* w_packed, int N, int K, int splitk, int nwaves,
+                    float* out_partial, void* stream);
+/* Linear -> chunk(2) -> silu(h1)*h2 (flow_head:250-251) / down_proj input act_fn(gate)*up (HF:82) */
+int bd_gemm_swiglu(const void* a_frag, int row_blocks, const void* w_packed_pairs, const void* bias_packed, int N2, int K,
+                   int nwaves, void* act_frag, void* stream);
+
+/* ---- context: named ints / floats / device pointers, then finalize.  Keys are listed in DESIGN.md. */
+bd_ctx* bd_ctx_create(void);
+void bd_ctx_destroy(bd_ctx* c);
+int bd_ctx_set_int(bd_ctx* c, const char* key, long long v);
+int bd_ctx_set_float(bd_ctx* c, const char* key, double v);
+int bd_ctx_set_ptr(bd_ctx* c, const char* key, const void* device_ptr);
+int bd_ctx_finalize(bd_ctx* c);                       /* validates dims, plans the workspaces */
+int bd_ctx_ws_count(bd_ctx* c);                       /* workspaces the caller must allocate (zero-filled) ... */
+const char* bd_ctx_ws_name(bd_ctx* c, int i);         /* ... and hand back with bd_ctx_set_ptr(name, ptr) */
+long long bd_ctx_ws_bytes(bd_ctx* c, int i);
+int bd_ctx_bind(bd_ctx* c);                           /* after all workspace pointers are set */
+
+/* ---- DiffHead.sample (flow_head_parallel_x.py:107-120 -> sampling_x.py:44-97).
+ * scalars: [n_steps+1][6] = {t, dt, den=clamp_min(1-t,.05), var, 1-t, noise_scale} per eval, computed by the
+ * host exactly as the reference computes its 0-dim tensors (last row: t=1-last_step, dt=last_step). */
+int bd_head_set_schedule(bd_ctx* c, int n_steps, const float* scalars, float cfg);
+int bd_head_sample(bd_ctx* c, void* stream);          /* cond (ws head.cond_frag) + noise -> head.pred / tokens */
+int bd_head_cond(bd_ctx* c, void* stream);            /* cond_embed(c) once per AR step (value-identical hoist) */
+int bd_head_eval(bd_ctx* c, int i, void* stream);     /* one TransEncoder.forward (:325-342) + sampler step i */
+
+/* ---- MLPconnector.forward (modeling/utils.py:16-20) + "+ pos_embed" (t2i_pipeline.py:249-253) */
+int bd_projector(bd_ctx* c, void* stream);
+
+/* ---- Qwen3Model.forward for one P-token block against the KV cache, cond+uncond batched
+ *      (t2i_pipeline.py:261-268; HF modeling_qwen3.py:367-427) */
+int bd_llm_step(bd_ctx* c, void* stream);
+
+/* ---- the AR step as hipGraphs: phase 0 = head sample (+sign/tokens), phase 1 = projector + LLM step + advance */
+int bd_graph_capture(bd_ctx* c, int phase, void* stream);
+int bd_graph_launch(bd_ctx* c, int phase, void* stream);
+int bd_step_reset(bd_ctx* c, const int* kv_len, int nseq, void* stream);   /* step = 0, kv_len[] after prefill */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
