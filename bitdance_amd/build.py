@@ -12,7 +12,9 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libbitdance_hip.so")
 SOURCES = ["bd_gemm.hip", "bd_rows.hip", "bd_attn.hip", "bd_api.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# -ffp-contract=off: the row kernels restate separately-rounded torch ops (bit-exact sampler update); HIP's
+# __fadd_rn/__fmul_rn are plain operators, so contraction must be disabled at the compiler level.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 
 
 def _hipcc() -> str:

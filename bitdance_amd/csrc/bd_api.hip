@@ -32,6 +32,9 @@ struct bd_ctx {
     std::map<std::string, GemmCfg> g;
     std::vector<SamplerScalars> sched;
     bool finalized = false, bound = false;
+    bool prof_on = false;
+    struct ProfRec { std::string name; hipEvent_t e0, e1; double bytes; };
+    std::vector<ProfRec> prof;
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     hipGraph_t graph[2] = {nullptr, nullptr};
 
@@ -59,22 +62,23 @@ struct bd_ctx {
 
 static int pad_rows(int m) { return m <= 32 ? 32 : (m <= 64 ? 64 : ((m + 127) / 128) * 128); }
 
+// Launch heuristics from the (nwaves, split-K) sweep on MI355X (tools/gemm_sweep.py, profiles/):
+//  * 8 waves (256 output columns per workgroup, A re-read halves) when N allows, else 4, else 2;
+//  * split-K so that ~240 workgroups exist (one per CU); very wide N additionally split 3x for tail balance;
+//  * SwiGLU: fused epilogue (S = 1) when the grid fills the chip, otherwise split-K slabs + swiglu_rows.
 static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K, bool swiglu) {
     GemmCfg g;
-    g.nw = (N % 128 == 0) ? 4 : 2;
+    g.nw = (N % 256 == 0 && N >= 7168) ? 8 : ((N % 128 == 0) ? 4 : 2);
     const int nst = K / 64;
-    if (swiglu) {
-        g.S = 1;
-        if (N / (32 * g.nw) < 200 && N % 64 == 0) g.nw = 2;
-    } else {
-        const int ntiles = N / (32 * g.nw);
-        int S = (int)std::lround(320.0 / ntiles);
-        if (S < 1) S = 1;
-        if (S > nst) S = nst;
-        g.S = S;
-    }
+    const int ntiles = N / (32 * g.nw);
+    int S = (int)std::lround(240.0 / ntiles);
+    if (S < 1) S = 1;
+    if (ntiles >= 200 && !swiglu) S = 3;
+    if (swiglu && ntiles >= 120) S = 1;
+    g.S = S;
     g.S = (int)c->geti("tune." + name + ".S", g.S);
     g.nw = (int)c->geti("tune." + name + ".nw", g.nw);
+    if (N % (32 * g.nw)) g.nw = (N % 128 == 0) ? 4 : 2;
     if (g.S > nst) g.S = nst;
     while (g.S > 1 && (g.S - 1) * ((nst + g.S - 1) / g.S) >= nst) --g.S;      // no empty split
     return g;
@@ -167,6 +171,7 @@ int bd_ctx_finalize(bd_ctx* c) {
             add("head.attn_frag", Mp * c->hD * 2);
             add("head.br_part", (long long)sbr * Mp * c->hD * 4);
             add("head.act_frag", Mp * c->hH * 2);
+            add("head.w1_part", (long long)c->g["head.w1"].S * Mp * 2 * c->hH * 4);
             add("head.pred", (long long)c->BP * c->hC * 4);
             add("head.tok_cur", (long long)c->BP * c->hC * 4);
             add("head.xhat", Mp * c->hC * 4);
@@ -188,6 +193,7 @@ int bd_ctx_finalize(bd_ctx* c) {
             c->g["llm.qkv"] = choose_cfg(c, "llm.qkv", c->lNqkv, c->lD, false);
             c->g["llm.o"] = choose_cfg(c, "llm.o", c->lD, c->lnh * 128, false);
             c->g["llm.gu"] = choose_cfg(c, "llm.gu", 2 * c->lF, c->lD, true);
+            c->g["llm.gu"].S = 1;                              // fused SwiGLU epilogue only
             c->g["llm.down"] = choose_cfg(c, "llm.down", c->lD, c->lF, false);
             const int nseq = c->branches * c->B, G = c->lnh / c->lnkv;
             const int sbr = std::max(c->g["llm.o"].S, c->g["llm.down"].S);
@@ -234,13 +240,28 @@ int bd_head_set_schedule(bd_ctx* c, int n_steps, const float* s, float cfg) {
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------------
+// every weight-streaming GEMM of the step goes through here; with profiling on (eager mode only) each launch is
+// bracketed by HIP events on the launch stream so bench.py can report in-situ per-launch durations.
+static int gemm(bd_ctx* c, const char* name, const void* A, int RB, const void* W, int N, int K, int S, int nw, int epi,
+                float* out, void* act, const void* bias, hipStream_t st) {
+    bd_ctx::ProfRec r;
+    if (c->prof_on) {
+        r.name = name; r.bytes = (double)N * K * 2;
+        hipEventCreate(&r.e0); hipEventCreate(&r.e1);
+        hipEventRecord(r.e0, st);
+    }
+    const int rc = bdk_gemm(A, RB, W, N, K, S, nw, epi, out, act, bias, st);
+    if (c->prof_on) { hipEventRecord(r.e1, st); c->prof.push_back(r); }
+    return rc;
+}
+
 static Partial part(const bd_ctx* c, const std::string& ws, const void* bias, int S, int N, int Mpad) {
     return Partial{(const float*)c->ptr(ws), bias, S, N, Mpad};
 }
 
 static int head_cond(bd_ctx* c, hipStream_t st) {
     const GemmCfg& g = c->g["head.cond"];
-    BD_TRY(bdk_gemm(c->ptr("head.cond_frag"), c->RB, c->ptr("head.cond_w"), c->hD, c->hDz, g.S, g.nw, BD_EPI_PARTIAL,
+    BD_TRY(gemm(c, "head.cond", c->ptr("head.cond_frag"), c->RB, c->ptr("head.cond_w"), c->hD, c->hDz, g.S, g.nw, BD_EPI_PARTIAL,
                     (float*)c->wptr("head.cond_part"), nullptr, nullptr, st));
     return 0;
 }
@@ -260,7 +281,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
     BD_TRY(bdk_head_prologue(pa, st));
 
     const GemmCfg& ga = c->g["head.ada"];
-    BD_TRY(bdk_gemm(c->ptr("head.y_frag"), RB, c->ptr("head.ada_w"), c->hNada, D, ga.S, ga.nw, BD_EPI_PARTIAL,
+    BD_TRY(gemm(c, "head.ada", c->ptr("head.y_frag"), RB, c->ptr("head.ada_w"), c->hNada, D, ga.S, ga.nw, BD_EPI_PARTIAL,
                     (float*)c->wptr("head.ada_part"), nullptr, nullptr, st));
     const Partial ada = part(c, "head.ada_part", c->ptr("head.ada_b"), ga.S, c->hNada, Mp);
     const int sw = c->hNB / c->hNA;
@@ -278,22 +299,31 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
         l1.ln_w = (const float*)c->ptr(pre + "ln1_w"); l1.ln_b = (const float*)c->ptr(pre + "ln1_b");
         l1.h_frag = c->wptr("head.h_frag"); l1.M = M; l1.D = D; l1.RB = RB; l1.eps = 1e-6f;
         BD_TRY(bdk_ln_mod(l1, st));
-        BD_TRY(bdk_gemm(c->ptr("head.h_frag"), RB, c->ptr(pre + "wqkv"), 3 * D, D, gq.S, gq.nw, BD_EPI_PARTIAL,
+        BD_TRY(gemm(c, "head.qkv", c->ptr("head.h_frag"), RB, c->ptr(pre + "wqkv"), 3 * D, D, gq.S, gq.nw, BD_EPI_PARTIAL,
                         (float*)c->wptr("head.qkv_part"), nullptr, nullptr, st));
         HeadAttnArgs at;
         at.qkv = part(c, "head.qkv_part", c->ptr(pre + "bqkv"), gq.S, 3 * D, Mp);
         at.o_frag = c->wptr("head.attn_frag"); at.nseq = M / 64; at.nhead = D / 128; at.D = D; at.RB = RB;
         BD_TRY(bdk_head_attn(at, st));
-        BD_TRY(bdk_gemm(c->ptr("head.attn_frag"), RB, c->ptr(pre + "wo"), D, D, go.S, go.nw, BD_EPI_PARTIAL,
+        BD_TRY(gemm(c, "head.wo", c->ptr("head.attn_frag"), RB, c->ptr(pre + "wo"), D, D, go.S, go.nw, BD_EPI_PARTIAL,
                         (float*)c->wptr("head.br_part"), nullptr, nullptr, st));
         LnModArgs l2 = l1;
         l2.pend = part(c, "head.br_part", c->ptr(pre + "bo"), go.S, D, Mp);
         l2.gate_off = base + 2 * D; l2.scale_off = base + 3 * D; l2.shift_off = base + 4 * D;
         l2.ln_w = (const float*)c->ptr(pre + "ln2_w"); l2.ln_b = (const float*)c->ptr(pre + "ln2_b");
         BD_TRY(bdk_ln_mod(l2, st));
-        BD_TRY(bdk_gemm(c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * H, D, 1, g1.nw, BD_EPI_SWIGLU, nullptr,
+        if (g1.S == 1) {
+            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * H, D, 1, g1.nw, BD_EPI_SWIGLU, nullptr,
                         c->wptr("head.act_frag"), c->ptr(pre + "b1"), st));
-        BD_TRY(bdk_gemm(c->ptr("head.act_frag"), RB, c->ptr(pre + "w2"), D, H, g2.S, g2.nw, BD_EPI_PARTIAL,
+        } else {   // split-K slabs in packed (gate|up interleaved) column order + row-wise SwiGLU
+            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * H, D, g1.S, g1.nw, BD_EPI_PARTIAL,
+                        (float*)c->wptr("head.w1_part"), nullptr, nullptr, st));
+            SwigluArgs sw_;
+            sw_.up = part(c, "head.w1_part", c->ptr(pre + "b1"), g1.S, 2 * H, Mp);
+            sw_.act_frag = c->wptr("head.act_frag"); sw_.M = M; sw_.F = H; sw_.RB = RB; sw_.interleaved = 1;
+            BD_TRY(bdk_swiglu_rows(sw_, st));
+        }
+        BD_TRY(gemm(c, "head.w2", c->ptr("head.act_frag"), RB, c->ptr(pre + "w2"), D, H, g2.S, g2.nw, BD_EPI_PARTIAL,
                         (float*)c->wptr("head.br_part"), nullptr, nullptr, st));
     }
     HeadFinalArgs fa;
@@ -334,7 +364,7 @@ static int projector(bd_ctx* c, hipStream_t st) {
                    c->BP, D, (int)c->geti("proj.C"), c->RBp};
     BD_TRY(bdk_proj_fc1(f1, st));
     const GemmCfg& g = c->g["proj.fc2"];
-    BD_TRY(bdk_gemm(c->ptr("proj.h_frag"), c->RBp, c->ptr("proj.w2"), D, D, g.S, g.nw, BD_EPI_PARTIAL,
+    BD_TRY(gemm(c, "proj.fc2", c->ptr("proj.h_frag"), c->RBp, c->ptr("proj.w2"), D, D, g.S, g.nw, BD_EPI_PARTIAL,
                     (float*)c->wptr("proj.part"), nullptr, nullptr, st));
     EmbedFinalizeArgs ef;
     ef.fc2 = Partial{(const float*)c->ptr("proj.part"), c->ptr("proj.b2"), g.S, D, c->BPpad};
@@ -360,7 +390,7 @@ static int llm_step(bd_ctx* c, hipStream_t st) {
         r1.hidden_out = nullptr; r1.cond_frag = nullptr; r1.pos = nullptr; r1.state = state;
         r1.M = M; r1.D = D; r1.RB = RB; r1.P = c->Pn; r1.eps = eps;
         BD_TRY(bdk_rms(r1, st));
-        BD_TRY(bdk_gemm(c->ptr("llm.a_frag"), RB, c->ptr(pre + "wqkv"), c->lNqkv, D, gq.S, gq.nw, BD_EPI_PARTIAL,
+        BD_TRY(gemm(c, "llm.qkv", c->ptr("llm.a_frag"), RB, c->ptr(pre + "wqkv"), c->lNqkv, D, gq.S, gq.nw, BD_EPI_PARTIAL,
                         (float*)c->wptr("llm.qkv_part"), nullptr, nullptr, st));
         QkvPostArgs qa;
         qa.qkv = part(c, "llm.qkv_part", nullptr, gq.S, c->lNqkv, Mp);
@@ -377,15 +407,15 @@ static int llm_step(bd_ctx* c, hipStream_t st) {
         aa.o_frag = c->wptr("llm.attn_frag"); aa.state = state;
         aa.nseq = nseq; aa.P = c->Pn; aa.nh = nh; aa.nkv = nkv; aa.Lmax = c->lLmax; aa.splits = c->lsplits; aa.RB = RB;
         BD_TRY(bdk_llm_attn(aa, st));
-        BD_TRY(bdk_gemm(c->ptr("llm.attn_frag"), RB, c->ptr(pre + "wo"), D, nh * 128, go.S, go.nw, BD_EPI_PARTIAL,
+        BD_TRY(gemm(c, "llm.o", c->ptr("llm.attn_frag"), RB, c->ptr(pre + "wo"), D, nh * 128, go.S, go.nw, BD_EPI_PARTIAL,
                         (float*)c->wptr("llm.br_part"), nullptr, nullptr, st));
         RmsArgs r2 = r1;
         r2.pend = part(c, "llm.br_part", nullptr, go.S, D, Mp);
         r2.w = c->ptr(pre + "post_norm");
         BD_TRY(bdk_rms(r2, st));
-        BD_TRY(bdk_gemm(c->ptr("llm.a_frag"), RB, c->ptr(pre + "wgu"), 2 * F, D, 1, gg.nw, BD_EPI_SWIGLU, nullptr,
+        BD_TRY(gemm(c, "llm.gu", c->ptr("llm.a_frag"), RB, c->ptr(pre + "wgu"), 2 * F, D, 1, gg.nw, BD_EPI_SWIGLU, nullptr,
                         c->wptr("llm.act_frag"), nullptr, st));
-        BD_TRY(bdk_gemm(c->ptr("llm.act_frag"), RB, c->ptr(pre + "wdown"), D, F, gd.S, gd.nw, BD_EPI_PARTIAL,
+        BD_TRY(gemm(c, "llm.down", c->ptr("llm.act_frag"), RB, c->ptr(pre + "wdown"), D, F, gd.S, gd.nw, BD_EPI_PARTIAL,
                         (float*)c->wptr("llm.br_part"), nullptr, nullptr, st));
     }
     StepAdvanceArgs sa{state, nseq, c->Pn};
@@ -430,10 +460,35 @@ int bd_step_reset(bd_ctx* c, const int* kv_len, int nseq, void* s) {
         return hipGetLastError() == hipSuccess ? 0 : fail("step_reset launch failed");)
 }
 
+int bd_prof_enable(bd_ctx* c, int on) {
+    for (auto& r : c->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    c->prof.clear();
+    c->prof_on = on != 0;
+    return 0;
+}
+int bd_prof_count(bd_ctx* c) { return (int)c->prof.size(); }
+/* after a stream sync: name (<=63 chars), elapsed ms and algorithmic weight bytes of the i-th profiled GEMM launch */
+int bd_prof_get(bd_ctx* c, int i, char* name, float* ms, double* bytes) {
+    if (i < 0 || i >= (int)c->prof.size()) return fail("bd_prof_get: index");
+    const auto& r = c->prof[i];
+    std::strncpy(name, r.name.c_str(), 63); name[63] = 0;
+    if (hipEventElapsedTime(ms, r.e0, r.e1) != hipSuccess) return fail("hipEventElapsedTime failed (sync the stream first)");
+    *bytes = r.bytes;
+    return 0;
+}
+/* the (split-K, nwaves) launch config the engine chose for a named GEMM, e.g. "head.wo" */
+int bd_gemm_config(bd_ctx* c, const char* name, int* splitk, int* nwaves) {
+    auto it = c->g.find(name);
+    if (it == c->g.end()) return fail(std::string("bd_gemm_config: unknown GEMM '") + name + "'");
+    *splitk = it->second.S; *nwaves = it->second.nw;
+    return 0;
+}
+
 int bd_graph_capture(bd_ctx* c, int phase, void* s) {
     BD_GUARD(
         if (phase < 0 || phase > 1) return fail("bd_graph_capture: phase must be 0 or 1");
         hipStream_t st = (hipStream_t)s;
+        if (c->prof_on) return fail("bd_graph_capture: disable profiling first");
         if (c->gexec[phase]) { hipGraphExecDestroy(c->gexec[phase]); c->gexec[phase] = nullptr; }
         if (c->graph[phase]) { hipGraphDestroy(c->graph[phase]); c->graph[phase] = nullptr; }
         if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) return fail("hipStreamBeginCapture failed");

@@ -78,9 +78,9 @@ struct InitLatentArgs { float* xt; const float* noise; long long noise_step_stri
 int bdk_init_latent(const InitLatentArgs& a, hipStream_t st);    // x_0 = first draw of this AR step (sampling_x.py:60)
 
 struct SwigluArgs {         // split-K fallback of the fused epilogue: act = silu(h1)*h2 from slabs
-    Partial up;             // [.,Mpad,2F] standard (un-interleaved) column order
+    Partial up;             // [.,Mpad,2F]; column order: interleaved ? packed pairs (16 gate | 16 up per 32) : [gate F | up F]
     void* act_frag;
-    int M, F, RB;
+    int M, F, RB, interleaved;
 };
 int bdk_swiglu_rows(const SwigluArgs& a, hipStream_t st);
 

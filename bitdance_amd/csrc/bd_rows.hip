@@ -221,8 +221,10 @@ __global__ __launch_bounds__(ROW_THREADS) void swiglu_rows_kernel(SwigluArgs a) 
     const int m = blockIdx.x;
     bf16_t* A = (bf16_t*)a.act_frag;
     for (int f = threadIdx.x; f < a.F; f += blockDim.x) {
-        const float g = slab_bf(a.up, m, f);
-        const float u = slab_bf(a.up, m, a.F + f);
+        const int cg = a.interleaved ? ((f >> 4) * 32 + (f & 15)) : f;
+        const int cu = a.interleaved ? cg + 16 : a.F + f;
+        const float g = slab_bf(a.up, m, cg);
+        const float u = slab_bf(a.up, m, cu);
         A[afrag_off(m, f, a.RB)] = f2bf(silu_bf(g) * u);
     }
 }

@@ -378,6 +378,32 @@ class Engine:
     def launch(self, phase: int) -> None:
         check(self.l.bd_graph_launch(self.ctx, phase, _stream()), "bd_graph_launch")
 
+    # -- measurement ---------------------------------------------------------------------------------------
+    def profile_gemms(self, fn) -> dict:
+        """Run ``fn`` (eager launches) with every GEMM launch bracketed by HIP events on the launch stream;
+        returns {gemm name: dict(count, ms, bytes)} (in-situ durations, weights not cache-resident)."""
+        check(self.l.bd_prof_enable(self.ctx, 1))
+        try:
+            fn()
+            torch.cuda.current_stream().synchronize()
+            out: dict = {}
+            name = C.create_string_buffer(64)
+            ms, nb = C.c_float(), C.c_double()
+            for i in range(self.l.bd_prof_count(self.ctx)):
+                check(self.l.bd_prof_get(self.ctx, i, name, C.byref(ms), C.byref(nb)), "bd_prof_get")
+                r = out.setdefault(name.value.decode(), dict(count=0, ms=0.0, bytes=0.0))
+                r["count"] += 1
+                r["ms"] += ms.value
+                r["bytes"] += nb.value
+            return out
+        finally:
+            check(self.l.bd_prof_enable(self.ctx, 0))
+
+    def gemm_config(self, name: str) -> tuple[int, int]:
+        s_, nw = C.c_int(), C.c_int()
+        check(self.l.bd_gemm_config(self.ctx, name.encode(), C.byref(s_), C.byref(nw)), "bd_gemm_config")
+        return s_.value, nw.value
+
     # convenient typed views of outputs
     def pred(self) -> torch.Tensor:
         return self.view("head.pred", torch.float32, (self.B, self.P, self.head.C))

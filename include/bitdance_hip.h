@@ -65,6 +65,12 @@ int bd_graph_capture(bd_ctx* c, int phase, void* stream);
 int bd_graph_launch(bd_ctx* c, int phase, void* stream);
 int bd_step_reset(bd_ctx* c, const int* kv_len, int nseq, void* stream);   /* step = 0, kv_len[] after prefill */
 
+/* ---- measurement support (bench.py): in-situ HIP-event timing of every weight-streaming GEMM launch (eager mode) */
+int bd_prof_enable(bd_ctx* c, int on);
+int bd_prof_count(bd_ctx* c);
+int bd_prof_get(bd_ctx* c, int i, char* name64, float* ms, double* weight_bytes);
+int bd_gemm_config(bd_ctx* c, const char* gemm_name, int* splitk, int* nwaves);
+
 #ifdef __cplusplus
 }
 #endif
