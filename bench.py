@@ -51,83 +51,28 @@ def parse():
 
 
 # ---------------------------------------------------------------------------------------------------------
-def gemm_roofline(pipe, reps: int = 20) -> dict:
-    """Time every distinct weight-streaming GEMM launch of one AR step in isolation (HIP events on the pipeline's
-    stream), weight by its launch count per image, and report algorithmic weight bytes / time."""
-    from bitdance_amd._lib import check, lib
+def gemm_roofline(pipe) -> dict:
+    """In-situ roofline of the dominant kernel family (the weight-streaming GEMM, bd_gemm.hip): one extra AR step is
+    run eagerly on the pipeline's stream with every GEMM launch bracketed by HIP events (bd_prof_*), so weights are
+    NOT cache-resident between launches.  achieved = algorithmic weight bytes (N*K*2 per launch) / event time."""
     eng = next(iter(pipe._engines.values()))
-    hw, lw, pw = pipe.head_w, pipe.llm_w, pipe.proj_w
-    L = lw.cfg["num_hidden_layers"]
-    D, F_, nh, nkv = lw.cfg["hidden_size"], lw.cfg["intermediate_size"], lw.cfg["num_attention_heads"], lw.cfg["num_key_value_heads"]
-    n_ev = eng.n_steps + 1
-    # (name, A frag ws, W ptr name, N, K, swiglu?, out ws, launches per AR step)
-    shapes = [
-        ("head.ada", "head.y_frag", "head.ada_w", hw.nada * 6 * hw.D + 2 * hw.D, hw.D, False, "head.ada_part", n_ev),
-        ("head.qkv", "head.h_frag", "head.blk0.wqkv", 3 * hw.D, hw.D, False, "head.qkv_part", n_ev * hw.nblocks),
-        ("head.wo", "head.attn_frag", "head.blk0.wo", hw.D, hw.D, False, "head.br_part", n_ev * hw.nblocks),
-        ("head.w1", "head.h_frag", "head.blk0.w1", 2 * hw.H, hw.D, True, "head.act_frag", n_ev * hw.nblocks),
-        ("head.w2", "head.act_frag", "head.blk0.w2", hw.D, hw.H, False, "head.br_part", n_ev * hw.nblocks),
-        ("llm.qkv", "llm.a_frag", "llm.l0.wqkv", (nh + 2 * nkv) * 128, D, False, "llm.qkv_part", L),
-        ("llm.o", "llm.attn_frag", "llm.l0.wo", D, nh * 128, False, "llm.br_part", L),
-        ("llm.gu", "llm.a_frag", "llm.l0.wgu", 2 * F_, D, True, "llm.act_frag", L),
-        ("llm.down", "llm.act_frag", "llm.l0.wdown", D, F_, False, "llm.br_part", L),
-    ]
-    cfgs = json.loads(os.environ.get("BD_GEMM_CFG", "{}"))
     st = pipe._stream
-    rows = []
-    rb = eng.Mpad // 32
     with torch.cuda.stream(st):
-        for name, a_ws, wname, N, K, swiglu, out_ws, count in shapes:
-            wt = eng._keep[wname]
-            S, nw = gemm_cfg(eng, name, N, K, swiglu)
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-
-            def launch():
-                if swiglu:
-                    check(lib().bd_gemm_swiglu(eng.ws[a_ws].data_ptr(), rb, wt.data_ptr(), None, N, K, nw,
-                                               eng.ws[out_ws].data_ptr(), st.cuda_stream))
-                else:
-                    check(lib().bd_gemm_partial(eng.ws[a_ws].data_ptr(), rb, wt.data_ptr(), N, K, S, nw,
-                                                eng.ws[out_ws].data_ptr(), st.cuda_stream))
-            for _ in range(3):
-                launch()
-            ev0.record(st)
-            for _ in range(reps):
-                launch()
-            ev1.record(st)
-            ev1.synchronize()
-            us = ev0.elapsed_time(ev1) * 1e3 / reps
-            wbytes = N * K * 2
-            rows.append(dict(name=name, N=N, K=K, S=S, nw=nw, us=round(us, 2), GBs=round(wbytes / us / 1e3, 1),
-                             count=count, bytes=wbytes))
-    tot_b = sum(r["bytes"] * r["count"] for r in rows)
-    tot_us = sum(r["us"] * r["count"] for r in rows)
-    n_launch = sum(r["count"] for r in rows)
-    ach = tot_b / tot_us / 1e3
+        prof = eng.profile_gemms(lambda: (eng.head_sample(), eng.projector(), eng.llm_step()))
+    tot_b = sum(r["bytes"] for r in prof.values())
+    tot_ms = sum(r["ms"] for r in prof.values())
+    n_launch = sum(r["count"] for r in prof.values())
+    ach = tot_b / tot_ms / 1e6
+    per = []
+    for name, r in sorted(prof.items()):
+        S, nw = eng.gemm_config(name)
+        per.append({"name": name, "launches": r["count"], "avg_us": round(r["ms"] / r["count"] * 1e3, 2),
+                    "GBs": round(r["bytes"] / r["ms"] / 1e6, 1), "splitk": S, "nwaves": nw})
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-            "kernel": "gemm_kernel<NW,MB,EPI> (weight-streaming skinny GEMM, all shapes of one AR step)",
-            "bytes_per_launch": int(tot_b / n_launch), "avg_launch_us": round(tot_us / n_launch, 2),
-            "per_shape": [{k: r[k] for k in ("name", "N", "K", "S", "nw", "us", "GBs", "count")} for r in rows]}
-
-
-def gemm_cfg(eng, name, N, K, swiglu):
-    """Mirror of choose_cfg in bd_api.hip (the launch config the engine itself uses)."""
-    tune = getattr(eng, "_tune", {}) or {}
-    nw = 4 if N % 128 == 0 else 2
-    nst = K // 64
-    if swiglu:
-        S = 1
-        if N // (32 * nw) < 200 and N % 64 == 0:
-            nw = 2
-    else:
-        S = max(1, min(nst, round(320.0 / (N // (32 * nw)))))
-    S = tune.get(name + ".S", S)
-    nw = tune.get(name + ".nw", nw)
-    S = min(S, nst)
-    while S > 1 and (S - 1) * ((nst + S - 1) // S) >= nst:
-        S -= 1
-    return S, nw
+            "kernel": "gemm_kernel<NW,MB,EPI> (bd_gemm.hip): every weight-streaming GEMM launch of one AR step, in situ",
+            "launches": n_launch, "bytes_per_launch": int(tot_b / n_launch),
+            "avg_launch_us": round(tot_ms / n_launch * 1e3, 2), "per_gemm": per}
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -261,8 +206,6 @@ def main():
     if rank == 0:
         n = world
         images = n * args.num_images * args.steps
-        eng = next(iter(pipe._engines.values()))
-        eng._tune = tune
         out = {
             "metric": "images/sec @1024px BitDance-14B-64x" if args.size == "14b-64x" else "images/sec (tiny smoke config)",
             "value": round(images / dt, 5), "unit": "images/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,

@@ -272,8 +272,9 @@ def test_gen_image_teacher_forced_vs_reference(golden_dir):
     assert err.mean() <= 0.2, err.mean()
     firm = ref.abs() > 0.5
     assert (torch.sign(pred)[firm] == torch.sign(ref)[firm]).float().mean() >= 0.97
-    # step 0 has no teacher-forcing dependence at all: tighter
-    assert err[0].mean() <= 0.12, err[0].mean()
+    # per-step bound = 1.5x what the CPU oracle itself shows against the reference ([0.21, 0.14, 0.06, 0.06])
+    for s_, bound in enumerate((0.32, 0.22, 0.12, 0.12)):
+        assert err[s_].mean() <= bound, (s_, err[s_].mean())
 
 
 def test_gen_image_graph_equals_eager_and_decodes(golden_dir):
