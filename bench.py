@@ -216,6 +216,7 @@ def main():
                                    if args.size == "14b-64x" else "tiny",
                        "ar_steps": kw["max_length"] // 64, "parallelism": f"replicas x{n}" if n > 1 else "single GPU",
                        "hipgraph": pipe.use_graph},
+            "phases_ms_last_step": {k: round(v, 1) for k, v in pipe.timings().items()},
         }
         if not args.no_roofline:
             out["roofline"] = gemm_roofline(pipe)

@@ -7,6 +7,10 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch ships its own libamdhip64.so; it must be loaded BEFORE our library so that both resolve to the same HIP
+# runtime instance (loading ours first binds /opt/rocm's copy and torch's device pointers become foreign to it).
+import torch  # noqa: F401
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libbitdance_hip.so")
 

@@ -155,6 +155,7 @@ int bd_ctx_finalize(bd_ctx* c) {
             c->hNada = c->hNA * 6 * c->hD + 2 * c->hD;
             c->g["head.cond"] = choose_cfg(c, "head.cond", c->hD, c->hDz, false);
             c->g["head.ada"] = choose_cfg(c, "head.ada", c->hNada, c->hD, false);
+            c->g["head.ada"].S = 1;                            // bf16(+bias) epilogue: 13 consumers read 2 B, not S x 4 B
             c->g["head.qkv"] = choose_cfg(c, "head.qkv", 3 * c->hD, c->hD, false);
             c->g["head.wo"] = choose_cfg(c, "head.wo", c->hD, c->hD, false);
             c->g["head.w1"] = choose_cfg(c, "head.w1", 2 * c->hH, c->hD, true);
@@ -165,7 +166,8 @@ int bd_ctx_finalize(bd_ctx* c) {
             add("head.xt", (long long)c->BP * c->hC * 4);
             add("head.y_frag", Mp * c->hD * 2);
             add("head.X", Mp * c->hD * 2);
-            add("head.ada_part", (long long)c->g["head.ada"].S * Mp * c->hNada * 4);
+            add("head.ada_bf", Mp * c->hNada * 2);
+            add("head.cemb", Mp * c->hD * 2);
             add("head.h_frag", Mp * c->hD * 2);
             add("head.qkv_part", (long long)c->g["head.qkv"].S * Mp * 3 * c->hD * 4);
             add("head.attn_frag", Mp * c->hD * 2);
@@ -262,7 +264,11 @@ static Partial part(const bd_ctx* c, const std::string& ws, const void* bias, in
 static int head_cond(bd_ctx* c, hipStream_t st) {
     const GemmCfg& g = c->g["head.cond"];
     BD_TRY(gemm(c, "head.cond", c->ptr("head.cond_frag"), c->RB, c->ptr("head.cond_w"), c->hD, c->hDz, g.S, g.nw, BD_EPI_PARTIAL,
-                    (float*)c->wptr("head.cond_part"), nullptr, nullptr, st));
+                (float*)c->wptr("head.cond_part"), nullptr, nullptr, st));
+    FinalizeRowsArgs fr;                      // cond_embed(c) is constant over the N+1 evals of this AR step
+    fr.in = Partial{(const float*)c->ptr("head.cond_part"), c->ptr("head.cond_b"), g.S, c->hD, c->Mpad};
+    fr.out = c->wptr("head.cemb"); fr.M = c->M; fr.N = c->hD;
+    BD_TRY(bdk_finalize_rows(fr, st));
     return 0;
 }
 
@@ -272,7 +278,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
     const int n_steps = (int)c->sched.size() - 1;
     const BdStepState* state = (const BdStepState*)c->ptr("state");
     HeadPrologueArgs pa;
-    pa.cond = part(c, "head.cond_part", c->ptr("head.cond_b"), c->g["head.cond"].S, D, Mp);
+    pa.cemb = c->ptr("head.cemb");
     pa.temb = (const bf16_t*)c->ptr("head.temb") + (size_t)i * D;
     pa.xt = (const float*)c->ptr("head.xt");
     pa.in_w = c->ptr("head.in_w"); pa.in_b = c->ptr("head.in_b");
@@ -281,9 +287,9 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
     BD_TRY(bdk_head_prologue(pa, st));
 
     const GemmCfg& ga = c->g["head.ada"];
-    BD_TRY(gemm(c, "head.ada", c->ptr("head.y_frag"), RB, c->ptr("head.ada_w"), c->hNada, D, ga.S, ga.nw, BD_EPI_PARTIAL,
-                    (float*)c->wptr("head.ada_part"), nullptr, nullptr, st));
-    const Partial ada = part(c, "head.ada_part", c->ptr("head.ada_b"), ga.S, c->hNada, Mp);
+    BD_TRY(gemm(c, "head.ada", c->ptr("head.y_frag"), RB, c->ptr("head.ada_w"), c->hNada, D, 1, ga.nw, BD_EPI_BF16,
+                nullptr, c->wptr("head.ada_bf"), c->ptr("head.ada_b"), st));
+    const void* ada = c->ptr("head.ada_bf");
     const int sw = c->hNB / c->hNA;
     const GemmCfg &gq = c->g["head.qkv"], &go = c->g["head.wo"], &g1 = c->g["head.w1"], &g2 = c->g["head.w2"];
     for (int b = 0; b < c->hNB; ++b) {
@@ -293,7 +299,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
         l1.X = c->wptr("head.X");
         if (b == 0) l1.pend = Partial{nullptr, nullptr, 0, 0, 0};
         else l1.pend = part(c, "head.br_part", c->ptr("head.blk" + std::to_string(b - 1) + ".b2"), g2.S, D, Mp);
-        l1.ada = ada;
+        l1.ada = ada; l1.ada_ld = c->hNada;
         l1.gate_off = ((b - 1 < 0 ? 0 : b - 1) / sw) * 6 * D + 5 * D;
         l1.scale_off = base; l1.shift_off = base + D;
         l1.ln_w = (const float*)c->ptr(pre + "ln1_w"); l1.ln_b = (const float*)c->ptr(pre + "ln1_b");
@@ -329,7 +335,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
     HeadFinalArgs fa;
     fa.X = c->ptr("head.X");
     fa.pend = part(c, "head.br_part", c->ptr("head.blk" + std::to_string(c->hNB - 1) + ".b2"), g2.S, D, Mp);
-    fa.ada = ada;
+    fa.ada = ada; fa.ada_ld = c->hNada;
     fa.gate_off = ((c->hNB - 1) / sw) * 6 * D + 5 * D;
     fa.scale_off = c->hNA * 6 * D; fa.shift_off = c->hNA * 6 * D + D;
     fa.lin_w = c->ptr("head.lin_w"); fa.lin_b = c->ptr("head.lin_b");
@@ -456,8 +462,8 @@ int bd_step_reset(bd_ctx* c, const int* kv_len, int nseq, void* s) {
         if (nseq > 16) return fail("bd_step_reset: nseq > 16");
         ResetArgs a; a.state = (BdStepState*)c->wptr("state"); a.nseq = nseq;
         for (int i = 0; i < 16; ++i) a.kv[i] = i < nseq ? kv_len[i] : 0;
-        hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, a);
-        return hipGetLastError() == hipSuccess ? 0 : fail("step_reset launch failed");)
+        BD_LAUNCH(step_reset_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, a);
+        return bd_launch_status() == 0 ? 0 : fail("step_reset launch failed");)
 }
 
 int bd_prof_enable(bd_ctx* c, int on) {

@@ -48,7 +48,7 @@ BD_DEV void p_to_afrags(const float* p, int lane, u32x4& a_lo, u32x4& a_hi) {
 // ------------------------------------------------------------------------------------------------
 // DiT head attention: seq = 64
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void head_attn_kernel(HeadAttnArgs a) {
+__global__ __launch_bounds__(256) void head_attn_kernel(HeadAttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * KSTR];
     __shared__ __attribute__((aligned(16))) bf16_t Vs[128 * VSTR];
     const int seq = blockIdx.x / a.nhead, h = blockIdx.x % a.nhead;
@@ -72,8 +72,8 @@ __global__ __launch_bounds__(128) void head_attn_kernel(HeadAttnArgs a) {
         }
     };
 
-    // stage K [key][d] and V^T [d][key] of this (seq, head)
-    for (int u = tid; u < 1024; u += 128) {
+    // stage K [key][d] and V^T [d][key] of this (seq, head): all 4 waves; waves 0/1 then own 32 queries each
+    for (int u = tid; u < 1024; u += 256) {
         const int key = u >> 4, dp = (u & 15) * 8;
         float v[8];
         load8(seq * 64 + key, D + h * 128 + dp, v);
@@ -85,14 +85,17 @@ __global__ __launch_bounds__(128) void head_attn_kernel(HeadAttnArgs a) {
     }
     // Q operand fragments (B of S^T = K Q^T): lane -> query (lane&31), 8 consecutive d
     u32x4 qf[8];
-    const int qrow = seq * 64 + wave * 32 + (lane & 31);
+    const int qrow = seq * 64 + (wave & 1) * 32 + (lane & 31);
+    if (wave < 2) {
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        float v[8];
-        load8(qrow, h * 128 + ks * 16 + (lane >> 5) * 8, v);
-        qf[ks] = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+        for (int ks = 0; ks < 8; ++ks) {
+            float v[8];
+            load8(qrow, h * 128 + ks * 16 + (lane >> 5) * 8, v);
+            qf[ks] = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+        }
     }
     __syncthreads();
+    if (wave >= 2) return;
 
     f32x16 sacc[2];
 #pragma unroll
@@ -151,8 +154,8 @@ __global__ __launch_bounds__(128) void head_attn_kernel(HeadAttnArgs a) {
 }
 
 int bdk_head_attn(const HeadAttnArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(head_attn_kernel, dim3(a.nseq * a.nhead), dim3(128), 0, st, a);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    BD_LAUNCH(head_attn_kernel, dim3(a.nseq * a.nhead), dim3(256), 0, st, a);
+    return bd_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(256) void llm_attn_combine_kernel(LlmAttnArgs a) {
 int bdk_llm_attn(const LlmAttnArgs& a, hipStream_t st) {
     const int G = a.nh / a.nkv;
     if (a.P != 64 || G * 2 * 64 > 640 || a.nh % a.nkv) return -2;   // G <= 5 (Qwen3-14B: 40/8)
-    hipLaunchKernelGGL(llm_attn_kernel, dim3(a.splits, a.nkv, a.nseq), dim3(G * 2 * 64), 0, st, a);
-    hipLaunchKernelGGL(llm_attn_combine_kernel, dim3(a.nseq * a.P, (a.nh + 3) / 4), dim3(256), 0, st, a);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    BD_LAUNCH(llm_attn_kernel, dim3(a.splits, a.nkv, a.nseq), dim3(G * 2 * 64), 0, st, a);
+    BD_LAUNCH(llm_attn_combine_kernel, dim3(a.nseq * a.P, (a.nh + 3) / 4), dim3(256), 0, st, a);
+    return bd_launch_status();
 }

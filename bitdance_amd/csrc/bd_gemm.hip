@@ -73,8 +73,8 @@ struct GemmP {
     const u32x4* A;      // fragment-major activations, RB row-blocks
     const u32x4* W;      // packed weights
     float* out;          // EPI_PARTIAL: [S][Mpad][N] fp32
-    bf16_t* act;         // EPI_SWIGLU : fragment-major bf16 [Mpad][N/2]
-    const bf16_t* bias;  // EPI_SWIGLU : [N] in PACKED row order (or null)
+    bf16_t* act;         // EPI_SWIGLU : fragment-major bf16 [Mpad][N/2];  EPI_BF16: row-major bf16 [Mpad][N]
+    const bf16_t* bias;  // EPI_SWIGLU : [N] in PACKED row order (or null); EPI_BF16: [N] (or null)
     int RB, N, K, S, Mpad;
 };
 
@@ -178,6 +178,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
                 const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 o[(size_t)row * p.N] = acc[m][r];
             }
+    } else if (EPI == BD_EPI_BF16) {   // Linear output rounded once to bf16 (what autocast's F.linear returns)
+        const float b = p.bias ? bf2f(p.bias[col]) : 0.f;
+        bf16_t* o = p.act + (size_t)mt * MB * 32 * p.N + col;
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                o[(size_t)row * p.N] = f2bf(acc[m][r] + b);
+            }
     } else {  // BD_EPI_SWIGLU: lanes (l&16)==0 hold gate feature f, lanes (l&16)!=0 the matching up feature
         const float b = p.bias ? bf2f(p.bias[col]) : 0.f;
         const int f = nb * 16 + (lane & 15);
@@ -204,10 +214,12 @@ static int launch_gemm(const GemmP& p, int epi, hipStream_t st) {
     dim3 grid(ntiles * p.S, p.RB / MB);
     const size_t lds = (size_t)2 * MB * 256 * 16;
     if (epi == BD_EPI_PARTIAL)
-        hipLaunchKernelGGL((gemm_kernel<NW, MB, BD_EPI_PARTIAL>), grid, dim3(NW * 64), lds, st, p);
+        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_PARTIAL>), grid, dim3(NW * 64), lds, st, p);
+    else if (epi == BD_EPI_BF16)
+        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_BF16>), grid, dim3(NW * 64), lds, st, p);
     else
-        hipLaunchKernelGGL((gemm_kernel<NW, MB, BD_EPI_SWIGLU>), grid, dim3(NW * 64), lds, st, p);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_SWIGLU>), grid, dim3(NW * 64), lds, st, p);
+    return bd_launch_status();
 }
 
 // A: fragment-major bf16, RB row blocks (RB must be 1, 2 or a multiple of 4).  W: packed.  N % (32*nw) == 0, K % 64 == 0.
@@ -216,7 +228,7 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw, 
     if (K % 64 || N % (32 * nw) || S < 1) return -2;
     const int nst_total = K / 64, q = (nst_total + S - 1) / S;
     if ((S - 1) * q >= nst_total) return -3;                       // an empty split
-    if (epi == BD_EPI_SWIGLU && S != 1) return -4;
+    if (epi != BD_EPI_PARTIAL && S != 1) return -4;
     GemmP p{(const u32x4*)A, (const u32x4*)W, out_partial, (bf16_t*)out_act, (const bf16_t*)bias, RB, N, K, S, RB * 32};
     const int MB = (RB % 4 == 0) ? 4 : RB;
     if (MB != 4 && MB != 2 && MB != 1) return -5;
@@ -232,16 +244,16 @@ int bdk_pack_w(void* dst, const void* src, const void* src2, int panels, int K, 
     if (K % 16) return -2;
     const size_t total = (size_t)panels * (K / 16) * 64;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(256), 0, st, (u32x4*)dst, (const bf16_t*)src,
+    BD_LAUNCH(pack_w_kernel, dim3(blocks), dim3(256), 0, st, (u32x4*)dst, (const bf16_t*)src,
                        (const bf16_t*)src2, panels, K, nb0, mode);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return bd_launch_status();
 }
 
 int bdk_rows_to_afrag(void* dst, const float* src32, const void* src16, int M, int K, int RB, hipStream_t st) {
     if (K % 8) return -2;
     const size_t total = (size_t)M * (K / 8);
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(rows_to_afrag_kernel, dim3(blocks), dim3(256), 0, st, (bf16_t*)dst, src32,
+    BD_LAUNCH(rows_to_afrag_kernel, dim3(blocks), dim3(256), 0, st, (bf16_t*)dst, src32,
                        (const bf16_t*)src16, M, K, RB);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return bd_launch_status();
 }

@@ -3,8 +3,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// hipGetLastError() is sticky per thread: another library's benign failure (torch probing peers, querying an
+// unfinished event ...) would otherwise be blamed on our launch.  Clear before, check after.
+#define BD_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+static inline int bd_launch_status() { return hipGetLastError() == hipSuccess ? 0 : -1; }
+
 #define BD_EPI_PARTIAL 0
 #define BD_EPI_SWIGLU 1
+#define BD_EPI_BF16 2       // out bf16 row-major [Mpad][N] = bf16(acc + bias), split-K must be 1
 
 struct BdStepState;
 
@@ -23,7 +29,7 @@ struct Partial {            // split-K slabs of a GEMM output: [S][Mpad][N] fp32
 
 // diffusion head
 struct HeadPrologueArgs {   // y = silu(t_emb + cond_embed(c)) ; x0 = input_proj(x_t)      flow_head:326-330
-    Partial cond;           // cond_embed GEMM slabs (+bias) [.,Mpad,D]
+    const void* cemb;       // cond_embed(c) finalised once per AR step: bf16 row-major [Mpad][D]
     const void* temb;       // [D] bf16: time_embed(t_i) for this eval
     const float* xt;        // [B*P][C] fp32 latent
     const void* in_w;       // [D][C] bf16
@@ -37,7 +43,8 @@ int bdk_head_prologue(const HeadPrologueArgs& a, hipStream_t st);
 struct LnModArgs {          // x (+= pending branch * gate) ; h = LN(x)*(1+scale)+shift        flow_head:242-252
     void* X;                // in/out bf16 row-major [Mpad][D]
     Partial pend;           // pending branch output (wo / w2 slabs + bias); p == nullptr -> none
-    Partial ada;            // adaLN GEMM slabs + bias, row-major [Mpad][Nada]
+    const void* ada;        // adaLN Linear output, bf16 row-major [Mpad][ada_ld]
+    int ada_ld;
     int gate_off, scale_off, shift_off;   // column offsets inside the adaLN output
     const float* ln_w;      // [D] fp32 or null (no affine)
     const float* ln_b;
@@ -54,7 +61,8 @@ struct SamplerScalars {     // data-independent scalars of one sampling step (sa
 struct HeadFinalArgs {      // pending update, final LN-mod, Linear(D->C), 2*sigmoid-1, SDE/ODE step, sign
     const void* X;          // bf16 row-major
     Partial pend;           // w2 slabs of the last block (+bias)
-    Partial ada;
+    const void* ada;        // bf16 row-major [Mpad][ada_ld]
+    int ada_ld;
     int gate_off, scale_off, shift_off;
     const void* lin_w;      // [C][D] bf16
     const void* lin_b;      // [C] bf16
@@ -73,6 +81,9 @@ struct HeadFinalArgs {      // pending update, final LN-mod, Linear(D->C), 2*sig
     float eps_ln;
 };
 int bdk_head_final(const HeadFinalArgs& a, hipStream_t st);
+
+struct FinalizeRowsArgs { Partial in; void* out; int M, N; };   // bf16 row-major out = bf16(sum of slabs + bias)
+int bdk_finalize_rows(const FinalizeRowsArgs& a, hipStream_t st);
 
 struct InitLatentArgs { float* xt; const float* noise; long long noise_step_stride; const BdStepState* state; int n; };
 int bdk_init_latent(const InitLatentArgs& a, hipStream_t st);    // x_0 = first draw of this AR step (sampling_x.py:60)

@@ -1,14 +1,59 @@
-// Row-wise kernels of the BitDance hot path (gfx950): one workgroup per activation row.
-// They reduce the split-K slabs of the preceding GEMM in their prologue, apply exactly the bf16/fp32
-// rounding points of the reference's autocast flow, and emit the next GEMM's A operand directly in
-// MFMA fragment-major order (bd_common.h) -- so between two weight-streaming GEMMs there is one small
+// Row-wise kernels of the BitDance hot path (gfx950): one workgroup per activation row, ONE THREAD PER 8
+// CONSECUTIVE CHANNELS.  Eight consecutive k of one row are exactly one lane's 16 bytes of an MFMA operand
+// chunk (bd_common.h afrag_off), so every kernel here ends in a single 16 B store per thread that lays down the
+// next GEMM's A operand; all inputs come in as 16 B loads (8 bf16, or 2 x float4 per split-K slab).  The
+// kernels reduce the split-K slabs of the preceding GEMM in their prologue and apply exactly the bf16/fp32
+// rounding points of the reference's autocast flow, so between two weight-streaming GEMMs there is one small
 // launch and no standalone elementwise pass.
 #include "bd_common.h"
 #include "bd_kernels.h"
 
-#define ROW_THREADS 256
+#define MAX_ROW_THREADS 1024
 
-// sum_s P[s][row][col] (+ bias) -> fp32
+static inline int row_threads(int D) {                    // D/8 threads rounded up to whole waves
+    int t = ((D / 8 + 63) / 64) * 64;
+    return t > MAX_ROW_THREADS ? -1 : t;
+}
+
+BD_DEV void ld_bf16x8(const bf16_t* p, float* v) {
+    const u32x4 q = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[2 * j] = bf2f((bf16_t)(q[j] & 0xffff)); v[2 * j + 1] = bf2f((bf16_t)(q[j] >> 16)); }
+}
+BD_DEV void ld_f32x8(const float* p, float* v) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+}
+BD_DEV void st_f32x8(float* p, const float* v) {
+    *reinterpret_cast<f32x4*>(p) = (f32x4){v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+}
+BD_DEV u32x4 pack8(const float* v) {
+    return (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+}
+// Linear output of 8 consecutive columns: bf16( sum of split-K slabs + bias )
+BD_DEV void slab8(const Partial& q, int row, int col, float* v) {
+    const float* p = q.p + (size_t)row * q.N + col;
+    const size_t slab = (size_t)q.Mpad * q.N;
+    ld_f32x8(p, v);
+    for (int s = 1; s < q.S; ++s) {
+        float t[8];
+        ld_f32x8(p + s * slab, t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += t[j];
+    }
+    if (q.bias) {
+        float b[8];
+        ld_bf16x8((const bf16_t*)q.bias + col, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += b[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = bfr(v[j]);
+}
+
+// scalar helpers (small kernels)
 BD_DEV float slab_sum(const Partial& q, int row, int col) {
     float a = 0.f;
     const float* p = q.p + (size_t)row * q.N + col;
@@ -16,19 +61,17 @@ BD_DEV float slab_sum(const Partial& q, int row, int col) {
     if (q.bias) a += bf2f(((const bf16_t*)q.bias)[col]);
     return a;
 }
-BD_DEV float slab_bf(const Partial& q, int row, int col) { return bfr(slab_sum(q, row, col)); }  // Linear output (bf16)
+BD_DEV float slab_bf(const Partial& q, int row, int col) { return bfr(slab_sum(q, row, col)); }
 
 // dot of an LDS fp32 vector with one bf16 weight row, K small (latent channels); 16 B loads when K % 8 == 0
 BD_DEV float small_dot(const float* x, const bf16_t* w, int K) {
     float acc = 0.f;
     if ((K & 7) == 0) {
         for (int k = 0; k < K; k += 8) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(w + k);
+            float wv[8];
+            ld_bf16x8(w + k, wv);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc += x[k + 2 * j] * bf2f((bf16_t)(v[j] & 0xffff));
-                acc += x[k + 2 * j + 1] * bf2f((bf16_t)(v[j] >> 16));
-            }
+            for (int j = 0; j < 8; ++j) acc += x[k + j] * wv[j];
         }
     } else {
         for (int k = 0; k < K; ++k) acc += x[k] * bf2f(w[k]);
@@ -37,146 +80,202 @@ BD_DEV float small_dot(const float* x, const bf16_t* w, int K) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 row-major finalisation of a split-K Linear output (cond_embed, once per AR step)
+// ------------------------------------------------------------------------------------------------
+__global__ void finalize_rows_kernel(FinalizeRowsArgs a) {
+    const int m = blockIdx.x;
+    for (int c = threadIdx.x; c < a.N / 8; c += blockDim.x) {
+        float v[8];
+        slab8(a.in, m, c * 8, v);
+        *reinterpret_cast<u32x4*>((bf16_t*)a.out + (size_t)m * a.N + c * 8) = pack8(v);
+    }
+}
+int bdk_finalize_rows(const FinalizeRowsArgs& a, hipStream_t st) {
+    if (a.N % 8) return -2;
+    BD_LAUNCH(finalize_rows_kernel, dim3(a.M), dim3(256), 0, st, a);
+    return bd_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
 // head prologue:  y = silu(time_embed(t) + cond_embed(c)),  x0 = input_proj(x_t)     flow_head:326-330
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(ROW_THREADS) void head_prologue_kernel(HeadPrologueArgs a) {
+__global__ void head_prologue_kernel(HeadPrologueArgs a) {
     extern __shared__ float sh[];                    // C floats of the latent row (bf16-rounded)
     const int m = blockIdx.x;
     const int src = m % a.BP;                        // cond / uncond rows share the latent (sampling_x.py:71)
     for (int k = threadIdx.x; k < a.C; k += blockDim.x) sh[k] = bfr(a.xt[(size_t)src * a.C + k]);
     __syncthreads();
-    const bf16_t* temb = (const bf16_t*)a.temb;
-    const bf16_t* inw = (const bf16_t*)a.in_w;
-    const bf16_t* inb = (const bf16_t*)a.in_b;
-    bf16_t* X = (bf16_t*)a.X;
-    bf16_t* Y = (bf16_t*)a.y_frag;
-    for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
-        const float ce = slab_bf(a.cond, m, d);
-        const float s = bfr(bf2f(temb[d]) + ce);     // bf16 + bf16 -> bf16
-        Y[afrag_off(m, d, a.RB)] = f2bf(silu_f(s));
-        X[(size_t)m * a.D + d] = f2bf(small_dot(sh, inw + (size_t)d * a.C, a.C) + bf2f(inb[d]));
+    const int d0 = threadIdx.x * 8;
+    if (d0 >= a.D) return;
+    float ce[8], te[8], y[8], x0[8], b[8];
+    ld_bf16x8((const bf16_t*)a.cemb + (size_t)m * a.D + d0, ce);
+    ld_bf16x8((const bf16_t*)a.temb + d0, te);
+    ld_bf16x8((const bf16_t*)a.in_b + d0, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        y[j] = silu_f(bfr(te[j] + ce[j]));           // bf16 + bf16 -> bf16 ; silu -> bf16 (rounded by pack8)
+        x0[j] = small_dot(sh, (const bf16_t*)a.in_w + (size_t)(d0 + j) * a.C, a.C) + b[j];
     }
+    *reinterpret_cast<u32x4*>((bf16_t*)a.y_frag + afrag_off(m, d0, a.RB)) = pack8(y);
+    *reinterpret_cast<u32x4*>((bf16_t*)a.X + (size_t)m * a.D + d0) = pack8(x0);
 }
-
 int bdk_head_prologue(const HeadPrologueArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(head_prologue_kernel, dim3(a.M), dim3(ROW_THREADS), a.C * sizeof(float), st, a);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    const int t = row_threads(a.D);
+    if (t < 0 || a.D % 8) return -2;
+    BD_LAUNCH(head_prologue_kernel, dim3(a.M), dim3(t), a.C * sizeof(float), st, a);
+    return bd_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------------
 // x += branch*gate (pending) ; h = LN(x)*(1+scale)+shift                            flow_head:242-252
 // ------------------------------------------------------------------------------------------------
-BD_DEV float ada_val(const Partial& ada, int row, int col) { return slab_bf(ada, row, col); }
-
-// loads the row (applying a pending gated-branch update) into LDS as fp32; returns nothing
-BD_DEV void load_row_with_pending(float* row, const bf16_t* X, bf16_t* Xw, const Partial& pend, const Partial& ada,
-                                  int gate_off, int m, int D) {
-    for (int d = threadIdx.x; d < D; d += blockDim.x) {
-        float x = bf2f(X[(size_t)m * D + d]);
-        if (pend.p) {
-            const float o = slab_bf(pend, m, d);                 // wo / w2 output, bf16
-            const float g = ada_val(ada, m, gate_off + d);
-            const float hg = bfr(o * g);                          // h * gate   (bf16*bf16 -> bf16)
-            x = bfr(x + hg);                                      // x + ...    (bf16+bf16 -> bf16)
-            if (Xw) Xw[(size_t)m * D + d] = f2bf(x);
-        }
-        row[d] = x;
+// x[8] of this thread with the pending gated branch applied:  x = bf16(x + bf16(bf16(branch) * gate))
+BD_DEV void load_x_pending(float* x, const bf16_t* X, const Partial& pend, const bf16_t* ada, int ada_ld, int gate_off,
+                           int m, int D, int d0) {
+    ld_bf16x8(X + (size_t)m * D + d0, x);
+    if (pend.p) {
+        float o[8], g[8];
+        slab8(pend, m, d0, o);
+        ld_bf16x8(ada + (size_t)m * ada_ld + gate_off + d0, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = bfr(x[j] + bfr(o[j] * g[j]));
     }
 }
 
-BD_DEV void row_stats(const float* row, int D, float eps, float* red, float& mean, float& rstd) {
+// LayerNorm statistics over the row; inactive threads contribute zeros.  Two-pass (mean, then centred variance).
+BD_DEV void ln_stats(const float* x, bool active, int D, float eps, float* red, float& mean, float& rstd) {
     float s = 0.f;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) s += row[d];
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += x[j];
+    }
     mean = block_sum(s, red) / (float)D;
     float v = 0.f;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) { const float c = row[d] - mean; v += c * c; }
-    const float var = block_sum(v, red) / (float)D;
-    rstd = rsqrtf(var + eps);
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float c = x[j] - mean; v += c * c; }
+    }
+    rstd = rsqrtf(block_sum(v, red) / (float)D + eps);
 }
 
-__global__ __launch_bounds__(ROW_THREADS) void ln_mod_kernel(LnModArgs a) {
-    extern __shared__ float sh[];
-    float* row = sh;
-    float* red = sh + a.D;
-    const int m = blockIdx.x;
-    load_row_with_pending(row, (const bf16_t*)a.X, (bf16_t*)a.X, a.pend, a.ada, a.gate_off, m, a.D);
-    __syncthreads();
-    float mean, rstd;
-    row_stats(row, a.D, a.eps, red, mean, rstd);
-    bf16_t* H = (bf16_t*)a.h_frag;
-    for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
-        float ln = (row[d] - mean) * rstd;
-        if (a.ln_w) ln = ln * a.ln_w[d] + a.ln_b[d];
-        const float sc = ada_val(a.ada, m, a.scale_off + d);
-        const float onep = bfr(1.0f + sc);                        // (1 + scale) is a bf16 tensor
-        const float sft = ada_val(a.ada, m, a.shift_off + d);
-        const float t = fadd(fmul(ln, onep), sft);                // fp32 * bf16 + bf16 -> fp32, separate ops
-        H[afrag_off(m, d, a.RB)] = f2bf(t);                        // cast by the following Linear
+// h = LN(x) * bf16(1 + scale) + shift   (fp32; the caller rounds when the following Linear casts)
+BD_DEV void modulate8(const float* x, float mean, float rstd, const float* lw, const float* lb, const bf16_t* ada_row,
+                      int scale_off, int shift_off, int d0, float* h) {
+    float sc[8], sf[8];
+    ld_bf16x8(ada_row + scale_off + d0, sc);
+    ld_bf16x8(ada_row + shift_off + d0, sf);
+    float w[8], b[8];
+    if (lw) { ld_f32x8(lw + d0, w); ld_f32x8(lb + d0, b); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float ln = (x[j] - mean) * rstd;
+        if (lw) ln = ln * w[j] + b[j];
+        h[j] = fadd(fmul(ln, bfr(1.0f + sc[j])), sf[j]);           // fp32 * bf16 + bf16 -> fp32, separate ops
     }
 }
 
+__global__ void ln_mod_kernel(LnModArgs a) {
+    __shared__ float red[32];
+    const int m = blockIdx.x, d0 = threadIdx.x * 8;
+    const bool active = d0 < a.D;
+    const bf16_t* ada = (const bf16_t*)a.ada;
+    float x[8];
+    if (active) {
+        load_x_pending(x, (const bf16_t*)a.X, a.pend, ada, a.ada_ld, a.gate_off, m, a.D, d0);
+        if (a.pend.p) *reinterpret_cast<u32x4*>((bf16_t*)a.X + (size_t)m * a.D + d0) = pack8(x);
+    }
+    float mean, rstd;
+    ln_stats(x, active, a.D, a.eps, red, mean, rstd);
+    if (!active) return;
+    float h[8];
+    modulate8(x, mean, rstd, a.ln_w, a.ln_b, ada + (size_t)m * a.ada_ld, a.scale_off, a.shift_off, d0, h);
+    *reinterpret_cast<u32x4*>((bf16_t*)a.h_frag + afrag_off(m, d0, a.RB)) = pack8(h);   // cast by the next Linear
+}
 int bdk_ln_mod(const LnModArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(ln_mod_kernel, dim3(a.M), dim3(ROW_THREADS), (a.D + 32) * sizeof(float), st, a);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    const int t = row_threads(a.D);
+    if (t < 0 || a.D % 8) return -2;
+    BD_LAUNCH(ln_mod_kernel, dim3(a.M), dim3(t), 0, st, a);
+    return bd_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------------
 // final layer + sampler step.  One workgroup per (image, patch position): its cond row and (CFG) uncond row.
 //   flow_head:169-173,342 ; sampling_x.py:77-95 (+ :6-41) ; t2i_pipeline.py:248 (sign)
+// The D -> 32 Linear: every thread accumulates its 8 channels into 2 x 32 partial dot products; a 63-shuffle
+// butterfly "transpose-reduce" leaves lane L of every wave with the wave total of accumulator L; waves are summed
+// through LDS.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(ROW_THREADS) void head_final_kernel(HeadFinalArgs a) {
-    extern __shared__ float sh[];
-    float* row = sh;                       // D
-    float* red = sh + a.D;                 // 32
-    float* part = red + 32;                // (ROW_THREADS/64) * C partial dot products
-    float* xh = part + (ROW_THREADS / 64) * a.C;   // 2*C : x_hat of the cond / uncond row
-    const int bp = blockIdx.x;
-    const int nrows = a.sc.cfg_mult;
-    const bf16_t* W = (const bf16_t*)a.lin_w;
-    const bf16_t* LB = (const bf16_t*)a.lin_b;
-    for (int r = 0; r < nrows; ++r) {
-        const int m = r * a.BP + bp;
-        __syncthreads();
-        load_row_with_pending(row, (const bf16_t*)a.X, nullptr, a.pend, a.ada, a.gate_off, m, a.D);
-        __syncthreads();
-        float mean, rstd;
-        row_stats(row, a.D, a.eps_ln, red, mean, rstd);
-        __syncthreads();
-        for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
-            const float ln = (row[d] - mean) * rstd;
-            const float onep = bfr(1.0f + ada_val(a.ada, m, a.scale_off + d));
-            const float sft = ada_val(a.ada, m, a.shift_off + d);
-            row[d] = bfr(fadd(fmul(ln, onep), sft));              // Linear input, bf16
-        }
-        __syncthreads();
-        // out[c] = sum_d row[d] * W[c][d]: wave w takes channels c = w, w+4, ...; lanes stride over d
-        const int wv = threadIdx.x >> 6, ln_ = threadIdx.x & 63;
-        for (int c = wv; c < a.C; c += ROW_THREADS / 64) {
-            float acc = 0.f;
-            const bf16_t* w = W + (size_t)c * a.D;
-            for (int d = ln_ * 2; d < a.D; d += 128) {
-                const unsigned pr = *reinterpret_cast<const unsigned*>(w + d);
-                acc += row[d] * bf2f((bf16_t)(pr & 0xffff)) + row[d + 1] * bf2f((bf16_t)(pr >> 16));
-            }
-            acc = wave_sum(acc);
-            if (ln_ == 0) {
-                const float o = bfr(acc + bf2f(LB[c]));            // Linear output bf16
-                const float sg = bfr(1.0f / (1.0f + expf(-o)));    // sigmoid (bf16)
-                const float xv = bfr(fsub(bfr(2.0f * sg), 1.0f));  // 2*sigmoid - 1 (bf16 ops)
-                xh[r * a.C + c] = xv;
-                if (a.xhat_out) a.xhat_out[(size_t)m * a.C + c] = xv;
+__global__ void head_final_kernel(HeadFinalArgs a) {
+    __shared__ float red[32];
+    __shared__ float wsum[16][64];
+    __shared__ float xh[64];
+    const int bp = blockIdx.x, d0 = threadIdx.x * 8, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwav = blockDim.x >> 6;
+    const bool active = d0 < a.D;
+    const bf16_t* ada = (const bf16_t*)a.ada;
+    float h[2][8];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[r][j] = 0.f;
+        if (r < a.sc.cfg_mult) {                                   // block-uniform
+            const int m = r * a.BP + bp;
+            float x[8];
+            if (active) load_x_pending(x, (const bf16_t*)a.X, a.pend, ada, a.ada_ld, a.gate_off, m, a.D, d0);
+            float mean, rstd;
+            ln_stats(x, active, a.D, a.eps_ln, red, mean, rstd);
+            if (active) {
+                modulate8(x, mean, rstd, nullptr, nullptr, ada + (size_t)m * a.ada_ld, a.scale_off, a.shift_off, d0, h[r]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) h[r][j] = bfr(h[r][j]);   // Linear input cast
             }
         }
     }
+    float acc[64];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = 0.f;
+        if (active && c < a.C) ld_bf16x8((const bf16_t*)a.lin_w + (size_t)c * a.D + d0, w);
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s0 += h[0][j] * w[j]; s1 += h[1][j] * w[j]; }
+        acc[c] = s0; acc[32 + c] = s1;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+#pragma unroll
+        for (int i = 0; i < s; ++i) {
+            const bool up = (lane & s) != 0;
+            const float keep = up ? acc[i + s] : acc[i];
+            const float send = up ? acc[i] : acc[i + s];
+            acc[i] = keep + __shfl_xor(send, s);
+        }
+    }
+    wsum[wave][lane] = acc[0];                                     // lane L: accumulator L = r*32 + c
     __syncthreads();
-    if (threadIdx.x < a.C) {
+    if (threadIdx.x < 64) {
+        float tot = 0.f;
+        for (int w = 0; w < nwav; ++w) tot += wsum[w][threadIdx.x];
+        const int r = threadIdx.x >> 5, c = threadIdx.x & 31;
+        if (c < a.C && r < a.sc.cfg_mult) {
+            const float o = bfr(tot + bf2f(((const bf16_t*)a.lin_b)[c]));   // Linear output bf16
+            const float sg = bfr(1.0f / (1.0f + expf(-o)));                 // sigmoid (bf16)
+            const float xv = bfr(fsub(bfr(2.0f * sg), 1.0f));               // 2*sigmoid - 1 (bf16 ops)
+            xh[threadIdx.x] = xv;
+            if (a.xhat_out) a.xhat_out[(size_t)(r * a.BP + bp) * a.C + c] = xv;
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < a.C) {
         const int c = threadIdx.x;
         const SamplerScalars& s = a.sc;
         const size_t idx = (size_t)bp * a.C + c;
         const float x = a.xt[idx];
         float v = fdiv(fsub(xh[c], x), s.den);                    // (x_hat - x) / clamp_min(1-t, .05)
         if (s.cfg_mult == 2) {
-            const float vu = fdiv(fsub(xh[a.C + c], x), s.den);
+            const float vu = fdiv(fsub(xh[32 + c], x), s.den);
             v = fadd(vu, fmul(s.cfg, fsub(v, vu)));                // v_u + cfg (v_c - v_u)
         }
         float xn;
@@ -198,11 +297,11 @@ __global__ __launch_bounds__(ROW_THREADS) void head_final_kernel(HeadFinalArgs a
         a.xt[idx] = xn;
     }
 }
-
 int bdk_head_final(const HeadFinalArgs& a, hipStream_t st) {
-    const size_t lds = (a.D + 32 + (ROW_THREADS / 64) * a.C + 2 * a.C) * sizeof(float);
-    hipLaunchKernelGGL(head_final_kernel, dim3(a.BP), dim3(ROW_THREADS), lds, st, a);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    const int t = row_threads(a.D);
+    if (t < 0 || a.D % 8 || a.C > 32) return -2;
+    BD_LAUNCH(head_final_kernel, dim3(a.BP), dim3(t), 0, st, a);
+    return bd_launch_status();
 }
 
 __global__ void init_latent_kernel(InitLatentArgs a) {
@@ -210,27 +309,33 @@ __global__ void init_latent_kernel(InitLatentArgs a) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) a.xt[i] = src[i];
 }
 int bdk_init_latent(const InitLatentArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(init_latent_kernel, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    BD_LAUNCH(init_latent_kernel, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+    return bd_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------------
-// SwiGLU from split-K slabs (fallback when the fused GEMM epilogue cannot be used): act = silu(h1)*h2
+// SwiGLU from split-K slabs (when the fused GEMM epilogue would leave the chip under-filled): act = silu(h1)*h2
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(ROW_THREADS) void swiglu_rows_kernel(SwigluArgs a) {
+__global__ void swiglu_rows_kernel(SwigluArgs a) {
     const int m = blockIdx.x;
-    bf16_t* A = (bf16_t*)a.act_frag;
-    for (int f = threadIdx.x; f < a.F; f += blockDim.x) {
-        const int cg = a.interleaved ? ((f >> 4) * 32 + (f & 15)) : f;
-        const int cu = a.interleaved ? cg + 16 : a.F + f;
-        const float g = slab_bf(a.up, m, cg);
-        const float u = slab_bf(a.up, m, cu);
-        A[afrag_off(m, f, a.RB)] = f2bf(silu_bf(g) * u);
+    for (int c = threadIdx.x; c < a.F / 8; c += blockDim.x) {
+        const int f0 = c * 8;
+        const int cg = a.interleaved ? ((f0 >> 4) * 32 + (f0 & 15)) : f0;
+        const int cu = a.interleaved ? cg + 16 : a.F + f0;
+        float g[8], u[8], o[8];
+        slab8(a.up, m, cg, g);
+        slab8(a.up, m, cu, u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = silu_bf(g[j]) * u[j];
+        *reinterpret_cast<u32x4*>((bf16_t*)a.act_frag + afrag_off(m, f0, a.RB)) = pack8(o);
     }
 }
 int bdk_swiglu_rows(const SwigluArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(swiglu_rows_kernel, dim3(a.M), dim3(ROW_THREADS), 0, st, a);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    if (a.F % 8) return -2;
+    int t = ((a.F / 8 + 63) / 64) * 64;
+    if (t > MAX_ROW_THREADS) t = MAX_ROW_THREADS;
+    BD_LAUNCH(swiglu_rows_kernel, dim3(a.M), dim3(t), 0, st, a);
+    return bd_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -241,76 +346,89 @@ BD_DEV float gelu_tanh_f(float x) {            // torch GeluCUDAKernelImpl, appr
     const float inner = kBeta * (x + 0.044715f * x * x * x);
     return 0.5f * x * (1.0f + tanhf(inner));
 }
-__global__ __launch_bounds__(ROW_THREADS) void proj_fc1_kernel(ProjFc1Args a) {
+__global__ void proj_fc1_kernel(ProjFc1Args a) {
     extern __shared__ float sh[];
     const int m = blockIdx.x;
     for (int k = threadIdx.x; k < a.C; k += blockDim.x) sh[k] = bfr(a.tok[(size_t)m * a.C + k]);
     __syncthreads();
-    const bf16_t* W = (const bf16_t*)a.w;
-    const bf16_t* B = (const bf16_t*)a.b;
-    bf16_t* H = (bf16_t*)a.h_frag;
-    for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
-        const float o = bfr(small_dot(sh, W + (size_t)d * a.C, a.C) + bf2f(B[d]));
-        H[afrag_off(m, d, a.RB)] = f2bf(gelu_tanh_f(o));
-    }
+    const int d0 = threadIdx.x * 8;
+    if (d0 >= a.D) return;
+    float b[8], o[8];
+    ld_bf16x8((const bf16_t*)a.b + d0, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        o[j] = gelu_tanh_f(bfr(small_dot(sh, (const bf16_t*)a.w + (size_t)(d0 + j) * a.C, a.C) + b[j]));
+    *reinterpret_cast<u32x4*>((bf16_t*)a.h_frag + afrag_off(m, d0, a.RB)) = pack8(o);
 }
 int bdk_proj_fc1(const ProjFc1Args& a, hipStream_t st) {
-    hipLaunchKernelGGL(proj_fc1_kernel, dim3(a.BP), dim3(ROW_THREADS), a.C * sizeof(float), st, a);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    const int t = row_threads(a.D);
+    if (t < 0 || a.D % 8) return -2;
+    BD_LAUNCH(proj_fc1_kernel, dim3(a.BP), dim3(t), a.C * sizeof(float), st, a);
+    return bd_launch_status();
 }
 
 // model_input = fc2 output (bf16) + 2-D pos-embed (fp32) -> fp32, same rows for every CFG branch
 // (t2i_pipeline.py:249-253; both halves of curr_tokens are identical copies)
-__global__ __launch_bounds__(ROW_THREADS) void embed_finalize_kernel(EmbedFinalizeArgs a) {
-    const int m = blockIdx.x;                    // 0..BP-1
-    const int p = m % a.P;
-    const int step = a.state->step;
-    const float* pos = a.pos + ((size_t)step * a.P + p) * a.D;
-    for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
-        const float e = slab_bf(a.fc2, m, d) + pos[d];
-        for (int br = 0; br < a.branches; ++br) a.R[((size_t)br * a.BP + m) * a.D + d] = e;
-    }
+__global__ void embed_finalize_kernel(EmbedFinalizeArgs a) {
+    const int m = blockIdx.x, d0 = threadIdx.x * 8;   // m: 0..BP-1
+    if (d0 >= a.D) return;
+    const float* pos = a.pos + ((size_t)a.state->step * a.P + (m % a.P)) * a.D + d0;
+    float e[8], p[8];
+    slab8(a.fc2, m, d0, e);
+    ld_f32x8(pos, p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] += p[j];
+    for (int br = 0; br < a.branches; ++br) st_f32x8(a.R + ((size_t)br * a.BP + m) * a.D + d0, e);
 }
 int bdk_embed_finalize(const EmbedFinalizeArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(embed_finalize_kernel, dim3(a.BP), dim3(ROW_THREADS), 0, st, a);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    const int t = row_threads(a.D);
+    if (t < 0 || a.D % 8) return -2;
+    BD_LAUNCH(embed_finalize_kernel, dim3(a.BP), dim3(t), 0, st, a);
+    return bd_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------------
 // LLM: residual add of the pending branch + RMSNorm                             HF:59-64, 294-323
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(ROW_THREADS) void rms_kernel(RmsArgs a) {
-    extern __shared__ float sh[];
-    float* row = sh;
-    float* red = sh + a.D;
-    const int m = blockIdx.x;
+__global__ void rms_kernel(RmsArgs a) {
+    __shared__ float red[32];
+    const int m = blockIdx.x, d0 = threadIdx.x * 8;
+    const bool active = d0 < a.D;
+    float r[8];
     float ss = 0.f;
-    for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
-        float r = a.R[(size_t)m * a.D + d];
+    if (active) {
+        ld_f32x8(a.R + (size_t)m * a.D + d0, r);
         if (a.pend.p) {
-            r = r + slab_bf(a.pend, m, d);                         // fp32 residual + bf16 branch -> fp32
-            a.R[(size_t)m * a.D + d] = r;
+            float o[8];
+            slab8(a.pend, m, d0, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] += o[j];             // fp32 residual + bf16 branch -> fp32
+            st_f32x8(a.R + (size_t)m * a.D + d0, r);
         }
-        row[d] = r;
-        ss += r * r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += r[j] * r[j];
     }
-    const float var = block_sum(ss, red) / (float)a.D;
-    const float rs = rsqrtf(var + a.eps);
-    const bf16_t* W = (const bf16_t*)a.w;
-    bf16_t* A = (bf16_t*)a.a_frag;
-    bf16_t* Cf = (bf16_t*)a.cond_frag;
-    const float* pos = nullptr;
-    if (a.pos) pos = a.pos + ((size_t)a.state->step * a.P + (m % a.P)) * a.D;
-    for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
-        const float n = fmul(bf2f(W[d]), fmul(row[d], rs));        // weight * (x * rsqrt(var+eps)), fp32
-        if (A) A[afrag_off(m, d, a.RB)] = f2bf(n);                  // cast by the following Linear
-        if (a.hidden_out) a.hidden_out[(size_t)m * a.D + d] = n;
-        if (Cf) Cf[afrag_off(m, d, a.RB)] = f2bf(fadd(n, pos[d]));  // cond = hidden + pos (t2i:244-245), cast by cond_embed
+    const float rs = rsqrtf(block_sum(ss, red) / (float)a.D + a.eps);
+    if (!active) return;
+    float w[8], n[8];
+    ld_bf16x8((const bf16_t*)a.w + d0, w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) n[j] = fmul(w[j], fmul(r[j], rs));   // weight * (x * rsqrt(var+eps)), fp32
+    if (a.a_frag) *reinterpret_cast<u32x4*>((bf16_t*)a.a_frag + afrag_off(m, d0, a.RB)) = pack8(n);   // cast by the next Linear
+    if (a.hidden_out) st_f32x8(a.hidden_out + (size_t)m * a.D + d0, n);
+    if (a.cond_frag) {                                             // cond = hidden + pos (t2i:244-245), cast by cond_embed
+        float p[8];
+        ld_f32x8(a.pos + ((size_t)a.state->step * a.P + (m % a.P)) * a.D + d0, p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[j] = fadd(n[j], p[j]);
+        *reinterpret_cast<u32x4*>((bf16_t*)a.cond_frag + afrag_off(m, d0, a.RB)) = pack8(p);
     }
 }
 int bdk_rms(const RmsArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(rms_kernel, dim3(a.M), dim3(ROW_THREADS), (a.D + 32) * sizeof(float), st, a);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    const int t = row_threads(a.D);
+    if (t < 0 || a.D % 8) return -2;
+    BD_LAUNCH(rms_kernel, dim3(a.M), dim3(t), 0, st, a);
+    return bd_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -357,8 +475,8 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(QkvPostArgs a) {
 }
 int bdk_qkv_post(const QkvPostArgs& a, hipStream_t st) {
     const int nslot = a.nh + 2 * a.nkv;
-    hipLaunchKernelGGL(qkv_post_kernel, dim3(a.M, (nslot + 3) / 4), dim3(256), 0, st, a);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    BD_LAUNCH(qkv_post_kernel, dim3(a.M, (nslot + 3) / 4), dim3(256), 0, st, a);
+    return bd_launch_status();
 }
 
 __global__ void step_advance_kernel(StepAdvanceArgs a) {
@@ -366,6 +484,6 @@ __global__ void step_advance_kernel(StepAdvanceArgs a) {
     if ((int)threadIdx.x < a.nseq) a.state->kv_len[threadIdx.x] += a.P;
 }
 int bdk_step_advance(const StepAdvanceArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, st, a);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    BD_LAUNCH(step_advance_kernel, dim3(1), dim3(64), 0, st, a);
+    return bd_launch_status();
 }

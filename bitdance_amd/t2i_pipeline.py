@@ -186,6 +186,7 @@ class BitDanceT2IPipeline:
         embed = self.llm_w.sd["model.embed_tokens.weight"]
         st = self._stream
         st.wait_stream(torch.cuda.current_stream())
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         with torch.cuda.stream(st):
             eng.set_schedule(num_sampling_steps, guidance_scale, num_steps)
             if noise is None:
@@ -194,6 +195,7 @@ class BitDanceT2IPipeline:
                 eng.load_noise(noise.to(dev))
             pos = self.get_2d_embed(h, w, ps=self.ps)
             eng.pos[: h * w].copy_(pos)
+            ev[0].record(st)
             hid = []
             kv = []
             for br, ids in enumerate([cond_ids, uncond_ids][:branches]):
@@ -210,6 +212,7 @@ class BitDanceT2IPipeline:
                 eng.capture(0)
                 if num_steps > 1:
                     eng.capture(1)
+            ev[1].record(st)
             for step in range(num_steps):
                 if self.use_graph:
                     eng.launch(0)
@@ -220,19 +223,37 @@ class BitDanceT2IPipeline:
                     if step + 1 < num_steps:
                         eng.projector()
                         eng.llm_step()
+            ev[2].record(st)
             tokens = eng.tok_all[:, : h * w].clone()
             if return_tokens:
                 out = tokens
             else:
                 out = self.decode_image(tokens, [h, w], ps=self.ps)
+            ev[3].record(st)
         torch.cuda.current_stream().wait_stream(st)
+        self._events = ev
         return out
 
+    def timings(self) -> dict:
+        """Milliseconds of the last gen_image call: prefill (+graph capture on first use), AR loop, AE decode."""
+        ev = self._events
+        ev[3].synchronize()
+        return {"prefill_ms": ev[0].elapsed_time(ev[1]), "ar_loop_ms": ev[1].elapsed_time(ev[2]),
+                "decode_ms": ev[2].elapsed_time(ev[3])}
+
     def decode_image(self, image_latents, image_size=None, ps=1):
+        """Un-raster the tokens and run the conv decoder (MIOpen).  MIOpen's immediate mode has no tuned entries for
+        gfx950 in this image and falls back to a naive direct convolution, so the decode runs under
+        cudnn.benchmark (MIOpen Find, cached per shape)."""
         if image_size is None:
             h = w = int(image_latents.size(1) ** 0.5)
         else:
             h, w = image_size
         b, _, c = image_latents.shape
         x = image_latents.view(b, h // ps, w // ps, ps, ps, c).permute(0, 5, 1, 3, 2, 4).reshape(b, c, h, w)
-        return self.ae.decode(x)
+        prev = torch.backends.cudnn.benchmark
+        torch.backends.cudnn.benchmark = True
+        try:
+            return self.ae.decode(x)
+        finally:
+            torch.backends.cudnn.benchmark = prev
