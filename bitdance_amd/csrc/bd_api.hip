@@ -68,10 +68,11 @@ static int pad_rows(int m) { return m <= 32 ? 32 : (m <= 64 ? 64 : ((m + 127) / 
 //  * SwiGLU: fused epilogue (S = 1) when the grid fills the chip, otherwise split-K slabs + swiglu_rows.
 static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K, bool swiglu) {
     GemmCfg g;
-    g.nw = (N % 256 == 0 && N >= 7168) ? 8 : ((N % 128 == 0) ? 4 : 2);
+    const bool two_images = (c->Mpad % 256 == 0);      // 256-row passes (MB = 8) need the 8-wave variant for occupancy
+    g.nw = (N % 256 == 0 && (N >= 7168 || two_images)) ? 8 : ((N % 128 == 0) ? 4 : 2);
     const int nst = K / 64;
     const int ntiles = N / (32 * g.nw);
-    int S = (int)std::lround(240.0 / ntiles);
+    int S = (int)std::lround((g.nw == 8 ? 200.0 : 240.0) / ntiles);
     if (S < 1) S = 1;
     if (ntiles >= 200 && !swiglu) S = 3;
     if (swiglu && ntiles >= 120) S = 1;

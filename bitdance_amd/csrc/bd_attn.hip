@@ -72,16 +72,19 @@ __global__ __launch_bounds__(256) void head_attn_kernel(HeadAttnArgs a) {
         }
     };
 
-    // stage K [key][d] and V^T [d][key] of this (seq, head): all 4 waves; waves 0/1 then own 32 queries each
-    for (int u = tid; u < 1024; u += 256) {
-        const int key = u >> 4, dp = (u & 15) * 8;
-        float v[8];
-        load8(seq * 64 + key, D + h * 128 + dp, v);
-        *reinterpret_cast<u32x4*>(&Ks[key * KSTR + dp]) =
-            (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
-        load8(seq * 64 + key, 2 * D + h * 128 + dp, v);
+    // stage K [key][d] and V^T [d][key] of this (seq, head): all 4 waves; waves 0/1 then own 32 queries each.
+    // Fully unrolled so that the 4 x (K + V) x S slab loads of a thread are all in flight together.
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Vs[(dp + j) * VSTR + key] = f2bf(v[j]);
+    for (int it = 0; it < 4; ++it) {
+        const int u = tid + it * 256;
+        const int key = u >> 4, dp = (u & 15) * 8;
+        float kv[8], vv[8];
+        load8(seq * 64 + key, D + h * 128 + dp, kv);
+        load8(seq * 64 + key, 2 * D + h * 128 + dp, vv);
+        *reinterpret_cast<u32x4*>(&Ks[key * KSTR + dp]) =
+            (u32x4){pack2(kv[0], kv[1]), pack2(kv[2], kv[3]), pack2(kv[4], kv[5]), pack2(kv[6], kv[7])};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Vs[(dp + j) * VSTR + key] = f2bf(vv[j]);
     }
     // Q operand fragments (B of S^T = K Q^T): lane -> query (lane&31), 8 consecutive d
     u32x4 qf[8];

@@ -230,9 +230,12 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw, 
     if ((S - 1) * q >= nst_total) return -3;                       // an empty split
     if (epi != BD_EPI_PARTIAL && S != 1) return -4;
     GemmP p{(const u32x4*)A, (const u32x4*)W, out_partial, (bf16_t*)out_act, (const bf16_t*)bias, RB, N, K, S, RB * 32};
-    const int MB = (RB % 4 == 0) ? 4 : RB;
-    if (MB != 4 && MB != 2 && MB != 1) return -5;
+    // rows per pass over the weights: 256 (two images with CFG: W streamed once for both) when the row count allows,
+    // else 128 / 64 / 32
+    const int MB = (RB % 8 == 0 && nw >= 4) ? 8 : ((RB % 4 == 0) ? 4 : RB);
+    if (MB != 8 && MB != 4 && MB != 2 && MB != 1) return -5;
 #define BD_CASE(NWV, MBV) if (nw == NWV && MB == MBV) return launch_gemm<NWV, MBV>(p, epi, st);
+    BD_CASE(4, 8) BD_CASE(8, 8)
     BD_CASE(2, 4) BD_CASE(4, 4) BD_CASE(8, 4)
     BD_CASE(2, 2) BD_CASE(4, 2) BD_CASE(8, 2)
     BD_CASE(2, 1) BD_CASE(4, 1) BD_CASE(8, 1)

@@ -201,11 +201,8 @@ int bdk_ln_mod(const LnModArgs& a, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // final layer + sampler step.  One workgroup per (image, patch position): its cond row and (CFG) uncond row.
 //   flow_head:169-173,342 ; sampling_x.py:77-95 (+ :6-41) ; t2i_pipeline.py:248 (sign)
-// The D -> 32 Linear: every thread accumulates its 8 channels into 2 x 32 partial dot products; a 63-shuffle
-// butterfly "transpose-reduce" leaves lane L of every wave with the wave total of accumulator L; waves are summed
-// through LDS.
 // ------------------------------------------------------------------------------------------------
-__global__ void head_final_kernel(HeadFinalArgs a) {
+__global__ __launch_bounds__(640) void head_final_kernel(HeadFinalArgs a) {
     __shared__ float red[32];
     __shared__ float wsum[16][64];
     __shared__ float xh[64];
@@ -231,29 +228,22 @@ __global__ void head_final_kernel(HeadFinalArgs a) {
             }
         }
     }
-    float acc[64];
+    // D -> C Linear: per channel every thread dots its 8 inputs with the weight row, a wave shuffle-sum folds the
+    // 64 lanes, lane 0 parks the wave total in LDS (the waves are summed below)
+    for (int r = 0; r < a.sc.cfg_mult; ++r) {
+#pragma unroll 4
+        for (int c = 0; c < a.C; ++c) {
+            float s0 = 0.f;
+            if (active) {
+                float w[8];
+                ld_bf16x8((const bf16_t*)a.lin_w + (size_t)c * a.D + d0, w);
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {
-        float w[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] = 0.f;
-        if (active && c < a.C) ld_bf16x8((const bf16_t*)a.lin_w + (size_t)c * a.D + d0, w);
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { s0 += h[0][j] * w[j]; s1 += h[1][j] * w[j]; }
-        acc[c] = s0; acc[32 + c] = s1;
-    }
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-#pragma unroll
-        for (int i = 0; i < s; ++i) {
-            const bool up = (lane & s) != 0;
-            const float keep = up ? acc[i + s] : acc[i];
-            const float send = up ? acc[i] : acc[i + s];
-            acc[i] = keep + __shfl_xor(send, s);
+                for (int j = 0; j < 8; ++j) s0 += (r == 0 ? h[0][j] : h[1][j]) * w[j];
+            }
+            s0 = wave_sum(s0);
+            if (lane == 0) wsum[wave][r * 32 + c] = s0;
         }
     }
-    wsum[wave][lane] = acc[0];                                     // lane L: accumulator L = r*32 + c
     __syncthreads();
     if (threadIdx.x < 64) {
         float tot = 0.f;
@@ -299,7 +289,7 @@ __global__ void head_final_kernel(HeadFinalArgs a) {
 }
 int bdk_head_final(const HeadFinalArgs& a, hipStream_t st) {
     const int t = row_threads(a.D);
-    if (t < 0 || a.D % 8 || a.C > 32) return -2;
+    if (t < 0 || t > 640 || a.D % 8 || a.C > 32) return -2;      // 64 accumulators/thread: register budget of 10 waves
     BD_LAUNCH(head_final_kernel, dim3(a.BP), dim3(t), 0, st, a);
     return bd_launch_status();
 }
