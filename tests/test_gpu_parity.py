@@ -46,7 +46,7 @@ def frag(eng_mod, x):
 
 @pytest.mark.parametrize("M,N,K,S,nw", [
     (128, 256, 256, 1, 4), (128, 256, 256, 4, 2), (128, 512, 384, 3, 8), (64, 256, 256, 2, 4),
-    (32, 128, 192, 1, 2), (256, 256, 256, 2, 4), (128, 5120, 5120, 4, 4), (128, 15360, 5120, 2, 4),
+    (32, 128, 192, 1, 2), (256, 256, 256, 2, 4), (256, 512, 384, 2, 8), (256, 5120, 5120, 6, 8), (128, 5120, 5120, 4, 4), (128, 15360, 5120, 2, 4),
     (128, 5120, 17408, 6, 4), (128, 7168, 5120, 3, 2)])
 def test_gemm_partial(eng_mod, M, N, K, S, nw):
     """F.linear under bf16 autocast == sum of the split-K slabs (fp32 accumulation of bf16 products)."""
