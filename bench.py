@@ -67,7 +67,7 @@ def gemm_roofline(pipe) -> dict:
     for name, r in sorted(prof.items()):
         S, nw = eng.gemm_config(name)
         per.append({"name": name, "launches": r["count"], "avg_us": round(r["ms"] / r["count"] * 1e3, 2),
-                    "GBs": round(r["bytes"] / r["ms"] / 1e6, 1), "splitk": S, "nwaves": nw})
+                    "GBs": round(r["bytes"] / r["ms"] / 1e6, 1), "splitk": S, "nwaves": nw & 15, "ring": nw >> 4})
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
             "kernel": "gemm_kernel<NW,MB,EPI> (bd_gemm.hip): every weight-streaming GEMM launch of one AR step, in situ",

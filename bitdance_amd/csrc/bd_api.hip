@@ -22,7 +22,7 @@ static int fail(const std::string& m) { g_err = m; return -1; }
         if (_r != 0) return fail(std::string(#expr) + " failed with " + std::to_string(_r)); \
     } while (0)
 
-struct GemmCfg { int S = 1, nw = 4; };
+struct GemmCfg { int S = 1, nw = 4, ring = 2; int code() const { return nw + 16 * ring; } };
 
 struct bd_ctx {
     std::map<std::string, long long> I;
@@ -77,8 +77,10 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
     if (ntiles >= 200 && !swiglu) S = 3;
     if (swiglu && ntiles >= 120) S = 1;
     g.S = S;
+    g.ring = two_images ? 2 : (g.nw == 8 ? 4 : (g.nw == 4 ? 3 : 2));   // K stages in flight per wave (register budget)
     g.S = (int)c->geti("tune." + name + ".S", g.S);
     g.nw = (int)c->geti("tune." + name + ".nw", g.nw);
+    g.ring = (int)c->geti("tune." + name + ".ring", g.ring);
     if (N % (32 * g.nw)) g.nw = (N % 128 == 0) ? 4 : 2;
     if (g.S > nst) g.S = nst;
     while (g.S > 1 && (g.S - 1) * ((nst + g.S - 1) / g.S) >= nst) --g.S;      // no empty split
@@ -264,7 +266,7 @@ static Partial part(const bd_ctx* c, const std::string& ws, const void* bias, in
 
 static int head_cond(bd_ctx* c, hipStream_t st) {
     const GemmCfg& g = c->g["head.cond"];
-    BD_TRY(gemm(c, "head.cond", c->ptr("head.cond_frag"), c->RB, c->ptr("head.cond_w"), c->hD, c->hDz, g.S, g.nw, BD_EPI_PARTIAL,
+    BD_TRY(gemm(c, "head.cond", c->ptr("head.cond_frag"), c->RB, c->ptr("head.cond_w"), c->hD, c->hDz, g.S, g.code(), BD_EPI_PARTIAL,
                 (float*)c->wptr("head.cond_part"), nullptr, nullptr, st));
     FinalizeRowsArgs fr;                      // cond_embed(c) is constant over the N+1 evals of this AR step
     fr.in = Partial{(const float*)c->ptr("head.cond_part"), c->ptr("head.cond_b"), g.S, c->hD, c->Mpad};
@@ -288,7 +290,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
     BD_TRY(bdk_head_prologue(pa, st));
 
     const GemmCfg& ga = c->g["head.ada"];
-    BD_TRY(gemm(c, "head.ada", c->ptr("head.y_frag"), RB, c->ptr("head.ada_w"), c->hNada, D, 1, ga.nw, BD_EPI_BF16,
+    BD_TRY(gemm(c, "head.ada", c->ptr("head.y_frag"), RB, c->ptr("head.ada_w"), c->hNada, D, 1, ga.code(), BD_EPI_BF16,
                 nullptr, c->wptr("head.ada_bf"), c->ptr("head.ada_b"), st));
     const void* ada = c->ptr("head.ada_bf");
     const int sw = c->hNB / c->hNA;
@@ -306,13 +308,13 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
         l1.ln_w = (const float*)c->ptr(pre + "ln1_w"); l1.ln_b = (const float*)c->ptr(pre + "ln1_b");
         l1.h_frag = c->wptr("head.h_frag"); l1.M = M; l1.D = D; l1.RB = RB; l1.eps = 1e-6f;
         BD_TRY(bdk_ln_mod(l1, st));
-        BD_TRY(gemm(c, "head.qkv", c->ptr("head.h_frag"), RB, c->ptr(pre + "wqkv"), 3 * D, D, gq.S, gq.nw, BD_EPI_PARTIAL,
+        BD_TRY(gemm(c, "head.qkv", c->ptr("head.h_frag"), RB, c->ptr(pre + "wqkv"), 3 * D, D, gq.S, gq.code(), BD_EPI_PARTIAL,
                         (float*)c->wptr("head.qkv_part"), nullptr, nullptr, st));
         HeadAttnArgs at;
         at.qkv = part(c, "head.qkv_part", c->ptr(pre + "bqkv"), gq.S, 3 * D, Mp);
         at.o_frag = c->wptr("head.attn_frag"); at.nseq = M / 64; at.nhead = D / 128; at.D = D; at.RB = RB;
         BD_TRY(bdk_head_attn(at, st));
-        BD_TRY(gemm(c, "head.wo", c->ptr("head.attn_frag"), RB, c->ptr(pre + "wo"), D, D, go.S, go.nw, BD_EPI_PARTIAL,
+        BD_TRY(gemm(c, "head.wo", c->ptr("head.attn_frag"), RB, c->ptr(pre + "wo"), D, D, go.S, go.code(), BD_EPI_PARTIAL,
                         (float*)c->wptr("head.br_part"), nullptr, nullptr, st));
         LnModArgs l2 = l1;
         l2.pend = part(c, "head.br_part", c->ptr(pre + "bo"), go.S, D, Mp);
@@ -320,17 +322,17 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
         l2.ln_w = (const float*)c->ptr(pre + "ln2_w"); l2.ln_b = (const float*)c->ptr(pre + "ln2_b");
         BD_TRY(bdk_ln_mod(l2, st));
         if (g1.S == 1) {
-            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * H, D, 1, g1.nw, BD_EPI_SWIGLU, nullptr,
+            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * H, D, 1, g1.code(), BD_EPI_SWIGLU, nullptr,
                         c->wptr("head.act_frag"), c->ptr(pre + "b1"), st));
         } else {   // split-K slabs in packed (gate|up interleaved) column order + row-wise SwiGLU
-            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * H, D, g1.S, g1.nw, BD_EPI_PARTIAL,
+            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * H, D, g1.S, g1.code(), BD_EPI_PARTIAL,
                         (float*)c->wptr("head.w1_part"), nullptr, nullptr, st));
             SwigluArgs sw_;
             sw_.up = part(c, "head.w1_part", c->ptr(pre + "b1"), g1.S, 2 * H, Mp);
             sw_.act_frag = c->wptr("head.act_frag"); sw_.M = M; sw_.F = H; sw_.RB = RB; sw_.interleaved = 1;
             BD_TRY(bdk_swiglu_rows(sw_, st));
         }
-        BD_TRY(gemm(c, "head.w2", c->ptr("head.act_frag"), RB, c->ptr(pre + "w2"), D, H, g2.S, g2.nw, BD_EPI_PARTIAL,
+        BD_TRY(gemm(c, "head.w2", c->ptr("head.act_frag"), RB, c->ptr(pre + "w2"), D, H, g2.S, g2.code(), BD_EPI_PARTIAL,
                         (float*)c->wptr("head.br_part"), nullptr, nullptr, st));
     }
     HeadFinalArgs fa;
@@ -371,7 +373,7 @@ static int projector(bd_ctx* c, hipStream_t st) {
                    c->BP, D, (int)c->geti("proj.C"), c->RBp};
     BD_TRY(bdk_proj_fc1(f1, st));
     const GemmCfg& g = c->g["proj.fc2"];
-    BD_TRY(gemm(c, "proj.fc2", c->ptr("proj.h_frag"), c->RBp, c->ptr("proj.w2"), D, D, g.S, g.nw, BD_EPI_PARTIAL,
+    BD_TRY(gemm(c, "proj.fc2", c->ptr("proj.h_frag"), c->RBp, c->ptr("proj.w2"), D, D, g.S, g.code(), BD_EPI_PARTIAL,
                     (float*)c->wptr("proj.part"), nullptr, nullptr, st));
     EmbedFinalizeArgs ef;
     ef.fc2 = Partial{(const float*)c->ptr("proj.part"), c->ptr("proj.b2"), g.S, D, c->BPpad};
@@ -397,7 +399,7 @@ static int llm_step(bd_ctx* c, hipStream_t st) {
         r1.hidden_out = nullptr; r1.cond_frag = nullptr; r1.pos = nullptr; r1.state = state;
         r1.M = M; r1.D = D; r1.RB = RB; r1.P = c->Pn; r1.eps = eps;
         BD_TRY(bdk_rms(r1, st));
-        BD_TRY(gemm(c, "llm.qkv", c->ptr("llm.a_frag"), RB, c->ptr(pre + "wqkv"), c->lNqkv, D, gq.S, gq.nw, BD_EPI_PARTIAL,
+        BD_TRY(gemm(c, "llm.qkv", c->ptr("llm.a_frag"), RB, c->ptr(pre + "wqkv"), c->lNqkv, D, gq.S, gq.code(), BD_EPI_PARTIAL,
                         (float*)c->wptr("llm.qkv_part"), nullptr, nullptr, st));
         QkvPostArgs qa;
         qa.qkv = part(c, "llm.qkv_part", nullptr, gq.S, c->lNqkv, Mp);
@@ -414,15 +416,15 @@ static int llm_step(bd_ctx* c, hipStream_t st) {
         aa.o_frag = c->wptr("llm.attn_frag"); aa.state = state;
         aa.nseq = nseq; aa.P = c->Pn; aa.nh = nh; aa.nkv = nkv; aa.Lmax = c->lLmax; aa.splits = c->lsplits; aa.RB = RB;
         BD_TRY(bdk_llm_attn(aa, st));
-        BD_TRY(gemm(c, "llm.o", c->ptr("llm.attn_frag"), RB, c->ptr(pre + "wo"), D, nh * 128, go.S, go.nw, BD_EPI_PARTIAL,
+        BD_TRY(gemm(c, "llm.o", c->ptr("llm.attn_frag"), RB, c->ptr(pre + "wo"), D, nh * 128, go.S, go.code(), BD_EPI_PARTIAL,
                         (float*)c->wptr("llm.br_part"), nullptr, nullptr, st));
         RmsArgs r2 = r1;
         r2.pend = part(c, "llm.br_part", nullptr, go.S, D, Mp);
         r2.w = c->ptr(pre + "post_norm");
         BD_TRY(bdk_rms(r2, st));
-        BD_TRY(gemm(c, "llm.gu", c->ptr("llm.a_frag"), RB, c->ptr(pre + "wgu"), 2 * F, D, 1, gg.nw, BD_EPI_SWIGLU, nullptr,
+        BD_TRY(gemm(c, "llm.gu", c->ptr("llm.a_frag"), RB, c->ptr(pre + "wgu"), 2 * F, D, 1, gg.code(), BD_EPI_SWIGLU, nullptr,
                         c->wptr("llm.act_frag"), nullptr, st));
-        BD_TRY(gemm(c, "llm.down", c->ptr("llm.act_frag"), RB, c->ptr(pre + "wdown"), D, F, gd.S, gd.nw, BD_EPI_PARTIAL,
+        BD_TRY(gemm(c, "llm.down", c->ptr("llm.act_frag"), RB, c->ptr(pre + "wdown"), D, F, gd.S, gd.code(), BD_EPI_PARTIAL,
                         (float*)c->wptr("llm.br_part"), nullptr, nullptr, st));
     }
     StepAdvanceArgs sa{state, nseq, c->Pn};
@@ -487,7 +489,7 @@ int bd_prof_get(bd_ctx* c, int i, char* name, float* ms, double* bytes) {
 int bd_gemm_config(bd_ctx* c, const char* name, int* splitk, int* nwaves) {
     auto it = c->g.find(name);
     if (it == c->g.end()) return fail(std::string("bd_gemm_config: unknown GEMM '") + name + "'");
-    *splitk = it->second.S; *nwaves = it->second.nw;
+    *splitk = it->second.S; *nwaves = it->second.code();   /* waves + 16 * ring depth */
     return 0;
 }
 

@@ -78,14 +78,21 @@ struct GemmP {
     int RB, N, K, S, Mpad;
 };
 
-template <int NW, int MB, int EPI>
+// R = depth of the per-wave W register ring = number of 64-deep K stages a wave keeps in flight.  The A stage is
+// prefetched equally far ahead (R-1 register slots, then one ds_write into the double-buffered LDS tile): vmcnt retires
+// in order, so an A load issued late would force every older W load to complete with it.
+// hipcc's s_waitcnt placement is exact inside a straight-line body but drains the whole queue at the first use after
+// a loop back-edge; U (8 or 12) phases per iteration make that one drain in U.
+template <int NW, int MB, int EPI, int R>
 __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
     constexpr int NT = NW * 64;
     constexpr int UNITS = MB * 256;                       // 16 B units per 64-deep A stage
     constexpr int XL = (UNITS + NT - 1) / NT;             // A loads per thread per stage
+    constexpr int XR = R - 1;                             // A register-ring slots
+    constexpr int U = (R == 2) ? 8 : 12;
+    static_assert(U % R == 0 && U % XR == 0 && U % 2 == 0, "static ring/buffer indices");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    u32x4* buf0 = reinterpret_cast<u32x4*>(smem);
-    u32x4* buf1 = buf0 + UNITS;
+    u32x4* const lds = reinterpret_cast<u32x4*>(smem);    // two A-stage buffers of UNITS each
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int S = p.S;
@@ -108,61 +115,69 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
     }
     const size_t a_stage = (size_t)4 * p.RB * 64;
 
-    u32x4 w0[4], w1[4], xr[XL];
+    u32x4 w[R][4], xr[XR][XL];
     f32x16 acc[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-    auto load_w = [&](u32x4(&w)[4], int i) {
+    auto load_w = [&](u32x4(&wr)[4], int i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = __builtin_nontemporal_load(Wp + ((size_t)i * 4 + j) * 64);
+        for (int j = 0; j < 4; ++j) wr[j] = __builtin_nontemporal_load(Wp + ((size_t)i * 4 + j) * 64);
     };
-    auto load_x = [&](int i) {
-#pragma unroll
-        for (int j = 0; j < XL; ++j)
-            if (UNITS % NT == 0 || tid + j * NT < UNITS) xr[j] = p.A[a_off[j] + (size_t)i * a_stage];
-    };
-    auto store_x = [&](u32x4* buf) {
+    auto load_x = [&](u32x4(&x)[XL], int i) {
 #pragma unroll
         for (int j = 0; j < XL; ++j)
-            if (UNITS % NT == 0 || tid + j * NT < UNITS) buf[tid + j * NT] = xr[j];
+            if (UNITS % NT == 0 || tid + j * NT < UNITS) x[j] = p.A[a_off[j] + (size_t)i * a_stage];
     };
-    auto compute = [&](const u32x4* buf, const u32x4(&w)[4]) {
+    auto store_x = [&](u32x4* buf, const u32x4(&x)[XL]) {
+#pragma unroll
+        for (int j = 0; j < XL; ++j)
+            if (UNITS % NT == 0 || tid + j * NT < UNITS) buf[tid + j * NT] = x[j];
+    };
+    auto compute = [&](const u32x4* buf, const u32x4(&wr)[4]) {
 #pragma unroll
         for (int ksl = 0; ksl < 4; ++ksl) {
             u32x4 xf[MB];
 #pragma unroll
             for (int m = 0; m < MB; ++m) xf[m] = buf[(ksl * MB + m) * 64 + lane];
 #pragma unroll
-            for (int m = 0; m < MB; ++m) acc[m] = mfma32(xf[m], w[ksl], acc[m]);
+            for (int m = 0; m < MB; ++m) acc[m] = mfma32(xf[m], wr[ksl], acc[m]);
         }
     };
 
-    if (nst > 0) {
-        load_x(0);
-        load_w(w0, 0);
-        if (nst > 1) load_w(w1, 1);
-        store_x(buf0);
-        if (nst > 1) load_x(1);
-        __syncthreads();
-        int i = 0;
-        for (; i + 3 < nst; i += 2) {
-            compute(buf0, w0); store_x(buf1); load_x(i + 2); load_w(w0, i + 2); __syncthreads();
-            compute(buf1, w1); store_x(buf0); load_x(i + 3); load_w(w1, i + 3); __syncthreads();
-        }
-        const int rem = nst - i;                         // 1, 2 or 3 stages left
-        compute(buf0, w0);
-        if (rem >= 2) {
-            store_x(buf1);
-            if (rem == 3) { load_x(i + 2); load_w(w0, i + 2); }
+    // prologue: stages 0..R-1 of A and W in flight; stage q of A lives in ring slot q % XR
+    load_x(xr[0], 0);
+    load_w(w[0], 0);
+    store_x(lds, xr[0]);
+#pragma unroll
+    for (int r = 1; r < R; ++r)
+        if (r < nst) { load_x(xr[r % XR], r); load_w(w[r], r); }
+    __syncthreads();
+
+    int i = 0;
+    // steady state: stage j = i + ph; every ring / buffer index below is a compile-time constant
+    for (; i + U + R - 1 < nst; i += U) {
+#pragma unroll
+        for (int ph = 0; ph < U; ++ph) {
+            compute(lds + (ph & 1) * UNITS, w[ph % R]);
+            store_x(lds + ((ph + 1) & 1) * UNITS, xr[(ph + 1) % XR]);
+            load_x(xr[(ph + 1) % XR], i + ph + R);          // same slot: (ph + R) % XR == (ph + 1) % XR
+            load_w(w[ph % R], i + ph + R);
             __syncthreads();
-            compute(buf1, w1);
-            if (rem == 3) {
-                store_x(buf0);
+        }
+    }
+    // tail: at most U + R - 1 stages, guarded (block-uniform conditions)
+#pragma unroll
+    for (int ph = 0; ph < U + R - 1; ++ph) {
+        const int j = i + ph;
+        if (j < nst) {
+            compute(lds + (ph & 1) * UNITS, w[ph % R]);
+            if (j + 1 < nst) {
+                store_x(lds + ((ph + 1) & 1) * UNITS, xr[(ph + 1) % XR]);
+                if (j + R < nst) { load_x(xr[(ph + 1) % XR], j + R); load_w(w[ph % R], j + R); }
                 __syncthreads();
-                compute(buf0, w0);
             }
         }
     }
@@ -208,23 +223,28 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
     }
 }
 
-template <int NW, int MB>
+template <int NW, int MB, int R>
 static int launch_gemm(const GemmP& p, int epi, hipStream_t st) {
     const int ntiles = p.N / (32 * NW);
     dim3 grid(ntiles * p.S, p.RB / MB);
     const size_t lds = (size_t)2 * MB * 256 * 16;
     if (epi == BD_EPI_PARTIAL)
-        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_PARTIAL>), grid, dim3(NW * 64), lds, st, p);
+        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_PARTIAL, R>), grid, dim3(NW * 64), lds, st, p);
     else if (epi == BD_EPI_BF16)
-        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_BF16>), grid, dim3(NW * 64), lds, st, p);
+        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_BF16, R>), grid, dim3(NW * 64), lds, st, p);
     else
-        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_SWIGLU>), grid, dim3(NW * 64), lds, st, p);
+        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_SWIGLU, R>), grid, dim3(NW * 64), lds, st, p);
     return bd_launch_status();
 }
 
 // A: fragment-major bf16, RB row blocks (RB must be 1, 2 or a multiple of 4).  W: packed.  N % (32*nw) == 0, K % 64 == 0.
-int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw, int epi,
+// `nw_ring` = waves per workgroup (2, 4, 8) + 16 * ring, ring in {0 (=2), 3, 4}: stages of W/A a wave keeps in flight.
+int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_ring, int epi,
              float* out_partial, void* out_act, const void* bias, hipStream_t st) {
+    const int nw = nw_ring & 15;
+    int ring = nw_ring >> 4;
+    if (ring == 0) ring = 2;
+    if (ring < 2 || ring > 4) return -7;
     if (K % 64 || N % (32 * nw) || S < 1) return -2;
     const int nst_total = K / 64, q = (nst_total + S - 1) / S;
     if ((S - 1) * q >= nst_total) return -3;                       // an empty split
@@ -234,11 +254,14 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw, 
     // else 128 / 64 / 32
     const int MB = (RB % 8 == 0 && nw >= 4) ? 8 : ((RB % 4 == 0) ? 4 : RB);
     if (MB != 8 && MB != 4 && MB != 2 && MB != 1) return -5;
-#define BD_CASE(NWV, MBV) if (nw == NWV && MB == MBV) return launch_gemm<NWV, MBV>(p, epi, st);
-    BD_CASE(4, 8) BD_CASE(8, 8)
-    BD_CASE(2, 4) BD_CASE(4, 4) BD_CASE(8, 4)
-    BD_CASE(2, 2) BD_CASE(4, 2) BD_CASE(8, 2)
-    BD_CASE(2, 1) BD_CASE(4, 1) BD_CASE(8, 1)
+    if (MB == 8 || nw == 2) ring = 2;                              // register budget
+#define BD_CASE(NWV, MBV, RV) if (nw == NWV && MB == MBV && ring == RV) return launch_gemm<NWV, MBV, RV>(p, epi, st);
+    if (MB <= 2 && ring == 3) ring = 4;
+    if (MB == 1) ring = 2;
+    BD_CASE(4, 8, 2) BD_CASE(8, 8, 2)
+    BD_CASE(2, 4, 2) BD_CASE(4, 4, 2) BD_CASE(8, 4, 2) BD_CASE(4, 4, 3) BD_CASE(8, 4, 3) BD_CASE(4, 4, 4) BD_CASE(8, 4, 4)
+    BD_CASE(2, 2, 2) BD_CASE(4, 2, 2) BD_CASE(8, 2, 2) BD_CASE(4, 2, 4) BD_CASE(8, 2, 4)
+    BD_CASE(2, 1, 2) BD_CASE(4, 1, 2) BD_CASE(8, 1, 2)
 #undef BD_CASE
     return -6;
 }

@@ -26,7 +26,8 @@ int bd_pack_weight_swiglu(void* dst_packed, const void* gate_bf16, const void* u
 int bd_rows_to_frag(void* dst_frag, const void* src, int src_is_fp32, int M, int K, int row_blocks, void* stream);
 
 /* ---- F.linear under bf16 autocast (flow_head_parallel_x.py:326-339, HF modeling_qwen3.py:81-83,252-279).
- *      out_partial: [splitk][row_blocks*32][N] fp32 slabs, summed (+bias, bf16 rounding) by the consumer. */
+ *      out_partial: [splitk][row_blocks*32][N] fp32 slabs, summed (+bias, bf16 rounding) by the consumer.
+ *      nwaves = waves per workgroup (2, 4, 8) [+ 16 * ring, ring in {2,3,4} = K stages a wave keeps in flight]. */
 int bd_gemm_partial(const void* a_frag, int row_blocks, const void* w_packed, int N, int K, int splitk, int nwaves,
                     float* out_partial, void* stream);
 /* Linear -> chunk(2) -> silu(h1)*h2 (flow_head:250-251) / down_proj input act_fn(gate)*up (HF:82) */
