@@ -62,22 +62,24 @@ struct bd_ctx {
 
 static int pad_rows(int m) { return m <= 32 ? 32 : (m <= 64 ? 64 : ((m + 127) / 128) * 128); }
 
-// Launch heuristics from the (nwaves, split-K) sweep on MI355X (tools/gemm_sweep.py, profiles/):
-//  * 8 waves (256 output columns per workgroup, A re-read halves) when N allows, else 4, else 2;
-//  * split-K so that ~240 workgroups exist (one per CU); very wide N additionally split 3x for tail balance;
+// Launch heuristics from the (nwaves, ring, split-K) sweeps on MI355X (tools/gemm_sweep.py, profiles/r01_gemm_sweep*):
+//  * 8 waves (256 output columns per workgroup: the A tile is re-read half as often) for wide N or deep K, else 4;
+//  * split-K so that ~180-240 workgroups exist (<= one wave of workgroups over 256 CUs);
 //  * SwiGLU: fused epilogue (S = 1) when the grid fills the chip, otherwise split-K slabs + swiglu_rows.
 static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K, bool swiglu) {
     GemmCfg g;
     const bool two_images = (c->Mpad % 256 == 0);      // 256-row passes (MB = 8) need the 8-wave variant for occupancy
-    g.nw = (N % 256 == 0 && (N >= 7168 || two_images)) ? 8 : ((N % 128 == 0) ? 4 : 2);
     const int nst = K / 64;
+    g.nw = (N % 256 == 0 && (N >= 8192 || K >= 16384 || two_images)) ? 8 : ((N % 128 == 0) ? 4 : 2);
+    // one workgroup per CU and a single wave of workgroups: 10-wave tiles when that lands N/320 just under 256 tiles
+    if (!two_images && N % 320 == 0 && N / 320 > 200 && N / 320 <= 256) g.nw = 10;
     const int ntiles = N / (32 * g.nw);
-    int S = (int)std::lround((g.nw == 8 ? 200.0 : 240.0) / ntiles);
+    int S = (int)std::lround((g.nw >= 8 ? 180.0 : 240.0) / ntiles);
     if (S < 1) S = 1;
-    if (ntiles >= 200 && !swiglu) S = 3;
+    if (ntiles >= 260 && !swiglu) S = 3;               // > 1 wave of workgroups: split for tail balance
     if (swiglu && ntiles >= 120) S = 1;
     g.S = S;
-    g.ring = two_images ? 2 : (g.nw == 8 ? 4 : (g.nw == 4 ? 3 : 2));   // K stages in flight per wave (register budget)
+    g.ring = 2;                                        // K stages in flight per wave; deeper rings measured no gain
     g.S = (int)c->geti("tune." + name + ".S", g.S);
     g.nw = (int)c->geti("tune." + name + ".nw", g.nw);
     g.ring = (int)c->geti("tune." + name + ".ring", g.ring);
@@ -105,6 +107,10 @@ int bd_pack_weight_swiglu(void* dst, const void* gate, const void* up, int F, in
 int bd_rows_to_frag(void* dst, const void* src, int src_is_fp32, int M, int K, int RB, void* stream) {
     BD_TRY(bdk_rows_to_afrag(dst, src_is_fp32 ? (const float*)src : nullptr, src_is_fp32 ? nullptr : src, M, K, RB,
                              (hipStream_t)stream));
+    return 0;
+}
+int bd_probe_read(const void* src, long long bytes, int blocks, void* sink, void* stream) {
+    BD_TRY(bdk_probe_read(src, (size_t)bytes, blocks, sink, (hipStream_t)stream));
     return 0;
 }
 int bd_gemm_partial(const void* a, int RB, const void* w, int N, int K, int S, int nw, float* out, void* stream) {

@@ -254,16 +254,36 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
     // else 128 / 64 / 32
     const int MB = (RB % 8 == 0 && nw >= 4) ? 8 : ((RB % 4 == 0) ? 4 : RB);
     if (MB != 8 && MB != 4 && MB != 2 && MB != 1) return -5;
-    if (MB == 8 || nw == 2) ring = 2;                              // register budget
+    if (MB == 8 || nw == 2 || nw == 10) ring = 2;                  // register budget
 #define BD_CASE(NWV, MBV, RV) if (nw == NWV && MB == MBV && ring == RV) return launch_gemm<NWV, MBV, RV>(p, epi, st);
     if (MB <= 2 && ring == 3) ring = 4;
     if (MB == 1) ring = 2;
-    BD_CASE(4, 8, 2) BD_CASE(8, 8, 2)
+    BD_CASE(4, 8, 2) BD_CASE(8, 8, 2) BD_CASE(10, 4, 2)
     BD_CASE(2, 4, 2) BD_CASE(4, 4, 2) BD_CASE(8, 4, 2) BD_CASE(4, 4, 3) BD_CASE(8, 4, 3) BD_CASE(4, 4, 4) BD_CASE(8, 4, 4)
     BD_CASE(2, 2, 2) BD_CASE(4, 2, 2) BD_CASE(8, 2, 2) BD_CASE(4, 2, 4) BD_CASE(8, 2, 4)
     BD_CASE(2, 1, 2) BD_CASE(4, 1, 2) BD_CASE(8, 1, 2)
 #undef BD_CASE
     return -6;
+}
+
+// measurement support: pure HBM read stream with the GEMM's access pattern (16 B/lane non-temporal loads), result
+// folded into one word per thread so the loads cannot be elided.  Gives the practical read roofline of this chip.
+__global__ __launch_bounds__(256) void probe_read_kernel(const u32x4* __restrict__ src, size_t n16, unsigned* sink) {
+    u32x4 acc = {0, 0, 0, 0};
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        const u32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        acc ^= a ^ b ^ c ^ d;
+    }
+    for (; i < n16; i += stride) acc ^= __builtin_nontemporal_load(src + i);
+    const unsigned r = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
+    if (r == 0x12345678u) sink[0] = r;
+}
+int bdk_probe_read(const void* src, size_t bytes, int blocks, void* sink, hipStream_t st) {
+    BD_LAUNCH(probe_read_kernel, dim3(blocks), dim3(256), 0, st, (const u32x4*)src, bytes / 16, (unsigned*)sink);
+    return bd_launch_status();
 }
 
 int bdk_pack_w(void* dst, const void* src, const void* src2, int panels, int K, int nb0, int mode, hipStream_t st) {

@@ -71,6 +71,8 @@ int bd_prof_enable(bd_ctx* c, int on);
 int bd_prof_count(bd_ctx* c);
 int bd_prof_get(bd_ctx* c, int i, char* name64, float* ms, double* weight_bytes);
 int bd_gemm_config(bd_ctx* c, const char* gemm_name, int* splitk, int* nwaves);
+/* pure HBM read stream with the GEMM's load pattern (16 B/lane non-temporal): the practical read roofline */
+int bd_probe_read(const void* src, long long bytes, int blocks, void* sink, void* stream);
 
 #ifdef __cplusplus
 }
