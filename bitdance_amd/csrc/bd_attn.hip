@@ -125,6 +125,8 @@ __global__ __launch_bounds__(256) void head_attn_kernel(HeadAttnArgs a) {
         for (int r = 0; r < 16; ++r) { p[kb][r] = __expf((sacc[kb][r] - mx) * scale); lsum += p[kb][r]; }
     lsum += __shfl_xor(lsum, 32);
 
+    // O^T = V^T P^T: D[row = d][col = query] -> a lane keeps ONE query (its own row sum normalises it, no shuffles) and
+    // four consecutive d per register quad (8-byte bf16 stores straight into the fragment-major operand of `wo`)
     f32x16 oacc[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
@@ -140,20 +142,23 @@ __global__ __launch_bounds__(256) void head_attn_kernel(HeadAttnArgs a) {
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
                 const u32x4 vf = *reinterpret_cast<const u32x4*>(&Vs[(nb * 32 + (lane & 31)) * VSTR + key0]);
-                oacc[nb] = mfma32(pa[hf], vf, oacc[nb]);
+                oacc[nb] = mfma32(vf, pa[hf], oacc[nb]);
             }
         }
     }
     bf16_t* O = (bf16_t*)a.o_frag;
+    const float inv = 1.0f / lsum;
+    const int row = seq * 64 + wave * 32 + (lane & 31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int qr = mfma_row(r, lane);
-        const float l = __shfl(lsum, qr);
-        const int row = seq * 64 + wave * 32 + qr;
+    for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-            O[afrag_off(row, h * 128 + nb * 32 + (lane & 31), a.RB)] = f2bf(oacc[nb][r] / l);
-    }
+        for (int qd = 0; qd < 4; ++qd) {
+            const int d0 = h * 128 + nb * 32 + 8 * qd + 4 * (lane >> 5);
+            *reinterpret_cast<uint2*>(O + afrag_off(row, d0, a.RB)) =
+                make_uint2(pack2(oacc[nb][4 * qd] / lsum, oacc[nb][4 * qd + 1] / lsum),
+                           pack2(oacc[nb][4 * qd + 2] / lsum, oacc[nb][4 * qd + 3] / lsum));
+        }
+    (void)inv;
 }
 
 int bdk_head_attn(const HeadAttnArgs& a, hipStream_t st) {
@@ -240,11 +245,9 @@ __global__ __launch_bounds__(640) void llm_attn_kernel(LlmAttnArgs a) {
         l_run = l_run * alpha + tsum;
         m_run = m_new;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float al = __shfl(alpha, mfma_row(r, lane));
+        for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) oacc[nb][r] *= al;
-        }
+            for (int nb = 0; nb < 4; ++nb) oacc[nb][r] *= alpha;     // O^T layout: the lane's own query
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             u32x4 pa[2];
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(640) void llm_attn_kernel(LlmAttnArgs a) {
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) {
                     const u32x4 vf = *reinterpret_cast<const u32x4*>(&Vs[(nb * 32 + (lane & 31)) * VSTR + key0]);
-                    oacc[nb] = mfma32(pa[hf], vf, oacc[nb]);
+                    oacc[nb] = mfma32(vf, pa[hf], oacc[nb]);        // O^T[d][query]
                 }
             }
         }
@@ -266,11 +269,14 @@ __global__ __launch_bounds__(640) void llm_attn_kernel(LlmAttnArgs a) {
     float* op = a.o_part + blk * rows * 128;
     float* ml = a.ml_part + blk * rows * 2;
     const int rbase = qh * a.P + half * 32;
+    {
+        float* orow = op + (size_t)(rbase + (lane & 31)) * 128 + 4 * (lane >> 5);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = rbase + mfma_row(r, lane);
+        for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) op[(size_t)row * 128 + nb * 32 + (lane & 31)] = oacc[nb][r];
+            for (int qd = 0; qd < 4; ++qd)
+                *reinterpret_cast<f32x4*>(orow + nb * 32 + 8 * qd) =
+                    (f32x4){oacc[nb][4 * qd], oacc[nb][4 * qd + 1], oacc[nb][4 * qd + 2], oacc[nb][4 * qd + 3]};
     }
     if (lane < 32) { ml[(rbase + lane) * 2] = m_run; ml[(rbase + lane) * 2 + 1] = l_run; }
 }
