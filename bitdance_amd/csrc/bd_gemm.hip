@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
 #pragma unroll
             for (int m = 0; m < MB; ++m) xf[m] = buf[(ksl * MB + m) * 64 + lane];
 #pragma unroll
-            for (int m = 0; m < MB; ++m) acc[m] = mfma32(wr[ksl], xf[m], acc[m]);   // D[n_local][m_local]
+            for (int m = 0; m < MB; ++m) acc[m] = mfma32(xf[m], wr[ksl], acc[m]);
         }
     };
 
@@ -182,60 +182,44 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
         }
     }
 
-    // ---- epilogue.  Operands are (A = W panel, B = activation rows), so D is the TRANSPOSED tile: lane -> activation
-    // row (lane&31), register r -> output column (r&3) + 8*(r>>2) + 4*(lane>>5).  Four consecutive registers are four
-    // consecutive columns: every store below is 16 B (fp32) or 8 B (bf16) wide instead of 4/2 B.
-    const int hh = lane >> 5;
+    // ---- epilogue.  D layout of the 32x32 MFMA: lane -> column (lane&31), reg r -> row (r&3)+8(r>>2)+4(lane>>5)
+    const int col = nb * 32 + (lane & 31);
     if (EPI == BD_EPI_PARTIAL) {
+        float* o = p.out + ((size_t)s * p.Mpad + (size_t)mt * MB * 32) * p.N + col;
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const int row = (mt * MB + m) * 32 + (lane & 31);
-            float* o = p.out + ((size_t)s * p.Mpad + row) * p.N + nb * 32 + 4 * hh;
+        for (int m = 0; m < MB; ++m)
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd)
-                *reinterpret_cast<f32x4*>(o + 8 * qd) =
-                    (f32x4){acc[m][4 * qd], acc[m][4 * qd + 1], acc[m][4 * qd + 2], acc[m][4 * qd + 3]};
-        }
+            for (int r = 0; r < 16; ++r) {
+                const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                o[(size_t)row * p.N] = acc[m][r];
+            }
     } else if (EPI == BD_EPI_BF16) {   // Linear output rounded once to bf16 (what autocast's F.linear returns)
-        float b[16];
+        const float b = p.bias ? bf2f(p.bias[col]) : 0.f;
+        bf16_t* o = p.act + (size_t)mt * MB * 32 * p.N + col;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) b[r] = p.bias ? bf2f(p.bias[nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh]) : 0.f;
+        for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const int row = (mt * MB + m) * 32 + (lane & 31);
-            bf16_t* o = p.act + (size_t)row * p.N + nb * 32 + 4 * hh;
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const unsigned lo = pack2(acc[m][4 * qd] + b[4 * qd], acc[m][4 * qd + 1] + b[4 * qd + 1]);
-                const unsigned hi = pack2(acc[m][4 * qd + 2] + b[4 * qd + 2], acc[m][4 * qd + 3] + b[4 * qd + 3]);
-                *reinterpret_cast<uint2*>(o + 8 * qd) = make_uint2(lo, hi);
+            for (int r = 0; r < 16; ++r) {
+                const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                o[(size_t)row * p.N] = f2bf(acc[m][r] + b);
             }
-        }
-    } else {  // BD_EPI_SWIGLU: panel rows 0..15 = gate features, 16..31 = the matching up features -> registers r and r+8
-        float bg[8], bu[8];
+    } else {  // BD_EPI_SWIGLU: lanes (l&16)==0 hold gate feature f, lanes (l&16)!=0 the matching up feature
+        const float b = p.bias ? bf2f(p.bias[col]) : 0.f;
+        const int f = nb * 16 + (lane & 15);
+        const int F = p.N >> 1;
+        (void)F;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int nl = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            bg[r] = p.bias ? bf2f(p.bias[nb * 32 + nl]) : 0.f;
-            bu[r] = p.bias ? bf2f(p.bias[nb * 32 + 16 + nl]) : 0.f;
-        }
+        for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const int row = (mt * MB + m) * 32 + (lane & 31);
-#pragma unroll
-            for (int qd = 0; qd < 2; ++qd) {
-                float a[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int r = 4 * qd + t;
-                    const float g = bfr(acc[m][r] + bg[r]);           // Linear outputs rounded to bf16
-                    const float u = bfr(acc[m][r + 8] + bu[r]);
-                    a[t] = silu_bf(g) * u;                            // silu -> bf16, product -> bf16 (pack2 rounds)
+            for (int r = 0; r < 16; ++r) {
+                const float v = bfr(acc[m][r] + b);               // Linear output rounded to bf16
+                const float other = __shfl_xor(v, 16);
+                if ((lane & 16) == 0) {
+                    const int row = (mt * MB + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float a = bfr(silu_bf(v) * other);        // silu -> bf16, product -> bf16
+                    p.act[afrag_off(row, f, p.RB)] = f2bf(a);
                 }
-                const int f0 = nb * 16 + 8 * qd + 4 * hh;
-                *reinterpret_cast<uint2*>(p.act + afrag_off(row, f0, p.RB)) = make_uint2(pack2(a[0], a[1]), pack2(a[2], a[3]));
             }
-        }
     }
 }
 
