@@ -77,9 +77,10 @@ def gemm_roofline(pipe) -> dict:
 
 # ---------------------------------------------------------------------------------------------------------
 def cpu_baseline(args) -> dict:
-    """The CPU oracle (port of the reference algorithm, oracle/) on the host cores: one head evaluation at M=128
-    rows and one LLM decoder layer over a 64-token block with ~2k cached tokens, both at true 14B shapes, timed
-    and extrapolated to one image: T = 64*(N+1)*t_head + 63*L*t_layer (AE decode and prefill not included)."""
+    """The CPU oracle (port of the reference algorithm, oracle/) on the host cores, bounded sample (~20 s): ONE of the
+    head's 6 transformer blocks + the stacked adaLN Linear (M = 128 rows) and ONE LLM decoder layer over a 2 x 64-token
+    block with 1k cached tokens, all at true 14B shapes; extrapolated to one image:
+    T = AR * (N+1) * (nblocks * t_block + t_ada) + (AR-1) * L * t_layer   (prefill, final layer, AE decode excluded)."""
     from oracle import diff_head, qwen3
     from oracle.numerics import Policy
     from bitdance_amd import synthetic as syn
@@ -87,30 +88,29 @@ def cpu_baseline(args) -> dict:
     big = args.size == "14b-64x"
     hc, lc = (syn.HEAD_14B_64X, syn.QWEN3_14B) if big else (syn.TINY_HEAD, syn.TINY_LLM)
     pol = Policy("autocast")
-    D, C, Z = hc["ch_latent"], hc["ch_target"], hc["ch_cond"]
+    D = hc["ch_latent"]
     H = int(D * 1.5)
     bf = torch.bfloat16
     cw = lambda *s: torch.full(s, 0.01, dtype=bf)
     w = {}
-    for nme, n, k in [("net.time_embed.mlp.0", D, 256), ("net.time_embed.mlp.2", D, D), ("net.cond_embed", D, Z),
-                      ("net.input_proj", D, C), ("net.final_layer.ada_ln_modulation", 2 * D, D),
-                      ("net.final_layer.linear", C, D)]:
-        w[nme + ".weight"], w[nme + ".bias"] = cw(n, k), cw(n)
-    for j in range(hc["depth_adanln"]):
-        w[f"net.ada_ln_blocks.{j}.weight"], w[f"net.ada_ln_blocks.{j}.bias"] = cw(6 * D, D), cw(6 * D)
-    for i in range(hc["depth_latent"]):
-        p = f"net.res_blocks.{i}."
-        for nn_ in ("norm1", "norm2"):
-            w[p + nn_ + ".weight"], w[p + nn_ + ".bias"] = torch.ones(D), torch.zeros(D)
-        for nme, n, k in [("attn.wqkv", 3 * D, D), ("attn.wo", D, D), ("w1", 2 * H, D), ("w2", D, H)]:
-            w[p + nme + ".weight"], w[p + nme + ".bias"] = cw(n, k), cw(n)
-    M = 128
-    x, t, c = torch.randn(M // 64, 64, C), torch.full((M // 64,), 0.3), torch.randn(M // 64, 64, Z)
-    t0 = time.perf_counter()
+    p = "net.res_blocks.0."
+    for nn_ in ("norm1", "norm2"):
+        w[p + nn_ + ".weight"], w[p + nn_ + ".bias"] = torch.ones(D), torch.zeros(D)
+    for nme, n, k in [("attn.wqkv", 3 * D, D), ("attn.wo", D, D), ("w1", 2 * H, D), ("w2", D, H)]:
+        w[p + nme + ".weight"], w[p + nme + ".bias"] = cw(n, k), cw(n)
+    nada = hc["depth_adanln"] * 6 * D + 2 * D
+    w_ada, b_ada = cw(nada, D), cw(nada)
+    x = torch.randn(2, 64, D).to(bf)
+    y = torch.randn(2, 64, D).to(bf)
+    mods = [torch.randn(2, 64, D).to(bf) * 0.1 for _ in range(6)]
     with torch.no_grad():
-        diff_head.net_forward(w, x, t, c, pol)
-    t_head = time.perf_counter() - t0
-    del w
+        t0 = time.perf_counter()
+        diff_head.trans_block(w, 0, x, mods, D // 128, pol)
+        t_block = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        pol.linear(y, w_ada, b_ada)
+        t_ada = time.perf_counter() - t0
+    del w, w_ada
     one = dict(lc, num_hidden_layers=1)
     Dl, nh, nkv, hd, ff = lc["hidden_size"], lc["num_attention_heads"], lc["num_key_value_heads"], lc["head_dim"], lc["intermediate_size"]
     lw = {"model.norm.weight": torch.ones(Dl, dtype=bf)}
@@ -120,7 +120,7 @@ def cpu_baseline(args) -> dict:
         lw[p + nme + ".weight"] = cw(n, k)
     for nme, n in [("self_attn.q_norm", hd), ("self_attn.k_norm", hd), ("input_layernorm", Dl), ("post_attention_layernorm", Dl)]:
         lw[p + nme + ".weight"] = torch.ones(n, dtype=bf)
-    past = 2048 if big else 128
+    past = 1024 if big else 128
     cache = [[torch.randn(2, nkv, past, hd).to(bf), torch.randn(2, nkv, past, hd).to(bf)]]
     xin = torch.randn(2, 64, Dl)
     ones = torch.ones(2, 1, 64, past + 64, dtype=torch.bool)
@@ -131,10 +131,12 @@ def cpu_baseline(args) -> dict:
     ar = (args.height // 16) * (args.width // 16) // 64
     n_ev = args.sampling_steps + 1
     L = lc["num_hidden_layers"]
+    t_head = hc["depth_latent"] * t_block + t_ada
     t_img = ar * n_ev * t_head + (ar - 1) * L * t_layer
     return {"value": round(1.0 / t_img, 8), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle (CPU port): 1 head eval M=128 ({t_head:.2f} s) + 1 LLM layer step, 2x64 tokens, "
-                      f"{past} cached ({t_layer:.2f} s), extrapolated x{ar * n_ev} / x{(ar - 1) * L}; excludes prefill+AE"}
+            "sample": f"oracle (CPU port), {'true 14B' if big else 'tiny'} shapes, M=128 rows: 1 head block ({t_block:.2f} s) + adaLN Linear "
+                      f"({t_ada:.2f} s) + 1 LLM layer step 2x64 tokens / {past} cached ({t_layer:.2f} s); extrapolated "
+                      f"x{ar * n_ev} evals, x{(ar - 1) * L} layer steps; excludes prefill, final layer, AE decode"}
 
 
 # ---------------------------------------------------------------------------------------------------------

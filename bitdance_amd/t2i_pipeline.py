@@ -22,6 +22,7 @@ import torch.nn.functional as F
 from .autoencoder import VQModel
 from .engine import Engine, HeadWeights, LlmWeights, ProjWeights
 from .llm import prefill_block
+from .seams import NativeConnector, NativeDiffHead, NativeQwen3Model
 
 IMAGE_SIZE_LIST = [
     [2048, 512], [1920, 512], [1536, 640], [1280, 768], [1152, 896], [1024, 1024], [896, 1152], [768, 1280],
@@ -104,6 +105,10 @@ class BitDanceT2IPipeline:
             raise NotImplementedError("the native path implements the 64x (parallel_num=64) models")
         self.ps = int(self.parallel_num ** 0.5)
         self.proj_w = ProjWeights.from_state_dict(proj_sd, device)
+        # the reference's operator seams (same attribute names), each backed by the native engine
+        self.llm_model = SimpleNamespace(model=NativeQwen3Model(self))
+        self.vision_head = NativeDiffHead(self)
+        self.embed_vision_mlp = NativeConnector(self)
         self.build_pos_embed()
         self._engines: dict = {}
         self._stream = torch.cuda.Stream(device=device)

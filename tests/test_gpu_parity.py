@@ -314,3 +314,45 @@ def test_seed_reproducible_and_rng_order():
             want.append(torch.randn_like(x))
     eng = next(iter(pipe._engines.values()))
     assert torch.equal(eng.noise.view(6, 2, 64, 32).cpu(), torch.stack(want).cpu())
+
+
+def test_reference_loop_on_seams_equals_fused_graph():
+    """The reference's gen_image loop (t2i_pipeline.py:199-268), driven through the drop-in operator seams
+    (llm_model.model / vision_head.sample / embed_vision_mlp), produces bit-identical tokens to the fused
+    hipGraph path for the same seed: same arithmetic per row, same RNG order."""
+    pipe = tiny_pipeline()
+    cfg, n, B, P = 3.0, 3, 1, 64
+    kw = dict(cond_prompt="a red fox", uncond_prompt="<|", guidance_scale=cfg, num_sampling_steps=n, max_length=128,
+              num_images=B, image_size=[256, 128], return_tokens=True)
+    torch.manual_seed(11)
+    fused = pipe.gen_image(**kw).cpu()
+    # --- the reference loop, restated against the seam attributes
+    torch.manual_seed(11)
+    model = pipe.llm_model.model
+    cond_ids, uncond_ids = pipe._prompt_ids("a red fox", "<|", [256, 128], True)
+    pos = pipe.get_2d_embed(16, 8, ps=8).unsqueeze(0)
+    hid, pkv = [], []
+    for ids in (cond_ids, uncond_ids):
+        x = model.embed_tokens(torch.tensor(ids, device=DEV))[None]
+        o = model(inputs_embeds=x[:, :-P], use_cache=True)
+        past = o.past_key_values[0][0].shape[2]
+        ones = torch.ones(B, 1, P, P + past, dtype=torch.bool, device=DEV)
+        o = model(inputs_embeds=x[:, -P:], past_key_values=o.past_key_values, use_cache=True, attention_mask=ones)
+        hid.append(o.last_hidden_state[:, -P:]); pkv.append(o.past_key_values)
+    out = []
+    for step in range(2):
+        sl = slice(step * P, (step + 1) * P)
+        hf = torch.cat(hid, dim=0) + pos[:, sl]
+        pred = pipe.vision_head.sample(hf, num_sampling_steps=n, cfg=cfg)
+        tok = torch.sign(pred)
+        out.append(tok[:B])
+        emb = pipe.embed_vision_mlp(tok) + pos[:, sl]
+        assert emb.dtype == torch.float32
+        ones = torch.ones(2 * B, 1, P, P + pkv[0][0][0].shape[2], dtype=torch.bool, device=DEV)
+        for br in range(2):
+            o = model(inputs_embeds=emb[br * B:(br + 1) * B], past_key_values=pkv[br], use_cache=True,
+                      attention_mask=ones[br * B:(br + 1) * B])
+            pkv[br] = o.past_key_values
+            hid[br] = o.last_hidden_state[:, -P:]
+    seam = torch.cat(out, dim=1).cpu()
+    assert torch.equal(seam, fused)
