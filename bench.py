@@ -179,8 +179,10 @@ def main():
               num_sampling_steps=args.sampling_steps, num_images=args.num_images,
               image_size=[args.height, args.width], max_length=(args.height // 16) * (args.width // 16))
 
+    from bitdance_amd.dist_util import job_throughput, max_over_ranks, rank_seed
+
     def one_pass(i):
-        torch.manual_seed(1234 + 977 * rank + i)
+        torch.manual_seed(rank_seed(1234, rank, i))
         with torch.amp.autocast("cuda", enabled=True, dtype=torch.bfloat16):
             img = pipe.gen_image(**kw)
         return img
@@ -199,15 +201,13 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     assert torch.isfinite(img).all()
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(dt, dist, dev)
 
     out = None
     if rank == 0:
         n = world
         images = n * args.num_images * args.steps
+        assert abs(images / dt - job_throughput(args.num_images, args.steps, dt, n)) < 1e-9
         out = {
             "metric": "images/sec @1024px BitDance-14B-64x" if args.size == "14b-64x" else "images/sec (tiny smoke config)",
             "value": round(images / dt, 5), "unit": "images/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
