@@ -139,7 +139,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
     // The whole A stage goes LDS -> registers in one burst (16 ds_read_b128 for 128 rows), then the MFMAs issue back to
     // back: with the reads interleaved two-at-a-time the matrix pipe idled on LDS latency (the loop was bound by the
     // ds_read -> MFMA chain, not by HBM).  For 256-row passes only half a stage fits the register budget.
-    constexpr int KG = (MB <= 4) ? 4 : 2;                 // k-steps whose A fragments are resident at once
+    constexpr int KG = (MB <= 4 && NW <= 8) ? 4 : 1;      // k-steps whose A fragments are resident at once (VGPR budget)
     auto compute = [&](const u32x4* buf, const u32x4(&wr)[4]) {
 #pragma unroll
         for (int k0 = 0; k0 < 4; k0 += KG) {
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
             for (int kk = 0; kk < KG; ++kk)
 #pragma unroll
                 for (int m = 0; m < MB; ++m) xf[kk][m] = buf[((k0 + kk) * MB + m) * 64 + lane];
-            __builtin_amdgcn_sched_barrier(0);        // keep the burst: hipcc otherwise re-interleaves 2 reads / 2 MFMAs
+            if constexpr (KG > 1) __builtin_amdgcn_sched_barrier(0);   // keep the burst: hipcc otherwise re-interleaves 2 reads / 2 MFMAs
 #pragma unroll
             for (int kk = 0; kk < KG; ++kk)
 #pragma unroll
