@@ -72,7 +72,7 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
     const int nst = K / 64;
     g.nw = (N % 256 == 0 && (N >= 8192 || K >= 16384 || two_images)) ? 8 : ((N % 128 == 0) ? 4 : 2);
     // one workgroup per CU and a single wave of workgroups: 10-wave tiles when that lands N/320 just under 256 tiles
-    if (!two_images && N % 320 == 0 && N / 320 > 200 && N / 320 <= 256) g.nw = 10;
+    if (!two_images && c->Mpad % 128 == 0 && N % 320 == 0 && N / 320 > 200 && N / 320 <= 256) g.nw = 10;
     const int ntiles = N / (32 * g.nw);
     int S = (int)std::lround((g.nw >= 8 ? 180.0 : 240.0) / ntiles);
     if (S < 1) S = 1;
@@ -140,7 +140,7 @@ int bd_ctx_finalize(bd_ctx* c) {
         c->B = (int)c->geti("B");
         c->branches = (int)c->geti("branches");
         c->Pn = (int)c->geti("P");
-        if (c->Pn != 64) return fail("only parallel_num = 64 (64x models) is supported by the native path");
+        if (c->Pn != 64 && c->Pn != 16) return fail("parallel_num must be 64 (64x models) or 16 (16x models)");
         c->BP = c->B * c->Pn;
         c->M = c->branches * c->BP;
         c->Mpad = pad_rows(c->M);
@@ -318,7 +318,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
                         (float*)c->wptr("head.qkv_part"), nullptr, nullptr, st));
         HeadAttnArgs at;
         at.qkv = part(c, "head.qkv_part", c->ptr(pre + "bqkv"), gq.S, 3 * D, Mp);
-        at.o_frag = c->wptr("head.attn_frag"); at.nseq = M / 64; at.nhead = D / 128; at.D = D; at.RB = RB;
+        at.o_frag = c->wptr("head.attn_frag"); at.nseq = M / c->Pn; at.nhead = D / 128; at.D = D; at.RB = RB; at.P = c->Pn;
         BD_TRY(bdk_head_attn(at, st));
         BD_TRY(gemm(c, "head.wo", c->ptr("head.attn_frag"), RB, c->ptr(pre + "wo"), D, D, go.S, go.code(), BD_EPI_PARTIAL,
                         (float*)c->wptr("head.br_part"), nullptr, nullptr, st));

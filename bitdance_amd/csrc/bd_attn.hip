@@ -161,8 +161,64 @@ __global__ __launch_bounds__(256) void head_attn_kernel(HeadAttnArgs a) {
     (void)inv;
 }
 
+// seq <= 32 branch of the reference (flow_head:203-208), here P = 16 (the 16x models): explicit softmax with the
+// reference's bf16 rounding points -- q*scale (bf16), scores = q k^T (bf16 matmul output), softmax in fp32, P cast to
+// bf16 by the second matmul, output bf16.  16x16 scores per head: plain VALU, one thread per (query, key) then per
+// (query, 8 channels).
+__global__ __launch_bounds__(256) void head_attn16_kernel(HeadAttnArgs a) {
+    __shared__ float qs[16 * 132], ks[16 * 132], vs[16 * 132], sc[16 * 17];
+    const int seq = blockIdx.x / a.nhead, h = blockIdx.x % a.nhead;
+    const int tid = threadIdx.x, D = a.D;
+    const Partial& q = a.qkv;
+    const bf16_t* bias = (const bf16_t*)q.bias;
+    const float scale = 0.08838834764831845f;
+    {   // thread -> (row i, 8 channels): Linear outputs (sum of slabs + bias) rounded to bf16
+        const int i = tid >> 4, d0 = (tid & 15) * 8;
+        for (int which = 0; which < 3; ++which) {
+            const int col = which * D + h * 128 + d0;
+            const float* p = q.p + (size_t)(seq * 16 + i) * q.N + col;
+            float* dst = (which == 0 ? qs : (which == 1 ? ks : vs)) + i * 132 + d0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = 0.f;
+                for (int s_ = 0; s_ < q.S; ++s_) v += p[(size_t)s_ * q.Mpad * q.N + j];
+                v = bfr(v + (bias ? bf2f(bias[col + j]) : 0.f));
+                dst[j] = (which == 0) ? bfr(v * scale) : v;        // xq = xq * scale (bf16)
+            }
+        }
+    }
+    __syncthreads();
+    {   // scores[i][j] = bf16( sum_d q_i[d] k_j[d] )
+        const int i = tid >> 4, j = tid & 15;
+        float acc = 0.f;
+        for (int d = 0; d < 128; ++d) acc += qs[i * 132 + d] * ks[j * 132 + d];
+        sc[i * 17 + j] = bfr(acc);
+    }
+    __syncthreads();
+    {   // softmax over j in fp32, then out[i][d0..d0+7] = bf16( sum_j bf16(p_ij) v_j[d] )
+        const int i = tid >> 4, d0 = (tid & 15) * 8;
+        float m = -INFINITY;
+        for (int j = 0; j < 16; ++j) m = fmaxf(m, sc[i * 17 + j]);
+        float e[16], sum = 0.f;
+        for (int j = 0; j < 16; ++j) { e[j] = expf(sc[i * 17 + j] - m); sum += e[j]; }
+        float o[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) o[t] = 0.f;
+        for (int j = 0; j < 16; ++j) {
+            const float pj = bfr(e[j] / sum);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) o[t] += pj * vs[j * 132 + d0 + t];
+        }
+        bf16_t* O = (bf16_t*)a.o_frag;
+        *reinterpret_cast<u32x4*>(O + afrag_off(seq * 16 + i, h * 128 + d0, a.RB)) =
+            (u32x4){pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
+    }
+}
+
 int bdk_head_attn(const HeadAttnArgs& a, hipStream_t st) {
-    BD_LAUNCH(head_attn_kernel, dim3(a.nseq * a.nhead), dim3(256), 0, st, a);
+    if (a.P == 64) BD_LAUNCH(head_attn_kernel, dim3(a.nseq * a.nhead), dim3(256), 0, st, a);
+    else if (a.P == 16) BD_LAUNCH(head_attn16_kernel, dim3(a.nseq * a.nhead), dim3(256), 0, st, a);
+    else return -2;
     return bd_launch_status();
 }
 
@@ -175,8 +231,10 @@ __global__ __launch_bounds__(640) void llm_attn_kernel(LlmAttnArgs a) {
     const int split = blockIdx.x, kvh = blockIdx.y, seq = blockIdx.z;
     const int G = a.nh / a.nkv;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = blockDim.x;
-    const int qh = wave >> 1, half = wave & 1;
+    const int halves = (a.P + 31) / 32;                       // P = 64: two 32-query halves per head; P = 16: one, padded
+    const int qh = wave / halves, half = wave % halves;
     const int head = kvh * G + qh;
+    const bool qvalid = half * 32 + (lane & 31) < a.P;
     const int L = a.state->kv_len[seq] + a.P;                // keys visible to this block of queries
     const int ntiles = (L + 63) >> 6;
     const int per = (ntiles + a.splits - 1) / a.splits;
@@ -187,7 +245,8 @@ __global__ __launch_bounds__(640) void llm_attn_kernel(LlmAttnArgs a) {
 
     u32x4 qf[8];
     {
-        const bf16_t* qp = (const bf16_t*)a.q + ((size_t)(seq * a.P + half * 32 + (lane & 31)) * a.nh + head) * 128 + (lane >> 5) * 8;
+        const int qrow = qvalid ? half * 32 + (lane & 31) : 0;   // padded lanes recompute row 0, never stored
+        const bf16_t* qp = (const bf16_t*)a.q + ((size_t)(seq * a.P + qrow) * a.nh + head) * 128 + (lane >> 5) * 8;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qp + ks * 16);
     }
@@ -269,7 +328,7 @@ __global__ __launch_bounds__(640) void llm_attn_kernel(LlmAttnArgs a) {
     float* op = a.o_part + blk * rows * 128;
     float* ml = a.ml_part + blk * rows * 2;
     const int rbase = qh * a.P + half * 32;
-    {
+    if (qvalid) {
         float* orow = op + (size_t)(rbase + (lane & 31)) * 128 + 4 * (lane >> 5);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
@@ -278,7 +337,7 @@ __global__ __launch_bounds__(640) void llm_attn_kernel(LlmAttnArgs a) {
                 *reinterpret_cast<f32x4*>(orow + nb * 32 + 8 * qd) =
                     (f32x4){oacc[nb][4 * qd], oacc[nb][4 * qd + 1], oacc[nb][4 * qd + 2], oacc[nb][4 * qd + 3]};
     }
-    if (lane < 32) { ml[(rbase + lane) * 2] = m_run; ml[(rbase + lane) * 2 + 1] = l_run; }
+    if (lane < 32 && qvalid) { ml[(rbase + lane) * 2] = m_run; ml[(rbase + lane) * 2 + 1] = l_run; }
 }
 
 __global__ __launch_bounds__(256) void llm_attn_combine_kernel(LlmAttnArgs a) {
@@ -311,8 +370,9 @@ __global__ __launch_bounds__(256) void llm_attn_combine_kernel(LlmAttnArgs a) {
 
 int bdk_llm_attn(const LlmAttnArgs& a, hipStream_t st) {
     const int G = a.nh / a.nkv;
-    if (a.P != 64 || G * 2 * 64 > 640 || a.nh % a.nkv) return -2;   // G <= 5 (Qwen3-14B: 40/8)
-    BD_LAUNCH(llm_attn_kernel, dim3(a.splits, a.nkv, a.nseq), dim3(G * 2 * 64), 0, st, a);
+    const int halves = (a.P + 31) / 32;
+    if ((a.P != 64 && a.P != 16) || G * halves * 64 > 640 || a.nh % a.nkv) return -2;   // G <= 5 (Qwen3-14B: 40/8)
+    BD_LAUNCH(llm_attn_kernel, dim3(a.splits, a.nkv, a.nseq), dim3(G * halves * 64), 0, st, a);
     BD_LAUNCH(llm_attn_combine_kernel, dim3(a.nseq * a.P, (a.nh + 3) / 4), dim3(256), 0, st, a);
     return bd_launch_status();
 }

@@ -149,10 +149,10 @@ struct StepAdvanceArgs { BdStepState* state; int nseq, P; };
 int bdk_step_advance(const StepAdvanceArgs& a, hipStream_t st);
 
 // ---- bd_attn.hip
-struct HeadAttnArgs {       // DiT attention, seq = P = 64, non-causal                           flow_head:192-220
+struct HeadAttnArgs {       // DiT attention over one patch (seq = P = 64 or 16), non-causal      flow_head:192-220
     Partial qkv;            // [.,Mpad,3D]
     void* o_frag;           // out fragment-major bf16 [Mpad][D]
-    int nseq, nhead, D, RB;
+    int nseq, nhead, D, RB, P;
 };
 int bdk_head_attn(const HeadAttnArgs& a, hipStream_t st);
 

@@ -235,11 +235,13 @@ class Engine:
 
     def __init__(self, head: HeadWeights | None, proj: ProjWeights | None, llm: LlmWeights | None, *,
                  num_images: int, branches: int, device, max_tokens: int = 64, max_kv: int = 256,
-                 attn_splits: int = 8, tune: dict | None = None):
+                 attn_splits: int = 8, tune: dict | None = None, parallel_num: int = 64):
         self.l = lib()
         self.device = torch.device(device)
         self.head, self.proj, self.llm = head, proj, llm
-        self.B, self.branches, self.P = num_images, branches, 64
+        if parallel_num not in (16, 64):
+            raise BitDanceHipError("parallel_num must be 64 (64x models) or 16 (16x models)")
+        self.B, self.branches, self.P = num_images, branches, parallel_num
         self.BP = self.B * self.P
         self.M = self.branches * self.BP
         self.max_tokens = max_tokens

@@ -33,12 +33,11 @@ class NativeDiffHead:
         pipe = self._p
         mult = 2 if cfg > 1.0 else 1
         rows, P, _ = z.shape
-        if P != 64:
-            raise NotImplementedError("native head: parallel_num must be 64")
         B = rows // mult
-        key = (B, mult)
+        key = (B, mult, P)
         if key not in self._eng:
-            self._eng[key] = Engine(pipe.head_w, None, None, num_images=B, branches=mult, device=pipe.device)
+            self._eng[key] = Engine(pipe.head_w, None, None, num_images=B, branches=mult, device=pipe.device,
+                                    max_tokens=P, parallel_num=P)
         eng = self._eng[key]
         eng.set_schedule(num_sampling_steps, cfg, 1)
         eng.draw_noise(1)                                   # randn + N x randn_like, the reference's RNG order
@@ -62,11 +61,13 @@ class NativeConnector:
         lead = tokens.shape[:-1]
         t = tokens.reshape(-1, tokens.shape[-1]).to(pipe.device, torch.float32).contiguous()
         n = t.shape[0]
-        if n % 64:
-            raise NotImplementedError("native connector: token count must be a multiple of 64")
-        B = n // 64
+        P = pipe.parallel_num
+        if n % P:
+            raise NotImplementedError(f"native connector: token count must be a multiple of parallel_num={P}")
+        B = n // P
         if B not in self._eng:
-            eng = Engine(None, pipe.proj_w, None, num_images=B, branches=1, device=pipe.device, max_tokens=64)
+            eng = Engine(None, pipe.proj_w, None, num_images=B, branches=1, device=pipe.device, max_tokens=P,
+                         parallel_num=P)
             eng._R = torch.zeros(eng.Mpad, pipe.proj_w.D, dtype=torch.float32, device=pipe.device)
             eng.set_ptr("llm.R", eng._R)
             self._eng[B] = eng
@@ -94,7 +95,7 @@ class NativeKVCache:
 
 class NativeQwen3Model:
     """Qwen3Model.forward as the reference calls it: bf16 prefill calls run on hipBLASLt/SDPA (llm.prefill_block),
-    fp32 64-token decode calls on the native step."""
+    fp32 P-token decode calls on the native step."""
 
     def __init__(self, pipe, max_kv: int = 4608):
         self._p = pipe
@@ -107,19 +108,21 @@ class NativeQwen3Model:
     def __call__(self, inputs_embeds=None, past_key_values=None, use_cache=True, attention_mask=None, **_):
         pipe = self._p
         B, T, _ = inputs_embeds.shape
+        P = pipe.parallel_num
         if past_key_values is None:
-            eng = Engine(None, None, pipe.llm_w, num_images=B, branches=1, device=pipe.device, max_kv=self.max_kv)
+            eng = Engine(None, None, pipe.llm_w, num_images=B, branches=1, device=pipe.device, max_kv=self.max_kv,
+                         max_tokens=P, parallel_num=P)
             eng.set_int("rt.emit_cond", 0)
             cache = NativeKVCache(eng, B, 0)
         else:
             cache = past_key_values
             eng = cache.eng
         past = cache.length
-        if inputs_embeds.dtype == torch.float32 and T == 64 and attention_mask is not None:
+        if inputs_embeds.dtype == torch.float32 and T == P and attention_mask is not None:
             eng.reset([past] * B)                           # decode: all-True mask = block-bidirectional
-            eng.residual()[: B * 64].copy_(inputs_embeds.reshape(B * 64, -1))
+            eng.residual()[: B * P].copy_(inputs_embeds.reshape(B * P, -1))
             eng.llm_step()
-            hidden = eng.hidden().clone().view(B, 64, -1)
+            hidden = eng.hidden().clone().view(B, P, -1)
         else:
             x = inputs_embeds.to(pipe.device, torch.bfloat16)
             hidden = prefill_block(eng, pipe.llm_w, x, 0, past, causal=attention_mask is None)

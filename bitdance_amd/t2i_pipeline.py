@@ -101,8 +101,8 @@ class BitDanceT2IPipeline:
         self.vision_head_config = head_config
         self.head_w = HeadWeights.from_state_dict(head_sd, device)
         self.parallel_num = head_config["parallel_num"]
-        if self.parallel_num != 64:
-            raise NotImplementedError("the native path implements the 64x (parallel_num=64) models")
+        if self.parallel_num not in (16, 64):
+            raise NotImplementedError("the native path implements the 64x and 16x models (parallel_num 64 / 16)")
         self.ps = int(self.parallel_num ** 0.5)
         self.proj_w = ProjWeights.from_state_dict(proj_sd, device)
         # the reference's operator seams (same attribute names), each backed by the native engine
@@ -162,7 +162,7 @@ class BitDanceT2IPipeline:
             torch.cuda.empty_cache()
             self._engines[key] = Engine(self.head_w, self.proj_w, self.llm_w, num_images=num_images,
                                         branches=branches, device=self.device, max_tokens=tokens, max_kv=lmax,
-                                        tune=getattr(self, "tune", None))
+                                        tune=getattr(self, "tune", None), parallel_num=self.parallel_num)
         return self._engines[key]
 
     def _prompt_ids(self, cond_prompt, uncond_prompt, image_size, cfg_on):

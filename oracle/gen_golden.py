@@ -40,10 +40,11 @@ def check_shapes(module, shapes, what):
     assert sd == want, f"{what}: state_dict mismatch: {set(sd) ^ set(want)}"
 
 
-def build_head():
+def build_head(cfg=None):
     from modeling.vision_head.flow_head_parallel_x import DiffHead
-    head = DiffHead(**tm.TINY_HEAD).eval()
-    shapes = tm.head_shapes(tm.TINY_HEAD)
+    cfg = cfg or tm.TINY_HEAD
+    head = DiffHead(**cfg).eval()
+    shapes = tm.head_shapes(cfg)
     check_shapes(head, shapes, "DiffHead")
     head.load_state_dict(tm.seeded_state(shapes, seed=11))
     return head
@@ -87,8 +88,9 @@ def build_ae():
     return ae, shapes
 
 
-def build_pipeline(dtype):
+def build_pipeline(dtype, head_cfg=None):
     from modeling.t2i_pipeline import BitDanceT2IPipeline
+    head_cfg = head_cfg or tm.TINY_HEAD
     pipe = object.__new__(BitDanceT2IPipeline)
     pipe.device = "cpu"
     pipe.tokenizer = tm.FakeTokenizer()
@@ -96,8 +98,8 @@ def build_pipeline(dtype):
     pipe.hidden_size = tm.TINY_LLM["hidden_size"]
     pipe.ae, _ = build_ae()
     pipe.vae_patch_size = 16
-    pipe.vision_head = build_head()
-    pipe.parallel_num = tm.TINY_HEAD["parallel_num"]
+    pipe.vision_head = build_head(head_cfg)
+    pipe.parallel_num = head_cfg["parallel_num"]
     pipe.ps = int(pipe.parallel_num ** 0.5)
     pipe.embed_vision_mlp = build_projector()
     pipe.build_pos_embed()
@@ -166,8 +168,11 @@ def gen_llm():
 
 
 def gen_pipeline():
-    for tag, dtype in (("fp32", torch.float32), ("amp", torch.bfloat16)):
-        pipe = build_pipeline(dtype)
+    jobs = [("gen_fp32", torch.float32, None, [256, 256], 256), ("gen_amp", torch.bfloat16, None, [256, 256], 256),
+            ("gen16_fp32", torch.float32, tm.TINY_HEAD16, [128, 128], 64), ("gen16_amp", torch.bfloat16, tm.TINY_HEAD16, [128, 128], 64)]
+    for name, dtype, hcfg, size, max_len in jobs:
+        tag = name.split("_")[1]
+        pipe = build_pipeline(dtype, hcfg)
         ctx = rh.CudaAutocastOnCpu() if tag == "amp" else torch.no_grad()
         captured = {}
         orig_decode = pipe.decode_image
@@ -188,8 +193,8 @@ def gen_pipeline():
         pipe.vision_head.sample = rec_sample
         with torch.no_grad(), ctx, rh.ReplayNoise(seed=13) as rn:
             img = pipe.gen_image(cond_prompt="a red fox", uncond_prompt="<|", guidance_scale=4.0,
-                                 num_sampling_steps=4, max_length=256, num_images=1, image_size=[256, 256])
-        save(f"gen_{tag}", tokens=captured["tokens"], preds=torch.stack(preds), image=img, noise=torch.stack(rn.record),
+                                 num_sampling_steps=4, max_length=max_len, num_images=1, image_size=size)
+        save(name, tokens=captured["tokens"], preds=torch.stack(preds), image=img, noise=torch.stack(rn.record),
              calls=rn.calls, cfg=np.float32(4.0), n_steps=4)
 
 

@@ -15,6 +15,7 @@ TINY_LLM = dict(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num
                 rope_theta=1000000.0)
 TINY_HEAD = dict(ch_target=32, ch_cond=256, ch_latent=256, depth_latent=4, depth_adanln=2,
                  parallel_num=64, use_swiglu=True, time_shift=1.0)
+TINY_HEAD16 = dict(TINY_HEAD, parallel_num=16)      # the 16x models: 16-token patches, <=32-token attention branch
 TINY_AE = dict(ddconfig=dict(double_z=False, z_channels=32, in_channels=3, out_ch=3, ch=32,
                              ch_mult=[1, 1, 2, 2, 4], num_res_blocks=1))
 

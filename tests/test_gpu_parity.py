@@ -223,14 +223,14 @@ def test_llm_second_step_uses_appended_kv(eng_mod, golden_dir):
 
 
 # ----------------------------------------------------------------------------------------------- whole loop
-def tiny_pipeline():
+def tiny_pipeline(head_cfg=None):
     from bitdance_amd.t2i_pipeline import BitDanceT2IPipeline
     from bitdance_amd.autoencoder import VQModel
     llm_sd = {k: v.to(torch.bfloat16) for k, v in tm.seeded_state(tm.llm_shapes(tm.TINY_LLM), seed=22).items()}
     ae_shapes = {k: tuple(v.shape) for k, v in VQModel(**tm.TINY_AE).state_dict().items()}
     return BitDanceT2IPipeline.from_components(
         tokenizer=tm.FakeTokenizer(), llm_cfg=tm.TINY_LLM, llm_sd=llm_sd, ae_config=tm.TINY_AE,
-        ae_sd=tm.seeded_state(ae_shapes, seed=44, gain=1.4), head_config=dict(tm.TINY_HEAD),
+        ae_sd=tm.seeded_state(ae_shapes, seed=44, gain=1.4), head_config=dict(head_cfg or tm.TINY_HEAD),
         head_sd=tm.seeded_state(tm.head_shapes(tm.TINY_HEAD), seed=11),
         proj_sd=tm.seeded_state(tm.proj_shapes(32, 256), seed=33), device=DEV)
 
@@ -356,3 +356,53 @@ def test_reference_loop_on_seams_equals_fused_graph():
             hid[br] = o.last_hidden_state[:, -P:]
     seam = torch.cat(out, dim=1).cpu()
     assert torch.equal(seam, fused)
+
+
+def test_16x_model_teacher_forced_and_graph(golden_dir):
+    """The 16x models (parallel_num = 16: 16-token patches, the reference's <=32-token attention branch, M = 32 rows):
+    teacher-forced pre-sign latents vs the reference (golden gen16_amp), graph == eager, decode shape."""
+    from bitdance_amd.llm import prefill_block
+    g = load(golden_dir, "gen16_amp")
+    pipe = tiny_pipeline(tm.TINY_HEAD16)
+    assert pipe.parallel_num == 16 and pipe.ps == 4
+    n, cfg, steps, P = int(g["n_steps"]), float(g["cfg"]), 4, 16
+    noise = g["noise"].view(steps, n + 1, 1, P, 32)
+    cond_ids, uncond_ids = pipe._prompt_ids("a red fox", "<|", [128, 128], True)
+    eng = pipe._engine(1, 2, 64, max(len(cond_ids), len(uncond_ids)) + 128)
+    eng.set_schedule(n, cfg, steps)
+    eng.load_noise(noise.to(DEV))
+    pos = pipe.get_2d_embed(8, 8, ps=4)
+    eng.pos[:64].copy_(pos)
+    embed = pipe.llm_w.sd["model.embed_tokens.weight"]
+    hid, kv = [], []
+    for br, ids in enumerate([cond_ids, uncond_ids]):
+        x = torch.nn.functional.embedding(torch.tensor(ids, device=DEV), embed)[None]
+        T0 = x.shape[1] - P
+        prefill_block(eng, pipe.llm_w, x[:, :T0], br, 0, causal=True)
+        hid.append(prefill_block(eng, pipe.llm_w, x[:, T0:], br, T0, causal=False))
+        kv.append(x.shape[1])
+    eng.set_cond((torch.cat(hid)[:, -P:] + pos[None, :P]).reshape(2 * P, -1))
+    eng.reset(kv)
+    preds = []
+    for s_ in range(steps):
+        eng.head_sample()
+        preds.append(eng.pred().clone())
+        eng.tok_cur().copy_(g["tokens"][:, s_ * P:(s_ + 1) * P].to(DEV))
+        if s_ + 1 < steps:
+            eng.projector(); eng.llm_step()
+    torch.cuda.synchronize()
+    pred, ref = torch.stack(preds).cpu(), g["preds"][:, :1]
+    err = (pred - ref).abs()
+    assert err.mean() <= 0.3, err.mean()
+    firm = ref.abs() > 0.5
+    assert (torch.sign(pred)[firm] == torch.sign(ref)[firm]).float().mean() >= 0.95
+    kw = dict(cond_prompt="a red fox", uncond_prompt="<|", guidance_scale=cfg, num_sampling_steps=n, max_length=64,
+              num_images=1, image_size=[128, 128], noise=noise)
+    pipe.use_graph = False
+    te = pipe.gen_image(return_tokens=True, **kw).cpu()
+    pipe.use_graph = True
+    tg = pipe.gen_image(return_tokens=True, **kw).cpu()
+    assert torch.equal(te, tg)
+    assert (tg[:, :P] == g["tokens"][:, :P]).float().mean() >= 0.8
+    img = pipe.gen_image(**kw)
+    assert img.shape == (1, 3, 128, 128) and torch.isfinite(img).all()

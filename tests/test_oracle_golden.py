@@ -95,14 +95,14 @@ def test_llm_amp(golden_dir):
         assert err.max() <= 0.12 and err.mean() <= 1e-2, (err.max(), err.mean())
 
 
-def run_gen(g, pol, dtype, force=None, trace=None):
+def run_gen(g, pol, dtype, force=None, trace=None, P=64, hw=16):
     lw = llm_weights(dtype)
     tok = tm.FakeTokenizer()
     return pipeline.gen_tokens(
         lw, tm.TINY_LLM, head_weights(), tm.seeded_state(tm.proj_shapes(32, 256), seed=33),
         lw["model.embed_tokens.weight"], tok.encode("a red fox"), tok.encode("<|"),
-        [tm.VISION_START, tm.RES_BASE + 16, tm.RES_BASE + 16], [tm.QUERY_BASE + i for i in range(1, 64)],
-        h=16, w=16, parallel_num=64, guidance_scale=float(g["cfg"]), num_sampling_steps=int(g["n_steps"]),
+        [tm.VISION_START, tm.RES_BASE + hw, tm.RES_BASE + hw], [tm.QUERY_BASE + i for i in range(1, P)],
+        h=hw, w=hw, parallel_num=P, guidance_scale=float(g["cfg"]), num_sampling_steps=int(g["n_steps"]),
         num_images=1, noise=list(g["noise"]), pol=Policy(pol), force_tokens=force, trace=trace)
 
 
@@ -129,6 +129,25 @@ def test_gen_tokens_amp_teacher_forced(golden_dir):
     firm = ref.abs() > 0.5                                      # tokens that are not coin flips
     assert (torch.sign(pred)[firm] == torch.sign(ref)[firm]).float().mean() >= 0.97
     assert (out == g["tokens"]).float().mean() >= 0.85
+
+
+def test_gen_tokens_16x_fp32(golden_dir):
+    """16x models (parallel_num = 16, the <=32-token attention branch flow_head:203-208): tokens exact in fp32."""
+    g = load(golden_dir, "gen16_fp32")
+    tr = {}
+    out = run_gen(g, "fp32", torch.float32, trace=tr, P=16, hw=8)
+    assert torch.equal(out, g["tokens"])
+    torch.testing.assert_close(torch.stack(tr["pred"]), g["preds"][:, :1], atol=2e-4, rtol=1e-3)
+
+
+def test_gen_tokens_16x_amp_teacher_forced(golden_dir):
+    g = load(golden_dir, "gen16_amp")
+    tr = {}
+    run_gen(g, "autocast", torch.bfloat16, force=g["tokens"], trace=tr, P=16, hw=8)
+    pred, ref = torch.stack(tr["pred"]), g["preds"][:, :1]
+    assert (pred - ref).abs().mean() <= 0.25
+    firm = ref.abs() > 0.5
+    assert (torch.sign(pred)[firm] == torch.sign(ref)[firm]).float().mean() >= 0.95
 
 
 def test_posembed(golden_dir):
