@@ -51,6 +51,8 @@ _PROTOS = {
     "bd_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "bd_prof_count": (C.c_int, [C.c_void_p]),
     "bd_prof_get": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
+    "bd_gfq_indices": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "bd_gfq_codes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "bd_probe_read": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p]),
     "bd_gemm_config": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }

@@ -109,6 +109,14 @@ int bd_rows_to_frag(void* dst, const void* src, int src_is_fp32, int M, int K, i
                              (hipStream_t)stream));
     return 0;
 }
+int bd_gfq_indices(const float* z, int* idx, int ntok, int ncodebooks, int bits, void* stream) {
+    BD_TRY(bdk_gfq_indices(z, idx, ntok, ncodebooks, bits, (hipStream_t)stream));
+    return 0;
+}
+int bd_gfq_codes(const int* idx, float* codes, int ntok, int ncodebooks, int bits, void* stream) {
+    BD_TRY(bdk_gfq_codes(idx, codes, ntok, ncodebooks, bits, (hipStream_t)stream));
+    return 0;
+}
 int bd_probe_read(const void* src, long long bytes, int blocks, void* sink, void* stream) {
     BD_TRY(bdk_probe_read(src, (size_t)bytes, blocks, sink, (hipStream_t)stream));
     return 0;

@@ -148,6 +148,9 @@ int bdk_qkv_post(const QkvPostArgs& a, hipStream_t st);
 struct StepAdvanceArgs { BdStepState* state; int nseq, P; };
 int bdk_step_advance(const StepAdvanceArgs& a, hipStream_t st);
 
+int bdk_gfq_indices(const float* z, int* idx, int ntok, int ncb, int bits, hipStream_t st);
+int bdk_gfq_codes(const int* idx, float* code, int ntok, int ncb, int bits, hipStream_t st);
+
 // ---- bd_attn.hip
 struct HeadAttnArgs {       // DiT attention over one patch (seq = P = 64 or 16), non-causal      flow_head:192-220
     Partial qkv;            // [.,Mpad,3D]

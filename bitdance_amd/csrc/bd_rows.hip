@@ -477,3 +477,32 @@ int bdk_step_advance(const StepAdvanceArgs& a, hipStream_t st) {
     BD_LAUNCH(step_advance_kernel, dim3(1), dim3(64), 0, st, a);
     return bd_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Group-wise lookup-free quantiser index math (imagenet_gen/src/gfq.py:217-239, :152-160): integer, bit exact.
+//   quantise: idx[t][c] = sum_k (z[t][c*bits + k] > 0) << k ;   codes: code[t][c*bits + k] = bit k of idx ? +1 : -1
+// ------------------------------------------------------------------------------------------------
+__global__ void gfq_indices_kernel(const float* __restrict__ z, int* __restrict__ idx, int ntok, int ncb, int bits) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ntok * ncb) return;
+    const float* p = z + (size_t)(i / ncb) * ncb * bits + (size_t)(i % ncb) * bits;
+    int v = 0;
+    for (int k = 0; k < bits; ++k) v |= (p[k] > 0.f) ? (1 << k) : 0;
+    idx[i] = v;
+}
+__global__ void gfq_codes_kernel(const int* __restrict__ idx, float* __restrict__ code, int ntok, int ncb, int bits) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ntok * ncb * bits) return;
+    const int k = i % bits, tc = i / bits;
+    code[i] = ((idx[tc] >> k) & 1) ? 1.f : -1.f;
+}
+int bdk_gfq_indices(const float* z, int* idx, int ntok, int ncb, int bits, hipStream_t st) {
+    if (bits < 1 || bits > 30) return -2;
+    BD_LAUNCH(gfq_indices_kernel, dim3((ntok * ncb + 255) / 256), dim3(256), 0, st, z, idx, ntok, ncb, bits);
+    return bd_launch_status();
+}
+int bdk_gfq_codes(const int* idx, float* code, int ntok, int ncb, int bits, hipStream_t st) {
+    if (bits < 1 || bits > 30) return -2;
+    BD_LAUNCH(gfq_codes_kernel, dim3((ntok * ncb * bits + 255) / 256), dim3(256), 0, st, idx, code, ntok, ncb, bits);
+    return bd_launch_status();
+}

@@ -66,6 +66,11 @@ int bd_graph_capture(bd_ctx* c, int phase, void* stream);
 int bd_graph_launch(bd_ctx* c, int phase, void* stream);
 int bd_step_reset(bd_ctx* c, const int* kv_len, int nseq, void* stream);   /* step = 0, kv_len[] after prefill */
 
+/* ---- GFQ bit <-> index math of the ImageNet tokenizer (imagenet_gen/src/gfq.py:152-160,217-239): integer, bit exact.
+ *      z/codes: [ntok][ncodebooks*bits] fp32 channels-last; idx: [ntok][ncodebooks] int32 (LSB = first channel). */
+int bd_gfq_indices(const float* z, int* idx, int ntok, int ncodebooks, int bits, void* stream);
+int bd_gfq_codes(const int* idx, float* codes, int ntok, int ncodebooks, int bits, void* stream);
+
 /* ---- measurement support (bench.py): in-situ HIP-event timing of every weight-streaming GEMM launch (eager mode) */
 int bd_prof_enable(bd_ctx* c, int on);
 int bd_prof_count(bd_ctx* c);

@@ -406,3 +406,24 @@ def test_16x_model_teacher_forced_and_graph(golden_dir):
     assert (tg[:, :P] == g["tokens"][:, :P]).float().mean() >= 0.8
     img = pipe.gen_image(**kw)
     assert img.shape == (1, 3, 128, 128) and torch.isfinite(img).all()
+
+
+def test_gfq_index_math_bit_exact():
+    """GFQ sign-quantise -> little-endian index and back (gfq.py:152-160,217-239): integer work, bit exact vs the oracle,
+    exhaustive over all 256 byte patterns plus random multi-codebook tokens with exact zeros."""
+    from bitdance_amd._lib import check, lib
+    from oracle import gfq
+    st = torch.cuda.current_stream().cuda_stream
+    allbits = gfq.codes_from_indices(np.arange(256), 8)                        # [256, 8] +-1
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(1000, 32, generator=g)
+    z[::7, ::5] = 0.0                                                          # zeros quantise to -1 (h > 0 test)
+    z = torch.cat([torch.from_numpy(np.tile(allbits, (1, 4))).float(), z])
+    zd = z.to(DEV).contiguous()
+    idx = torch.empty(z.shape[0], 4, dtype=torch.int32, device=DEV)
+    check(lib().bd_gfq_indices(zd.data_ptr(), idx.data_ptr(), z.shape[0], 4, 8, st))
+    q_ref, idx_ref = gfq.quantize_to_indices(z.numpy(), 4)
+    assert np.array_equal(idx.cpu().numpy(), idx_ref.astype(np.int32))
+    codes = torch.empty_like(zd)
+    check(lib().bd_gfq_codes(idx.data_ptr(), codes.data_ptr(), z.shape[0], 4, 8, st))
+    assert np.array_equal(codes.cpu().numpy(), q_ref)                          # round trip == sign quantisation
