@@ -73,11 +73,13 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
     g.nw = (N % 256 == 0 && (N >= 8192 || K >= 16384 || two_images)) ? 8 : ((N % 128 == 0) ? 4 : 2);
     // one workgroup per CU and a single wave of workgroups: 10-wave tiles when that lands N/320 just under 256 tiles
     if (!two_images && c->Mpad % 128 == 0 && N % 320 == 0 && N / 320 > 200 && N / 320 <= 256) g.nw = 10;
+    // ~120 tiles of 128 columns: two splits give 240 workgroups and only TWO slabs for the consumer to re-read
+    if (!two_images && N % 128 == 0 && N / 128 >= 100 && N / 128 <= 128 && K <= 8192) g.nw = 4;
     const int ntiles = N / (32 * g.nw);
     int S = (int)std::lround((g.nw >= 8 ? 180.0 : 240.0) / ntiles);
     if (S < 1) S = 1;
     if (ntiles >= 260 && !swiglu) S = 3;               // > 1 wave of workgroups: split for tail balance
-    if (swiglu && ntiles >= 120) S = 1;
+    if (swiglu && ntiles >= 130) S = 1;
     g.S = S;
     g.ring = 2;                                        // K stages in flight per wave; deeper rings measured no gain
     g.S = (int)c->geti("tune." + name + ".S", g.S);

@@ -202,6 +202,18 @@ int bdk_ln_mod(const LnModArgs& a, hipStream_t st) {
 // final layer + sampler step.  One workgroup per (image, patch position): its cond row and (CFG) uncond row.
 //   flow_head:169-173,342 ; sampling_x.py:77-95 (+ :6-41) ; t2i_pipeline.py:248 (sign)
 // ------------------------------------------------------------------------------------------------
+// block-wide sum of TWO values at once (cond / uncond row): halves the number of barrier round trips
+BD_DEV void block_sum2(float& v0, float& v1, float* red) {
+    v0 = wave_sum(v0); v1 = wave_sum(v1);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[w] = v0; red[16 + w] = v1; }
+    __syncthreads();
+    float t0 = 0.f, t1 = 0.f;
+    for (int i = 0; i < nw; ++i) { t0 += red[i]; t1 += red[16 + i]; }
+    v0 = t0; v1 = t1;
+}
+
 __global__ __launch_bounds__(640) void head_final_kernel(HeadFinalArgs a) {
     __shared__ float red[32];
     __shared__ float wsum[16][64];
@@ -209,40 +221,48 @@ __global__ __launch_bounds__(640) void head_final_kernel(HeadFinalArgs a) {
     const int bp = blockIdx.x, d0 = threadIdx.x * 8, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwav = blockDim.x >> 6;
     const bool active = d0 < a.D;
+    const bool two = a.sc.cfg_mult == 2;                         // block-uniform
     const bf16_t* ada = (const bf16_t*)a.ada;
-    float h[2][8];
+    const int m0 = bp, m1 = a.BP + bp;
+    // both rows' loads are issued together, their LayerNorm statistics reduced together
+    float x0[8], x1[8], h0[8], h1[8];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) h[r][j] = 0.f;
-        if (r < a.sc.cfg_mult) {                                   // block-uniform
-            const int m = r * a.BP + bp;
-            float x[8];
-            if (active) load_x_pending(x, (const bf16_t*)a.X, a.pend, ada, a.ada_ld, a.gate_off, m, a.D, d0);
-            float mean, rstd;
-            ln_stats(x, active, a.D, a.eps_ln, red, mean, rstd);
-            if (active) {
-                modulate8(x, mean, rstd, nullptr, nullptr, ada + (size_t)m * a.ada_ld, a.scale_off, a.shift_off, d0, h[r]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) h[r][j] = bfr(h[r][j]);   // Linear input cast
-            }
-        }
+    for (int j = 0; j < 8; ++j) { x0[j] = x1[j] = h0[j] = h1[j] = 0.f; }
+    if (active) {
+        load_x_pending(x0, (const bf16_t*)a.X, a.pend, ada, a.ada_ld, a.gate_off, m0, a.D, d0);
+        if (two) load_x_pending(x1, (const bf16_t*)a.X, a.pend, ada, a.ada_ld, a.gate_off, m1, a.D, d0);
     }
-    // D -> C Linear: per channel every thread dots its 8 inputs with the weight row, a wave shuffle-sum folds the
-    // 64 lanes, lane 0 parks the wave total in LDS (the waves are summed below)
-    for (int r = 0; r < a.sc.cfg_mult; ++r) {
-#pragma unroll 4
-        for (int c = 0; c < a.C; ++c) {
-            float s0 = 0.f;
-            if (active) {
-                float w[8];
-                ld_bf16x8((const bf16_t*)a.lin_w + (size_t)c * a.D + d0, w);
+    float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s0 += (r == 0 ? h[0][j] : h[1][j]) * w[j];
-            }
-            s0 = wave_sum(s0);
-            if (lane == 0) wsum[wave][r * 32 + c] = s0;
+    for (int j = 0; j < 8; ++j) { s0 += x0[j]; s1 += x1[j]; }
+    block_sum2(s0, s1, red);
+    const float mean0 = s0 / (float)a.D, mean1 = s1 / (float)a.D;
+    float v0 = 0.f, v1 = 0.f;
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float c0 = x0[j] - mean0, c1 = x1[j] - mean1; v0 += c0 * c0; v1 += c1 * c1; }
+    }
+    block_sum2(v0, v1, red);
+    const float rstd0 = rsqrtf(v0 / (float)a.D + a.eps_ln), rstd1 = rsqrtf(v1 / (float)a.D + a.eps_ln);
+    if (active) {
+        modulate8(x0, mean0, rstd0, nullptr, nullptr, ada + (size_t)m0 * a.ada_ld, a.scale_off, a.shift_off, d0, h0);
+        if (two) modulate8(x1, mean1, rstd1, nullptr, nullptr, ada + (size_t)m1 * a.ada_ld, a.scale_off, a.shift_off, d0, h1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { h0[j] = bfr(h0[j]); h1[j] = bfr(h1[j]); }     // Linear input cast
+    }
+    // D -> C Linear: per channel one 16 B weight load serves both rows; wave shuffle-sums, lane 0 parks the wave totals
+#pragma unroll 8
+    for (int c = 0; c < a.C; ++c) {
+        float p0 = 0.f, p1 = 0.f;
+        if (active) {
+            float w[8];
+            ld_bf16x8((const bf16_t*)a.lin_w + (size_t)c * a.D + d0, w);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { p0 += h0[j] * w[j]; p1 += h1[j] * w[j]; }
         }
+        p0 = wave_sum(p0);
+        p1 = wave_sum(p1);
+        if (lane == 0) { wsum[wave][c] = p0; wsum[wave][32 + c] = p1; }
     }
     __syncthreads();
     if (threadIdx.x < 64) {
