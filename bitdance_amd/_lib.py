@@ -28,6 +28,8 @@ _PROTOS = {
     "bd_pack_weight_swiglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "bd_rows_to_frag": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "bd_gemm_partial": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bd_gemm_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                             C.c_void_p, C.c_void_p, C.c_void_p]),
     "bd_gemm_swiglu": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bd_ctx_create": (C.c_void_p, []),
     "bd_ctx_destroy": (None, [C.c_void_p]),

@@ -124,11 +124,16 @@ int bd_probe_read(const void* src, long long bytes, int blocks, void* sink, void
     return 0;
 }
 int bd_gemm_partial(const void* a, int RB, const void* w, int N, int K, int S, int nw, float* out, void* stream) {
-    BD_TRY(bdk_gemm(a, RB, w, N, K, S, nw, BD_EPI_PARTIAL, out, nullptr, nullptr, (hipStream_t)stream));
+    BD_TRY(bdk_gemm(a, RB, w, N, K, S, nw, BD_EPI_PARTIAL, out, nullptr, nullptr, nullptr, (hipStream_t)stream));
+    return 0;
+}
+int bd_gemm_bf16(const void* a, int RB, const void* w, const void* bias, int N, int K, int S, int nw, float* scratch,
+                 int* counters, void* out_bf16, void* stream) {
+    BD_TRY(bdk_gemm(a, RB, w, N, K, S, nw, BD_EPI_BF16, scratch, out_bf16, bias, counters, (hipStream_t)stream));
     return 0;
 }
 int bd_gemm_swiglu(const void* a, int RB, const void* w, const void* bias, int N2, int K, int nw, void* act, void* stream) {
-    BD_TRY(bdk_gemm(a, RB, w, N2, K, 1, nw, BD_EPI_SWIGLU, nullptr, act, bias, (hipStream_t)stream));
+    BD_TRY(bdk_gemm(a, RB, w, N2, K, 1, nw, BD_EPI_SWIGLU, nullptr, act, bias, nullptr, (hipStream_t)stream));
     return 0;
 }
 
@@ -164,6 +169,7 @@ int bd_ctx_finalize(bd_ctx* c) {
         c->ws.clear();
         auto add = [&](const std::string& n, long long bytes) { c->ws.push_back({n, bytes}); };
         add("state", sizeof(BdStepState));
+        add("gemm.cnt", 16384 * sizeof(int));          // split-K arrival counters (one per output tile), zero between launches
         const long long Mp = c->Mpad;
         if (c->has_head) {
             c->hD = (int)c->geti("head.D"); c->hC = (int)c->geti("head.C"); c->hDz = (int)c->geti("head.Dz");
@@ -189,6 +195,8 @@ int bd_ctx_finalize(bd_ctx* c) {
             add("head.cemb", Mp * c->hD * 2);
             add("head.h_frag", Mp * c->hD * 2);
             add("head.qkv_part", (long long)c->g["head.qkv"].S * Mp * 3 * c->hD * 4);
+            add("head.qkv_bf", Mp * 3 * c->hD * 2);
+            add("head.br_bf", Mp * c->hD * 2);
             add("head.attn_frag", Mp * c->hD * 2);
             add("head.br_part", (long long)sbr * Mp * c->hD * 4);
             add("head.act_frag", Mp * c->hH * 2);
@@ -202,6 +210,7 @@ int bd_ctx_finalize(bd_ctx* c) {
             c->g["proj.fc2"] = choose_cfg(c, "proj.fc2", D, D, false);
             add("proj.h_frag", (long long)c->BPpad * D * 2);
             add("proj.part", (long long)c->g["proj.fc2"].S * c->BPpad * D * 4);
+            add("proj.out_bf", (long long)c->BPpad * D * 2);
         }
         if (c->has_llm) {
             c->lD = (int)c->geti("llm.D"); c->lL = (int)c->geti("llm.L"); c->lnh = (int)c->geti("llm.nh");
@@ -214,13 +223,16 @@ int bd_ctx_finalize(bd_ctx* c) {
             c->g["llm.qkv"] = choose_cfg(c, "llm.qkv", c->lNqkv, c->lD, false);
             c->g["llm.o"] = choose_cfg(c, "llm.o", c->lD, c->lnh * 128, false);
             c->g["llm.gu"] = choose_cfg(c, "llm.gu", 2 * c->lF, c->lD, true);
-            c->g["llm.gu"].S = 1;                              // fused SwiGLU epilogue only
+
             c->g["llm.down"] = choose_cfg(c, "llm.down", c->lD, c->lF, false);
             const int nseq = c->branches * c->B, G = c->lnh / c->lnkv;
             const int sbr = std::max(c->g["llm.o"].S, c->g["llm.down"].S);
             add("llm.R", Mp * c->lD * 4);
             add("llm.a_frag", Mp * c->lD * 2);
             add("llm.qkv_part", (long long)c->g["llm.qkv"].S * Mp * c->lNqkv * 4);
+            add("llm.qkv_bf", Mp * c->lNqkv * 2);
+            add("llm.br_bf", Mp * c->lD * 2);
+            add("llm.gu_part", (long long)c->g["llm.gu"].S * Mp * 2 * c->lF * 4);
             add("llm.q", Mp * c->lnh * 128 * 2);
             add("llm.k_cache", (long long)c->lL * nseq * c->lnkv * c->lLmax * 128 * 2);
             add("llm.vt_cache", (long long)c->lL * nseq * c->lnkv * c->lLmax * 128 * 2);
@@ -271,7 +283,8 @@ static int gemm(bd_ctx* c, const char* name, const void* A, int RB, const void* 
         hipEventCreate(&r.e0); hipEventCreate(&r.e1);
         hipEventRecord(r.e0, st);
     }
-    const int rc = bdk_gemm(A, RB, W, N, K, S, nw, epi, out, act, bias, st);
+    int* cnt = (epi != BD_EPI_PARTIAL && S > 1) ? (int*)c->wptr("gemm.cnt") : nullptr;
+    const int rc = bdk_gemm(A, RB, W, N, K, S, nw, epi, out, act, bias, cnt, st);
     if (c->prof_on) { hipEventRecord(r.e1, st); c->prof.push_back(r); }
     return rc;
 }
@@ -280,14 +293,14 @@ static Partial part(const bd_ctx* c, const std::string& ws, const void* bias, in
     return Partial{(const float*)c->ptr(ws), bias, S, N, Mpad};
 }
 
-static int head_cond(bd_ctx* c, hipStream_t st) {
+static Partial done(const bd_ctx* c, const std::string& ws, int N, int Mpad) {   // finished bf16 Linear output
+    return Partial{(const float*)c->ptr(ws), nullptr, 0, N, Mpad};
+}
+
+static int head_cond(bd_ctx* c, hipStream_t st) {   // cond_embed(c) is constant over the N+1 evals of this AR step
     const GemmCfg& g = c->g["head.cond"];
-    BD_TRY(gemm(c, "head.cond", c->ptr("head.cond_frag"), c->RB, c->ptr("head.cond_w"), c->hD, c->hDz, g.S, g.code(), BD_EPI_PARTIAL,
-                (float*)c->wptr("head.cond_part"), nullptr, nullptr, st));
-    FinalizeRowsArgs fr;                      // cond_embed(c) is constant over the N+1 evals of this AR step
-    fr.in = Partial{(const float*)c->ptr("head.cond_part"), c->ptr("head.cond_b"), g.S, c->hD, c->Mpad};
-    fr.out = c->wptr("head.cemb"); fr.M = c->M; fr.N = c->hD;
-    BD_TRY(bdk_finalize_rows(fr, st));
+    BD_TRY(gemm(c, "head.cond", c->ptr("head.cond_frag"), c->RB, c->ptr("head.cond_w"), c->hD, c->hDz, g.S, g.code(), BD_EPI_BF16,
+                (float*)c->wptr("head.cond_part"), c->wptr("head.cemb"), c->ptr("head.cond_b"), st));
     return 0;
 }
 
@@ -317,43 +330,35 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
         LnModArgs l1;
         l1.X = c->wptr("head.X");
         if (b == 0) l1.pend = Partial{nullptr, nullptr, 0, 0, 0};
-        else l1.pend = part(c, "head.br_part", c->ptr("head.blk" + std::to_string(b - 1) + ".b2"), g2.S, D, Mp);
+        else l1.pend = done(c, "head.br_bf", D, Mp);       // w2 output of the previous block (+bias), finished by its GEMM
         l1.ada = ada; l1.ada_ld = c->hNada;
         l1.gate_off = ((b - 1 < 0 ? 0 : b - 1) / sw) * 6 * D + 5 * D;
         l1.scale_off = base; l1.shift_off = base + D;
         l1.ln_w = (const float*)c->ptr(pre + "ln1_w"); l1.ln_b = (const float*)c->ptr(pre + "ln1_b");
         l1.h_frag = c->wptr("head.h_frag"); l1.M = M; l1.D = D; l1.RB = RB; l1.eps = 1e-6f;
         BD_TRY(bdk_ln_mod(l1, st));
-        BD_TRY(gemm(c, "head.qkv", c->ptr("head.h_frag"), RB, c->ptr(pre + "wqkv"), 3 * D, D, gq.S, gq.code(), BD_EPI_PARTIAL,
-                        (float*)c->wptr("head.qkv_part"), nullptr, nullptr, st));
+        BD_TRY(gemm(c, "head.qkv", c->ptr("head.h_frag"), RB, c->ptr(pre + "wqkv"), 3 * D, D, gq.S, gq.code(), BD_EPI_BF16,
+                        (float*)c->wptr("head.qkv_part"), c->wptr("head.qkv_bf"), c->ptr(pre + "bqkv"), st));
         HeadAttnArgs at;
-        at.qkv = part(c, "head.qkv_part", c->ptr(pre + "bqkv"), gq.S, 3 * D, Mp);
+        at.qkv = done(c, "head.qkv_bf", 3 * D, Mp);
         at.o_frag = c->wptr("head.attn_frag"); at.nseq = M / c->Pn; at.nhead = D / 128; at.D = D; at.RB = RB; at.P = c->Pn;
         BD_TRY(bdk_head_attn(at, st));
-        BD_TRY(gemm(c, "head.wo", c->ptr("head.attn_frag"), RB, c->ptr(pre + "wo"), D, D, go.S, go.code(), BD_EPI_PARTIAL,
-                        (float*)c->wptr("head.br_part"), nullptr, nullptr, st));
+        BD_TRY(gemm(c, "head.wo", c->ptr("head.attn_frag"), RB, c->ptr(pre + "wo"), D, D, go.S, go.code(), BD_EPI_BF16,
+                        (float*)c->wptr("head.br_part"), c->wptr("head.br_bf"), c->ptr(pre + "bo"), st));
         LnModArgs l2 = l1;
-        l2.pend = part(c, "head.br_part", c->ptr(pre + "bo"), go.S, D, Mp);
+        l2.pend = done(c, "head.br_bf", D, Mp);
         l2.gate_off = base + 2 * D; l2.scale_off = base + 3 * D; l2.shift_off = base + 4 * D;
         l2.ln_w = (const float*)c->ptr(pre + "ln2_w"); l2.ln_b = (const float*)c->ptr(pre + "ln2_b");
         BD_TRY(bdk_ln_mod(l2, st));
-        if (g1.S == 1) {
-            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * H, D, 1, g1.code(), BD_EPI_SWIGLU, nullptr,
-                        c->wptr("head.act_frag"), c->ptr(pre + "b1"), st));
-        } else {   // split-K slabs in packed (gate|up interleaved) column order + row-wise SwiGLU
-            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * H, D, g1.S, g1.code(), BD_EPI_PARTIAL,
-                        (float*)c->wptr("head.w1_part"), nullptr, nullptr, st));
-            SwigluArgs sw_;
-            sw_.up = part(c, "head.w1_part", c->ptr(pre + "b1"), g1.S, 2 * H, Mp);
-            sw_.act_frag = c->wptr("head.act_frag"); sw_.M = M; sw_.F = H; sw_.RB = RB; sw_.interleaved = 1;
-            BD_TRY(bdk_swiglu_rows(sw_, st));
-        }
-        BD_TRY(gemm(c, "head.w2", c->ptr("head.act_frag"), RB, c->ptr(pre + "w2"), D, H, g2.S, g2.code(), BD_EPI_PARTIAL,
-                        (float*)c->wptr("head.br_part"), nullptr, nullptr, st));
+        // Linear -> chunk(2) -> silu(h1)*h2, K-slices reduced in the launch, activation written as the next operand
+        BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * H, D, g1.S, g1.code(), BD_EPI_SWIGLU,
+                    (float*)c->wptr("head.w1_part"), c->wptr("head.act_frag"), c->ptr(pre + "b1"), st));
+        BD_TRY(gemm(c, "head.w2", c->ptr("head.act_frag"), RB, c->ptr(pre + "w2"), D, H, g2.S, g2.code(), BD_EPI_BF16,
+                        (float*)c->wptr("head.br_part"), c->wptr("head.br_bf"), c->ptr(pre + "b2"), st));
     }
     HeadFinalArgs fa;
     fa.X = c->ptr("head.X");
-    fa.pend = part(c, "head.br_part", c->ptr("head.blk" + std::to_string(c->hNB - 1) + ".b2"), g2.S, D, Mp);
+    fa.pend = done(c, "head.br_bf", D, Mp);
     fa.ada = ada; fa.ada_ld = c->hNada;
     fa.gate_off = ((c->hNB - 1) / sw) * 6 * D + 5 * D;
     fa.scale_off = c->hNA * 6 * D; fa.shift_off = c->hNA * 6 * D + D;
@@ -389,10 +394,10 @@ static int projector(bd_ctx* c, hipStream_t st) {
                    c->BP, D, (int)c->geti("proj.C"), c->RBp};
     BD_TRY(bdk_proj_fc1(f1, st));
     const GemmCfg& g = c->g["proj.fc2"];
-    BD_TRY(gemm(c, "proj.fc2", c->ptr("proj.h_frag"), c->RBp, c->ptr("proj.w2"), D, D, g.S, g.code(), BD_EPI_PARTIAL,
-                    (float*)c->wptr("proj.part"), nullptr, nullptr, st));
+    BD_TRY(gemm(c, "proj.fc2", c->ptr("proj.h_frag"), c->RBp, c->ptr("proj.w2"), D, D, g.S, g.code(), BD_EPI_BF16,
+                    (float*)c->wptr("proj.part"), c->wptr("proj.out_bf"), c->ptr("proj.b2"), st));
     EmbedFinalizeArgs ef;
-    ef.fc2 = Partial{(const float*)c->ptr("proj.part"), c->ptr("proj.b2"), g.S, D, c->BPpad};
+    ef.fc2 = done(c, "proj.out_bf", D, c->BPpad);
     ef.pos = (const float*)c->ptr("pos"); ef.R = (float*)c->wptr("llm.R");
     ef.state = (const BdStepState*)c->ptr("state"); ef.BP = c->BP; ef.P = c->Pn; ef.D = D; ef.branches = c->branches;
     BD_TRY(bdk_embed_finalize(ef, st));
@@ -410,15 +415,15 @@ static int llm_step(bd_ctx* c, hipStream_t st) {
         const std::string pre = "llm.l" + std::to_string(l) + ".";
         RmsArgs r1;
         r1.R = (float*)c->wptr("llm.R");
-        r1.pend = (l == 0) ? Partial{nullptr, nullptr, 0, 0, 0} : part(c, "llm.br_part", nullptr, gd.S, D, Mp);
+        r1.pend = (l == 0) ? Partial{nullptr, nullptr, 0, 0, 0} : done(c, "llm.br_bf", D, Mp);
         r1.w = c->ptr(pre + "in_norm"); r1.a_frag = c->wptr("llm.a_frag");
         r1.hidden_out = nullptr; r1.cond_frag = nullptr; r1.pos = nullptr; r1.state = state;
         r1.M = M; r1.D = D; r1.RB = RB; r1.P = c->Pn; r1.eps = eps;
         BD_TRY(bdk_rms(r1, st));
-        BD_TRY(gemm(c, "llm.qkv", c->ptr("llm.a_frag"), RB, c->ptr(pre + "wqkv"), c->lNqkv, D, gq.S, gq.code(), BD_EPI_PARTIAL,
-                        (float*)c->wptr("llm.qkv_part"), nullptr, nullptr, st));
+        BD_TRY(gemm(c, "llm.qkv", c->ptr("llm.a_frag"), RB, c->ptr(pre + "wqkv"), c->lNqkv, D, gq.S, gq.code(), BD_EPI_BF16,
+                        (float*)c->wptr("llm.qkv_part"), c->wptr("llm.qkv_bf"), nullptr, st));
         QkvPostArgs qa;
-        qa.qkv = part(c, "llm.qkv_part", nullptr, gq.S, c->lNqkv, Mp);
+        qa.qkv = done(c, "llm.qkv_bf", c->lNqkv, Mp);
         qa.qn_w = c->ptr(pre + "q_norm"); qa.kn_w = c->ptr(pre + "k_norm");
         qa.cos = (const float*)c->ptr("llm.cos"); qa.sin = (const float*)c->ptr("llm.sin");
         qa.q_out = c->wptr("llm.q");
@@ -432,22 +437,22 @@ static int llm_step(bd_ctx* c, hipStream_t st) {
         aa.o_frag = c->wptr("llm.attn_frag"); aa.state = state;
         aa.nseq = nseq; aa.P = c->Pn; aa.nh = nh; aa.nkv = nkv; aa.Lmax = c->lLmax; aa.splits = c->lsplits; aa.RB = RB;
         BD_TRY(bdk_llm_attn(aa, st));
-        BD_TRY(gemm(c, "llm.o", c->ptr("llm.attn_frag"), RB, c->ptr(pre + "wo"), D, nh * 128, go.S, go.code(), BD_EPI_PARTIAL,
-                        (float*)c->wptr("llm.br_part"), nullptr, nullptr, st));
+        BD_TRY(gemm(c, "llm.o", c->ptr("llm.attn_frag"), RB, c->ptr(pre + "wo"), D, nh * 128, go.S, go.code(), BD_EPI_BF16,
+                        (float*)c->wptr("llm.br_part"), c->wptr("llm.br_bf"), nullptr, st));
         RmsArgs r2 = r1;
-        r2.pend = part(c, "llm.br_part", nullptr, go.S, D, Mp);
+        r2.pend = done(c, "llm.br_bf", D, Mp);
         r2.w = c->ptr(pre + "post_norm");
         BD_TRY(bdk_rms(r2, st));
-        BD_TRY(gemm(c, "llm.gu", c->ptr("llm.a_frag"), RB, c->ptr(pre + "wgu"), 2 * F, D, 1, gg.code(), BD_EPI_SWIGLU, nullptr,
-                        c->wptr("llm.act_frag"), nullptr, st));
-        BD_TRY(gemm(c, "llm.down", c->ptr("llm.act_frag"), RB, c->ptr(pre + "wdown"), D, F, gd.S, gd.code(), BD_EPI_PARTIAL,
-                        (float*)c->wptr("llm.br_part"), nullptr, nullptr, st));
+        BD_TRY(gemm(c, "llm.gu", c->ptr("llm.a_frag"), RB, c->ptr(pre + "wgu"), 2 * F, D, gg.S, gg.code(), BD_EPI_SWIGLU,
+                        (float*)c->wptr("llm.gu_part"), c->wptr("llm.act_frag"), nullptr, st));
+        BD_TRY(gemm(c, "llm.down", c->ptr("llm.act_frag"), RB, c->ptr(pre + "wdown"), D, F, gd.S, gd.code(), BD_EPI_BF16,
+                        (float*)c->wptr("llm.br_part"), c->wptr("llm.br_bf"), nullptr, st));
     }
     StepAdvanceArgs sa{state, nseq, c->Pn};
     BD_TRY(bdk_step_advance(sa, st));                       // step+1 / kv_len += P: the next patch's position
     RmsArgs rf;
     rf.R = (float*)c->wptr("llm.R");
-    rf.pend = part(c, "llm.br_part", nullptr, gd.S, D, Mp);
+    rf.pend = done(c, "llm.br_bf", D, Mp);
     rf.w = c->ptr("llm.final_norm"); rf.a_frag = nullptr;
     rf.hidden_out = (float*)c->wptr("llm.hidden");
     const bool emit = c->geti("rt.emit_cond", 1) != 0 && c->has_head;

@@ -59,6 +59,12 @@ __global__ __launch_bounds__(256) void head_attn_kernel(HeadAttnArgs a) {
     const size_t slab = (size_t)q.Mpad * q.N;
 
     auto load8 = [&](int row, int col, float* v) {          // Linear output (sum of slabs + bias), bf16-rounded
+        if (q.S == 0) {                                     // finished bf16 tensor: one 16 B load
+            const u32x4 w = *reinterpret_cast<const u32x4*>((const bf16_t*)q.p + (size_t)row * q.N + col);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[2 * j] = bf2f((bf16_t)(w[j] & 0xffff)); v[2 * j + 1] = bf2f((bf16_t)(w[j] >> 16)); }
+            return;
+        }
         const float* p = q.p + (size_t)row * q.N + col;
         f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
         for (int s = 1; s < q.S; ++s) {
@@ -181,8 +187,12 @@ __global__ __launch_bounds__(256) void head_attn16_kernel(HeadAttnArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float v = 0.f;
-                for (int s_ = 0; s_ < q.S; ++s_) v += p[(size_t)s_ * q.Mpad * q.N + j];
-                v = bfr(v + (bias ? bf2f(bias[col + j]) : 0.f));
+                if (q.S == 0) {
+                    v = bf2f(((const bf16_t*)q.p)[(size_t)(seq * 16 + i) * q.N + col + j]);
+                } else {
+                    for (int s_ = 0; s_ < q.S; ++s_) v += p[(size_t)s_ * q.Mpad * q.N + j];
+                    v = bfr(v + (bias ? bf2f(bias[col + j]) : 0.f));
+                }
                 dst[j] = (which == 0) ? bfr(v * scale) : v;        // xq = xq * scale (bf16)
             }
         }

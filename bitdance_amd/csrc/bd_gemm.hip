@@ -75,6 +75,7 @@ struct GemmP {
     float* out;          // EPI_PARTIAL: [S][Mpad][N] fp32
     bf16_t* act;         // EPI_SWIGLU : fragment-major bf16 [Mpad][N/2];  EPI_BF16: row-major bf16 [Mpad][N]
     const bf16_t* bias;  // EPI_SWIGLU : [N] in PACKED row order (or null); EPI_BF16: [N] (or null)
+    int* cnt;            // EPI_BF16 / EPI_SWIGLU with S > 1: one arrival counter per output tile (zero between launches)
     int RB, N, K, S, Mpad;
 };
 
@@ -193,6 +194,41 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
 
     // ---- epilogue.  D layout of the 32x32 MFMA: lane -> column (lane&31), reg r -> row (r&3)+8(r>>2)+4(lane>>5)
     const int col = nb * 32 + (lane & 31);
+    if (EPI != BD_EPI_PARTIAL && S > 1) {
+        // In-launch split-K reduction ("last arriver reduces"): every K-slice parks its fp32 slab, takes a ticket on the
+        // tile's counter; the slice that draws S-1 adds the other slabs to its registers and runs the real epilogue, so
+        // the consumers read ONE finished bf16 tensor instead of S fp32 slabs.  Placement-independent agent-scope
+        // release/acquire exactly as cdna_hip_programming.md section 5 item 2 / guideline 16 prescribe.
+        float* o = p.out + ((size_t)s * p.Mpad + (size_t)mt * MB * 32) * p.N + col;
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                o[(size_t)(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = acc[m][r];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every storing wave drains its stores
+        __syncthreads();                                                  // (also: all waves are done with the LDS tiles)
+        int* const flag = reinterpret_cast<int*>(smem);
+        int* const ticket = p.cnt + (mt * (p.N / (32 * NW)) + nt);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the compiler may drop the wait behind buffer_wbl2
+            flag[0] = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (flag[0] != S - 1) return;                                     // not the last slice of this tile
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // drop this CU's stale L1 lines
+        __syncthreads();
+        for (int s2 = 0; s2 < S; ++s2) {
+            if (s2 == s) continue;                                        // own slice is still in registers
+            const float* q2 = p.out + ((size_t)s2 * p.Mpad + (size_t)mt * MB * 32) * p.N + col;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[m][r] += q2[(size_t)(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N];
+        }
+        if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+    }
     if (EPI == BD_EPI_PARTIAL) {
         float* o = p.out + ((size_t)s * p.Mpad + (size_t)mt * MB * 32) * p.N + col;
 #pragma unroll
@@ -249,7 +285,7 @@ static int launch_gemm(const GemmP& p, int epi, hipStream_t st) {
 // A: fragment-major bf16, RB row blocks (RB must be 1, 2 or a multiple of 4).  W: packed.  N % (32*nw) == 0, K % 64 == 0.
 // `nw_ring` = waves per workgroup (2, 4, 8) + 16 * ring, ring in {0 (=2), 3, 4}: stages of W/A a wave keeps in flight.
 int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_ring, int epi,
-             float* out_partial, void* out_act, const void* bias, hipStream_t st) {
+             float* out_partial, void* out_act, const void* bias, int* cnt, hipStream_t st) {
     const int nw = nw_ring & 15;
     int ring = nw_ring >> 4;
     if (ring == 0) ring = 2;
@@ -257,8 +293,8 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
     if (K % 64 || N % (32 * nw) || S < 1) return -2;
     const int nst_total = K / 64, q = (nst_total + S - 1) / S;
     if ((S - 1) * q >= nst_total) return -3;                       // an empty split
-    if (epi != BD_EPI_PARTIAL && S != 1) return -4;
-    GemmP p{(const u32x4*)A, (const u32x4*)W, out_partial, (bf16_t*)out_act, (const bf16_t*)bias, RB, N, K, S, RB * 32};
+    if (epi != BD_EPI_PARTIAL && S != 1 && (out_partial == nullptr || cnt == nullptr)) return -4;   // needs slab scratch + counters
+    GemmP p{(const u32x4*)A, (const u32x4*)W, out_partial, (bf16_t*)out_act, (const bf16_t*)bias, cnt, RB, N, K, S, RB * 32};
     // rows per pass over the weights: 256 (two images with CFG: W streamed once for both) when the row count allows,
     // else 128 / 64 / 32
     const int MB = (RB % 8 == 0 && nw >= 4) ? 8 : ((RB % 4 == 0) ? 4 : RB);

@@ -16,16 +16,16 @@ struct BdStepState;
 
 // ---- bd_gemm.hip
 int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw, int epi,
-             float* out_partial, void* out_act, const void* bias, hipStream_t st);
+             float* out_partial, void* out_act, const void* bias, int* tile_counters, hipStream_t st);
 int bdk_pack_w(void* dst, const void* src, const void* src2, int panels, int K, int nb0, int mode, hipStream_t st);
 int bdk_probe_read(const void* src, size_t bytes, int blocks, void* sink, hipStream_t st);
 int bdk_rows_to_afrag(void* dst, const float* src32, const void* src16, int M, int K, int RB, hipStream_t st);
 
 // ---- bd_rows.hip : row-wise kernels (one workgroup per activation row)
-struct Partial {            // split-K slabs of a GEMM output: [S][Mpad][N] fp32 (+ optional bf16 bias[N])
-    const float* p;
-    const void* bias;
-    int S, N, Mpad;
+struct Partial {            // a Linear output as the consumer sees it:
+    const float* p;         //   S >= 1: split-K slabs [S][Mpad][N] fp32 (+ optional bf16 bias[N]) to be summed and rounded
+    const void* bias;       //   S == 0: p is a FINISHED bf16 row-major [Mpad][N] tensor (bias added, rounded) -- the
+    int S, N, Mpad;         //           GEMM reduced its own K-slices (last-arriver epilogue)
 };
 
 // diffusion head

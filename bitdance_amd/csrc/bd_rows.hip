@@ -34,6 +34,10 @@ BD_DEV u32x4 pack8(const float* v) {
 }
 // Linear output of 8 consecutive columns: bf16( sum of split-K slabs + bias )
 BD_DEV void slab8(const Partial& q, int row, int col, float* v) {
+    if (q.S == 0) {                                     // finished bf16 tensor (the GEMM reduced its own K-slices)
+        ld_bf16x8((const bf16_t*)q.p + (size_t)row * q.N + col, v);
+        return;
+    }
     const float* p = q.p + (size_t)row * q.N + col;
     const size_t slab = (size_t)q.Mpad * q.N;
     ld_f32x8(p, v);
@@ -55,6 +59,7 @@ BD_DEV void slab8(const Partial& q, int row, int col, float* v) {
 
 // scalar helpers (small kernels)
 BD_DEV float slab_sum(const Partial& q, int row, int col) {
+    if (q.S == 0) return bf2f(((const bf16_t*)q.p)[(size_t)row * q.N + col]);
     float a = 0.f;
     const float* p = q.p + (size_t)row * q.N + col;
     for (int s = 0; s < q.S; ++s) a += p[(size_t)s * q.Mpad * q.N];

@@ -30,6 +30,11 @@ int bd_rows_to_frag(void* dst_frag, const void* src, int src_is_fp32, int M, int
  *      nwaves = waves per workgroup (2, 4, 8) [+ 16 * ring, ring in {2,3,4} = K stages a wave keeps in flight]. */
 int bd_gemm_partial(const void* a_frag, int row_blocks, const void* w_packed, int N, int K, int splitk, int nwaves,
                     float* out_partial, void* stream);
+/* The same Linear with the split-K slices reduced INSIDE the launch (the last-arriving slice of each tile sums the
+ * others' slabs, adds the bias and rounds once): out_bf16 [row_blocks*32][N] row-major is exactly what F.linear returns
+ * under autocast.  scratch: [splitk][rows][N] fp32; counters: one int per output tile, zero on entry, zero on exit. */
+int bd_gemm_bf16(const void* a_frag, int row_blocks, const void* w_packed, const void* bias_bf16, int N, int K, int splitk,
+                 int nwaves, float* scratch, int* counters, void* out_bf16, void* stream);
 /* Linear -> chunk(2) -> silu(h1)*h2 (flow_head:250-251) / down_proj input act_fn(gate)*up (HF:82) */
 int bd_gemm_swiglu(const void* a_frag, int row_blocks, const void* w_packed_pairs, const void* bias_packed, int N2, int K,
                    int nwaves, void* act_frag, void* stream);

@@ -427,3 +427,36 @@ def test_gfq_index_math_bit_exact():
     codes = torch.empty_like(zd)
     check(lib().bd_gfq_codes(idx.data_ptr(), codes.data_ptr(), z.shape[0], 4, 8, st))
     assert np.array_equal(codes.cpu().numpy(), q_ref)                          # round trip == sign quantisation
+
+
+@pytest.mark.parametrize("M,N,K,S,nw", [(128, 256, 256, 4, 4), (128, 5120, 5120, 6, 4), (128, 15360, 5120, 2, 4),
+                                         (128, 15360, 5120, 3, 8), (256, 5120, 7680, 9, 8), (32, 512, 384, 3, 2)])
+def test_gemm_in_launch_splitk_reduction(eng_mod, M, N, K, S, nw):
+    """Split-K slices reduced inside the launch (last-arriver epilogue, agent-scope release/acquire): the bf16 output
+    equals bf16(fp64 reference + bias) up to accumulation-order flips, on every one of several back-to-back launches
+    (the tile counters must re-arm themselves), and under concurrent load from a streaming kernel."""
+    from bitdance_amd._lib import check, lib
+    g = torch.Generator(device=DEV).manual_seed(N + K + S)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = (torch.randn(N, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+    xf, rb = frag(eng_mod, x)
+    wp = eng_mod.pack_linear([w], DEV)
+    scratch = torch.empty(S * rb * 32 * N, device=DEV)
+    cnt = torch.zeros(16384, dtype=torch.int32, device=DEV)
+    ref = (x.to(torch.bfloat16).double() @ w.double().t() + b.double())[:M]
+    st = torch.cuda.current_stream().cuda_stream
+    big = torch.empty(1 << 28, dtype=torch.uint8, device=DEV)
+    sink = torch.zeros(4, dtype=torch.int32, device=DEV)
+    for it in range(6):
+        out = torch.full((rb * 32, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        if it % 2:                                           # uneven background load on the memory system
+            check(lib().bd_probe_read(big.data_ptr(), big.numel(), 97, sink.data_ptr(), st))
+        check(lib().bd_gemm_bf16(xf.data_ptr(), rb, wp.data_ptr(), b.data_ptr(), N, K, S, nw, scratch.data_ptr(),
+                                 cnt.data_ptr(), out.data_ptr(), st))
+        torch.cuda.synchronize()
+        assert int(cnt.abs().sum()) == 0                     # counters re-armed
+        d = (out[:M].double() - ref).abs()
+        tol = 2.0 ** -7 * ref.abs().clamp_min(1.0)           # one bf16 ulp
+        assert bool((d <= tol).all()), (it, float(d.max()))
+        assert float((d > 2.0 ** -9 * ref.abs().clamp_min(1.0)).double().mean()) <= 0.02
