@@ -79,28 +79,50 @@ __global__ __launch_bounds__(256) void head_attn_kernel(HeadAttnArgs a) {
     };
 
     // stage K [key][d] and V^T [d][key] of this (seq, head): all 4 waves; waves 0/1 then own 32 queries each.
-    // Fully unrolled so that the 4 x (K + V) x S slab loads of a thread are all in flight together.
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int u = tid + it * 256;
-        const int key = u >> 4, dp = (u & 15) * 8;
-        float kv[8], vv[8];
-        load8(seq * 64 + key, D + h * 128 + dp, kv);
-        load8(seq * 64 + key, 2 * D + h * 128 + dp, vv);
-        *reinterpret_cast<u32x4*>(&Ks[key * KSTR + dp]) =
-            (u32x4){pack2(kv[0], kv[1]), pack2(kv[2], kv[3]), pack2(kv[4], kv[5]), pack2(kv[6], kv[7])};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) Vs[(dp + j) * VSTR + key] = f2bf(vv[j]);
-    }
-    // Q operand fragments (B of S^T = K Q^T): lane -> query (lane&31), 8 consecutive d
     u32x4 qf[8];
     const int qrow = seq * 64 + (wave & 1) * 32 + (lane & 31);
-    if (wave < 2) {
+    if (q.S == 0) {
+        // finished bf16 qkv (the GEMM reduced its K-slices): K rows are straight 16 B copies, Q fragments 16 B loads
+        const bf16_t* base = (const bf16_t*)q.p;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            float v[8];
-            load8(qrow, h * 128 + ks * 16 + (lane >> 5) * 8, v);
-            qf[ks] = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+        for (int it = 0; it < 4; ++it) {
+            const int u = tid + it * 256;
+            const int key = u >> 4, dp = (u & 15) * 8;
+            const bf16_t* row = base + (size_t)(seq * 64 + key) * q.N + h * 128 + dp;
+            *reinterpret_cast<u32x4*>(&Ks[key * KSTR + dp]) = *reinterpret_cast<const u32x4*>(row + D);
+            const u32x4 vv = *reinterpret_cast<const u32x4*>(row + 2 * D);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                Vs[(dp + 2 * j) * VSTR + key] = (bf16_t)(vv[j] & 0xffff);
+                Vs[(dp + 2 * j + 1) * VSTR + key] = (bf16_t)(vv[j] >> 16);
+            }
+        }
+        if (wave < 2) {
+            const bf16_t* qp = base + (size_t)qrow * q.N + h * 128 + (lane >> 5) * 8;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qp + ks * 16);
+        }
+    } else {
+        // split-K slabs: fully unrolled so that the 4 x (K + V) x S slab loads of a thread are all in flight together
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int u = tid + it * 256;
+            const int key = u >> 4, dp = (u & 15) * 8;
+            float kv[8], vv[8];
+            load8(seq * 64 + key, D + h * 128 + dp, kv);
+            load8(seq * 64 + key, 2 * D + h * 128 + dp, vv);
+            *reinterpret_cast<u32x4*>(&Ks[key * KSTR + dp]) =
+                (u32x4){pack2(kv[0], kv[1]), pack2(kv[2], kv[3]), pack2(kv[4], kv[5]), pack2(kv[6], kv[7])};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Vs[(dp + j) * VSTR + key] = f2bf(vv[j]);
+        }
+        if (wave < 2) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                float v[8];
+                load8(qrow, h * 128 + ks * 16 + (lane >> 5) * 8, v);
+                qf[ks] = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+            }
         }
     }
     __syncthreads();
