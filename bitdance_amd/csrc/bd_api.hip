@@ -297,10 +297,28 @@ static Partial done(const bd_ctx* c, const std::string& ws, int N, int Mpad) {  
     return Partial{(const float*)c->ptr(ws), nullptr, 0, N, Mpad};
 }
 
+// A Linear whose output the consumer reads as bf16(sum + bias).  Few K-slices: the GEMM reduces them in the launch
+// (last-arriver epilogue) and the consumer reads one bf16 tensor.  Many K-slices: the serial tail of a single reducing
+// workgroup (S x 64-128 KiB through one CU) costs more than it saves, so the slabs stay and the consumer sums them.
+static int linear(bd_ctx* c, const char* name, const void* A, int RB, const void* W, int N, int K, const GemmCfg& g,
+                  const char* scratch_ws, const char* out_ws, const void* bias, int Mpad, Partial* res, hipStream_t st,
+                  bool force_reduce = false) {
+    const int max_s = (int)c->geti("tune.reduce_max_s", 3);
+    if (g.S <= max_s || force_reduce) {
+        BD_TRY(gemm(c, name, A, RB, W, N, K, g.S, g.code(), BD_EPI_BF16, (float*)c->wptr(scratch_ws), c->wptr(out_ws), bias, st));
+        *res = Partial{(const float*)c->ptr(out_ws), nullptr, 0, N, Mpad};
+    } else {
+        BD_TRY(gemm(c, name, A, RB, W, N, K, g.S, g.code(), BD_EPI_PARTIAL, (float*)c->wptr(scratch_ws), nullptr, nullptr, st));
+        *res = Partial{(const float*)c->ptr(scratch_ws), bias, g.S, N, Mpad};
+    }
+    return 0;
+}
+
 static int head_cond(bd_ctx* c, hipStream_t st) {   // cond_embed(c) is constant over the N+1 evals of this AR step
     const GemmCfg& g = c->g["head.cond"];
-    BD_TRY(gemm(c, "head.cond", c->ptr("head.cond_frag"), c->RB, c->ptr("head.cond_w"), c->hD, c->hDz, g.S, g.code(), BD_EPI_BF16,
-                (float*)c->wptr("head.cond_part"), c->wptr("head.cemb"), c->ptr("head.cond_b"), st));
+    Partial unused;
+    BD_TRY(linear(c, "head.cond", c->ptr("head.cond_frag"), c->RB, c->ptr("head.cond_w"), c->hD, c->hDz, g, "head.cond_part",
+                  "head.cemb", c->ptr("head.cond_b"), c->Mpad, &unused, st, /*force_reduce=*/true));
     return 0;
 }
 
@@ -324,41 +342,39 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
     const void* ada = c->ptr("head.ada_bf");
     const int sw = c->hNB / c->hNA;
     const GemmCfg &gq = c->g["head.qkv"], &go = c->g["head.wo"], &g1 = c->g["head.w1"], &g2 = c->g["head.w2"];
+    Partial br{nullptr, nullptr, 0, 0, 0};                    // pending gated branch output (wo / w2)
     for (int b = 0; b < c->hNB; ++b) {
         const std::string pre = "head.blk" + std::to_string(b) + ".";
         const int base = (b / sw) * 6 * D;
         LnModArgs l1;
         l1.X = c->wptr("head.X");
-        if (b == 0) l1.pend = Partial{nullptr, nullptr, 0, 0, 0};
-        else l1.pend = done(c, "head.br_bf", D, Mp);       // w2 output of the previous block (+bias), finished by its GEMM
+        l1.pend = br;                                      // w2 output of the previous block (none for block 0)
         l1.ada = ada; l1.ada_ld = c->hNada;
         l1.gate_off = ((b - 1 < 0 ? 0 : b - 1) / sw) * 6 * D + 5 * D;
         l1.scale_off = base; l1.shift_off = base + D;
         l1.ln_w = (const float*)c->ptr(pre + "ln1_w"); l1.ln_b = (const float*)c->ptr(pre + "ln1_b");
         l1.h_frag = c->wptr("head.h_frag"); l1.M = M; l1.D = D; l1.RB = RB; l1.eps = 1e-6f;
         BD_TRY(bdk_ln_mod(l1, st));
-        BD_TRY(gemm(c, "head.qkv", c->ptr("head.h_frag"), RB, c->ptr(pre + "wqkv"), 3 * D, D, gq.S, gq.code(), BD_EPI_BF16,
-                        (float*)c->wptr("head.qkv_part"), c->wptr("head.qkv_bf"), c->ptr(pre + "bqkv"), st));
         HeadAttnArgs at;
-        at.qkv = done(c, "head.qkv_bf", 3 * D, Mp);
+        BD_TRY(linear(c, "head.qkv", c->ptr("head.h_frag"), RB, c->ptr(pre + "wqkv"), 3 * D, D, gq, "head.qkv_part", "head.qkv_bf",
+                      c->ptr(pre + "bqkv"), Mp, &at.qkv, st));
         at.o_frag = c->wptr("head.attn_frag"); at.nseq = M / c->Pn; at.nhead = D / 128; at.D = D; at.RB = RB; at.P = c->Pn;
         BD_TRY(bdk_head_attn(at, st));
-        BD_TRY(gemm(c, "head.wo", c->ptr("head.attn_frag"), RB, c->ptr(pre + "wo"), D, D, go.S, go.code(), BD_EPI_BF16,
-                        (float*)c->wptr("head.br_part"), c->wptr("head.br_bf"), c->ptr(pre + "bo"), st));
         LnModArgs l2 = l1;
-        l2.pend = done(c, "head.br_bf", D, Mp);
+        BD_TRY(linear(c, "head.wo", c->ptr("head.attn_frag"), RB, c->ptr(pre + "wo"), D, D, go, "head.br_part", "head.br_bf",
+                      c->ptr(pre + "bo"), Mp, &l2.pend, st));
         l2.gate_off = base + 2 * D; l2.scale_off = base + 3 * D; l2.shift_off = base + 4 * D;
         l2.ln_w = (const float*)c->ptr(pre + "ln2_w"); l2.ln_b = (const float*)c->ptr(pre + "ln2_b");
         BD_TRY(bdk_ln_mod(l2, st));
         // Linear -> chunk(2) -> silu(h1)*h2, K-slices reduced in the launch, activation written as the next operand
         BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * H, D, g1.S, g1.code(), BD_EPI_SWIGLU,
                     (float*)c->wptr("head.w1_part"), c->wptr("head.act_frag"), c->ptr(pre + "b1"), st));
-        BD_TRY(gemm(c, "head.w2", c->ptr("head.act_frag"), RB, c->ptr(pre + "w2"), D, H, g2.S, g2.code(), BD_EPI_BF16,
-                        (float*)c->wptr("head.br_part"), c->wptr("head.br_bf"), c->ptr(pre + "b2"), st));
+        BD_TRY(linear(c, "head.w2", c->ptr("head.act_frag"), RB, c->ptr(pre + "w2"), D, H, g2, "head.br_part", "head.br_bf",
+                      c->ptr(pre + "b2"), Mp, &br, st));
     }
     HeadFinalArgs fa;
     fa.X = c->ptr("head.X");
-    fa.pend = done(c, "head.br_bf", D, Mp);
+    fa.pend = br;
     fa.ada = ada; fa.ada_ld = c->hNada;
     fa.gate_off = ((c->hNB - 1) / sw) * 6 * D + 5 * D;
     fa.scale_off = c->hNA * 6 * D; fa.shift_off = c->hNA * 6 * D + D;
@@ -394,10 +410,11 @@ static int projector(bd_ctx* c, hipStream_t st) {
                    c->BP, D, (int)c->geti("proj.C"), c->RBp};
     BD_TRY(bdk_proj_fc1(f1, st));
     const GemmCfg& g = c->g["proj.fc2"];
-    BD_TRY(gemm(c, "proj.fc2", c->ptr("proj.h_frag"), c->RBp, c->ptr("proj.w2"), D, D, g.S, g.code(), BD_EPI_BF16,
-                    (float*)c->wptr("proj.part"), c->wptr("proj.out_bf"), c->ptr("proj.b2"), st));
+    Partial fc2;
+    BD_TRY(linear(c, "proj.fc2", c->ptr("proj.h_frag"), c->RBp, c->ptr("proj.w2"), D, D, g, "proj.part", "proj.out_bf",
+                  c->ptr("proj.b2"), c->BPpad, &fc2, st));
     EmbedFinalizeArgs ef;
-    ef.fc2 = done(c, "proj.out_bf", D, c->BPpad);
+    ef.fc2 = fc2;
     ef.pos = (const float*)c->ptr("pos"); ef.R = (float*)c->wptr("llm.R");
     ef.state = (const BdStepState*)c->ptr("state"); ef.BP = c->BP; ef.P = c->Pn; ef.D = D; ef.branches = c->branches;
     BD_TRY(bdk_embed_finalize(ef, st));
@@ -411,19 +428,20 @@ static int llm_step(bd_ctx* c, hipStream_t st) {
     BdStepState* state = (BdStepState*)c->wptr("state");
     const GemmCfg &gq = c->g["llm.qkv"], &go = c->g["llm.o"], &gg = c->g["llm.gu"], &gd = c->g["llm.down"];
     const size_t layer_elems = (size_t)nseq * nkv * c->lLmax * 128;
+    Partial br{nullptr, nullptr, 0, 0, 0};                    // pending branch output (o_proj / down_proj)
     for (int l = 0; l < c->lL; ++l) {
         const std::string pre = "llm.l" + std::to_string(l) + ".";
         RmsArgs r1;
         r1.R = (float*)c->wptr("llm.R");
-        r1.pend = (l == 0) ? Partial{nullptr, nullptr, 0, 0, 0} : done(c, "llm.br_bf", D, Mp);
+        r1.pend = br;                                      // down_proj output of the previous layer (none for layer 0)
         r1.w = c->ptr(pre + "in_norm"); r1.a_frag = c->wptr("llm.a_frag");
         r1.hidden_out = nullptr; r1.cond_frag = nullptr; r1.pos = nullptr; r1.state = state;
         r1.M = M; r1.D = D; r1.RB = RB; r1.P = c->Pn; r1.eps = eps;
         BD_TRY(bdk_rms(r1, st));
-        BD_TRY(gemm(c, "llm.qkv", c->ptr("llm.a_frag"), RB, c->ptr(pre + "wqkv"), c->lNqkv, D, gq.S, gq.code(), BD_EPI_BF16,
-                        (float*)c->wptr("llm.qkv_part"), c->wptr("llm.qkv_bf"), nullptr, st));
+
         QkvPostArgs qa;
-        qa.qkv = done(c, "llm.qkv_bf", c->lNqkv, Mp);
+        BD_TRY(linear(c, "llm.qkv", c->ptr("llm.a_frag"), RB, c->ptr(pre + "wqkv"), c->lNqkv, D, gq, "llm.qkv_part", "llm.qkv_bf",
+                      nullptr, Mp, &qa.qkv, st));
         qa.qn_w = c->ptr(pre + "q_norm"); qa.kn_w = c->ptr(pre + "k_norm");
         qa.cos = (const float*)c->ptr("llm.cos"); qa.sin = (const float*)c->ptr("llm.sin");
         qa.q_out = c->wptr("llm.q");
@@ -437,22 +455,22 @@ static int llm_step(bd_ctx* c, hipStream_t st) {
         aa.o_frag = c->wptr("llm.attn_frag"); aa.state = state;
         aa.nseq = nseq; aa.P = c->Pn; aa.nh = nh; aa.nkv = nkv; aa.Lmax = c->lLmax; aa.splits = c->lsplits; aa.RB = RB;
         BD_TRY(bdk_llm_attn(aa, st));
-        BD_TRY(gemm(c, "llm.o", c->ptr("llm.attn_frag"), RB, c->ptr(pre + "wo"), D, nh * 128, go.S, go.code(), BD_EPI_BF16,
-                        (float*)c->wptr("llm.br_part"), c->wptr("llm.br_bf"), nullptr, st));
+
         RmsArgs r2 = r1;
-        r2.pend = done(c, "llm.br_bf", D, Mp);
+        BD_TRY(linear(c, "llm.o", c->ptr("llm.attn_frag"), RB, c->ptr(pre + "wo"), D, nh * 128, go, "llm.br_part", "llm.br_bf",
+                      nullptr, Mp, &r2.pend, st));
         r2.w = c->ptr(pre + "post_norm");
         BD_TRY(bdk_rms(r2, st));
         BD_TRY(gemm(c, "llm.gu", c->ptr("llm.a_frag"), RB, c->ptr(pre + "wgu"), 2 * F, D, gg.S, gg.code(), BD_EPI_SWIGLU,
                         (float*)c->wptr("llm.gu_part"), c->wptr("llm.act_frag"), nullptr, st));
-        BD_TRY(gemm(c, "llm.down", c->ptr("llm.act_frag"), RB, c->ptr(pre + "wdown"), D, F, gd.S, gd.code(), BD_EPI_BF16,
-                        (float*)c->wptr("llm.br_part"), c->wptr("llm.br_bf"), nullptr, st));
+        BD_TRY(linear(c, "llm.down", c->ptr("llm.act_frag"), RB, c->ptr(pre + "wdown"), D, F, gd, "llm.br_part", "llm.br_bf",
+                      nullptr, Mp, &br, st));
     }
     StepAdvanceArgs sa{state, nseq, c->Pn};
     BD_TRY(bdk_step_advance(sa, st));                       // step+1 / kv_len += P: the next patch's position
     RmsArgs rf;
     rf.R = (float*)c->wptr("llm.R");
-    rf.pend = done(c, "llm.br_bf", D, Mp);
+    rf.pend = br;
     rf.w = c->ptr("llm.final_norm"); rf.a_frag = nullptr;
     rf.hidden_out = (float*)c->wptr("llm.hidden");
     const bool emit = c->geti("rt.emit_cond", 1) != 0 && c->has_head;

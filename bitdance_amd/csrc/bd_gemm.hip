@@ -84,7 +84,7 @@ struct GemmP {
 // in order, so an A load issued late would force every older W load to complete with it.
 // hipcc's s_waitcnt placement is exact inside a straight-line body but drains the whole queue at the first use after
 // a loop back-edge; U (8 or 12) phases per iteration make that one drain in U.
-template <int NW, int MB, int EPI, int R>
+template <int NW, int MB, int EPI, int R, bool RED>
 __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
     constexpr int NT = NW * 64;
     constexpr int UNITS = MB * 256;                       // 16 B units per 64-deep A stage
@@ -194,17 +194,42 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
 
     // ---- epilogue.  D layout of the 32x32 MFMA: lane -> column (lane&31), reg r -> row (r&3)+8(r>>2)+4(lane>>5)
     const int col = nb * 32 + (lane & 31);
-    if (EPI != BD_EPI_PARTIAL && S > 1) {
-        // In-launch split-K reduction ("last arriver reduces"): every K-slice parks its fp32 slab, takes a ticket on the
-        // tile's counter; the slice that draws S-1 adds the other slabs to its registers and runs the real epilogue, so
-        // the consumers read ONE finished bf16 tensor instead of S fp32 slabs.  Placement-independent agent-scope
-        // release/acquire exactly as cdna_hip_programming.md section 5 item 2 / guideline 16 prescribe.
+    const float bias_col = (EPI != BD_EPI_PARTIAL && p.bias) ? bf2f(p.bias[col]) : 0.f;
+    auto finalize = [&](int m) {
+        if (EPI == BD_EPI_PARTIAL) {
+            float* o = p.out + ((size_t)s * p.Mpad + (size_t)(mt * MB + m) * 32) * p.N + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = acc[m][r];
+        } else if (EPI == BD_EPI_BF16) {   // Linear output rounded once to bf16 (what autocast's F.linear returns)
+            bf16_t* o = p.act + (size_t)(mt * MB + m) * 32 * p.N + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = f2bf(acc[m][r] + bias_col);
+        } else {  // BD_EPI_SWIGLU: lanes (l&16)==0 hold gate feature f, lanes (l&16)!=0 the matching up feature
+            const int f = nb * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = bfr(acc[m][r] + bias_col);            // Linear output rounded to bf16
+                const float other = __shfl_xor(v, 16);
+                if ((lane & 16) == 0) {
+                    const int row = (mt * MB + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    p.act[afrag_off(row, f, p.RB)] = f2bf(silu_bf(v) * other);   // silu -> bf16, product -> bf16
+                }
+            }
+        }
+    };
+    if constexpr (RED) {
+        // In-launch split-K reduction ("last arriver reduces"): every K-slice parks its fp32 slab and takes a ticket on
+        // the tile's counter; the slice that draws S-1 re-reads ALL slabs in slice order (a fixed summation order: the
+        // result does not depend on which slice happened to arrive last) and runs the real epilogue, so the consumers
+        // read ONE finished bf16 tensor instead of S fp32 slabs.  Placement-independent agent-scope release/acquire as
+        // cdna_hip_programming.md section 5 item 2 / guideline 16 prescribe.
         float* o = p.out + ((size_t)s * p.Mpad + (size_t)mt * MB * 32) * p.N + col;
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
+        for (int m = 0; m < MB; ++m) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                o[(size_t)(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = acc[m][r];
+            for (int r = 0; r < 16; ++r) o[(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = acc[m][r];
+            __builtin_amdgcn_sched_barrier(0);                            // one row-block of addresses live at a time
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every storing wave drains its stores
         __syncthreads();                                                  // (also: all waves are done with the LDS tiles)
         int* const flag = reinterpret_cast<int*>(smem);
@@ -218,71 +243,47 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
         if (flag[0] != S - 1) return;                                     // not the last slice of this tile
         if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // drop this CU's stale L1 lines
         __syncthreads();
-        for (int s2 = 0; s2 < S; ++s2) {
-            if (s2 == s) continue;                                        // own slice is still in registers
-            const float* q2 = p.out + ((size_t)s2 * p.Mpad + (size_t)mt * MB * 32) * p.N + col;
 #pragma unroll
-            for (int m = 0; m < MB; ++m)
+        for (int m = 0; m < MB; ++m) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[m][r] += q2[(size_t)(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N];
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+            for (int s2 = 0; s2 < S; ++s2) {
+                const float* q2 = p.out + ((size_t)s2 * p.Mpad + (size_t)(mt * MB + m) * 32) * p.N + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][r] += q2[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N];
+            }
+            finalize(m);                                                  // row-block by row-block: short live ranges
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+        return;
     }
-    if (EPI == BD_EPI_PARTIAL) {
-        float* o = p.out + ((size_t)s * p.Mpad + (size_t)mt * MB * 32) * p.N + col;
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                o[(size_t)row * p.N] = acc[m][r];
-            }
-    } else if (EPI == BD_EPI_BF16) {   // Linear output rounded once to bf16 (what autocast's F.linear returns)
-        const float b = p.bias ? bf2f(p.bias[col]) : 0.f;
-        bf16_t* o = p.act + (size_t)mt * MB * 32 * p.N + col;
-#pragma unroll
-        for (int m = 0; m < MB; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                o[(size_t)row * p.N] = f2bf(acc[m][r] + b);
-            }
-    } else {  // BD_EPI_SWIGLU: lanes (l&16)==0 hold gate feature f, lanes (l&16)!=0 the matching up feature
-        const float b = p.bias ? bf2f(p.bias[col]) : 0.f;
-        const int f = nb * 16 + (lane & 15);
-        const int F = p.N >> 1;
-        (void)F;
-#pragma unroll
-        for (int m = 0; m < MB; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = bfr(acc[m][r] + b);               // Linear output rounded to bf16
-                const float other = __shfl_xor(v, 16);
-                if ((lane & 16) == 0) {
-                    const int row = (mt * MB + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const float a = bfr(silu_bf(v) * other);        // silu -> bf16, product -> bf16
-                    p.act[afrag_off(row, f, p.RB)] = f2bf(a);
-                }
-            }
-    }
+    for (int m = 0; m < MB; ++m) finalize(m);
 }
 
-template <int NW, int MB, int R>
-static int launch_gemm(const GemmP& p, int epi, hipStream_t st) {
+template <int NW, int MB, int R, bool RED>
+static int launch_gemm_r(const GemmP& p, int epi, hipStream_t st) {
     const int ntiles = p.N / (32 * NW);
     dim3 grid(ntiles * p.S, p.RB / MB);
     const size_t lds = (size_t)2 * MB * 256 * 16;
     if (epi == BD_EPI_PARTIAL)
-        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_PARTIAL, R>), grid, dim3(NW * 64), lds, st, p);
+        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_PARTIAL, R, false>), grid, dim3(NW * 64), lds, st, p);
     else if (epi == BD_EPI_BF16)
-        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_BF16, R>), grid, dim3(NW * 64), lds, st, p);
+        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_BF16, R, RED>), grid, dim3(NW * 64), lds, st, p);
     else
-        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_SWIGLU, R>), grid, dim3(NW * 64), lds, st, p);
+        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_SWIGLU, R, RED>), grid, dim3(NW * 64), lds, st, p);
     return bd_launch_status();
 }
 
 // A: fragment-major bf16, RB row blocks (RB must be 1, 2 or a multiple of 4).  W: packed.  N % (32*nw) == 0, K % 64 == 0.
+template <int NW, int MB, int R>
+static int launch_gemm(const GemmP& p, int epi, hipStream_t st) {
+    if constexpr (NW == 10) return launch_gemm_r<NW, MB, R, false>(p, epi, st);          // single-slice tiles only
+    else return (p.S > 1 && epi != BD_EPI_PARTIAL) ? launch_gemm_r<NW, MB, R, true>(p, epi, st)
+                                                   : launch_gemm_r<NW, MB, R, false>(p, epi, st);
+}
+
 // `nw_ring` = waves per workgroup (2, 4, 8) + 16 * ring, ring in {0 (=2), 3, 4}: stages of W/A a wave keeps in flight.
 int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_ring, int epi,
              float* out_partial, void* out_act, const void* bias, int* cnt, hipStream_t st) {
@@ -293,7 +294,7 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
     if (K % 64 || N % (32 * nw) || S < 1) return -2;
     const int nst_total = K / 64, q = (nst_total + S - 1) / S;
     if ((S - 1) * q >= nst_total) return -3;                       // an empty split
-    if (epi != BD_EPI_PARTIAL && S != 1 && (out_partial == nullptr || cnt == nullptr)) return -4;   // needs slab scratch + counters
+    if (epi != BD_EPI_PARTIAL && S != 1 && (out_partial == nullptr || cnt == nullptr || nw == 10)) return -4;   // needs slab scratch + counters
     GemmP p{(const u32x4*)A, (const u32x4*)W, out_partial, (bf16_t*)out_act, (const bf16_t*)bias, cnt, RB, N, K, S, RB * 32};
     // rows per pass over the weights: 256 (two images with CFG: W streamed once for both) when the row count allows,
     // else 128 / 64 / 32
