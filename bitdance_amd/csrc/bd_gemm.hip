@@ -221,36 +221,40 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
         // In-launch split-K reduction ("last arriver reduces"): every K-slice parks its fp32 slab and takes a ticket on
         // the tile's counter; the slice that draws S-1 re-reads ALL slabs in slice order (a fixed summation order: the
         // result does not depend on which slice happened to arrive last) and runs the real epilogue, so the consumers
-        // read ONE finished bf16 tensor instead of S fp32 slabs.  Placement-independent agent-scope release/acquire as
-        // cdna_hip_programming.md section 5 item 2 / guideline 16 prescribe.
+        // read ONE finished bf16 tensor instead of S fp32 slabs.
+        // The XCD L2s are not coherent with each other, so the slab traffic is agent-scope relaxed atomics: `sc1`
+        // write-through stores, drained by vmcnt(0) before the ticket, and `sc1` loads on the reducing side
+        // (MI355X_MICROARCH.md "publish-large": 3.0 vs 8.2 us for plain stores + release fence; the fence form also
+        // writes back / invalidates the whole L2 under the other workgroups' A-operand reuse).
         float* o = p.out + ((size_t)s * p.Mpad + (size_t)mt * MB * 32) * p.N + col;
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = acc[m][r];
+            for (int r = 0; r < 16; ++r)
+                __hip_atomic_store(o + (size_t)(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N, acc[m][r],
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_sched_barrier(0);                            // one row-block of addresses live at a time
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every storing wave drains its stores
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every storing wave drains its write-throughs
         __syncthreads();                                                  // (also: all waves are done with the LDS tiles)
         int* const flag = reinterpret_cast<int*>(smem);
         int* const ticket = p.cnt + (mt * (p.N / (32 * NW)) + nt);
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the compiler may drop the wait behind buffer_wbl2
-            flag[0] = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (tid == 0) flag[0] = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (flag[0] != S - 1) return;                                     // not the last slice of this tile
-        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // drop this CU's stale L1 lines
-        __syncthreads();
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
             for (int s2 = 0; s2 < S; ++s2) {
                 const float* q2 = p.out + ((size_t)s2 * p.Mpad + (size_t)(mt * MB + m) * 32) * p.N + col;
+                float v[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][r] += q2[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N];
+                for (int r = 0; r < 16; ++r)
+                    v[r] = __hip_atomic_load(q2 + (size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N,
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][r] += v[r];
             }
             finalize(m);                                                  // row-block by row-block: short live ranges
             __builtin_amdgcn_sched_barrier(0);
