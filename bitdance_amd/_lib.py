@@ -24,7 +24,8 @@ class BitDanceHipError(RuntimeError):
 _PROTOS = {
     "bd_version": (C.c_int, []),
     "bd_last_error": (C.c_char_p, []),
-    "bd_pack_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "bd_pack_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "bd_set_weight_layout": (C.c_int, [C.c_int]),
     "bd_pack_weight_swiglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "bd_rows_to_frag": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "bd_gemm_partial": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -96,14 +96,20 @@ extern "C" {
 int bd_version(void) { return 1; }
 const char* bd_last_error(void) { return g_err.c_str(); }
 
-int bd_pack_weight(void* dst, const void* src, int rows, int K, int dst_row0, void* stream) {
-    if (rows % 32 || dst_row0 % 32) return fail("bd_pack_weight: rows and dst_row0 must be multiples of 32");
-    BD_TRY(bdk_pack_w(dst, src, nullptr, rows / 32, K, dst_row0 / 32, 0, (hipStream_t)stream));
+int bd_pack_weight(void* dst, const void* src, int rows, int K, int dst_row0, int dst_rows_total, void* stream) {
+    if (rows % 32 || dst_row0 % 32 || dst_rows_total % 32 || dst_row0 + rows > dst_rows_total)
+        return fail("bd_pack_weight: rows, dst_row0, dst_rows_total must be multiples of 32 and nest");
+    BD_TRY(bdk_pack_w(dst, src, nullptr, rows / 32, K, dst_row0 / 32, dst_rows_total / 32, 0, (hipStream_t)stream));
+    return 0;
+}
+int bd_set_weight_layout(int stage_major) {
+    if (stage_major != 0 && stage_major != 1) return fail("bd_set_weight_layout: 0 (panel-major) or 1 (stage-major)");
+    bdk_set_w_layout(stage_major);
     return 0;
 }
 int bd_pack_weight_swiglu(void* dst, const void* gate, const void* up, int F, int K, void* stream) {
     if (F % 16) return fail("bd_pack_weight_swiglu: F must be a multiple of 16");
-    BD_TRY(bdk_pack_w(dst, gate, up, F / 16, K, 0, 1, (hipStream_t)stream));
+    BD_TRY(bdk_pack_w(dst, gate, up, F / 16, K, 0, F / 16, 1, (hipStream_t)stream));
     return 0;
 }
 int bd_rows_to_frag(void* dst, const void* src, int src_is_fp32, int M, int K, int RB, void* stream) {
@@ -366,9 +372,20 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
         l2.gate_off = base + 2 * D; l2.scale_off = base + 3 * D; l2.shift_off = base + 4 * D;
         l2.ln_w = (const float*)c->ptr(pre + "ln2_w"); l2.ln_b = (const float*)c->ptr(pre + "ln2_b");
         BD_TRY(bdk_ln_mod(l2, st));
-        // Linear -> chunk(2) -> silu(h1)*h2, K-slices reduced in the launch, activation written as the next operand
-        BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * H, D, g1.S, g1.code(), BD_EPI_SWIGLU,
-                    (float*)c->wptr("head.w1_part"), c->wptr("head.act_frag"), c->ptr(pre + "b1"), st));
+        // Linear -> chunk(2) -> silu(h1)*h2.  Fused epilogue (on the last-arriving K-slice when split) writes the next
+        // operand: 46.9 + 22.9 us (w1 + w2) against 40.8 + 9.5 + 26.0 us for slabs + swiglu_rows on the same MI355X
+        // (tune.w1_fused = 0 selects the latter).
+        if (g1.S == 1 || c->geti("tune.w1_fused", 1)) {
+            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * H, D, g1.S, g1.code(), BD_EPI_SWIGLU,
+                        (float*)c->wptr("head.w1_part"), c->wptr("head.act_frag"), c->ptr(pre + "b1"), st));
+        } else {
+            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * H, D, g1.S, g1.code(), BD_EPI_PARTIAL,
+                        (float*)c->wptr("head.w1_part"), nullptr, nullptr, st));
+            SwigluArgs sw_;
+            sw_.up = part(c, "head.w1_part", c->ptr(pre + "b1"), g1.S, 2 * H, Mp);
+            sw_.act_frag = c->wptr("head.act_frag"); sw_.M = M; sw_.F = H; sw_.RB = RB; sw_.interleaved = 1;
+            BD_TRY(bdk_swiglu_rows(sw_, st));
+        }
         BD_TRY(linear(c, "head.w2", c->ptr("head.act_frag"), RB, c->ptr(pre + "w2"), D, H, g2, "head.br_part", "head.br_bf",
                       c->ptr(pre + "b2"), Mp, &br, st));
     }

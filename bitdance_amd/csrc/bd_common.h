@@ -13,13 +13,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 BD_DEV float bf2f(bf16_t x) { return __uint_as_float(((unsigned)x) << 16); }
 
-// fp32 -> bf16 round-to-nearest-even (what torch's .to(bfloat16) does), NaN kept quiet.
-BD_DEV bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16 round-to-nearest-even (what torch's .to(bfloat16) does): gfx950 has it in hardware (v_cvt_pk_bf16_f32).
+BD_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 BD_DEV float bfr(float f) { return bf2f(f2bf(f)); }                 // round through bf16
 BD_DEV unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
 
@@ -29,7 +24,9 @@ BD_DEV float fadd(float a, float b) { return __fadd_rn(a, b); }
 BD_DEV float fsub(float a, float b) { return __fsub_rn(a, b); }
 BD_DEV float fdiv(float a, float b) { return __fdiv_rn(a, b); }
 
-BD_DEV float silu_f(float x) { return x / (1.0f + expf(-x)); }      // torch silu opmath
+// torch silu opmath x / (1 + exp(-x)) in fp32; every caller rounds the result to bf16, so the hardware exp2 / rcp
+// (1 ulp each) are indistinguishable from libm's expf and an IEEE divide after that rounding, at a fifth of the VALU work
+BD_DEV float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x)); }
 BD_DEV float silu_bf(float x_bf) { return bfr(silu_f(x_bf)); }       // bf16 tensor in -> bf16 out
 
 // MFMA-operand ("fragment-major") activation layout.

@@ -27,12 +27,25 @@ BD_DEV f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
                                                    __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
 }
 
+// Packed-weight order in HBM.  0 = panel-major  [panel][K/64 stages][4 k-steps][64 lanes]: every wave walks its own
+// contiguous 32-column panel.  1 = stage-major [K/64 stages][panel][4 k-steps][64 lanes]: the waves of the whole grid,
+// which advance through K in lockstep, read ONE contiguous moving window of (N/32) x 4 KiB per stage, so the stream
+// is spread over every HBM channel the way a flat copy is, instead of N/32 streams 2K bytes apart.
+static int g_w_layout = 0;   // measured identical on MI355X (profiles/r01_gemm_fixed_cost.log): panel-major keeps N-slices contiguous
+void bdk_set_w_layout(int v) { g_w_layout = v; }
+int bdk_get_w_layout() { return g_w_layout; }
+void bdk_w_strides(int panels_total, int K, size_t* PS, size_t* SS) {
+    if (g_w_layout == 0) { *PS = (size_t)(K >> 4) * 64; *SS = 256; }
+    else { *PS = 256; *SS = (size_t)panels_total * 256; }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // weight packing: src [rows][K] bf16 row-major  ->  dst panels [nb0 + rows/32][K/16][64 lanes][8 bf16]
 // mode 0: packed row r <- src row r.   mode 1 (SwiGLU pair): panel p, row i<16 <- gate[p*16+i], i>=16 <- up[p*16+i-16]
 // ---------------------------------------------------------------------------------------------------
+// dst unit (16 B) of (panel pn, k-step ks, lane l) = pn * PS + (ks >> 2) * SS + (ks & 3) * 64 + l  (see bdk_w_strides)
 __global__ void pack_w_kernel(u32x4* __restrict__ dst, const bf16_t* __restrict__ src, const bf16_t* __restrict__ src2,
-                              int panels, int K, int nb0, int mode) {
+                              int panels, int K, int nb0, int mode, size_t PS, size_t SS) {
     const int KS = K >> 4;
     const size_t total = (size_t)panels * KS * 64;
     for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (size_t)gridDim.x * blockDim.x) {
@@ -45,7 +58,7 @@ __global__ void pack_w_kernel(u32x4* __restrict__ dst, const bf16_t* __restrict_
         if (mode == 0) row = src + ((size_t)pn * 32 + i) * K;
         else row = (i < 16) ? src + ((size_t)pn * 16 + i) * K : src2 + ((size_t)pn * 16 + (i - 16)) * K;
         const u32x4 v = *reinterpret_cast<const u32x4*>(row + ks * 16 + (l >> 5) * 8);
-        dst[((size_t)(nb0 + pn) * KS + ks) * 64 + l] = v;
+        dst[(size_t)(nb0 + pn) * PS + (size_t)(ks >> 2) * SS + (ks & 3) * 64 + l] = v;
     }
 }
 
@@ -77,6 +90,7 @@ struct GemmP {
     const bf16_t* bias;  // EPI_SWIGLU : [N] in PACKED row order (or null); EPI_BF16: [N] (or null)
     int* cnt;            // EPI_BF16 / EPI_SWIGLU with S > 1: one arrival counter per output tile (zero between launches)
     int RB, N, K, S, Mpad;
+    size_t PS, SS;       // packed-W strides in 16 B units: panel stride, 64-deep-K-stage stride
 };
 
 // R = depth of the per-wave W register ring = number of 64-deep K stages a wave keeps in flight.  The A stage is
@@ -105,7 +119,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
     const int st0 = s * q;
     const int nst = min(q, nst_total - st0);
 
-    const u32x4* Wp = p.W + ((size_t)nb * KS + (size_t)st0 * 4) * 64 + lane;
+    const u32x4* Wp = p.W + (size_t)nb * p.PS + (size_t)st0 * p.SS + lane;
+    const size_t w_stage = p.SS;
     // A: unit u of a stage = chunk (ksl = (u>>6)/MB, mb = (u>>6)%MB), lane u&63
     size_t a_off[XL];
 #pragma unroll
@@ -125,7 +140,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
 
     auto load_w = [&](u32x4(&wr)[4], int i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wr[j] = __builtin_nontemporal_load(Wp + ((size_t)i * 4 + j) * 64);
+        for (int j = 0; j < 4; ++j) wr[j] = __builtin_nontemporal_load(Wp + (size_t)i * w_stage + j * 64);
     };
     auto load_x = [&](u32x4(&x)[XL], int i) {
 #pragma unroll
@@ -242,6 +257,30 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
         if (tid == 0) flag[0] = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (flag[0] != S - 1) return;                                     // not the last slice of this tile
+        if (S == 2) {
+            // two slices: own + other == other + own bit for bit, so the last arriver keeps its accumulators and
+            // fetches only the other slab, four row-blocks (64 loads per lane) in flight at once
+            const float* q2 = p.out + ((size_t)(1 - s) * p.Mpad + (size_t)mt * MB * 32) * p.N + col;
+            constexpr int MG = (NW >= 8) ? 1 : (MB < 4 ? MB : 4);     // 16 * MG loads per lane in flight (VGPR budget)
+#pragma unroll
+            for (int m0 = 0; m0 < MB; m0 += MG) {
+                float v[MG][16];
+#pragma unroll
+                for (int m = 0; m < MG; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        v[m][r] = __hip_atomic_load(q2 + (size_t)((m0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N,
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int m = 0; m < MG; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m0 + m][r] += v[m][r];
+                    finalize(m0 + m);
+                }
+            }
+            if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
 #pragma unroll
@@ -299,7 +338,9 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
     const int nst_total = K / 64, q = (nst_total + S - 1) / S;
     if ((S - 1) * q >= nst_total) return -3;                       // an empty split
     if (epi != BD_EPI_PARTIAL && S != 1 && (out_partial == nullptr || cnt == nullptr || nw == 10)) return -4;   // needs slab scratch + counters
-    GemmP p{(const u32x4*)A, (const u32x4*)W, out_partial, (bf16_t*)out_act, (const bf16_t*)bias, cnt, RB, N, K, S, RB * 32};
+    size_t PS, SS;
+    bdk_w_strides(N / 32, K, &PS, &SS);
+    GemmP p{(const u32x4*)A, (const u32x4*)W, out_partial, (bf16_t*)out_act, (const bf16_t*)bias, cnt, RB, N, K, S, RB * 32, PS, SS};
     // rows per pass over the weights: 256 (two images with CFG: W streamed once for both) when the row count allows,
     // else 128 / 64 / 32
     const int MB = (RB % 8 == 0 && nw >= 4) ? 8 : ((RB % 4 == 0) ? 4 : RB);
@@ -336,12 +377,14 @@ int bdk_probe_read(const void* src, size_t bytes, int blocks, void* sink, hipStr
     return bd_launch_status();
 }
 
-int bdk_pack_w(void* dst, const void* src, const void* src2, int panels, int K, int nb0, int mode, hipStream_t st) {
-    if (K % 16) return -2;
+int bdk_pack_w(void* dst, const void* src, const void* src2, int panels, int K, int nb0, int panels_total, int mode, hipStream_t st) {
+    size_t PS, SS;
+    bdk_w_strides(panels_total, K, &PS, &SS);
+    if (K % 64 || nb0 + panels > panels_total) return -2;
     const size_t total = (size_t)panels * (K / 16) * 64;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     BD_LAUNCH(pack_w_kernel, dim3(blocks), dim3(256), 0, st, (u32x4*)dst, (const bf16_t*)src,
-                       (const bf16_t*)src2, panels, K, nb0, mode);
+                       (const bf16_t*)src2, panels, K, nb0, mode, PS, SS);
     return bd_launch_status();
 }
 

@@ -17,7 +17,10 @@ struct BdStepState;
 // ---- bd_gemm.hip
 int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw, int epi,
              float* out_partial, void* out_act, const void* bias, int* tile_counters, hipStream_t st);
-int bdk_pack_w(void* dst, const void* src, const void* src2, int panels, int K, int nb0, int mode, hipStream_t st);
+int bdk_pack_w(void* dst, const void* src, const void* src2, int panels, int K, int nb0, int panels_total, int mode, hipStream_t st);
+void bdk_set_w_layout(int v);
+int bdk_get_w_layout();
+void bdk_w_strides(int panels_total, int K, size_t* PS, size_t* SS);
 int bdk_probe_read(const void* src, size_t bytes, int blocks, void* sink, hipStream_t st);
 int bdk_rows_to_afrag(void* dst, const float* src32, const void* src16, int M, int K, int RB, hipStream_t st);
 

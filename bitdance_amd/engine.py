@@ -34,7 +34,7 @@ def pack_linear(ws: list[torch.Tensor], device) -> torch.Tensor:
     row = 0
     for w in ws:
         src = _bf16(w, device)
-        check(lib().bd_pack_weight(out.data_ptr(), src.data_ptr(), src.shape[0], K, row, _stream()), "bd_pack_weight")
+        check(lib().bd_pack_weight(out.data_ptr(), src.data_ptr(), src.shape[0], K, row, n, _stream()), "bd_pack_weight")
         row += src.shape[0]
     torch.cuda.current_stream().synchronize()
     return out

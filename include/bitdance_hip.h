@@ -21,7 +21,10 @@ const char* bd_last_error(void);
 
 /* ---- weight / activation layout conversion (load time; replaces nothing in the reference: the reference
  *      keeps nn.Linear weights [N][K] row-major, t2i_pipeline.py:50-74 -- we re-pack once into MFMA order) */
-int bd_pack_weight(void* dst_packed, const void* src_bf16, int rows, int K, int dst_row0, void* stream);
+int bd_pack_weight(void* dst_packed, const void* src_bf16, int rows, int K, int dst_row0, int dst_rows_total, void* stream);
+/* packed order in HBM: 0 (default) = panel-major; 1 = stage-major, the whole grid reads one contiguous window per
+ * 64-deep K stage (an experiment: measured identical on MI355X).  Process-wide; set before packing, weights packed under one setting must be used under it. */
+int bd_set_weight_layout(int stage_major);
 int bd_pack_weight_swiglu(void* dst_packed, const void* gate_bf16, const void* up_bf16, int F, int K, void* stream);
 int bd_rows_to_frag(void* dst_frag, const void* src, int src_is_fp32, int M, int K, int row_blocks, void* stream);
 
