@@ -309,7 +309,8 @@ static Partial done(const bd_ctx* c, const std::string& ws, int N, int Mpad) {  
 static int linear(bd_ctx* c, const char* name, const void* A, int RB, const void* W, int N, int K, const GemmCfg& g,
                   const char* scratch_ws, const char* out_ws, const void* bias, int Mpad, Partial* res, hipStream_t st,
                   bool force_reduce = false) {
-    const int max_s = (int)c->geti("tune.reduce_max_s", 3);
+    // 256-row passes run the 4-wave x 2-panel kernel, which has no in-launch reduction: slabs for the consumer there
+    const int max_s = (int)c->geti("tune.reduce_max_s", (c->Mpad % 256 == 0) ? 0 : 3);
     if (g.S <= max_s || force_reduce) {
         BD_TRY(gemm(c, name, A, RB, W, N, K, g.S, g.code(), BD_EPI_BF16, (float*)c->wptr(scratch_ws), c->wptr(out_ws), bias, st));
         *res = Partial{(const float*)c->ptr(out_ws), nullptr, 0, N, Mpad};
@@ -375,7 +376,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
         // Linear -> chunk(2) -> silu(h1)*h2.  Fused epilogue (on the last-arriving K-slice when split) writes the next
         // operand: 46.9 + 22.9 us (w1 + w2) against 40.8 + 9.5 + 26.0 us for slabs + swiglu_rows on the same MI355X
         // (tune.w1_fused = 0 selects the latter).
-        if (g1.S == 1 || c->geti("tune.w1_fused", 1)) {
+        if (g1.S == 1 || c->geti("tune.w1_fused", (c->Mpad % 256 == 0) ? 0 : 1)) {
             BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * H, D, g1.S, g1.code(), BD_EPI_SWIGLU,
                         (float*)c->wptr("head.w1_part"), c->wptr("head.act_frag"), c->ptr(pre + "b1"), st));
         } else {

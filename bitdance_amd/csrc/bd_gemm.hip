@@ -17,6 +17,8 @@
 //    to fp32 slabs that the consumer row-kernels reduce in their prologue (bd_rows.hip) -- no extra launch.
 //  * fused SwiGLU epilogue (gate/up rows interleaved 16/16 inside each packed panel so the partner value is
 //    one cross-lane exchange away) writes the bf16 activation in fragment-major order for the next GEMM.
+#include <cstdlib>
+#include <type_traits>
 #include "bd_common.h"
 #include "bd_kernels.h"
 
@@ -98,8 +100,13 @@ struct GemmP {
 // in order, so an A load issued late would force every older W load to complete with it.
 // hipcc's s_waitcnt placement is exact inside a straight-line body but drains the whole queue at the first use after
 // a loop back-edge; U (8 or 12) phases per iteration make that one drain in U.
-template <int NW, int MB, int EPI, int R, bool RED>
+// NPW = 32-column panels per wave.  1: the HBM-bound 128-row passes (one A fragment feeds one MFMA: 1 KiB of LDS per MFMA
+// is fine while the matrix pipe idles).  2: the 256-row passes, where 32 MFMAs per wave and k-step would otherwise be
+// bound by LDS reads; each A fragment now feeds two MFMAs, the accumulators (MB x 2 x 16 = 256) live in AGPRs, one
+// wave per SIMD, and the next k-step's fragments are fetched from LDS while the current one multiplies.
+template <int NW, int MB, int EPI, int R, bool RED, int NPW = 1>
 __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
+    static_assert(NPW == 1 || !RED, "in-launch reduction is only built for one panel per wave");
     constexpr int NT = NW * 64;
     constexpr int UNITS = MB * 256;                       // 16 B units per 64-deep A stage
     constexpr int XL = (UNITS + NT - 1) / NT;             // A loads per thread per stage
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int S = p.S;
     const int s = blockIdx.x % S, nt = blockIdx.x / S, mt = blockIdx.y;
-    const int nb = nt * NW + wave;
+    const int nb = (nt * NW + wave) * NPW;                 // first panel of this wave
     const int KS = p.K >> 4;
     const int nst_total = p.K >> 6;
     const int q = (nst_total + S - 1) / S;
@@ -131,16 +138,19 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
     }
     const size_t a_stage = (size_t)4 * p.RB * 64;
 
-    u32x4 w[R][4], xr[XR][XL];
-    f32x16 acc[MB];
+    u32x4 w[R][NPW * 4], xr[XR][XL];
+    f32x16 acc[MB * NPW];                                  // [m * NPW + pn]
 #pragma unroll
-    for (int m = 0; m < MB; ++m)
+    for (int m = 0; m < MB * NPW; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-    auto load_w = [&](u32x4(&wr)[4], int i) {
+    auto load_w = [&](u32x4(&wr)[NPW * 4], int i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wr[j] = __builtin_nontemporal_load(Wp + (size_t)i * w_stage + j * 64);
+        for (int pn = 0; pn < NPW; ++pn)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                wr[pn * 4 + j] = __builtin_nontemporal_load(Wp + (size_t)pn * p.PS + (size_t)i * w_stage + j * 64);
     };
     auto load_x = [&](u32x4(&x)[XL], int i) {
 #pragma unroll
@@ -156,19 +166,39 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
     // back: with the reads interleaved two-at-a-time the matrix pipe idled on LDS latency (the loop was bound by the
     // ds_read -> MFMA chain, not by HBM).  For 256-row passes only half a stage fits the register budget.
     constexpr int KG = (MB <= 4 && NW <= 8) ? 4 : 1;      // k-steps whose A fragments are resident at once (VGPR budget)
-    auto compute = [&](const u32x4* buf, const u32x4(&wr)[4]) {
+    auto compute = [&](const u32x4* buf, const u32x4(&wr)[NPW * 4]) {
+        if constexpr (NPW == 1) {
 #pragma unroll
-        for (int k0 = 0; k0 < 4; k0 += KG) {
-            u32x4 xf[KG][MB];
+            for (int k0 = 0; k0 < 4; k0 += KG) {
+                u32x4 xf[KG][MB];
 #pragma unroll
-            for (int kk = 0; kk < KG; ++kk)
+                for (int kk = 0; kk < KG; ++kk)
 #pragma unroll
-                for (int m = 0; m < MB; ++m) xf[kk][m] = buf[((k0 + kk) * MB + m) * 64 + lane];
-            if constexpr (KG > 1) __builtin_amdgcn_sched_barrier(0);   // keep the burst: hipcc otherwise re-interleaves 2 reads / 2 MFMAs
+                    for (int m = 0; m < MB; ++m) xf[kk][m] = buf[((k0 + kk) * MB + m) * 64 + lane];
+                if constexpr (KG > 1) __builtin_amdgcn_sched_barrier(0);   // keep the burst: hipcc otherwise re-interleaves 2 reads / 2 MFMAs
 #pragma unroll
-            for (int kk = 0; kk < KG; ++kk)
+                for (int kk = 0; kk < KG; ++kk)
 #pragma unroll
-                for (int m = 0; m < MB; ++m) acc[m] = mfma32(xf[kk][m], wr[k0 + kk], acc[m]);
+                    for (int m = 0; m < MB; ++m) acc[m] = mfma32(xf[kk][m], wr[k0 + kk], acc[m]);
+            }
+        } else {
+            u32x4 xf[2][MB];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) xf[0][m] = buf[m * 64 + lane];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < 3) {                          // next k-step's fragments land while this one's 2*MB MFMAs run
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) xf[(k + 1) & 1][m] = buf[((k + 1) * MB + m) * 64 + lane];
+                }
+                __builtin_amdgcn_sched_barrier(0);    // hipcc otherwise collapses the prefetch to one fragment ahead
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int pn = 0; pn < NPW; ++pn)
+                        acc[m * NPW + pn] = mfma32(xf[k & 1][m], wr[pn * 4 + k], acc[m * NPW + pn]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
 
@@ -208,22 +238,28 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
     }
 
     // ---- epilogue.  D layout of the 32x32 MFMA: lane -> column (lane&31), reg r -> row (r&3)+8(r>>2)+4(lane>>5)
-    const int col = nb * 32 + (lane & 31);
-    const float bias_col = (EPI != BD_EPI_PARTIAL && p.bias) ? bf2f(p.bias[col]) : 0.f;
-    auto finalize = [&](int m) {
+    const int col = nb * 32 + (lane & 31);                 // panel pn of this wave: + pn * 32
+    float bias_pn[NPW];
+#pragma unroll
+    for (int pn = 0; pn < NPW; ++pn) bias_pn[pn] = (EPI != BD_EPI_PARTIAL && p.bias) ? bf2f(p.bias[col + pn * 32]) : 0.f;
+    const float bias_col = bias_pn[0];
+    (void)bias_col;
+    auto finalize_pn = [&](int m, int pn) {
+        const f32x16& a = acc[m * NPW + pn];
+        const int colp = col + pn * 32;
         if (EPI == BD_EPI_PARTIAL) {
-            float* o = p.out + ((size_t)s * p.Mpad + (size_t)(mt * MB + m) * 32) * p.N + col;
+            float* o = p.out + ((size_t)s * p.Mpad + (size_t)(mt * MB + m) * 32) * p.N + colp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = acc[m][r];
+            for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = a[r];
         } else if (EPI == BD_EPI_BF16) {   // Linear output rounded once to bf16 (what autocast's F.linear returns)
-            bf16_t* o = p.act + (size_t)(mt * MB + m) * 32 * p.N + col;
+            bf16_t* o = p.act + (size_t)(mt * MB + m) * 32 * p.N + colp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = f2bf(acc[m][r] + bias_col);
+            for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = f2bf(a[r] + bias_pn[pn]);
         } else {  // BD_EPI_SWIGLU: lanes (l&16)==0 hold gate feature f, lanes (l&16)!=0 the matching up feature
-            const int f = nb * 16 + (lane & 15);
+            const int f = (nb + pn) * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = bfr(acc[m][r] + bias_col);            // Linear output rounded to bf16
+                const float v = bfr(a[r] + bias_pn[pn]);              // Linear output rounded to bf16
                 const float other = __shfl_xor(v, 16);
                 if ((lane & 16) == 0) {
                     const int row = (mt * MB + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -231,6 +267,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
                 }
             }
         }
+    };
+    auto finalize = [&](int m) {
+#pragma unroll
+        for (int pn = 0; pn < NPW; ++pn) finalize_pn(m, pn);
     };
     if constexpr (RED) {
         // In-launch split-K reduction ("last arriver reduces"): every K-slice parks its fp32 slab and takes a ticket on
@@ -305,17 +345,195 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
     for (int m = 0; m < MB; ++m) finalize(m);
 }
 
-template <int NW, int MB, int R, bool RED>
+// ---------------------------------------------------------------------------------------------------
+// 256-row passes (two images with CFG, or 4 as two row tiles): the matrix pipe, not HBM, is the scarce unit here
+// (256 FLOP per weight byte), so this variant is organised around keeping MFMAs issuing back to back:
+//   * 4 waves, one per SIMD, each 256 rows x 64 columns = 16 accumulators (256 AGPRs); an A fragment read from
+//     LDS feeds two MFMAs;
+//   * the A stage is TRIPLE buffered in LDS and loaded three stages ahead, so that the first fragments of the next
+//     stage are already in registers when the per-stage barrier falls (with two buffers every stage began with an
+//     exposed ds_read latency on an otherwise idle SIMD);
+//   * fragment reads, the ds_write of the stage after next and the global loads are issued one per MFMA pair inside
+//     the MFMA stream (sched_barrier pins the order), not in a block between stages;
+//   * loads past the last stage are clamped to it instead of branched around: every phase issues the same number of
+//     loads, which keeps hipcc's s_waitcnt counts exact (the redundant lines are L2 hits).
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
+    constexpr int MB = 8, NPW = 2, NT = 256, UNITS = MB * 256, XL = UNITS / NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4* const lds = reinterpret_cast<u32x4*>(smem);    // three A-stage buffers of UNITS each (96 KiB)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int S = p.S;
+    const int s = blockIdx.x % S, nt = blockIdx.x / S, mt = blockIdx.y;
+    const int nb = (nt * 4 + wave) * NPW;
+    const int nst_total = p.K >> 6;
+    const int q = (nst_total + S - 1) / S;
+    const int st0 = s * q;
+    const int nst = min(q, nst_total - st0);
+    const int last = nst - 1;
+
+    const u32x4* Wp = p.W + (size_t)nb * p.PS + (size_t)st0 * p.SS + lane;
+    const size_t w_stage = p.SS;
+    size_t a_off[XL];
+#pragma unroll
+    for (int j = 0; j < XL; ++j) {
+        const int u = tid + j * NT;
+        const int c = u >> 6;
+        a_off[j] = (((size_t)(st0 * 4 + c / MB) * p.RB) + mt * MB + (c % MB)) * 64 + (u & 63);
+    }
+    const size_t a_stage = (size_t)4 * p.RB * 64;
+
+    u32x4 w[2][NPW * 4], xr[XL], xf[2][MB];
+    f32x16 acc[MB * NPW];
+#pragma unroll
+    for (int m = 0; m < MB * NPW; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    auto load_w = [&](u32x4(&wr)[NPW * 4], int i) {
+        i = min(i, last);
+#pragma unroll
+        for (int pn = 0; pn < NPW; ++pn)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                wr[pn * 4 + j] = __builtin_nontemporal_load(Wp + (size_t)pn * p.PS + (size_t)i * w_stage + j * 64);
+    };
+    auto load_x = [&](int i) {
+        i = min(i, last);
+#pragma unroll
+        for (int j = 0; j < XL; ++j) xr[j] = p.A[a_off[j] + (size_t)i * a_stage];
+    };
+    auto store_x = [&](u32x4* buf) {
+#pragma unroll
+        for (int j = 0; j < XL; ++j) buf[tid + j * NT] = xr[j];
+    };
+
+    // prologue: A stages 0 and 1 into LDS, stage 2 in registers; W stages 0 and 1 in registers
+    u32x4 *cur = lds, *nxt = lds + UNITS, *wr3 = lds + 2 * UNITS;
+    load_x(0);
+    load_w(w[0], 0);
+    store_x(cur);
+    load_x(1);
+    store_x(nxt);
+    load_x(2);                                // issue order A(j+2), W(j+1) as in the steady state: the waitcnt states
+    load_w(w[1], 1);                          // merged at the loop header then agree and stay exact
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MB; ++m) xf[0][m] = cur[m * 64 + lane];
+
+    // one phase = one 64-deep K stage j: 4 k-steps x 16 MFMAs.  PAR = j & 1 selects the W register slot.
+    auto phase = [&](auto PAR, int j) {
+        constexpr int P = decltype(PAR)::value;
+        // k-step 0 (xf[0]) | read k-step 1 -> xf[1]
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            xf[1][m] = cur[(1 * MB + m) * 64 + lane];
+            acc[m * 2 + 0] = mfma32(xf[0][m], w[P][0], acc[m * 2 + 0]);
+            acc[m * 2 + 1] = mfma32(xf[0][m], w[P][4], acc[m * 2 + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // k-step 1 (xf[1]) | read k-step 2 -> xf[0] | write A stage j+2 (loaded during phase j-1)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            xf[0][m] = cur[(2 * MB + m) * 64 + lane];
+            wr3[tid + m * NT] = xr[m];
+            acc[m * 2 + 0] = mfma32(xf[1][m], w[P][1], acc[m * 2 + 0]);
+            acc[m * 2 + 1] = mfma32(xf[1][m], w[P][5], acc[m * 2 + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // k-step 2 (xf[0]) | read k-step 3 -> xf[1] | load A stage j+3
+        const int ix = min(j + 3, last);
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            xf[1][m] = cur[(3 * MB + m) * 64 + lane];
+            xr[m] = p.A[a_off[m] + (size_t)ix * a_stage];
+            acc[m * 2 + 0] = mfma32(xf[0][m], w[P][2], acc[m * 2 + 0]);
+            acc[m * 2 + 1] = mfma32(xf[0][m], w[P][6], acc[m * 2 + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // k-step 3 (xf[1]) | read k-step 0 of stage j+1 -> xf[0] (visible since the previous barrier)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            xf[0][m] = nxt[m * 64 + lane];
+            acc[m * 2 + 0] = mfma32(xf[1][m], w[P][3], acc[m * 2 + 0]);
+            acc[m * 2 + 1] = mfma32(xf[1][m], w[P][7], acc[m * 2 + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        load_w(w[P], j + 2);                  // this slot's MFMAs have all issued
+        __syncthreads();
+        u32x4* t = cur; cur = nxt; nxt = wr3; wr3 = t;
+    };
+
+    int j = 0;
+    for (; j + 1 < nst; j += 2) {
+        phase(std::integral_constant<int, 0>{}, j);
+        phase(std::integral_constant<int, 1>{}, j + 1);
+    }
+    if (j < nst) phase(std::integral_constant<int, 0>{}, j);
+
+    // ---- epilogue (same forms as gemm_kernel)
+    const int col = nb * 32 + (lane & 31);
+    float bias_pn[NPW];
+#pragma unroll
+    for (int pn = 0; pn < NPW; ++pn) bias_pn[pn] = (EPI != BD_EPI_PARTIAL && p.bias) ? bf2f(p.bias[col + pn * 32]) : 0.f;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int pn = 0; pn < NPW; ++pn) {
+            const f32x16& a = acc[m * NPW + pn];
+            const int colp = col + pn * 32;
+            if (EPI == BD_EPI_PARTIAL) {
+                float* o = p.out + ((size_t)s * p.Mpad + (size_t)(mt * MB + m) * 32) * p.N + colp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = a[r];
+            } else if (EPI == BD_EPI_BF16) {
+                bf16_t* o = p.act + (size_t)(mt * MB + m) * 32 * p.N + colp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = f2bf(a[r] + bias_pn[pn]);
+            } else {
+                const int f = (nb + pn) * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = bfr(a[r] + bias_pn[pn]);
+                    const float other = __shfl_xor(v, 16);
+                    if ((lane & 16) == 0) {
+                        const int row = (mt * MB + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        p.act[afrag_off(row, f, p.RB)] = f2bf(silu_bf(v) * other);
+                    }
+                }
+            }
+        }
+}
+
+static int launch_gemm_wide(const GemmP& p, int epi, hipStream_t st) {
+    const int ntiles = p.N / 256;
+    dim3 grid(ntiles * p.S, p.RB / 8);
+    const size_t lds = (size_t)3 * 8 * 256 * 16;
+    static const bool lds_ok = [] {                            // 96 KiB of dynamic LDS needs the opt-in
+        const int n = 3 * 8 * 256 * 16;
+        return hipFuncSetAttribute((const void*)gemm_wide_kernel<BD_EPI_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, n) == hipSuccess &&
+               hipFuncSetAttribute((const void*)gemm_wide_kernel<BD_EPI_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, n) == hipSuccess &&
+               hipFuncSetAttribute((const void*)gemm_wide_kernel<BD_EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, n) == hipSuccess;
+    }();
+    if (!lds_ok) return -8;
+    if (epi == BD_EPI_PARTIAL) BD_LAUNCH((gemm_wide_kernel<BD_EPI_PARTIAL>), grid, dim3(256), lds, st, p);
+    else if (epi == BD_EPI_BF16) BD_LAUNCH((gemm_wide_kernel<BD_EPI_BF16>), grid, dim3(256), lds, st, p);
+    else BD_LAUNCH((gemm_wide_kernel<BD_EPI_SWIGLU>), grid, dim3(256), lds, st, p);
+    return bd_launch_status();
+}
+
+template <int NW, int MB, int R, bool RED, int NPW = 1>
 static int launch_gemm_r(const GemmP& p, int epi, hipStream_t st) {
-    const int ntiles = p.N / (32 * NW);
+    const int ntiles = p.N / (32 * NW * NPW);
     dim3 grid(ntiles * p.S, p.RB / MB);
     const size_t lds = (size_t)2 * MB * 256 * 16;
     if (epi == BD_EPI_PARTIAL)
-        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_PARTIAL, R, false>), grid, dim3(NW * 64), lds, st, p);
+        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_PARTIAL, R, false, NPW>), grid, dim3(NW * 64), lds, st, p);
     else if (epi == BD_EPI_BF16)
-        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_BF16, R, RED>), grid, dim3(NW * 64), lds, st, p);
+        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_BF16, R, RED, NPW>), grid, dim3(NW * 64), lds, st, p);
     else
-        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_SWIGLU, R, RED>), grid, dim3(NW * 64), lds, st, p);
+        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_SWIGLU, R, RED, NPW>), grid, dim3(NW * 64), lds, st, p);
     return bd_launch_status();
 }
 
@@ -346,6 +564,10 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
     const int MB = (RB % 8 == 0 && nw >= 4) ? 8 : ((RB % 4 == 0) ? 4 : RB);
     if (MB != 8 && MB != 4 && MB != 2 && MB != 1) return -5;
     if (MB == 8 || nw == 2 || nw == 10) ring = 2;                  // register budget
+    // 256-row passes over 256-column tiles: 4 waves x 2 panels (MFMA-friendly, see NPW) instead of 8 waves x 1 panel;
+    // same grid.  BD_GEMM_WIDE=0 keeps the 8-wave form (A/B switch for measurements).
+    static const bool wide = [] { const char* e = getenv("BD_GEMM_WIDE"); return !(e && e[0] == '0'); }();
+    if (wide && MB == 8 && nw == 8 && !(S > 1 && epi != BD_EPI_PARTIAL)) return launch_gemm_wide(p, epi, st);
 #define BD_CASE(NWV, MBV, RV) if (nw == NWV && MB == MBV && ring == RV) return launch_gemm<NWV, MBV, RV>(p, epi, st);
     if (MB <= 2 && ring == 3) ring = 4;
     if (MB == 1) ring = 2;

@@ -18,7 +18,8 @@ SHAPES = [("head.ada", 71680, 5120, False), ("head.qkv", 15360, 5120, False), ("
 
 def main():
     quick = "--quick" in sys.argv
-    M = 128
+    M = int(sys.argv[sys.argv.index("--M") + 1]) if "--M" in sys.argv else 128
+    RB = M // 32
     res = []
     st = torch.cuda.current_stream().cuda_stream
     for name, N, K, swiglu in SHAPES:
@@ -27,10 +28,10 @@ def main():
         del w
         x = torch.randn(M, K, device=DEV)
         xf = torch.zeros(M * K, dtype=torch.bfloat16, device=DEV)
-        check(lib().bd_rows_to_frag(xf.data_ptr(), x.data_ptr(), 1, M, K, 4, st))
+        check(lib().bd_rows_to_frag(xf.data_ptr(), x.data_ptr(), 1, M, K, RB, st))
         out = torch.empty(16 * M * N if not swiglu else M * N, dtype=torch.float32, device=DEV)
         Ss = [1] if swiglu else [1, 2, 3, 4, 6, 8, 12]
-        for nw, ring in [(2, 2), (4, 2), (4, 3), (8, 2), (8, 3), (8, 4)]:
+        for nw, ring in ([(2, 2), (4, 2), (4, 3), (8, 2), (8, 3), (8, 4)] if M == 128 else [(4, 2), (8, 2)]):
             if N % (32 * nw):
                 continue
             code = nw + 16 * ring
@@ -39,14 +40,15 @@ def main():
                 if S > nst or (S > 1 and (S - 1) * ((nst + S - 1) // S) >= nst):
                     continue
                 blocks = N // (32 * nw) * S
+                blocks *= max(1, M // 256)
                 if blocks < 100 or blocks > 1300:
                     continue
 
                 def launch():
                     if swiglu:
-                        check(lib().bd_gemm_swiglu(xf.data_ptr(), 4, wp.data_ptr(), None, N, K, code, out.data_ptr(), st))
+                        check(lib().bd_gemm_swiglu(xf.data_ptr(), RB, wp.data_ptr(), None, N, K, code, out.data_ptr(), st))
                     else:
-                        check(lib().bd_gemm_partial(xf.data_ptr(), 4, wp.data_ptr(), N, K, S, code, out.data_ptr(), st))
+                        check(lib().bd_gemm_partial(xf.data_ptr(), RB, wp.data_ptr(), N, K, S, code, out.data_ptr(), st))
                 for _ in range(3):
                     launch()
                 reps = 10 if quick else 30
@@ -58,8 +60,9 @@ def main():
                 e1.synchronize()
                 us = e0.elapsed_time(e1) * 1e3 / reps
                 gbs = N * K * 2 / us / 1e3
+                tfs = 2.0 * M * N * K / us / 1e6
                 res.append(dict(name=name, N=N, K=K, nw=nw, ring=ring, S=S, blocks=blocks, us=round(us, 1), GBs=round(gbs)))
-                print(f"{name:9s} N={N:6d} K={K:6d} nw={nw} R={ring} S={S:2d} blocks={blocks:5d}  {us:8.1f} us  {gbs:7.0f} GB/s", flush=True)
+                print(f"{name:9s} N={N:6d} K={K:6d} nw={nw} R={ring} S={S:2d} blocks={blocks:5d}  {us:8.1f} us  {gbs:7.0f} GB/s  {tfs:6.0f} TFLOP/s", flush=True)
         del wp
     best = {}
     for r in res:
