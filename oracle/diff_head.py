@@ -94,13 +94,13 @@ def count(w: dict, prefix: str) -> int:
 
 
 def net_forward(w: dict, x: torch.Tensor, t: torch.Tensor, c: torch.Tensor, pol: Policy,
-                final_sigmoid: bool = True, trace: dict | None = None) -> torch.Tensor:
+                final_sigmoid: bool = True, trace: dict | None = None, head_dim: int = 128) -> torch.Tensor:
     """TransEncoder.forward :325-342.  x [M',P,C] fp32, t [M'] fp32, c [M',P,Dz] fp32."""
     n_blocks = count(w, "net.res_blocks.")
     n_ada = count(w, "net.ada_ln_blocks.")
     switch = max(1, n_blocks // n_ada)
     dim = w["net.input_proj.weight"].shape[0]
-    n_head = dim // 128                       # TransBlock.__init__ :227
+    n_head = dim // head_dim                  # TransBlock.__init__ :227 (128); imagenet diff_head_parallel.py:207 (64)
     x = pol.linear(x, w["net.input_proj.weight"], w["net.input_proj.bias"])
     te = time_embed(w, t, pol).unsqueeze(1)
     ce = pol.linear(c, w["net.cond_embed.weight"], w["net.cond_embed.bias"])

@@ -224,15 +224,57 @@ def gen_misc():
     save("gfq", idx=idx, bits=bits, back=back, codebook=q.codebook)
 
 
+def gen_imagenet():
+    """Class-conditional ImageNet BitDance (imagenet_gen/src/model_parallel.py), tiny dims, 4 AR steps x 3 sampling steps."""
+    os.environ["TORCHDYNAMO_DISABLE"] = "1"                      # the reference decorates with @torch.compile
+    sys.path.insert(0, os.path.join(rh.REF_ROOT, "imagenet_gen"))
+    from src.model_parallel import BitDance
+    c = tm.TINY_IN
+    shapes = tm.imagenet_shapes(c)
+    for tag in ("fp32", "amp"):
+        torch.manual_seed(0)
+        m = BitDance(dim=c["dim"], n_layer=c["n_layer"], n_head=c["n_head"], diff_layers=c["diff_layers"],
+                     diff_dim=c["diff_dim"], diff_adanln_layers=c["diff_adanln_layers"], latent_dim=c["latent_dim"],
+                     down_size=c["down_size"], patch_size=c["patch_size"], resolution=c["resolution"], diff_batch_mul=1,
+                     cls_token_num=c["cls_token_num"], num_classes=c["num_classes"], parallel_num=c["parallel_num"],
+                     parallel_mode="patch", time_shift=c["time_shift"]).eval()
+        sd = {k: tuple(v.shape) for k, v in m.state_dict().items() if not k.startswith("vae.")}
+        assert sd == {k: tuple(v) for k, v in shapes.items()}, set(sd) ^ set(shapes)
+        m.load_state_dict(tm.seeded_state(shapes, seed=29), strict=False)
+        m.vae.decode = lambda x: x                               # stop at the latent: the AE is pinned by ae_roundtrip
+        conds, preds = [], []
+        orig = m.head.sample
+
+        def rec(z, cfg, num_sampling_steps):
+            conds.append(z.detach().float().clone())
+            o = orig(z, cfg=cfg, num_sampling_steps=num_sampling_steps)
+            preds.append(o.detach().clone())
+            return o
+
+        m.head.sample = rec
+        ids = torch.tensor([3, 7])
+        ctx = rh.CudaAutocastOnCpu() if tag == "amp" else torch.no_grad()
+        with torch.no_grad(), ctx, rh.ReplayNoise(seed=17) as rn:
+            lat = m.sample(ids, sample_steps=3, cfg_scale=3.0, cfg_schedule="linear")
+        n0 = [t for t in rn.record if t.shape[0] == 4]
+        n1 = [t for t in rn.record if t.shape[0] == 2]
+        save(f"imagenet_{tag}", ids=ids, latent=lat, preds=torch.cat(preds, dim=1), conds=torch.cat(conds, dim=1),
+             noise0=torch.stack(n0), noise1=torch.stack(n1), calls=rn.calls, cfg=np.float32(3.0), n_steps=3,
+             rope=m.freqs_cis, mask=m.attn_mask[0, 0])
+
+
 def main():
     rh.install()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "imagenet":
+        return gen_imagenet()
     gen_sampler()
     gen_head()
     gen_llm()
     gen_pipeline()
     gen_misc()
+    gen_imagenet()
 
 
 if __name__ == "__main__":

@@ -19,6 +19,11 @@ TINY_HEAD16 = dict(TINY_HEAD, parallel_num=16)      # the 16x models: 16-token p
 TINY_AE = dict(ddconfig=dict(double_z=False, z_channels=32, in_channels=3, out_ch=3, ch=32,
                              ch_mult=[1, 1, 2, 2, 4], num_res_blocks=1))
 
+# class-conditional ImageNet model (imagenet_gen/src/model_parallel.py BitDance.__init__), 128 px -> 8x8 tokens, 4 AR steps
+TINY_IN = dict(dim=256, n_layer=2, n_head=4, diff_layers=4, diff_dim=256, diff_adanln_layers=2, latent_dim=16,
+               down_size=16, patch_size=1, resolution=128, cls_token_num=8, num_classes=10, parallel_num=16,
+               time_shift=1.0)
+
 VISION_START, RES_BASE, QUERY_BASE = 300, 301, 430
 
 
@@ -68,6 +73,33 @@ def head_shapes(cfg: dict) -> dict:
         lin(f"net.ada_ln_blocks.{j}", 6 * D, D)
     lin("net.final_layer.ada_ln_modulation", 2 * D, D)
     lin("net.final_layer.linear", C, D)
+    return s
+
+
+def imagenet_shapes(cfg: dict) -> dict:
+    """state_dict() of imagenet_gen BitDance minus ``vae.*`` (names/shapes asserted against the reference module)."""
+    D, L = cfg["dim"], cfg["latent_dim"] * cfg["patch_size"] ** 2
+    hid = int(D * 1.5)
+    ff = int(2 * 4.0 * D / 3)
+    ff = ff if ff % 256 == 0 else ff + 256 - ff % 256                    # find_multiple(.., 256)
+    hw = cfg["resolution"] // (cfg["down_size"] * cfg["patch_size"])
+    s = {"query_token": (1, cfg["parallel_num"] - 1, D),
+         "cls_embedding.weight": (cfg["num_classes"] + 1, D * cfg["cls_token_num"]),
+         "proj_in.w1.weight": (2 * hid, L), "proj_in.w1.bias": (2 * hid,),
+         "proj_in.w2.weight": (D, hid), "proj_in.w2.bias": (D,),
+         "emb_norm.weight": (D,), "norm.weight": (D,), "pos_for_diff.weight": (hw * hw, D)}
+    for i in range(cfg["n_layer"]):
+        p = f"layers.{i}."
+        s[p + "attention.wqkv.weight"] = (3 * D, D)
+        s[p + "attention.wo.weight"] = (D, D)
+        s[p + "feed_forward.w1.weight"] = (2 * ff, D)
+        s[p + "feed_forward.w2.weight"] = (D, ff)
+        s[p + "attention_norm.weight"] = (D,)
+        s[p + "ffn_norm.weight"] = (D,)
+    hcfg = dict(ch_target=L, ch_cond=D, ch_latent=cfg["diff_dim"], depth_latent=cfg["diff_layers"],
+                depth_adanln=cfg["diff_adanln_layers"])
+    for k, v in head_shapes(hcfg).items():
+        s["head." + k] = v
     return s
 
 

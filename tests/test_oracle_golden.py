@@ -165,3 +165,51 @@ def test_gfq_index_math(golden_dir):
     assert np.array_equal(bits, g["bits"].numpy().astype(bool))
     assert np.array_equal(gfq.bits_to_indices(bits), g["back"].numpy())
     assert np.array_equal(gfq.codes_from_indices(idx, 8), g["codebook"].numpy())
+
+
+# ------------------------------------------------------------- class-conditional ImageNet model
+def _imagenet_run(g, pol, force=None):
+    from oracle import imagenet
+    w = tm.seeded_state(tm.imagenet_shapes(tm.TINY_IN), seed=29)
+    noise = list(g["noise0"]) + list(g["noise1"])
+    cfg = dict(tm.TINY_IN)
+    return imagenet.sample(w, cfg, g["ids"], int(g["n_steps"]), float(g["cfg"]), noise, pol, force_tokens=force)
+
+
+def test_imagenet_tables(golden_dir):
+    """2-D RoPE table in patch-raster order and the block-causal mask are exact (layers_parallel.py:255-270,
+    model_parallel.py:90-101,197-215)."""
+    from oracle import imagenet
+    g = load(golden_dir, "imagenet_fp32")
+    c = tm.TINY_IN
+    assert torch.equal(imagenet.rope_table(c), g["rope"])
+    hw = c["resolution"] // 16
+    assert torch.equal(imagenet.block_causal_mask(hw * hw + c["cls_token_num"] - 1, c["cls_token_num"] - 1,
+                                                  c["parallel_num"]), g["mask"])
+    assert int(g["calls"]) == (hw * hw // c["parallel_num"]) * (int(g["n_steps"]) + 1)      # RNG draws per AR step: 1 + N
+
+
+def test_imagenet_sample_fp32(golden_dir):
+    """BitDance.sample end to end in fp32: every token identical, pre-sign latents to 1e-4 (CFG ramp, the un-mixed
+    first step, KV-cached block-causal transformer, head with head_dim 64 and no final sigmoid)."""
+    g = load(golden_dir, "imagenet_fp32")
+    lat, tokens, preds = _imagenet_run(g, Policy("fp32"))
+    torch.testing.assert_close(preds, g["preds"], atol=2e-4, rtol=1e-3)
+    assert torch.equal(lat, g["latent"])
+    assert torch.equal(tokens[:2], torch.sign(g["preds"])[:2])
+
+
+def test_imagenet_sample_amp_teacher_forced(golden_dir):
+    """Emulated CUDA bf16 autocast, reference tokens fed back (teacher forcing): per-step latents at bf16-noise level."""
+    g = load(golden_dir, "imagenet_amp")
+    ref_tok = torch.sign(g["preds"])
+    _, tokens, preds = _imagenet_run(g, Policy("autocast"), force=ref_tok)
+    P, steps = tm.TINY_IN["parallel_num"], preds.shape[1] // tm.TINY_IN["parallel_num"]
+    for i in range(steps):                                     # bf16 noise of the evals, amplified ~(2 cfg_i - 1) by the CFG mix
+        sl = slice(i * P, (i + 1) * P)
+        cfg_i = 1.0 + (float(g["cfg"]) - 1.0) * i / steps
+        ref = g["preds"][:, sl]
+        d = (preds[:, sl] - ref).abs()
+        assert d.mean().item() <= 0.045 * max(1.0, 2 * cfg_i - 1) * ref.abs().mean().item(), (i, d.mean())
+        firm = ref.abs() > 0.5
+        assert (torch.sign(preds[:, sl])[firm] == torch.sign(ref)[firm]).float().mean().item() >= 0.97, i
