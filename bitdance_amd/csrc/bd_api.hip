@@ -365,7 +365,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
         HeadAttnArgs at;
         BD_TRY(linear(c, "head.qkv", c->ptr("head.h_frag"), RB, c->ptr(pre + "wqkv"), 3 * D, D, gq, "head.qkv_part", "head.qkv_bf",
                       c->ptr(pre + "bqkv"), Mp, &at.qkv, st));
-        at.o_frag = c->wptr("head.attn_frag"); at.nseq = M / c->Pn; at.nhead = D / 128; at.D = D; at.RB = RB; at.P = c->Pn;
+        at.o_frag = c->wptr("head.attn_frag"); at.nseq = M / c->Pn; at.dh = (int)c->geti("head.dh", 128); at.nhead = D / at.dh; at.D = D; at.RB = RB; at.P = c->Pn;
         BD_TRY(bdk_head_attn(at, st));
         LnModArgs l2 = l1;
         BD_TRY(linear(c, "head.wo", c->ptr("head.attn_frag"), RB, c->ptr(pre + "wo"), D, D, go, "head.br_part", "head.br_bf",
@@ -406,7 +406,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
     fa.T = c->hT; fa.P = c->Pn;
     fa.xhat_out = c->geti("rt.dump_xhat", 0) ? (float*)c->wptr("head.xhat") : nullptr;
     fa.sc = c->sched[i];
-    fa.BP = c->BP; fa.D = D; fa.C = c->hC; fa.M = M; fa.eps_ln = 1e-6f;
+    fa.BP = c->BP; fa.D = D; fa.C = c->hC; fa.M = M; fa.eps_ln = 1e-6f; fa.sigmoid = (int)c->geti("head.sigmoid", 1);
     BD_TRY(bdk_head_final(fa, st));
     return 0;
 }

@@ -196,14 +196,15 @@ __global__ __launch_bounds__(256) void head_attn_kernel(HeadAttnArgs a) {
 __global__ __launch_bounds__(256) void head_attn16_kernel(HeadAttnArgs a) {
     __shared__ float qs[16 * 132], ks[16 * 132], vs[16 * 132], sc[16 * 17];
     const int seq = blockIdx.x / a.nhead, h = blockIdx.x % a.nhead;
-    const int tid = threadIdx.x, D = a.D;
+    const int tid = threadIdx.x, D = a.D, dh = a.dh;           // dh = 128 (T2I heads) or 64 (imagenet diff_head_parallel.py:207)
     const Partial& q = a.qkv;
     const bf16_t* bias = (const bf16_t*)q.bias;
-    const float scale = 0.08838834764831845f;
-    {   // thread -> (row i, 8 channels): Linear outputs (sum of slabs + bias) rounded to bf16
+    const float scale = (dh == 64) ? 0.125f : 0.08838834764831845f;     // head_dim ** -0.5
+    const bool act = (tid & 15) * 8 < dh;                      // thread -> (row i, 8 channels d0..d0+7)
+    if (act) {   // Linear outputs (sum of slabs + bias) rounded to bf16
         const int i = tid >> 4, d0 = (tid & 15) * 8;
         for (int which = 0; which < 3; ++which) {
-            const int col = which * D + h * 128 + d0;
+            const int col = which * D + h * dh + d0;
             const float* p = q.p + (size_t)(seq * 16 + i) * q.N + col;
             float* dst = (which == 0 ? qs : (which == 1 ? ks : vs)) + i * 132 + d0;
 #pragma unroll
@@ -223,11 +224,11 @@ __global__ __launch_bounds__(256) void head_attn16_kernel(HeadAttnArgs a) {
     {   // scores[i][j] = bf16( sum_d q_i[d] k_j[d] )
         const int i = tid >> 4, j = tid & 15;
         float acc = 0.f;
-        for (int d = 0; d < 128; ++d) acc += qs[i * 132 + d] * ks[j * 132 + d];
+        for (int d = 0; d < dh; ++d) acc += qs[i * 132 + d] * ks[j * 132 + d];
         sc[i * 17 + j] = bfr(acc);
     }
     __syncthreads();
-    {   // softmax over j in fp32, then out[i][d0..d0+7] = bf16( sum_j bf16(p_ij) v_j[d] )
+    if (act) {   // softmax over j in fp32, then out[i][d0..d0+7] = bf16( sum_j bf16(p_ij) v_j[d] )
         const int i = tid >> 4, d0 = (tid & 15) * 8;
         float m = -INFINITY;
         for (int j = 0; j < 16; ++j) m = fmaxf(m, sc[i * 17 + j]);
@@ -242,12 +243,13 @@ __global__ __launch_bounds__(256) void head_attn16_kernel(HeadAttnArgs a) {
             for (int t = 0; t < 8; ++t) o[t] += pj * vs[j * 132 + d0 + t];
         }
         bf16_t* O = (bf16_t*)a.o_frag;
-        *reinterpret_cast<u32x4*>(O + afrag_off(seq * 16 + i, h * 128 + d0, a.RB)) =
+        *reinterpret_cast<u32x4*>(O + afrag_off(seq * 16 + i, h * dh + d0, a.RB)) =
             (u32x4){pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
     }
 }
 
 int bdk_head_attn(const HeadAttnArgs& a, hipStream_t st) {
+    if (a.dh != 128 && !(a.dh == 64 && a.P == 16)) return -2;
     if (a.P == 64) BD_LAUNCH(head_attn_kernel, dim3(a.nseq * a.nhead), dim3(256), 0, st, a);
     else if (a.P == 16) BD_LAUNCH(head_attn16_kernel, dim3(a.nseq * a.nhead), dim3(256), 0, st, a);
     else return -2;

@@ -83,6 +83,7 @@ struct HeadFinalArgs {      // pending update, final LN-mod, Linear(D->C), 2*sig
     SamplerScalars sc;
     int BP, D, C, M;
     float eps_ln;
+    int sigmoid;            // 1: x_hat = 2*sigmoid(out)-1 (flow_head_parallel_x.py:342); 0: x_hat = out (diff_head_parallel.py:310)
 };
 int bdk_head_final(const HeadFinalArgs& a, hipStream_t st);
 
@@ -159,6 +160,7 @@ struct HeadAttnArgs {       // DiT attention over one patch (seq = P = 64 or 16)
     Partial qkv;            // [.,Mpad,3D]
     void* o_frag;           // out fragment-major bf16 [Mpad][D]
     int nseq, nhead, D, RB, P;
+    int dh;                 // head dim: 128, or 64 with P = 16 (imagenet head)
 };
 int bdk_head_attn(const HeadAttnArgs& a, hipStream_t st);
 

@@ -276,8 +276,11 @@ __global__ __launch_bounds__(640) void head_final_kernel(HeadFinalArgs a) {
         const int r = threadIdx.x >> 5, c = threadIdx.x & 31;
         if (c < a.C && r < a.sc.cfg_mult) {
             const float o = bfr(tot + bf2f(((const bf16_t*)a.lin_b)[c]));   // Linear output bf16
-            const float sg = bfr(1.0f / (1.0f + expf(-o)));                 // sigmoid (bf16)
-            const float xv = bfr(fsub(bfr(2.0f * sg), 1.0f));               // 2*sigmoid - 1 (bf16 ops)
+            float xv = o;
+            if (a.sigmoid) {
+                const float sg = bfr(1.0f / (1.0f + expf(-o)));             // sigmoid (bf16)
+                xv = bfr(fsub(bfr(2.0f * sg), 1.0f));                       // 2*sigmoid - 1 (bf16 ops)
+            }
             xh[threadIdx.x] = xv;
             if (a.xhat_out) a.xhat_out[(size_t)(r * a.BP + bp) * a.C + c] = xv;
         }

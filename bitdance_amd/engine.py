@@ -69,6 +69,8 @@ class HeadWeights:
     H: int
     nblocks: int
     nada: int
+    head_dim: int = 128                             # 128: T2I heads (flow_head_parallel_x.py:227); 64: imagenet (diff_head_parallel.py:207)
+    final_sigmoid: bool = True                      # 2*sigmoid(out)-1 (flow_head_parallel_x.py:342); imagenet head: identity
     ptrs: dict = field(default_factory=dict)        # name -> tensor (kept alive)
     time_w0: torch.Tensor = None
     time_b0: torch.Tensor = None
@@ -76,7 +78,7 @@ class HeadWeights:
     time_b2: torch.Tensor = None
 
     @staticmethod
-    def from_state_dict(sd: dict, device) -> "HeadWeights":
+    def from_state_dict(sd: dict, device, head_dim: int = 128, final_sigmoid: bool = True) -> "HeadWeights":
         g = lambda k: sd[k]
         D, C = g("net.input_proj.weight").shape
         Dz = g("net.cond_embed.weight").shape[1]
@@ -85,7 +87,9 @@ class HeadWeights:
         if "net.res_blocks.0.w1.weight" not in sd:
             raise BitDanceHipError("native head requires the SwiGLU variant (use_swiglu=True)")
         H = g("net.res_blocks.0.w2.weight").shape[1]
-        hw = HeadWeights(D=D, C=C, Dz=Dz, H=H, nblocks=nb, nada=na)
+        if head_dim not in (64, 128) or D % head_dim:
+            raise BitDanceHipError(f"native head: head_dim {head_dim} unsupported for D={D}")
+        hw = HeadWeights(D=D, C=C, Dz=Dz, H=H, nblocks=nb, nada=na, head_dim=head_dim, final_sigmoid=final_sigmoid)
         p = hw.ptrs
         p["head.cond_w"] = pack_linear([g("net.cond_embed.weight")], device)
         p["head.cond_b"] = _bf16(g("net.cond_embed.bias"), device)
@@ -119,7 +123,8 @@ class HeadWeights:
 
     def ints(self) -> dict:
         return {"head.D": self.D, "head.C": self.C, "head.Dz": self.Dz, "head.H": self.H,
-                "head.nblocks": self.nblocks, "head.nada": self.nada}
+                "head.nblocks": self.nblocks, "head.nada": self.nada, "head.dh": self.head_dim,
+                "head.sigmoid": int(self.final_sigmoid)}
 
     def time_table(self, ts: torch.Tensor) -> torch.Tensor:
         """time_embed(t_i) for every eval of the schedule, bf16 [N+1, D]  (flow_head_parallel_x.py:12-27,140-143).

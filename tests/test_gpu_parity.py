@@ -464,3 +464,65 @@ def test_gemm_in_launch_splitk_reduction(eng_mod, M, N, K, S, nw):
         if it == 0:
             first = out.clone()
         assert torch.equal(out[:M], first[:M])               # fixed summation order: bit-identical run to run
+
+
+# ----------------------------------------------------------------------------------------------- imagenet (I1-I3)
+def test_imagenet_head_eval_dh64_vs_oracle(eng_mod):
+    """diff_head_parallel.TransEncoder (head_dim 64, explicit-softmax attention, no final sigmoid) on the HIP head:
+    one evaluation against the oracle's autocast policy.  Tolerance: bf16 noise of a 4-block head on outputs of O(1)."""
+    c = tm.TINY_IN
+    sd = tm.seeded_state(tm.imagenet_shapes(c), seed=29)
+    hsd = {k[len("head."):]: v for k, v in sd.items() if k.startswith("head.")}
+    hw = eng_mod.HeadWeights.from_state_dict(hsd, DEV, head_dim=64, final_sigmoid=False)
+    B, P, C, D = 2, 16, c["latent_dim"], c["dim"]
+    eng = eng_mod.Engine(hw, None, None, num_images=B, branches=2, device=DEV, max_tokens=P, parallel_num=P)
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(2 * B, P, D, generator=g)
+    noise = torch.randn(1, 4, B, P, C, generator=g)
+    eng.set_schedule(3, 2.0, 1)
+    eng.load_noise(noise.to(DEV))
+    eng.reset([0] * (2 * B))
+    eng.set_int("rt.dump_xhat", 1)
+    eng.set_cond(z.to(DEV))
+    x0 = noise[0, 0]
+    eng.view("head.xt", torch.float32, (B * P, C)).copy_(x0.reshape(B * P, C))     # eval 0: latent = first draw
+    eng.head_cond()
+    eng.head_eval(0)
+    torch.cuda.synchronize()
+    xhat = eng.view("head.xhat", torch.float32, (eng.Mpad, C))[: 2 * B * P].cpu().view(2 * B, P, C)
+    ref = diff_head.net_forward(hsd, torch.cat([x0, x0]), torch.zeros(2 * B), z, Policy("autocast"),
+                                final_sigmoid=False, head_dim=64).float()
+    d = (xhat - ref).abs()
+    assert d.max() <= 0.08 * ref.abs().max() + 0.02 and d.mean() <= 0.01 * ref.abs().mean() + 2e-3, (d.max(), d.mean())
+
+
+def test_imagenet_sample_teacher_forced_vs_reference(golden_dir):
+    """BitDance.sample (model_parallel.py:371-419) with the reference's noise and tokens fed back: per-AR-step pre-sign
+    latents against the reference's own (golden imagenet_amp).  Bound per step: the oracle-vs-reference bf16 noise
+    (tests/test_oracle_golden.py) x 1.5, scaled by the CFG amplification (2 cfg_i - 1) of the linear ramp."""
+    from bitdance_amd.imagenet import BitDance
+    g = load(golden_dir, "imagenet_amp")
+    c = tm.TINY_IN
+    m = BitDance(tm.seeded_state(tm.imagenet_shapes(c), seed=29), device=DEV, **c)
+    N, P = int(g["n_steps"]), c["parallel_num"]
+    steps = (c["resolution"] // 16) ** 2 // P
+    noise = [g["noise0"]] + [g["noise1"][k * (N + 1):(k + 1) * (N + 1)] for k in range(steps - 1)]
+    ref_tok = torch.sign(g["preds"])
+    lat, tokens, preds = m.sample(g["ids"], N, cfg_scale=float(g["cfg"]), noise=noise, force_tokens=ref_tok,
+                                  return_tokens=True)
+    preds, lat = preds.cpu(), lat.cpu()
+    assert torch.equal(lat, g["latent"])                      # teacher-forced tokens, un-patchified: index work exact
+    for i in range(steps):
+        sl = slice(i * P, (i + 1) * P)
+        cfg_i = 1.0 + (float(g["cfg"]) - 1.0) * i / steps
+        ref = g["preds"][:, sl]
+        d = (preds[:, sl] - ref).abs()
+        assert d.mean().item() <= 0.07 * max(1.0, 2 * cfg_i - 1) * ref.abs().mean().item(), (i, d.mean())
+        firm = ref.abs() > 0.5
+        assert (torch.sign(preds[:, sl])[firm] == torch.sign(ref)[firm]).float().mean().item() >= 0.96, i
+    # free-running: same seed -> same latent; RNG consumption = AR_steps * (1 + N) draws in the reference's order
+    torch.manual_seed(7)
+    a = m.sample(g["ids"], N, cfg_scale=float(g["cfg"]))
+    torch.manual_seed(7)
+    b = m.sample(g["ids"], N, cfg_scale=float(g["cfg"]))
+    assert torch.equal(a, b) and a.shape == (2, c["latent_dim"], 8, 8) and set(a.unique().tolist()) <= {-1.0, 0.0, 1.0}
