@@ -68,8 +68,20 @@ def gemm_roofline(pipe) -> dict:
         S, nw = eng.gemm_config(name)
         per.append({"name": name, "launches": r["count"], "avg_us": round(r["ms"] / r["count"] * 1e3, 2),
                     "GBs": round(r["bytes"] / r["ms"] / 1e6, 1), "splitk": S, "nwaves": nw & 15, "ring": nw >> 4})
+    # HBM bytes per launch from the PMC pass (rocprofv3 --pmc FETCH_SIZE in its own run, x2 gfx950 correction:
+    # tools/pmc_gemm_traffic.py -> profiles/r01_pmc_gemm_traffic.json), weighted by this step's launch mix; only
+    # valid for the shapes / launch configs that pass measured, else null
+    traffic, traffic_src = None, None
+    pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_gemm_traffic.json")
+    if os.path.exists(pj) and eng.M == 128:
+        pm = json.load(open(pj))["gemms"]
+        cfgs = {q["name"]: q for q in per}
+        if all(n in pm and pm[n]["splitk"] == cfgs[n]["splitk"] and pm[n]["nwaves"] == cfgs[n]["nwaves"] and
+               pm[n]["N"] * pm[n]["K"] * 2 * r["count"] == int(r["bytes"]) for n, r in prof.items()):
+            traffic = int(sum(pm[n]["hbm_read_bytes"] * r["count"] for n, r in prof.items()) / n_launch)
+            traffic_src = "profiles/r01_pmc_gemm_traffic.json (FETCH_SIZE, read bytes per launch, launch-mix weighted)"
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "kernel": "gemm_kernel<NW,MB,EPI> (bd_gemm.hip): every weight-streaming GEMM launch of one AR step, in situ",
             "launches": n_launch, "bytes_per_launch": int(tot_b / n_launch),
             "avg_launch_us": round(tot_ms / n_launch * 1e3, 2), "per_gemm": per}
