@@ -42,6 +42,7 @@ struct bd_ctx {
     int B = 1, branches = 2, Pn = 64, BP = 64, M = 128, RB = 4, RBp = 2, Mpad = 128, BPpad = 64;
     int hD = 0, hC = 0, hDz = 0, hH = 0, hNB = 0, hNA = 0, hNada = 0, hT = 0;
     int lD = 0, lL = 0, lnh = 0, lnkv = 0, lF = 0, lLmax = 0, lsplits = 8, lNqkv = 0;
+    int ldh = 128, lvariant = 0;          // lvariant 1: imagenet transformer (head_dim 64, MHA, 2-D RoPE, bf16 residual)
     bool has_head = false, has_llm = false, has_proj = false;
 
     long long geti(const std::string& k) const {
@@ -213,8 +214,10 @@ int bd_ctx_finalize(bd_ctx* c) {
         }
         if (c->has_proj) {
             const int D = (int)c->geti("proj.D");
-            c->g["proj.fc2"] = choose_cfg(c, "proj.fc2", D, D, false);
-            add("proj.h_frag", (long long)c->BPpad * D * 2);
+            const int hk = (int)c->geti("proj.variant", 0) ? (int)c->geti("proj.hid") : D;     // K of the second Linear
+            if (hk % 64) return fail("proj hidden width must be a multiple of 64");
+            c->g["proj.fc2"] = choose_cfg(c, "proj.fc2", D, hk, false);
+            add("proj.h_frag", (long long)c->BPpad * hk * 2);
             add("proj.part", (long long)c->g["proj.fc2"].S * c->BPpad * D * 4);
             add("proj.out_bf", (long long)c->BPpad * D * 2);
         }
@@ -222,12 +225,15 @@ int bd_ctx_finalize(bd_ctx* c) {
             c->lD = (int)c->geti("llm.D"); c->lL = (int)c->geti("llm.L"); c->lnh = (int)c->geti("llm.nh");
             c->lnkv = (int)c->geti("llm.nkv"); c->lF = (int)c->geti("llm.F"); c->lLmax = (int)c->geti("llm.Lmax");
             c->lsplits = (int)c->geti("llm.splits", 8);
-            if (c->geti("llm.head_dim", 128) != 128) return fail("llm.head_dim must be 128");
+            c->ldh = (int)c->geti("llm.head_dim", 128);
+            c->lvariant = (int)c->geti("llm.variant", 0);
+            if (!((c->ldh == 128 && c->lvariant == 0) || (c->ldh == 64 && c->lvariant == 1 && c->lnkv == c->lnh && c->Pn == 16)))
+                return fail("llm: head_dim 128 (Qwen3) or head_dim 64 + variant 1 (imagenet transformer, MHA, P = 16)");
             if (c->lLmax % 64) return fail("llm.Lmax must be a multiple of 64");
-            c->lNqkv = (c->lnh + 2 * c->lnkv) * 128;
+            c->lNqkv = (c->lnh + 2 * c->lnkv) * c->ldh;
             if (c->lD % 64 || c->lF % 64) return fail("llm dims must be multiples of 64");
             c->g["llm.qkv"] = choose_cfg(c, "llm.qkv", c->lNqkv, c->lD, false);
-            c->g["llm.o"] = choose_cfg(c, "llm.o", c->lD, c->lnh * 128, false);
+            c->g["llm.o"] = choose_cfg(c, "llm.o", c->lD, c->lnh * c->ldh, false);
             c->g["llm.gu"] = choose_cfg(c, "llm.gu", 2 * c->lF, c->lD, true);
 
             c->g["llm.down"] = choose_cfg(c, "llm.down", c->lD, c->lF, false);
@@ -239,12 +245,12 @@ int bd_ctx_finalize(bd_ctx* c) {
             add("llm.qkv_bf", Mp * c->lNqkv * 2);
             add("llm.br_bf", Mp * c->lD * 2);
             add("llm.gu_part", (long long)c->g["llm.gu"].S * Mp * 2 * c->lF * 4);
-            add("llm.q", Mp * c->lnh * 128 * 2);
-            add("llm.k_cache", (long long)c->lL * nseq * c->lnkv * c->lLmax * 128 * 2);
-            add("llm.vt_cache", (long long)c->lL * nseq * c->lnkv * c->lLmax * 128 * 2);
+            add("llm.q", Mp * c->lnh * c->ldh * 2);
+            add("llm.k_cache", (long long)c->lL * nseq * c->lnkv * c->lLmax * c->ldh * 2);
+            add("llm.vt_cache", (long long)c->lL * nseq * c->lnkv * c->lLmax * c->ldh * 2);
             add("llm.attn_opart", (long long)nseq * c->lnkv * c->lsplits * G * c->Pn * 128 * 4);
             add("llm.attn_ml", (long long)nseq * c->lnkv * c->lsplits * G * c->Pn * 2 * 4);
-            add("llm.attn_frag", Mp * c->lnh * 128 * 2);
+            add("llm.attn_frag", Mp * c->lnh * c->ldh * 2);
             add("llm.br_part", (long long)sbr * Mp * c->lD * 4);
             add("llm.act_frag", Mp * c->lF * 2);
             add("llm.hidden", Mp * c->lD * 4);
@@ -422,7 +428,26 @@ static int head_sample(bd_ctx* c, hipStream_t st) {
     return 0;
 }
 
+// imagenet MLPConnector (model_parallel.py:73-75) + emb_norm (:344): the normalised bf16 value starts the residual stream
+static int projector_in(bd_ctx* c, hipStream_t st) {
+    const int D = (int)c->geti("proj.D"), hid = (int)c->geti("proj.hid");
+    InProjFc1Args f1{(const float*)c->ptr("head.tok_cur"), c->ptr("proj.w1"), c->ptr("proj.b1"), c->wptr("proj.h_frag"),
+                     c->BP, hid, (int)c->geti("proj.C"), c->RBp};
+    BD_TRY(bdk_in_proj_fc1(f1, st));
+    const GemmCfg& g = c->g["proj.fc2"];
+    InRmsArgs e;
+    BD_TRY(linear(c, "proj.fc2", c->ptr("proj.h_frag"), c->RBp, c->ptr("proj.w2"), D, hid, g, "proj.part", "proj.out_bf",
+                  c->ptr("proj.b2"), c->BPpad, &e.pend, st));
+    e.R = (float*)c->wptr("llm.R"); e.init_from_pend = 1; e.renorm_to_R = 1; e.w = (const float*)c->ptr("llm.emb_norm");
+    e.a_frag = nullptr; e.hidden_out = nullptr; e.cond_frag = nullptr; e.pos = nullptr;
+    e.state = (const BdStepState*)c->ptr("state"); e.M = c->BP; e.D = D; e.RB = c->RBp; e.P = c->Pn;
+    e.eps = (float)c->getf("llm.eps", 1e-6);
+    BD_TRY(bdk_in_rms(e, st));
+    return 0;
+}
+
 static int projector(bd_ctx* c, hipStream_t st) {
+    if (c->geti("proj.variant", 0)) return projector_in(c, st);
     const int D = (int)c->geti("proj.D");
     ProjFc1Args f1{(const float*)c->ptr("head.tok_cur"), c->ptr("proj.w1"), c->ptr("proj.b1"), c->wptr("proj.h_frag"),
                    c->BP, D, (int)c->geti("proj.C"), c->RBp};
@@ -439,7 +464,58 @@ static int projector(bd_ctx* c, hipStream_t st) {
     return 0;
 }
 
+// forward_model for one 16-token block of the imagenet transformer (model_parallel.py:342-350, layers_parallel.py:229-241)
+static int llm_step_in(bd_ctx* c, hipStream_t st) {
+    const int D = c->lD, F = c->lF, Mp = c->Mpad, RB = c->RB, M = c->M, nh = c->lnh;
+    const int nseq = c->branches * c->B;
+    const float eps = (float)c->getf("llm.eps", 1e-6);
+    BdStepState* state = (BdStepState*)c->wptr("state");
+    const GemmCfg &gq = c->g["llm.qkv"], &go = c->g["llm.o"], &gg = c->g["llm.gu"], &gd = c->g["llm.down"];
+    const size_t layer_elems = (size_t)nseq * nh * c->lLmax * 64;
+    Partial br{nullptr, nullptr, 0, 0, 0};
+    InRmsArgs r1;
+    r1.R = (float*)c->wptr("llm.R"); r1.init_from_pend = 0; r1.renorm_to_R = 0;
+    r1.a_frag = c->wptr("llm.a_frag"); r1.hidden_out = nullptr; r1.cond_frag = nullptr; r1.pos = nullptr; r1.state = state;
+    r1.M = M; r1.D = D; r1.RB = RB; r1.P = c->Pn; r1.eps = eps;
+    for (int l = 0; l < c->lL; ++l) {
+        const std::string pre = "llm.l" + std::to_string(l) + ".";
+        r1.pend = br;
+        r1.w = (const float*)c->ptr(pre + "in_norm");
+        BD_TRY(bdk_in_rms(r1, st));
+        InQkvPostArgs qa;
+        BD_TRY(linear(c, "llm.qkv", c->ptr("llm.a_frag"), RB, c->ptr(pre + "wqkv"), c->lNqkv, D, gq, "llm.qkv_part", "llm.qkv_bf",
+                      nullptr, Mp, &qa.qkv, st));
+        qa.rope = (const float*)c->ptr("llm.rope2d"); qa.q_out = c->wptr("llm.q");
+        qa.k_cache = (bf16_t*)c->wptr("llm.k_cache") + l * layer_elems;
+        qa.v_cache = (bf16_t*)c->wptr("llm.vt_cache") + l * layer_elems;
+        qa.state = state; qa.M = M; qa.P = c->Pn; qa.nh = nh; qa.Lmax = c->lLmax;
+        BD_TRY(bdk_in_qkv_post(qa, st));
+        InAttnArgs aa{c->ptr("llm.q"), qa.k_cache, qa.v_cache, c->wptr("llm.attn_frag"), state, nseq, c->Pn, nh, c->lLmax, RB};
+        BD_TRY(bdk_in_attn(aa, st));
+        InRmsArgs r2 = r1;
+        BD_TRY(linear(c, "llm.o", c->ptr("llm.attn_frag"), RB, c->ptr(pre + "wo"), D, D, go, "llm.br_part", "llm.br_bf",
+                      nullptr, Mp, &r2.pend, st));
+        r2.w = (const float*)c->ptr(pre + "post_norm");
+        BD_TRY(bdk_in_rms(r2, st));
+        BD_TRY(gemm(c, "llm.gu", c->ptr("llm.a_frag"), RB, c->ptr(pre + "wgu"), 2 * F, D, gg.S, gg.code(), BD_EPI_SWIGLU,
+                    (float*)c->wptr("llm.gu_part"), c->wptr("llm.act_frag"), nullptr, st));
+        BD_TRY(linear(c, "llm.down", c->ptr("llm.act_frag"), RB, c->ptr(pre + "wdown"), D, F, gd, "llm.br_part", "llm.br_bf",
+                      nullptr, Mp, &br, st));
+    }
+    StepAdvanceArgs sa{state, nseq < 16 ? nseq : 16, c->Pn};
+    BD_TRY(bdk_step_advance(sa, st));
+    InRmsArgs rf = r1;
+    rf.pend = br; rf.w = (const float*)c->ptr("llm.final_norm"); rf.a_frag = nullptr;
+    rf.hidden_out = (float*)c->wptr("llm.hidden");
+    const bool emit = c->geti("rt.emit_cond", 1) != 0 && c->has_head;
+    rf.cond_frag = emit ? c->wptr("head.cond_frag") : nullptr;
+    rf.pos = emit ? (const float*)c->ptr("pos") : nullptr;
+    BD_TRY(bdk_in_rms(rf, st));
+    return 0;
+}
+
 static int llm_step(bd_ctx* c, hipStream_t st) {
+    if (c->lvariant == 1) return llm_step_in(c, st);
     const int D = c->lD, F = c->lF, Mp = c->Mpad, RB = c->RB, M = c->M, nh = c->lnh, nkv = c->lnkv;
     const int nseq = c->branches * c->B;
     const float eps = (float)c->getf("llm.eps", 1e-6);

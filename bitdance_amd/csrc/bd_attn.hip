@@ -257,6 +257,90 @@ int bdk_head_attn(const HeadAttnArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// ImageNet transformer decode attention = the reference's naive_attention (layers_parallel.py:120-133) with its rounding
+// points: scores = bf16(q_scaled k^T) (autocast matmul output), + mask (all zeros for a decode block: every cached key
+// and the block itself are visible), softmax in fp32, P cast to bf16 by the second matmul, output bf16.
+// One workgroup per (sequence, head): 16 queries x L <= 1152 keys x 64 dims -- plain VALU through LDS, the whole
+// transformer is 4 % of this model's FLOPs.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void in_attn_kernel(InAttnArgs a) {
+    extern __shared__ float smem_f[];
+    const int seq = blockIdx.x / a.nh, h = blockIdx.x % a.nh, tid = threadIdx.x;
+    const int L = a.state->kv_len[0] + a.P;
+    const int LS = ((L + 63) & ~63) + 1;
+    float* qs = smem_f;                  // [16][64]
+    float* kt = qs + 16 * 64;            // [64][65]
+    float* sc = kt + 64 * 65;            // [16][LS]
+    const int D = a.nh * 64;
+    const bf16_t* Q = (const bf16_t*)a.q + (size_t)seq * a.P * D + h * 64;
+    const bf16_t* Kc = a.k_cache + ((size_t)seq * a.nh + h) * a.Lmax * 64;
+    const bf16_t* Vc = a.v_cache + ((size_t)seq * a.nh + h) * a.Lmax * 64;
+    for (int e = tid; e < 16 * 64; e += 256) qs[e] = (e >> 6) < a.P ? bf2f(Q[(size_t)(e >> 6) * D + (e & 63)]) : 0.f;
+    const int i = tid >> 4, jb = tid & 15;
+    for (int t0 = 0; t0 < L; t0 += 64) {
+        __syncthreads();
+        for (int e = tid; e < 64 * 64; e += 256) {
+            const int j = e >> 6, d = e & 63;
+            kt[j * 65 + d] = (t0 + j < L) ? bf2f(Kc[(size_t)(t0 + j) * 64 + d]) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = jb + 16 * jj;
+            float acc = 0.f;
+            for (int d = 0; d < 64; ++d) acc += qs[i * 64 + d] * kt[j * 65 + d];
+            if (t0 + j < L) sc[i * LS + t0 + j] = bfr(acc);
+        }
+    }
+    __syncthreads();
+    {   // softmax over the row in fp32; 16 threads per row
+        float mx = -INFINITY;
+        for (int j = jb; j < L; j += 16) mx = fmaxf(mx, sc[i * LS + j]);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+        for (int j = jb; j < L; j += 16) { const float e = expf(sc[i * LS + j] - mx); sc[i * LS + j] = e; sum += e; }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        for (int j = jb; j < L; j += 16) sc[i * LS + j] = bfr(sc[i * LS + j] / sum);
+    }
+    float o4[4] = {0.f, 0.f, 0.f, 0.f};
+    const int d0 = jb * 4;
+    for (int t0 = 0; t0 < L; t0 += 64) {
+        __syncthreads();
+        for (int e = tid; e < 64 * 64; e += 256) {
+            const int j = e >> 6, d = e & 63;
+            kt[j * 65 + d] = (t0 + j < L) ? bf2f(Vc[(size_t)(t0 + j) * 64 + d]) : 0.f;
+        }
+        __syncthreads();
+        const int nj = min(64, L - t0);
+        for (int j = 0; j < nj; ++j) {
+            const float pj = sc[i * LS + t0 + j];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o4[t] += pj * kt[j * 65 + d0 + t];
+        }
+    }
+    if (i < a.P) {
+        bf16_t* O = (bf16_t*)a.o_frag;
+        *reinterpret_cast<uint2*>(O + afrag_off(seq * a.P + i, h * 64 + d0, a.RB)) =
+            make_uint2(pack2(o4[0], o4[1]), pack2(o4[2], o4[3]));
+    }
+}
+int bdk_in_attn(const InAttnArgs& a, hipStream_t st) {
+    if (a.P > 16) return -2;
+    const int Lcap = a.Lmax + 64;
+    const size_t lds = (size_t)(16 * 64 + 64 * 65 + 16 * (Lcap + 1)) * sizeof(float);
+    if (lds > 160 * 1024) return -3;
+    static bool once = false;
+    if (!once) {
+        if (hipFuncSetAttribute((const void*)in_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -8;
+        once = true;
+    }
+    BD_LAUNCH(in_attn_kernel, dim3(a.nseq * a.nh), dim3(256), lds, st, a);
+    return bd_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
 // LLM decode attention (flash-decode over the static KV cache) + combine
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(640) void llm_attn_kernel(LlmAttnArgs a) {

@@ -149,6 +149,53 @@ struct QkvPostArgs {        // q/k RMS-norm + RoPE + KV-cache append            
 };
 int bdk_qkv_post(const QkvPostArgs& a, hipStream_t st);
 
+// ---- class-conditional ImageNet transformer (imagenet_gen/src/layers_parallel.py, model_parallel.py) -------------
+struct InProjFc1Args {      // MLPConnector.forward first half: w1 -> chunk -> silu(h1)*h2          model_parallel.py:73-75
+    const float* tok;       // [rows][C] fp32 in {-1,0,1}
+    const void* w;          // [2*hid][C] bf16 row-major (h1 rows, then h2 rows)
+    const void* b;          // [2*hid] bf16
+    void* act_frag;         // out fragment-major bf16 [rows_pad][hid]
+    int rows, hid, C, RB;
+};
+int bdk_in_proj_fc1(const InProjFc1Args& a, hipStream_t st);
+
+struct InRmsArgs {          // nn.RMSNorm on a bf16 residual stream: bf16( x * rsqrt(mean(x^2)+eps) * w ), w fp32
+    float* R;               // residual stream, fp32 storage of bf16 values [Mpad][D]
+    Partial pend;           // branch output to add first (bf16 + bf16 -> bf16); p == nullptr -> none
+    int init_from_pend;     // 1: x = pend (proj_in output) instead of R + pend
+    int renorm_to_R;        // 1: the normalised value becomes the residual stream (emb_norm, model_parallel.py:344)
+    const float* w;         // [D] fp32
+    void* a_frag;           // out fragment-major bf16 (may be null)
+    float* hidden_out;      // fp32 [M][D] (may be null)
+    void* cond_frag;        // bf16(normed + pos[step]) fragment-major (may be null)
+    const float* pos;
+    const BdStepState* state;
+    int M, D, RB, P;
+    float eps;
+};
+int bdk_in_rms(const InRmsArgs& a, hipStream_t st);
+
+struct InQkvPostArgs {      // interleaved 2-D RoPE on q,k + KV append, head_dim 64, MHA       layers_parallel.py:135-160,273-290
+    Partial qkv;            // [.,Mpad,3*D], q | k | v thirds
+    const float* rope;      // [tokens][32][2] (cos, sin)
+    void* q_out;            // bf16 [Mpad][D], already multiplied by head_dim^-0.5 (exact in bf16)
+    bf16_t* k_cache;        // [seq][nh][Lmax][64]
+    bf16_t* v_cache;
+    const BdStepState* state;
+    int M, P, nh, Lmax;
+};
+int bdk_in_qkv_post(const InQkvPostArgs& a, hipStream_t st);
+
+struct InAttnArgs {         // naive_attention with the reference's rounding points          layers_parallel.py:120-133
+    const void* q;
+    const bf16_t* k_cache;
+    const bf16_t* v_cache;
+    void* o_frag;           // out fragment-major bf16 [Mpad][D]
+    const BdStepState* state;
+    int nseq, P, nh, Lmax, RB;
+};
+int bdk_in_attn(const InAttnArgs& a, hipStream_t st);
+
 struct StepAdvanceArgs { BdStepState* state; int nseq, P; };
 int bdk_step_advance(const StepAdvanceArgs& a, hipStream_t st);
 

@@ -497,6 +497,110 @@ int bdk_qkv_post(const QkvPostArgs& a, hipStream_t st) {
     return bd_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Class-conditional ImageNet transformer rows (imagenet_gen/src): bf16 residual stream, fp32 norm weights
+// ------------------------------------------------------------------------------------------------
+__global__ void in_proj_fc1_kernel(InProjFc1Args a) {
+    extern __shared__ float sh[];
+    const int m = blockIdx.x;
+    for (int k = threadIdx.x; k < a.C; k += blockDim.x) sh[k] = bfr(a.tok[(size_t)m * a.C + k]);
+    __syncthreads();
+    const int d0 = threadIdx.x * 8;
+    if (d0 >= a.hid) return;
+    const bf16_t* W = (const bf16_t*)a.w;
+    float b1[8], b2[8], o[8];
+    ld_bf16x8((const bf16_t*)a.b + d0, b1);
+    ld_bf16x8((const bf16_t*)a.b + a.hid + d0, b2);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float h1 = bfr(small_dot(sh, W + (size_t)(d0 + j) * a.C, a.C) + b1[j]);            // Linear -> bf16
+        const float h2 = bfr(small_dot(sh, W + (size_t)(a.hid + d0 + j) * a.C, a.C) + b2[j]);
+        o[j] = silu_bf(h1) * h2;                                                                 // silu -> bf16; product rounded by pack8
+    }
+    *reinterpret_cast<u32x4*>((bf16_t*)a.act_frag + afrag_off(m, d0, a.RB)) = pack8(o);
+}
+int bdk_in_proj_fc1(const InProjFc1Args& a, hipStream_t st) {
+    const int t = row_threads(a.hid);
+    if (t < 0 || a.hid % 8) return -2;
+    BD_LAUNCH(in_proj_fc1_kernel, dim3(a.rows), dim3(t), a.C * sizeof(float), st, a);
+    return bd_launch_status();
+}
+
+__global__ void in_rms_kernel(InRmsArgs a) {
+    __shared__ float red[32];
+    const int m = blockIdx.x, d0 = threadIdx.x * 8;
+    const bool active = d0 < a.D;
+    float x[8];
+    float ss = 0.f;
+    if (active) {
+        if (a.init_from_pend) {
+            slab8(a.pend, m, d0, x);                               // proj_in output: bf16(sum + bias)
+        } else {
+            ld_f32x8(a.R + (size_t)m * a.D + d0, x);
+            if (a.pend.p) {
+                float o[8];
+                slab8(a.pend, m, d0, o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = bfr(x[j] + o[j]);   // bf16 residual + bf16 branch -> bf16
+            }
+        }
+        if (!a.renorm_to_R && (a.pend.p || a.init_from_pend)) st_f32x8(a.R + (size_t)m * a.D + d0, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += x[j] * x[j];
+    }
+    const float rs = rsqrtf(block_sum(ss, red) / (float)a.D + a.eps);
+    if (!active) return;
+    float w[8], n[8];
+    ld_f32x8(a.w + d0, w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) n[j] = bfr(fmul(fmul(x[j], rs), w[j]));   // rms_norm composite: one rounding to the input dtype
+    if (a.renorm_to_R) st_f32x8(a.R + (size_t)m * a.D + d0, n);
+    if (a.a_frag) *reinterpret_cast<u32x4*>((bf16_t*)a.a_frag + afrag_off(m, d0, a.RB)) = pack8(n);
+    if (a.hidden_out) st_f32x8(a.hidden_out + (size_t)m * a.D + d0, n);
+    if (a.cond_frag) {                                             // z = norm(x) + pos_for_diff (fp32), cast by cond_embed
+        float p[8];
+        ld_f32x8(a.pos + ((size_t)a.state->step * a.P + (m % a.P)) * a.D + d0, p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[j] = fadd(n[j], p[j]);
+        *reinterpret_cast<u32x4*>((bf16_t*)a.cond_frag + afrag_off(m, d0, a.RB)) = pack8(p);
+    }
+}
+int bdk_in_rms(const InRmsArgs& a, hipStream_t st) {
+    const int t = row_threads(a.D);
+    if (t < 0 || a.D % 8) return -2;
+    BD_LAUNCH(in_rms_kernel, dim3(a.M), dim3(t), 0, st, a);
+    return bd_launch_status();
+}
+
+// one wave per (row, q/k/v head slot of 64 dims): lane = dim; the RoPE partner of dim 2i is lane 2i+1
+__global__ __launch_bounds__(256) void in_qkv_post_kernel(InQkvPostArgs a) {
+    const int m = blockIdx.x, lane = threadIdx.x & 63;
+    const int D = a.nh * 64, nslot = 3 * a.nh;
+    const int seq = m / a.P, p = m % a.P;
+    const int pos = a.state->kv_len[0] + p;                        // every sequence has the same length here
+    for (int slot = blockIdx.y * 4 + (threadIdx.x >> 6); slot < nslot; slot += gridDim.y * 4) {
+        const int which = slot / a.nh, h = slot % a.nh;
+        float x = slab_bf(a.qkv, m, which * D + h * 64 + lane);
+        if (which < 2) {
+            const float other = __shfl_xor(x, 1);
+            const float c = a.rope[((size_t)pos * 32 + (lane >> 1)) * 2], s = a.rope[((size_t)pos * 32 + (lane >> 1)) * 2 + 1];
+            const float y = (lane & 1) ? fadd(fmul(x, c), fmul(other, s))          // x1*cos + x0*sin
+                                       : fsub(fmul(x, c), fmul(other, s));         // x0*cos - x1*sin
+            x = bfr(y);                                                             // .type_as(x)
+        }
+        if (which == 0) {
+            ((bf16_t*)a.q_out)[(size_t)m * D + h * 64 + lane] = f2bf(x * 0.125f);   // xq * head_dim**-0.5 (bf16, exact)
+        } else {
+            bf16_t* dst = (which == 1 ? a.k_cache : a.v_cache) + (((size_t)seq * a.nh + h) * a.Lmax + pos) * 64;
+            dst[lane] = f2bf(x);
+        }
+    }
+}
+int bdk_in_qkv_post(const InQkvPostArgs& a, hipStream_t st) {
+    BD_LAUNCH(in_qkv_post_kernel, dim3(a.M, (3 * a.nh + 3) / 4), dim3(256), 0, st, a);
+    return bd_launch_status();
+}
+
 __global__ void step_advance_kernel(StepAdvanceArgs a) {
     if (threadIdx.x == 0) a.state->step += 1;
     if ((int)threadIdx.x < a.nseq) a.state->kv_len[threadIdx.x] += a.P;

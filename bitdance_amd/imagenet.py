@@ -5,12 +5,15 @@ Mirrors the inference surface of ``imagenet_gen/src/model_parallel.py`` (SURVEY.
 (:352-369), the un-mixed first AR step (cfg_iter == 1.0 there, so cond and uncond rows are sampled independently),
 LFQ ``sign`` and the patch-raster un-patchify.  State-dict keys are the reference's (minus ``vae.*``).
 
-What runs where (round 1):
+What runs where:
   * I3 ``diff_head_parallel.TransEncoder`` + ``sampling_parallel.euler_maruyama`` (>= 70 % of the model's FLOPs): the HIP
     head -- the T2I kernels with head_dim 64 attention and no final sigmoid (engine.HeadWeights(head_dim=64,
     final_sigmoid=False));
-  * I2 the KV-cached block-causal transformer (4 % of the FLOPs): torch ops under bf16 autocast, i.e. the reference's own
-    arithmetic on hipBLASLt; its native kernels (head_dim-64 attention, interleaved 2-D RoPE) are the next row;
+  * I2 the KV-cached block-causal transformer: every 16-token decode step (``proj_in`` -> ``forward_model``) on the HIP
+    engine (``bd_projector`` / ``bd_llm_step`` in their imagenet variant: bf16 residual stream, fp32 norm weights,
+    interleaved 2-D RoPE, head_dim-64 attention with the reference's rounding points, static K/V cache); the first step
+    (class tokens + query tokens under the mixed causal / block mask, once per image) runs as torch ops and writes the
+    same K/V cache -- like the T2I prefill;
   * the conv decoder stays on MIOpen (north star).
 """
 from __future__ import annotations
@@ -18,9 +21,53 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
-from .engine import Engine, HeadWeights
+from .engine import Engine, HeadWeights, pack_linear, pack_swiglu, _bf16
 
 __all__ = ["BitDance"]
+
+
+class _InProj:
+    """MLPConnector (model_parallel.py:62-75) for the engine: w1 row-major bf16 (VALU, K = latent channels), w2 packed."""
+
+    def __init__(self, sd: dict, device):
+        w1, w2 = sd["proj_in.w1.weight"], sd["proj_in.w2.weight"]
+        self.D, self.hid, self.C = w2.shape[0], w2.shape[1], w1.shape[1]
+        self.ptrs = {"proj.w1": _bf16(w1, device), "proj.b1": _bf16(sd["proj_in.w1.bias"], device),
+                     "proj.w2": pack_linear([w2], device), "proj.b2": _bf16(sd["proj_in.w2.bias"], device)}
+
+    def ints(self) -> dict:
+        return {"proj.D": self.D, "proj.C": self.C, "proj.hid": self.hid, "proj.variant": 1}
+
+
+class _InTransformer:
+    """layers_parallel.TransformerBlock stack for the engine (llm.variant = 1)."""
+    variant = 1
+
+    def __init__(self, sd: dict, n_layer: int, n_head: int, rope: torch.Tensor, device):
+        D = sd["norm.weight"].shape[0]
+        F_ = sd["layers.0.feed_forward.w2.weight"].shape[1]
+        self.cfg = {"hidden_size": D, "rms_norm_eps": 1e-6}
+        self.D, self.F, self.L, self.nh = D, F_, n_layer, n_head
+        f32 = lambda t: t.detach().to(device, torch.float32).contiguous()
+        p = {"llm.final_norm": f32(sd["norm.weight"]), "llm.emb_norm": f32(sd["emb_norm.weight"]),
+             "llm.rope2d": f32(rope)}
+        for i in range(n_layer):
+            s_, d = f"layers.{i}.", f"llm.l{i}."
+            p[d + "in_norm"] = f32(sd[s_ + "attention_norm.weight"])
+            p[d + "post_norm"] = f32(sd[s_ + "ffn_norm.weight"])
+            p[d + "wqkv"] = pack_linear([sd[s_ + "attention.wqkv.weight"]], device)
+            p[d + "wo"] = pack_linear([sd[s_ + "attention.wo.weight"]], device)
+            w1 = sd[s_ + "feed_forward.w1.weight"]
+            p[d + "wgu"] = pack_swiglu(w1[:F_], w1[F_:], device)
+            p[d + "wdown"] = pack_linear([sd[s_ + "feed_forward.w2.weight"]], device)
+        self.ptrs = p
+
+    def ints(self, Lmax: int, splits: int) -> dict:
+        return {"llm.D": self.D, "llm.L": self.L, "llm.nh": self.nh, "llm.nkv": self.nh, "llm.F": self.F,
+                "llm.Lmax": Lmax, "llm.splits": splits, "llm.head_dim": 64, "llm.variant": 1}
+
+    def rope_tables(self, max_pos: int, device):           # the rotate-half tables of the Qwen3 path are unused here
+        return self.ptrs["llm.rope2d"], self.ptrs["llm.rope2d"]
 
 
 def _pos_2d(resolution: int, patch: int) -> torch.Tensor:
@@ -53,6 +100,7 @@ class BitDance:
         self.latent_dim = latent_dim
         self.total_tokens = self.h * self.w + cls_token_num
         self.vae = vae
+        self.native_transformer = True                       # False: torch ops for every step (reference arithmetic)
         sd = {k: v.detach().to(self.device, torch.float32) for k, v in state_dict.items() if not k.startswith("vae.")}
         self.w_ = sd
         head_sd = {k[len("head."):]: v for k, v in sd.items() if k.startswith("head.")}
@@ -74,6 +122,11 @@ class BitDance:
         for i in range(causal, tot, parallel_num):
             m[i:i + parallel_num, i:i + parallel_num] = 0
         self.attn_mask = m[None, None].to(self.device)
+        if dim // n_head != 64:
+            raise NotImplementedError("native imagenet transformer: head_dim must be 64")
+        self.proj_w = _InProj(sd, self.device)
+        self.tr_w = _InTransformer(sd, n_layer, n_head, self.freqs_cis, self.device)
+        self._tr: dict = {}
 
     # ------------------------------------------------------------------ transformer (torch, reference arithmetic)
     def _rope(self, x, fc):
@@ -112,6 +165,36 @@ class BitDance:
         w = self.w_
         h1, h2 = F.linear(x, w["proj_in.w1.weight"], w["proj_in.w1.bias"]).chunk(2, dim=-1)
         return F.linear(F.silu(h1) * h2, w["proj_in.w2.weight"], w["proj_in.w2.bias"])
+
+    # ------------------------------------------------------------------ transformer decode step (HIP)
+    def _tr_engine(self, bsz: int) -> Engine:
+        if bsz not in self._tr:
+            eng = Engine(None, self.proj_w, self.tr_w, num_images=bsz, branches=1, device=self.device,
+                         max_tokens=self.P, max_kv=self.total_tokens, parallel_num=self.P)
+            eng.set_int("rt.emit_cond", 0)
+            eng._tok = torch.zeros(bsz * self.P, self.proj_w.C, dtype=torch.float32, device=self.device)
+            eng.set_ptr("head.tok_cur", eng._tok)
+            self._tr[bsz] = eng
+        return self._tr[bsz]
+
+    def _load_cache(self, eng: Engine, caches, T0: int) -> None:
+        """K/V of the torch first step -> the engine's static cache [layer][seq][head][Lmax][64] bf16."""
+        bsz = caches[0][0].shape[0]
+        shape = (self.n_layer, bsz, self.n_head, eng.Lmax, 64)
+        kc = eng.view("llm.k_cache", torch.bfloat16, shape)
+        vc = eng.view("llm.vt_cache", torch.bfloat16, shape)
+        for l, (k, v) in enumerate(caches):
+            kc[l, :, :, :T0].copy_(k[:, :, :T0])
+            vc[l, :, :, :T0].copy_(v[:, :, :T0])
+        eng.reset([T0] * min(bsz, 16))
+
+    def _decode_step(self, eng: Engine, tokens: torch.Tensor) -> torch.Tensor:
+        """proj_in + forward_model for one 16-token block on the engine; returns norm(x) [bsz, P, D] (bf16 values)."""
+        bsz = tokens.shape[0]
+        eng._tok.copy_(tokens.reshape(bsz * self.P, -1))
+        eng.projector()
+        eng.llm_step()
+        return eng.hidden().view(bsz, self.P, -1)
 
     # ------------------------------------------------------------------ head (HIP)
     def _head_sample(self, z: torch.Tensor, cfg: float, steps: int, noise=None) -> torch.Tensor:
@@ -154,17 +237,23 @@ class BitDance:
         seq_len = self.h * self.w // P
         w = self.w_
         toks, preds, last = [], [], None
+        eng_t = self._tr_engine(bsz) if self.native_transformer else None
         for i in range(seq_len):
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                if i == 0:
+            if i == 0:
+                with torch.autocast("cuda", dtype=torch.bfloat16):
                     T0 = n_cls + P - 1
                     c = F.embedding(ids, w["cls_embedding.weight"]).view(bsz, n_cls, -1)
                     x = torch.cat([c, w["query_token"].repeat(bsz, 1, 1)], dim=1)
-                    x = self._forward_model(x, self.attn_mask[:, :, :T0, :T0], 0, T0, caches)
-                else:
+                    x = self._forward_model(x, self.attn_mask[:, :, :T0, :T0], 0, T0, caches)[:, -P:, :]
+                if eng_t is not None:
+                    self._load_cache(eng_t, caches, T0)
+            elif eng_t is not None:
+                x = self._decode_step(eng_t, last)
+            else:
+                with torch.autocast("cuda", dtype=torch.bfloat16):
                     s0 = P * (i - 1) + n_cls + P - 1
                     x = self._forward_model(self._proj_in(last), self.attn_mask[:, :, s0:s0 + P, :s0 + P], s0, s0 + P, caches)
-                z = x[:, -P:, :] + w["pos_for_diff.weight"][i * P:(i + 1) * P, :]
+            z = x.float() + w["pos_for_diff.weight"][i * P:(i + 1) * P, :]
             if cfg_scale > 1.0:
                 if cfg_schedule == "constant":
                     ci = cfg_scale

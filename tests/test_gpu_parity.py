@@ -520,9 +520,49 @@ def test_imagenet_sample_teacher_forced_vs_reference(golden_dir):
         assert d.mean().item() <= 0.07 * max(1.0, 2 * cfg_i - 1) * ref.abs().mean().item(), (i, d.mean())
         firm = ref.abs() > 0.5
         assert (torch.sign(preds[:, sl])[firm] == torch.sign(ref)[firm]).float().mean().item() >= 0.96, i
+    # the HIP transformer decode steps against the same steps as torch ops (the reference's own arithmetic): identical
+    # rounding points, so the two differ by accumulation order only
+    m.native_transformer = False
+    _, _, preds_t = m.sample(g["ids"], N, cfg_scale=float(g["cfg"]), noise=noise, force_tokens=ref_tok, return_tokens=True)
+    m.native_transformer = True
+    dt = (preds - preds_t.cpu()).abs()
+    assert dt.mean().item() <= 0.09 * g["preds"].abs().mean().item(), dt.mean()      # bf16 noise x CFG amplification, as above
     # free-running: same seed -> same latent; RNG consumption = AR_steps * (1 + N) draws in the reference's order
     torch.manual_seed(7)
     a = m.sample(g["ids"], N, cfg_scale=float(g["cfg"]))
     torch.manual_seed(7)
     b = m.sample(g["ids"], N, cfg_scale=float(g["cfg"]))
     assert torch.equal(a, b) and a.shape == (2, c["latent_dim"], 8, 8) and set(a.unique().tolist()) <= {-1.0, 0.0, 1.0}
+
+
+def test_imagenet_transformer_decode_step_vs_oracle():
+    """One proj_in + forward_model block (model_parallel.py:342-350, layers_parallel.py:120-168,229-241) on the HIP engine
+    against the oracle's autocast policy, K/V cache pre-filled by the oracle's first step.  Output = norm(x): bf16 values
+    of O(1); tolerance = a few bf16 ulps of accumulated GEMM-order noise over 2 layers."""
+    from bitdance_amd.imagenet import BitDance
+    from oracle import imagenet as oim
+    c = dict(tm.TINY_IN)
+    sd = tm.seeded_state(tm.imagenet_shapes(c), seed=29)
+    m = BitDance(sd, device=DEV, **c)
+    pol = Policy("autocast")
+    bsz, P, ncls = 4, c["parallel_num"], c["cls_token_num"]
+    hw = c["resolution"] // 16
+    total = hw * hw + ncls
+    hd = c["dim"] // c["n_head"]
+    caches = [(torch.zeros(bsz, c["n_head"], total, hd), torch.zeros(bsz, c["n_head"], total, hd)) for _ in range(c["n_layer"])]
+    fc, mask = oim.rope_table(c), oim.block_causal_mask(hw * hw + ncls - 1, ncls - 1, P)[None, None]
+    ids = torch.tensor([1, 4, 10, 10])
+    x0 = torch.cat([torch.nn.functional.embedding(ids, sd["cls_embedding.weight"]).view(bsz, ncls, -1),
+                    sd["query_token"].repeat(bsz, 1, 1)], dim=1)
+    T0 = ncls + P - 1
+    oim.forward_model(sd, c, x0, mask[:, :, :T0, :T0], fc[:T0], caches, 0, T0, pol)
+    g = torch.Generator().manual_seed(3)
+    tok = torch.sign(torch.randn(bsz, P, c["latent_dim"], generator=g))
+    ref = oim.forward_model(sd, c, oim.proj_in(sd, tok, pol), mask[:, :, T0:T0 + P, :T0 + P], fc[T0:T0 + P],
+                            [(k.clone(), v.clone()) for k, v in caches], T0, T0 + P, pol).float()
+    eng = m._tr_engine(bsz)
+    m._load_cache(eng, [(k.to(DEV), v.to(DEV)) for k, v in caches], T0)
+    got = m._decode_step(eng, tok.to(DEV)).float().cpu()
+    d = (got - ref).abs()
+    assert d.max().item() <= 0.06 * ref.abs().max().item() + 0.02 and d.mean().item() <= 0.01 * ref.abs().mean().item() + 1e-3, \
+        (d.max(), d.mean(), ref.abs().mean())
