@@ -566,3 +566,32 @@ def test_imagenet_transformer_decode_step_vs_oracle():
     d = (got - ref).abs()
     assert d.max().item() <= 0.06 * ref.abs().max().item() + 0.02 and d.mean().item() <= 0.01 * ref.abs().mean().item() + 1e-3, \
         (d.max(), d.mean(), ref.abs().mean())
+
+
+def test_imagenet_bitdance_b_dims_run():
+    """BitDance-B-16x at its real dimensions (model_parallel.py:456-465: dim 768, 24 layers, 12 heads of 64, FFN 2048;
+    head 6 blocks / 2 adaLN at 768; 256 px -> 16 AR steps; 64 class tokens), random weights, 2 sampling steps: shape /
+    divisibility coverage of every kernel on the non-power-of-two widths, HIP transformer == torch transformer within
+    bf16 noise on the first decode steps, deterministic."""
+    from bitdance_amd.imagenet import BitDance
+    c = dict(dim=768, n_layer=24, n_head=12, diff_layers=6, diff_dim=768, diff_adanln_layers=2, latent_dim=32, down_size=16,
+             patch_size=1, resolution=256, cls_token_num=64, num_classes=1000, parallel_num=16, time_shift=1.0)
+    sd = {k: v for k, v in tm.seeded_state(tm.imagenet_shapes(c), seed=5).items()}
+    m = BitDance(sd, device=DEV, **c)
+    ids = torch.tensor([1, 207, 980, 33])
+    torch.manual_seed(11)
+    lat, tok, pred = m.sample(ids, 2, cfg_scale=4.0, return_tokens=True)
+    torch.manual_seed(11)
+    lat2, tok2, pred2 = m.sample(ids, 2, cfg_scale=4.0, return_tokens=True)
+    assert lat.shape == (4, 32, 16, 16) and torch.isfinite(pred).all() and torch.equal(pred, pred2)
+    m.native_transformer = False
+    torch.manual_seed(11)
+    _, _, pred_t = m.sample(ids, 2, cfg_scale=4.0, force_tokens=tok, return_tokens=True)
+    m.native_transformer = True
+    torch.manual_seed(11)
+    _, _, pred_n = m.sample(ids, 2, cfg_scale=4.0, force_tokens=tok, return_tokens=True)
+    P = 16
+    for i in (0, 1, 2):                                        # step 0 shares the torch first step: identical up to the head
+        d = (pred_n[:, i * P:(i + 1) * P] - pred_t[:, i * P:(i + 1) * P]).abs().mean().item()
+        ref = pred_t[:, i * P:(i + 1) * P].abs().mean().item()
+        assert d <= (0.0 if i == 0 else 0.08) * ref + 1e-6, (i, d, ref)
