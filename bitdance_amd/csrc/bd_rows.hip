@@ -20,6 +20,11 @@ BD_DEV void ld_bf16x8(const bf16_t* p, float* v) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) { v[2 * j] = bf2f((bf16_t)(q[j] & 0xffff)); v[2 * j + 1] = bf2f((bf16_t)(q[j] >> 16)); }
 }
+BD_DEV u32x4 ld_raw8(const bf16_t* p) { return *reinterpret_cast<const u32x4*>(p); }   // issue now, unpack later
+BD_DEV void unpack8(const u32x4 q, float* v) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[2 * j] = bf2f((bf16_t)(q[j] & 0xffff)); v[2 * j + 1] = bf2f((bf16_t)(q[j] >> 16)); }
+}
 BD_DEV void ld_f32x8(const float* p, float* v) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
 #pragma unroll
@@ -40,16 +45,25 @@ BD_DEV void slab8(const Partial& q, int row, int col, float* v) {
     }
     const float* p = q.p + (size_t)row * q.N + col;
     const size_t slab = (size_t)q.Mpad * q.N;
-    ld_f32x8(p, v);
-    for (int s = 1; s < q.S; ++s) {
-        float t[8];
-        ld_f32x8(p + s * slab, t);
+    u32x4 braw = {0, 0, 0, 0};
+    if (q.bias) braw = ld_raw8((const bf16_t*)q.bias + col);
+    // all slab loads of a batch in flight before the first add: a `for (s < S)` loop with a runtime S serialises S
+    // dependent L2/MALL round trips (the whole row kernel is that latency chain); same summation order as before
+    for (int s0 = 0; s0 < q.S; s0 += 6) {
+        float t[6][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += t[j];
+        for (int s = 0; s < 6; ++s)
+            if (s0 + s < q.S) ld_f32x8(p + (size_t)(s0 + s) * slab, t[s]);
+#pragma unroll
+        for (int s = 0; s < 6; ++s)
+            if (s0 + s < q.S) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (s0 + s == 0) ? t[s][j] : v[j] + t[s][j];
+            }
     }
     if (q.bias) {
         float b[8];
-        ld_bf16x8((const bf16_t*)q.bias + col, b);
+        unpack8(braw, b);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += b[j];
     }
@@ -183,17 +197,41 @@ __global__ void ln_mod_kernel(LnModArgs a) {
     __shared__ float red[32];
     const int m = blockIdx.x, d0 = threadIdx.x * 8;
     const bool active = d0 < a.D;
-    const bf16_t* ada = (const bf16_t*)a.ada;
-    float x[8];
+    const bf16_t* ada = (const bf16_t*)a.ada + (size_t)m * a.ada_ld;
+    float x[8], w[8], b[8];
+    u32x4 xr, gr, scr, sfr;
     if (active) {
-        load_x_pending(x, (const bf16_t*)a.X, a.pend, ada, a.ada_ld, a.gate_off, m, a.D, d0);
-        if (a.pend.p) *reinterpret_cast<u32x4*>((bf16_t*)a.X + (size_t)m * a.D + d0) = pack8(x);
+        // every load of the kernel is issued up front (the row is one latency chain otherwise: slabs, then X, then
+        // gate, then -- after two block reductions -- scale, shift and the LN affine); unpacked where needed
+        xr = ld_raw8((const bf16_t*)a.X + (size_t)m * a.D + d0);
+        scr = ld_raw8(ada + a.scale_off + d0);
+        sfr = ld_raw8(ada + a.shift_off + d0);
+        if (a.ln_w) { ld_f32x8(a.ln_w + d0, w); ld_f32x8(a.ln_b + d0, b); }
+        if (a.pend.p) {
+            gr = ld_raw8(ada + a.gate_off + d0);
+            float o[8], g[8];
+            slab8(a.pend, m, d0, o);
+            unpack8(xr, x);
+            unpack8(gr, g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = bfr(x[j] + bfr(o[j] * g[j]));       // x = bf16(x + bf16(bf16(branch) * gate))
+            *reinterpret_cast<u32x4*>((bf16_t*)a.X + (size_t)m * a.D + d0) = pack8(x);
+        } else {
+            unpack8(xr, x);
+        }
     }
     float mean, rstd;
     ln_stats(x, active, a.D, a.eps, red, mean, rstd);
     if (!active) return;
-    float h[8];
-    modulate8(x, mean, rstd, a.ln_w, a.ln_b, ada + (size_t)m * a.ada_ld, a.scale_off, a.shift_off, d0, h);
+    float h[8], sc[8], sf[8];
+    unpack8(scr, sc);
+    unpack8(sfr, sf);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float ln = (x[j] - mean) * rstd;
+        if (a.ln_w) ln = ln * w[j] + b[j];
+        h[j] = fadd(fmul(ln, bfr(1.0f + sc[j])), sf[j]);           // fp32 * bf16 + bf16 -> fp32, separate ops
+    }
     *reinterpret_cast<u32x4*>((bf16_t*)a.h_frag + afrag_off(m, d0, a.RB)) = pack8(h);   // cast by the next Linear
 }
 int bdk_ln_mod(const LnModArgs& a, hipStream_t st) {
@@ -414,7 +452,9 @@ __global__ void rms_kernel(RmsArgs a) {
     const bool active = d0 < a.D;
     float r[8];
     float ss = 0.f;
+    u32x4 wr;
     if (active) {
+        wr = ld_raw8((const bf16_t*)a.w + d0);                     // in flight across the reduction
         ld_f32x8(a.R + (size_t)m * a.D + d0, r);
         if (a.pend.p) {
             float o[8];
@@ -429,7 +469,7 @@ __global__ void rms_kernel(RmsArgs a) {
     const float rs = rsqrtf(block_sum(ss, red) / (float)a.D + a.eps);
     if (!active) return;
     float w[8], n[8];
-    ld_bf16x8((const bf16_t*)a.w + d0, w);
+    unpack8(wr, w);
 #pragma unroll
     for (int j = 0; j < 8; ++j) n[j] = fmul(w[j], fmul(r[j], rs));   // weight * (x * rsqrt(var+eps)), fp32
     if (a.a_frag) *reinterpret_cast<u32x4*>((bf16_t*)a.a_frag + afrag_off(m, d0, a.RB)) = pack8(n);   // cast by the next Linear
