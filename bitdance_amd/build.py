@@ -1,6 +1,7 @@
 """Build libbitdance_hip.so (gfx950) in-tree with hipcc.  `python -m bitdance_amd.build`"""
 from __future__ import annotations
 
+import fcntl
 import os
 import shutil
 import subprocess
@@ -32,10 +33,20 @@ def _newer(target: str, deps: list[str]) -> bool:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile what is out of date and link.  Safe to call from every rank of a multi-process launch: one process builds
+    under an exclusive file lock, the others wait and then find everything up to date; the library is replaced atomically."""
     os.makedirs(OBJ, exist_ok=True)
+    with open(os.path.join(OBJ, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "bitdance_hip.h"))
-    hipcc = _hipcc()
     jobs = []
     objs = []
     for src in SOURCES:
@@ -43,7 +54,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
         if force or not _newer(o, [s] + headers):
-            jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
+            jobs.append((s, o))
+    if not jobs and _newer(LIB, objs):
+        return LIB
+    hipcc = _hipcc()
 
     def run(cmd):
         if verbose:
@@ -54,9 +68,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return r
 
     with ThreadPoolExecutor(max_workers=4) as ex:
-        list(ex.map(run, jobs))
-    if jobs or not os.path.exists(LIB):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
+        list(ex.map(lambda so: run([hipcc, *FLAGS, "-c", so[0], "-o", so[1]]), jobs))
+    tmp = LIB + f".tmp{os.getpid()}"
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp])
+    os.replace(tmp, LIB)
     return LIB
 
 
