@@ -261,6 +261,15 @@ def gen_imagenet():
         save(f"imagenet_{tag}", ids=ids, latent=lat, preds=torch.cat(preds, dim=1), conds=torch.cat(conds, dim=1),
              noise0=torch.stack(n0), noise1=torch.stack(n1), calls=rn.calls, cfg=np.float32(3.0), n_steps=3,
              rope=m.freqs_cis, mask=m.attn_mask[0, 0])
+        # the other two head_sample branches (model_parallel.py:356-365): constant CFG (mixed from the first step on)
+        # and no CFG (cfg_scale <= 1: a single branch, no null-class rows)
+        for name, kw in (("const", dict(cfg_scale=2.0, cfg_schedule="constant")), ("nocfg", dict(cfg_scale=1.0))):
+            conds.clear(); preds.clear()
+            ctx = rh.CudaAutocastOnCpu() if tag == "amp" else torch.no_grad()
+            with torch.no_grad(), ctx, rh.ReplayNoise(seed=23) as rn:
+                lat = m.sample(ids, sample_steps=2, **kw)
+            save(f"imagenet_{name}_{tag}", ids=ids, latent=lat, preds=torch.cat(preds, dim=1), noise=torch.stack(rn.record),
+                 calls=rn.calls, cfg=np.float32(kw["cfg_scale"]), n_steps=2)
 
 
 def main():

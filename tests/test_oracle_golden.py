@@ -213,3 +213,17 @@ def test_imagenet_sample_amp_teacher_forced(golden_dir):
         assert d.mean().item() <= 0.045 * max(1.0, 2 * cfg_i - 1) * ref.abs().mean().item(), (i, d.mean())
         firm = ref.abs() > 0.5
         assert (torch.sign(preds[:, sl])[firm] == torch.sign(ref)[firm]).float().mean().item() >= 0.97, i
+
+
+@pytest.mark.parametrize("name,schedule", [("const", "constant"), ("nocfg", "linear")])
+def test_imagenet_other_cfg_branches_fp32(golden_dir, name, schedule):
+    """head_sample's other branches (model_parallel.py:356-365): constant CFG, and cfg_scale <= 1 (one branch, no
+    null-class rows): tokens identical to the reference in fp32."""
+    from oracle import imagenet
+    g = load(golden_dir, f"imagenet_{name}_fp32")
+    w = tm.seeded_state(tm.imagenet_shapes(tm.TINY_IN), seed=29)
+    lat, tokens, preds = imagenet.sample(w, dict(tm.TINY_IN), g["ids"], int(g["n_steps"]), float(g["cfg"]),
+                                         list(g["noise"]), Policy("fp32"), cfg_schedule=schedule)
+    assert int(g["calls"]) == 4 * (int(g["n_steps"]) + 1)
+    torch.testing.assert_close(preds, g["preds"], atol=2e-4, rtol=1e-3)
+    assert torch.equal(lat, g["latent"])
