@@ -169,8 +169,16 @@ def gen_llm():
 
 def gen_pipeline():
     jobs = [("gen_fp32", torch.float32, None, [256, 256], 256), ("gen_amp", torch.bfloat16, None, [256, 256], 256),
-            ("gen16_fp32", torch.float32, tm.TINY_HEAD16, [128, 128], 64), ("gen16_amp", torch.bfloat16, tm.TINY_HEAD16, [128, 128], 64)]
+            ("gen16_fp32", torch.float32, tm.TINY_HEAD16, [128, 128], 64), ("gen16_amp", torch.bfloat16, tm.TINY_HEAD16, [128, 128], 64),
+            # two images per call (M = 256 rows with CFG) and guidance_scale <= 1 (single branch, no uncond prefill)
+            ("genb2_fp32", torch.float32, None, [256, 128], 128), ("genb2_amp", torch.bfloat16, None, [256, 128], 128),
+            ("gennocfg_fp32", torch.float32, None, [256, 128], 128), ("gennocfg_amp", torch.bfloat16, None, [256, 128], 128)]
+    only = sys.argv[2] if len(sys.argv) > 2 else None
     for name, dtype, hcfg, size, max_len in jobs:
+        if only and not name.startswith(only):
+            continue
+        n_img = 2 if name.startswith("genb2") else 1
+        gs = 1.0 if name.startswith("gennocfg") else 4.0
         tag = name.split("_")[1]
         pipe = build_pipeline(dtype, hcfg)
         ctx = rh.CudaAutocastOnCpu() if tag == "amp" else torch.no_grad()
@@ -192,10 +200,11 @@ def gen_pipeline():
 
         pipe.vision_head.sample = rec_sample
         with torch.no_grad(), ctx, rh.ReplayNoise(seed=13) as rn:
-            img = pipe.gen_image(cond_prompt="a red fox", uncond_prompt="<|", guidance_scale=4.0,
-                                 num_sampling_steps=4, max_length=max_len, num_images=1, image_size=size)
-        save(name, tokens=captured["tokens"], preds=torch.stack(preds), image=img, noise=torch.stack(rn.record),
-             calls=rn.calls, cfg=np.float32(4.0), n_steps=4)
+            img = pipe.gen_image(cond_prompt="a red fox", uncond_prompt="<|", guidance_scale=gs,
+                                 num_sampling_steps=4, max_length=max_len, num_images=n_img, image_size=size)
+        extra = {} if name.startswith(("genb2", "gennocfg")) else {"image": img}     # keep the newer fixtures small
+        save(name, tokens=captured["tokens"], preds=torch.stack(preds), noise=torch.stack(rn.record),
+             calls=rn.calls, cfg=np.float32(gs), n_steps=4, **extra)
 
 
 def gen_misc():
@@ -278,6 +287,8 @@ def main():
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "imagenet":
         return gen_imagenet()
+    if len(sys.argv) > 1 and sys.argv[1] == "pipeline":
+        return gen_pipeline()
     gen_sampler()
     gen_head()
     gen_llm()

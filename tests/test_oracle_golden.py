@@ -95,15 +95,16 @@ def test_llm_amp(golden_dir):
         assert err.max() <= 0.12 and err.mean() <= 1e-2, (err.max(), err.mean())
 
 
-def run_gen(g, pol, dtype, force=None, trace=None, P=64, hw=16):
+def run_gen(g, pol, dtype, force=None, trace=None, P=64, hw=16, w=None, num_images=1):
     lw = llm_weights(dtype)
     tok = tm.FakeTokenizer()
+    w = hw if w is None else w
     return pipeline.gen_tokens(
         lw, tm.TINY_LLM, head_weights(), tm.seeded_state(tm.proj_shapes(32, 256), seed=33),
         lw["model.embed_tokens.weight"], tok.encode("a red fox"), tok.encode("<|"),
-        [tm.VISION_START, tm.RES_BASE + hw, tm.RES_BASE + hw], [tm.QUERY_BASE + i for i in range(1, P)],
-        h=hw, w=hw, parallel_num=P, guidance_scale=float(g["cfg"]), num_sampling_steps=int(g["n_steps"]),
-        num_images=1, noise=list(g["noise"]), pol=Policy(pol), force_tokens=force, trace=trace)
+        [tm.VISION_START, tm.RES_BASE + hw, tm.RES_BASE + w], [tm.QUERY_BASE + i for i in range(1, P)],
+        h=hw, w=w, parallel_num=P, guidance_scale=float(g["cfg"]), num_sampling_steps=int(g["n_steps"]),
+        num_images=num_images, noise=list(g["noise"]), pol=Policy(pol), force_tokens=force, trace=trace)
 
 
 def test_gen_tokens_fp32(golden_dir):
@@ -227,3 +228,15 @@ def test_imagenet_other_cfg_branches_fp32(golden_dir, name, schedule):
     assert int(g["calls"]) == 4 * (int(g["n_steps"]) + 1)
     torch.testing.assert_close(preds, g["preds"], atol=2e-4, rtol=1e-3)
     assert torch.equal(lat, g["latent"])
+
+
+@pytest.mark.parametrize("name,n_img", [("genb2", 2), ("gennocfg", 1)])
+def test_gen_tokens_batch2_and_nocfg_fp32(golden_dir, name, n_img):
+    """gen_image with num_images = 2 (rows [cond x2 | uncond x2], per-image noise) and with guidance_scale <= 1 (single
+    branch: no uncond prefill, no CFG mix), 256x128: every token equals the reference's in fp32."""
+    g = load(golden_dir, name + "_fp32")
+    assert int(g["calls"]) == 2 * (int(g["n_steps"]) + 1)       # 2 AR steps x (1 + N) draws, independent of num_images
+    tr = {}
+    out = run_gen(g, "fp32", torch.float32, trace=tr, hw=16, w=8, num_images=n_img)
+    assert torch.equal(out, g["tokens"])
+    torch.testing.assert_close(torch.stack(tr["pred"]), g["preds"][:, :n_img], atol=2e-4, rtol=1e-3)
