@@ -213,7 +213,7 @@ class BitDance:
             eng.draw_noise(1)                                # randn + N x randn_like: the reference's RNG order
         else:
             eng.load_noise(noise.view(1, steps + 1, B, self.P, -1))
-        eng.reset([0] * rows)
+        eng.reset([0] * min(rows, 16))                        # the head reads only the step counter
         eng.set_cond(z)
         eng.head_sample()
         x = eng.pred().clone()

@@ -41,7 +41,7 @@ class NativeDiffHead:
         eng = self._eng[key]
         eng.set_schedule(num_sampling_steps, cfg, 1)
         eng.draw_noise(1)                                   # randn + N x randn_like, the reference's RNG order
-        eng.reset([0] * (B * mult))
+        eng.reset([0] * min(B * mult, 16))                  # the head reads only the step counter
         eng.set_cond(z.to(pipe.device))
         eng.head_sample()
         x = eng.pred().clone()
