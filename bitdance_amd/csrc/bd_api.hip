@@ -169,10 +169,13 @@ int bd_ctx_finalize(bd_ctx* c) {
         c->BPpad = pad_rows(c->BP);
         c->RB = c->Mpad / 32;
         c->RBp = c->BPpad / 32;
-        if (c->branches * c->B > 16) return fail("too many sequences (max 16)");
         c->has_head = c->I.count("head.D") > 0;
         c->has_llm = c->I.count("llm.D") > 0;
         c->has_proj = c->I.count("proj.D") > 0;
+        // the step state has 16 per-sequence KV-length slots: a limit of the Qwen3 decode path only (prompts differ in
+        // length); head-only contexts read just the step counter, imagenet sequences all share slot 0
+        if (c->branches * c->B > 16 && c->has_llm && c->geti("llm.variant", 0) == 0)
+            return fail("too many sequences for the Qwen3 decode path (max 16)");
         c->ws.clear();
         auto add = [&](const std::string& n, long long bytes) { c->ws.push_back({n, bytes}); };
         add("state", sizeof(BdStepState));

@@ -665,3 +665,28 @@ def test_gen_image_batch2_and_nocfg_vs_reference(golden_dir, name, n_img):
         assert err[s_].mean() <= bound, (s_, err[s_].mean())
     firm = ref.abs() > 0.5
     assert (torch.sign(pred)[firm] == torch.sign(ref)[firm]).float().mean() >= 0.97
+
+
+def test_imagenet_more_than_16_sequences():
+    """Batches beyond the 16 per-sequence length slots of the step state (the eval batch is 384 classes): every imagenet
+    sequence has the same length, so slot 0 serves all of them.  40 sequences: HIP transformer == torch transformer within
+    bf16 noise, per-sample results independent of the batch they are in."""
+    from bitdance_amd.imagenet import BitDance
+    c = tm.TINY_IN
+    m = BitDance(tm.seeded_state(tm.imagenet_shapes(c), seed=29), device=DEV, **c)
+    ids = torch.arange(20) % 10
+    g = torch.Generator().manual_seed(9)
+    N, P, steps = 2, c["parallel_num"], 4
+    noise = [torch.randn(N + 1, 40 if i == 0 else 20, P, c["latent_dim"], generator=g) for i in range(steps)]
+    lat, tok, pred = m.sample(ids, N, cfg_scale=2.0, noise=noise, return_tokens=True)
+    m.native_transformer = False
+    _, _, pred_t = m.sample(ids, N, cfg_scale=2.0, noise=noise, force_tokens=tok, return_tokens=True)
+    m.native_transformer = True
+    _, _, pred_n = m.sample(ids, N, cfg_scale=2.0, noise=noise, force_tokens=tok, return_tokens=True)
+    d = (pred_n - pred_t).abs().mean().item()
+    assert d <= 0.06 * pred_t.abs().mean().item(), d
+    # sample 3 alone (same noise rows) == sample 3 inside the batch of 20
+    sub = [torch.cat([nz[:, 3:4], nz[:, 23:24]], dim=1) if nz.shape[1] == 40 else nz[:, 3:4] for nz in noise]
+    tok_sub = torch.cat([tok[3:4], tok[23:24]])
+    _, _, pred_1 = m.sample(ids[3:4], N, cfg_scale=2.0, noise=sub, force_tokens=tok_sub, return_tokens=True)
+    torch.testing.assert_close(pred_1[0], pred_n[3], atol=2e-2, rtol=2e-2)
