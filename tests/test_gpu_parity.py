@@ -690,3 +690,36 @@ def test_imagenet_more_than_16_sequences():
     tok_sub = torch.cat([tok[3:4], tok[23:24]])
     _, _, pred_1 = m.sample(ids[3:4], N, cfg_scale=2.0, noise=sub, force_tokens=tok_sub, return_tokens=True)
     torch.testing.assert_close(pred_1[0], pred_n[3], atol=2e-2, rtol=2e-2)
+
+
+def test_c_abi_error_behaviour(eng_mod):
+    """Every entry point returns 0 or a negative code with text in bd_last_error(); Python raises BitDanceHipError --
+    never a silent fallback.  Unsupported shapes, empty split-K slices, out-of-schedule evals, unbound contexts."""
+    from bitdance_amd._lib import BitDanceHipError, check, lib
+    l = lib()
+    st = torch.cuda.current_stream().cuda_stream
+    buf = torch.zeros(1 << 20, dtype=torch.float32, device=DEV)
+    assert l.bd_gemm_partial(buf.data_ptr(), 4, buf.data_ptr(), 256, 100, 1, 4, buf.data_ptr(), st) != 0      # K % 64
+    assert l.bd_gemm_partial(buf.data_ptr(), 4, buf.data_ptr(), 200, 128, 1, 4, buf.data_ptr(), st) != 0      # N % (32 nw)
+    assert l.bd_gemm_partial(buf.data_ptr(), 4, buf.data_ptr(), 256, 128, 3, 4, buf.data_ptr(), st) != 0      # empty K slice
+    assert l.bd_last_error()
+    with pytest.raises(BitDanceHipError):
+        check(l.bd_pack_weight(buf.data_ptr(), buf.data_ptr(), 48, 64, 0, 48, st), "bd_pack_weight")          # rows % 32
+    sd, eng = tiny_head_engine(eng_mod)
+    with pytest.raises(BitDanceHipError):
+        eng.head_sample()                                                                                      # no schedule set
+    eng.set_schedule(3, 2.0, 1)
+    with pytest.raises(BitDanceHipError):
+        eng.head_eval(7)                                                                                       # outside the schedule
+    ctx = l.bd_ctx_create()
+    assert l.bd_ctx_bind(ctx) != 0 and l.bd_head_sample(ctx, st) != 0                                         # not finalized / bound
+    l.bd_ctx_destroy(ctx)
+    with pytest.raises(BitDanceHipError):
+        eng_mod.Engine(None, None, None, num_images=1, branches=2, device=DEV, parallel_num=32)               # P must be 16 or 64
+    # the library is still healthy afterwards
+    eng.load_noise(torch.zeros(1, 4, 2, 64, 32))
+    eng.reset([0, 0, 0, 0])
+    eng.set_cond(torch.zeros(256, 256, device=DEV))
+    eng.head_sample()
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.pred()).all()
