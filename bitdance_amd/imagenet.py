@@ -83,6 +83,28 @@ def _patch_raster(x: torch.Tensor, p: int, H: int, W: int) -> torch.Tensor:
     return x.reshape(H // p, p, W // p, p, -1).permute(0, 2, 1, 3, 4).reshape(H * W, *tail)
 
 
+def rope_table_2d(head_dim: int, resolution: int, patch: int, cls_token_num: int, parallel_num: int) -> torch.Tensor:
+    """[cls + P-1 + h*w - P, head_dim/2, 2] (cos, sin): position 0 for class/query tokens, (x+1, y+1) cell centres for the
+    image tokens in patch-raster order, the last P rows dropped (model_parallel.py:197-212, layers_parallel.py:255-270)."""
+    n = resolution // patch
+    half = head_dim // 2
+    freqs = 1.0 / (10000 ** (torch.arange(0, half, 2)[: half // 2].float() / half))
+    t = torch.cat([torch.zeros(cls_token_num + parallel_num - 1, 2), _pos_2d(resolution, patch) + 1.0])
+    fr = torch.outer(t.flatten(), freqs).view(t.shape[0], -1)
+    fc = torch.stack([torch.cos(fr), torch.sin(fr)], dim=-1)
+    fc[-n * n:] = _patch_raster(fc[-n * n:], int(parallel_num ** 0.5), n, n)
+    return fc[:-parallel_num]
+
+
+def block_causal_mask(total: int, causal: int, block: int) -> torch.Tensor:
+    """Additive mask: causal, each `block`-token group after the first `causal` tokens bidirectional (model_parallel.py:90-101)."""
+    m = torch.zeros(total, total)
+    m.masked_fill_(torch.triu(torch.ones(total, total), diagonal=1).bool(), float("-inf"))
+    for i in range(causal, total, block):
+        m[i:i + block, i:i + block] = 0
+    return m
+
+
 class BitDance:
     def __init__(self, state_dict: dict, *, dim: int, n_layer: int, n_head: int, latent_dim: int, resolution: int = 256,
                  down_size: int = 16, patch_size: int = 1, cls_token_num: int = 64, num_classes: int = 1000,
@@ -106,22 +128,9 @@ class BitDance:
         head_sd = {k[len("head."):]: v for k, v in sd.items() if k.startswith("head.")}
         self.head_w = HeadWeights.from_state_dict(head_sd, self.device, head_dim=64, final_sigmoid=False)
         self._eng: dict = {}
-        # RoPE table [cls + P-1 + h*w - P, hd/2, 2] and block-causal mask (model_parallel.py:197-215)
-        hd = dim // n_head
-        half = hd // 2
-        freqs = 1.0 / (10000 ** (torch.arange(0, half, 2)[: half // 2].float() / half))
-        t = torch.cat([torch.zeros(cls_token_num + parallel_num - 1, 2), _pos_2d(resolution, down_size * patch_size) + 1.0])
-        fr = torch.outer(t.flatten(), freqs).view(t.shape[0], -1)
-        fc = torch.stack([torch.cos(fr), torch.sin(fr)], dim=-1)
-        n_img = self.h * self.w
-        fc[-n_img:] = _patch_raster(fc[-n_img:], int(parallel_num ** 0.5), self.h, self.w)
-        self.freqs_cis = fc[:-parallel_num].to(self.device)
-        tot, causal = n_img + cls_token_num - 1, cls_token_num - 1
-        m = torch.zeros(tot, tot)
-        m.masked_fill_(torch.triu(torch.ones(tot, tot), diagonal=1).bool(), float("-inf"))
-        for i in range(causal, tot, parallel_num):
-            m[i:i + parallel_num, i:i + parallel_num] = 0
-        self.attn_mask = m[None, None].to(self.device)
+        self.freqs_cis = rope_table_2d(dim // n_head, resolution, down_size * patch_size, cls_token_num, parallel_num).to(self.device)
+        self.attn_mask = block_causal_mask(self.h * self.w + cls_token_num - 1, cls_token_num - 1, parallel_num)[None, None] \
+            .to(self.device)
         if dim // n_head != 64:
             raise NotImplementedError("native imagenet transformer: head_dim must be 64")
         self.proj_w = _InProj(sd, self.device)

@@ -97,3 +97,20 @@ def test_pos_embed_and_unraster_match_reference(golden_dir):
 def test_row_block_padding():
     from bitdance_amd.engine import row_blocks
     assert [row_blocks(m) for m in (1, 32, 33, 64, 65, 128, 129, 256, 512)] == [1, 1, 2, 2, 4, 4, 8, 8, 16]
+
+
+def test_imagenet_rope_and_mask_tables_match_reference(golden_dir):
+    """The product's own 2-D RoPE table (patch-raster order) and block-causal mask against the reference's buffers
+    (golden imagenet_fp32: model.freqs_cis / model.attn_mask), exact; plus BitDance-B's real geometry."""
+    import numpy as np
+    from bitdance_amd.imagenet import block_causal_mask, rope_table_2d
+    from oracle import tiny_models as tm
+    z = np.load(os.path.join(golden_dir, "imagenet_fp32.npz"))
+    c = tm.TINY_IN
+    fc = rope_table_2d(c["dim"] // c["n_head"], c["resolution"], 16, c["cls_token_num"], c["parallel_num"])
+    assert torch.equal(fc, torch.from_numpy(z["rope"]))
+    hw = c["resolution"] // 16
+    m = block_causal_mask(hw * hw + c["cls_token_num"] - 1, c["cls_token_num"] - 1, c["parallel_num"])
+    assert torch.equal(m, torch.from_numpy(z["mask"]))
+    fc = rope_table_2d(64, 256, 16, 64, 16)                    # BitDance-B-16x: 64 cls + 15 query + 256 - 16 image positions
+    assert fc.shape == (64 + 15 + 256 - 16, 32, 2) and bool((fc[:79, :, 0] == 1).all()) and bool((fc[:79, :, 1] == 0).all())
