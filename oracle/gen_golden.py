@@ -207,6 +207,44 @@ def gen_pipeline():
              calls=rn.calls, cfg=np.float32(gs), n_steps=4, **extra)
 
 
+def gen_mllm_equiv():
+    """MLLModel.gen_image_block_causal (modeling/mllm.py:386-501), the second copy of the hot loop the north star names,
+    on the same components / prompt / injected noise as gen_fp32: its tokens are recorded so the tests can pin
+    "t2i_pipeline.gen_image == mllm.gen_image" (SURVEY 8a P1).  MLLModel.__init__ needs liger_kernel / omegaconf
+    (absent): the instance is assembled with object.__new__ and exactly the attributes the loop reads."""
+    from types import SimpleNamespace
+    import modeling.mllm as mm
+
+    class Tiny(mm.MLLModel):
+        device = "cpu"
+
+    base = build_pipeline(torch.float32)
+    tok = tm.FakeTokenizer()
+    tk = SimpleNamespace(encode=tok.encode, start_of_image_id=tm.VISION_START)
+    for n in range(1, 129):
+        setattr(tk, f"res_{n}_id", tm.RES_BASE + n)
+    for i in range(1, 64):
+        setattr(tk, f"query_{i}_id", tm.QUERY_BASE + i)
+    m = object.__new__(Tiny)
+    torch.nn.Module.__init__(m)
+    m.tokenizer = tk
+    m.config = SimpleNamespace(vit_patch_size=16)
+    m.llm_model = base.llm_model
+    m.hidden_size = base.hidden_size
+    m.parallel_num, m.ps = 64, 8
+    m.vision_diffusion_head = base.vision_head
+    m.embed_vision_mlp = base.embed_vision_mlp
+    m.register_buffer("pos_embed_1d", m._get_1d_sincos_pos_embed(m.hidden_size // 2, 256), persistent=False)
+    captured = {}
+    m.decode_image = lambda lat, image_size=None, ps=1: captured.setdefault("tokens", lat.clone())
+    with torch.no_grad(), rh.ReplayNoise(seed=13) as rn:
+        m.gen_image_block_causal("a red fox", "<|", 4.0, 4, 256, 1, [256, 256], False)
+    ref = np.load(os.path.join(OUT, "gen_fp32.npz"))
+    assert rn.calls == int(ref["calls"]) and np.array_equal(captured["tokens"].numpy(), ref["tokens"]), \
+        "mllm.gen_image_block_causal and t2i_pipeline.gen_image disagree"
+    save("mllm_equiv", tokens=captured["tokens"], calls=rn.calls)
+
+
 def gen_misc():
     pipe = build_pipeline(torch.float32)
     save("posembed", table=pipe.pos_embed_1d, e_4_6_2=pipe.get_2d_embed(4, 6, ps=2),
@@ -289,12 +327,15 @@ def main():
         return gen_imagenet()
     if len(sys.argv) > 1 and sys.argv[1] == "pipeline":
         return gen_pipeline()
+    if len(sys.argv) > 1 and sys.argv[1] == "mllm":
+        return gen_mllm_equiv()
     gen_sampler()
     gen_head()
     gen_llm()
     gen_pipeline()
     gen_misc()
     gen_imagenet()
+    gen_mllm_equiv()
 
 
 if __name__ == "__main__":

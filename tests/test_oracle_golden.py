@@ -240,3 +240,11 @@ def test_gen_tokens_batch2_and_nocfg_fp32(golden_dir, name, n_img):
     out = run_gen(g, "fp32", torch.float32, trace=tr, hw=16, w=8, num_images=n_img)
     assert torch.equal(out, g["tokens"])
     torch.testing.assert_close(torch.stack(tr["pred"]), g["preds"][:, :n_img], atol=2e-4, rtol=1e-3)
+
+
+def test_mllm_gen_image_is_the_same_loop(golden_dir):
+    """modeling/mllm.py:386-501 (MLLModel.gen_image_block_causal) on the same components, prompt and injected noise
+    produced exactly the tokens of t2i_pipeline.gen_image (golden gen_fp32) with the same number of RNG draws, so one
+    oracle / one native loop covers both copies of the hot path the north star names."""
+    a, b = load(golden_dir, "mllm_equiv"), load(golden_dir, "gen_fp32")
+    assert int(a["calls"]) == int(b["calls"]) and torch.equal(a["tokens"], b["tokens"])
