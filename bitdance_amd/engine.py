@@ -320,11 +320,13 @@ class Engine:
         return row_blocks(self.M) * 32
 
     # -- schedule / noise ---------------------------------------------------------------------------
-    def set_schedule(self, n_steps: int, cfg: float, ar_steps: int) -> None:
-        key = (n_steps, float(cfg), ar_steps)
+    def set_schedule(self, n_steps: int, cfg: float, ar_steps: int, time_shift: float = 1.0) -> None:
+        """Sampler scalars of DiffHead.sample (sampling_x.py:62-64; ``time_shift`` = the head config's, 1.0 in the
+        released configs), the time-embedding table and the noise buffer."""
+        key = (n_steps, float(cfg), ar_steps, float(time_shift))
         if self._sched_key == key:
             return
-        sc, ts = sampler_scalars(n_steps, self.device)
+        sc, ts = sampler_scalars(n_steps, self.device, time_shift=float(time_shift))
         self._sc = sc
         check(self.l.bd_head_set_schedule(self.ctx, n_steps, sc.data_ptr(), float(cfg)), "bd_head_set_schedule")
         self.temb = self.head.time_table(ts)

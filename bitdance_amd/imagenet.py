@@ -113,8 +113,7 @@ class BitDance:
             raise RuntimeError("bitdance_amd.imagenet.BitDance needs a GPU (HIP head); there is no CPU fallback")
         if parallel_num != 16:
             raise NotImplementedError("native imagenet path: parallel_num must be 16 (the 16x checkpoints)")
-        if time_shift != 1.0:
-            raise NotImplementedError("time_shift != 1 is not wired into the native sampler schedule")
+        self.time_shift = float(time_shift)
         self.device = torch.device(device)
         self.dim, self.n_layer, self.n_head = dim, n_layer, n_head
         self.P, self.cls_token_num, self.num_classes = parallel_num, cls_token_num, num_classes
@@ -217,7 +216,7 @@ class BitDance:
             self._eng[key] = Engine(self.head_w, None, None, num_images=B, branches=mult, device=self.device,
                                     max_tokens=self.P, parallel_num=self.P)
         eng = self._eng[key]
-        eng.set_schedule(steps, cfg, 1)
+        eng.set_schedule(steps, cfg, 1, time_shift=self.time_shift)
         if noise is None:
             eng.draw_noise(1)                                # randn + N x randn_like: the reference's RNG order
         else:

@@ -39,7 +39,7 @@ class NativeDiffHead:
             self._eng[key] = Engine(pipe.head_w, None, None, num_images=B, branches=mult, device=pipe.device,
                                     max_tokens=P, parallel_num=P)
         eng = self._eng[key]
-        eng.set_schedule(num_sampling_steps, cfg, 1)
+        eng.set_schedule(num_sampling_steps, cfg, 1, time_shift=float(pipe.vision_head_config.get("time_shift", 1.0)))
         eng.draw_noise(1)                                   # randn + N x randn_like, the reference's RNG order
         eng.reset([0] * min(B * mult, 16))                  # the head reads only the step counter
         eng.set_cond(z.to(pipe.device))

@@ -193,7 +193,8 @@ class BitDanceT2IPipeline:
         st.wait_stream(torch.cuda.current_stream())
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         with torch.cuda.stream(st):
-            eng.set_schedule(num_sampling_steps, guidance_scale, num_steps)
+            eng.set_schedule(num_sampling_steps, guidance_scale, num_steps,
+                             time_shift=float(self.vision_head_config.get("time_shift", 1.0)))
             if noise is None:
                 eng.draw_noise(num_steps)
             else:

@@ -47,13 +47,14 @@ def test_pipeline_refuses_cpu():
                                             head_config={}, head_sd={}, proj_sd={}, device="cpu")
 
 
-@pytest.mark.parametrize("n", [3, 6, 50])
-def test_sampler_scalars_match_oracle(n):
-    """Host schedule == the oracle's restatement of the reference's 0-dim tensor arithmetic, bit for bit."""
+@pytest.mark.parametrize("n,shift", [(3, 1.0), (6, 1.0), (50, 1.0), (20, 3.0)])
+def test_sampler_scalars_match_oracle(n, shift):
+    """Host schedule == the oracle's restatement of the reference's 0-dim tensor arithmetic, bit for bit (also with a
+    head-config time_shift != 1, sampling_x.py:3-4,62-63)."""
     from bitdance_amd.engine import sampler_scalars
     from oracle import sampler
-    sc, ts = sampler_scalars(n, "cpu")
-    ots, odts = sampler.step_table(n)
+    sc, ts = sampler_scalars(n, "cpu", time_shift=shift)
+    ots, odts = sampler.step_table(n, time_shift=shift)
     for i in range(n):
         t, dt = ots[i], odts[i]
         want = torch.stack([t, dt, (1 - t).clamp_min(0.05), (1 - t) ** 2 - (t / 1) * -1 * (1 - t), 1 - t,
