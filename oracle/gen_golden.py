@@ -245,6 +245,25 @@ def gen_mllm_equiv():
     save("mllm_equiv", tokens=captured["tokens"], calls=rn.calls)
 
 
+def gen_ae_c1():
+    """BASELINE config 1: ae_d16c32 encode -> binary quantise -> decode of one 256x256 image on CPU (fp32), the
+    reference VQModel at full size with seeded weights.  Stored small: the packed sign pattern of the 32x16x16 latent,
+    4096 sampled output pixels and the output statistics."""
+    from modeling.vision_encoder.autoencoder import VQModel
+    ae = VQModel(**tm.AE_D16C32).eval()
+    shapes = {k: tuple(v.shape) for k, v in ae.state_dict().items()}
+    ae.load_state_dict(tm.seeded_state(shapes, seed=61, gain=1.4))
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+    with torch.no_grad():
+        q = ae.encode(img)
+        dec = ae.decode(q)
+    idx = torch.randperm(dec.numel(), generator=g)[:4096]
+    save("ae_c1", quant_bits=np.packbits((q > 0).numpy().reshape(-1)), quant_shape=np.array(q.shape),
+         sample_idx=idx, dec_samples=dec.reshape(-1)[idx], dec_mean=dec.mean(), dec_std=dec.std(),
+         n_tensors=np.int64(len(shapes)), n_params=np.int64(sum(int(np.prod(v)) for v in shapes.values())))
+
+
 def gen_misc():
     pipe = build_pipeline(torch.float32)
     save("posembed", table=pipe.pos_embed_1d, e_4_6_2=pipe.get_2d_embed(4, 6, ps=2),
@@ -329,6 +348,8 @@ def main():
         return gen_pipeline()
     if len(sys.argv) > 1 and sys.argv[1] == "mllm":
         return gen_mllm_equiv()
+    if len(sys.argv) > 1 and sys.argv[1] == "ae_c1":
+        return gen_ae_c1()
     gen_sampler()
     gen_head()
     gen_llm()
@@ -336,6 +357,7 @@ def main():
     gen_misc()
     gen_imagenet()
     gen_mllm_equiv()
+    gen_ae_c1()
 
 
 if __name__ == "__main__":

@@ -24,6 +24,10 @@ TINY_IN = dict(dim=256, n_layer=2, n_head=4, diff_layers=4, diff_dim=256, diff_a
                down_size=16, patch_size=1, resolution=128, cls_token_num=8, num_classes=10, parallel_num=16,
                time_shift=1.0)
 
+# BASELINE config 1: the released ae_d16c32 tokenizer at full size (bitdance_14b_64x.yaml:9-16), 256x256 round trip on CPU
+AE_D16C32 = dict(ddconfig=dict(double_z=False, z_channels=32, in_channels=3, out_ch=3, ch=256, ch_mult=[1, 1, 2, 2, 4],
+                               num_res_blocks=4), gan_decoder=False)
+
 VISION_START, RES_BASE, QUERY_BASE = 300, 301, 430
 
 

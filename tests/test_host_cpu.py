@@ -115,3 +115,26 @@ def test_imagenet_rope_and_mask_tables_match_reference(golden_dir):
     assert torch.equal(m, torch.from_numpy(z["mask"]))
     fc = rope_table_2d(64, 256, 16, 64, 16)                    # BitDance-B-16x: 64 cls + 15 query + 256 - 16 image positions
     assert fc.shape == (64 + 15 + 256 - 16, 32, 2) and bool((fc[:79, :, 0] == 1).all()) and bool((fc[:79, :, 1] == 0).all())
+
+
+def test_ae_d16c32_round_trip_config1(golden_dir):
+    """BASELINE config 1 (ae_d16c32 tokenizer, one 256x256 image, CPU fp32): our VQModel with the reference's keys at the
+    released size reproduces the reference's binary latent bit for bit and its decoded pixels to fp32 conv-order noise."""
+    import numpy as np
+    from bitdance_amd.autoencoder import VQModel
+    from oracle import tiny_models as tm
+    z = np.load(os.path.join(golden_dir, "ae_c1.npz"))
+    ae = VQModel(**tm.AE_D16C32).eval()
+    shapes = {k: tuple(v.shape) for k, v in ae.state_dict().items()}
+    assert len(shapes) == int(z["n_tensors"]) and sum(int(np.prod(v)) for v in shapes.values()) == int(z["n_params"])
+    ae.load_state_dict(tm.seeded_state(shapes, seed=61, gain=1.4))
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+    with torch.no_grad():
+        q = ae.encode(img)
+        dec = ae.decode(q)
+    assert tuple(q.shape) == tuple(z["quant_shape"]) == (1, 32, 16, 16) and set(q.unique().tolist()) <= {-1.0, 1.0}
+    assert np.array_equal(np.packbits((q > 0).numpy().reshape(-1)), z["quant_bits"])          # binary tokens: exact
+    got = dec.reshape(-1)[torch.from_numpy(z["sample_idx"])]
+    torch.testing.assert_close(got, torch.from_numpy(z["dec_samples"]), atol=1e-3, rtol=1e-3)
+    assert abs(float(dec.mean()) - float(z["dec_mean"])) < 1e-3 and abs(float(dec.std()) - float(z["dec_std"])) < 1e-3
