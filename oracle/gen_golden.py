@@ -286,8 +286,13 @@ def gen_misc():
     back = q.bits_to_indices(bits)
     g = torch.Generator().manual_seed(404)
     z = torch.randn(2, 32, 3, 5, generator=g)
-    quant, _, indices, _ = q(z, return_loss=False) if False else (None, None, None, None)
-    save("gfq", idx=idx, bits=bits, back=back, codebook=q.codebook)
+    z[0, :, 0, 0] = 0.0                                           # exact zeros quantise to -1 (x > 0 is false)
+    z[1, 5, 1, 2] = -0.0
+    q.eval()
+    with torch.no_grad():
+        quant, _, indices = q(z, return_loss=False)              # GFQ.forward :196-291, 4 codebooks x 8 bits
+    save("gfq", idx=idx, bits=bits, back=back, codebook=q.codebook, fwd_z=z, fwd_quant=quant,
+         fwd_indices=torch.stack(indices))
 
 
 def gen_imagenet():
@@ -350,6 +355,8 @@ def main():
         return gen_mllm_equiv()
     if len(sys.argv) > 1 and sys.argv[1] == "ae_c1":
         return gen_ae_c1()
+    if len(sys.argv) > 1 and sys.argv[1] == "misc":
+        return gen_misc()
     gen_sampler()
     gen_head()
     gen_llm()

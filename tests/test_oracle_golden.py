@@ -166,6 +166,15 @@ def test_gfq_index_math(golden_dir):
     assert np.array_equal(bits, g["bits"].numpy().astype(bool))
     assert np.array_equal(gfq.bits_to_indices(bits), g["back"].numpy())
     assert np.array_equal(gfq.codes_from_indices(idx, 8), g["codebook"].numpy())
+    # GFQ.forward (gfq.py:196-291) on a random latent with exact +0 / -0 entries (both quantise to -1): codes and the
+    # four per-codebook index streams, bit exact
+    z = g["fwd_z"].numpy()                                       # [b, 32, h, w]
+    zt = np.transpose(z, (0, 2, 3, 1)).reshape(z.shape[0], -1, 32)
+    quant, ind = gfq.quantize_to_indices(zt, 4)
+    want_q = np.transpose(g["fwd_quant"].numpy(), (0, 2, 3, 1)).reshape(z.shape[0], -1, 32)
+    assert np.array_equal(quant, want_q)
+    assert np.array_equal(np.transpose(ind, (2, 0, 1)).reshape(4, -1), g["fwd_indices"].numpy())
+    assert quant[0, 0].tolist() == [-1.0] * 32                  # the all-zero token
 
 
 # ------------------------------------------------------------- class-conditional ImageNet model
