@@ -1,0 +1,143 @@
+"""True-dimension parity cases: the HIP path vs this oracle at the sizes the headline benchmark launches.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py): called by tests/test_gpu_true_dims.py (which asserts the bounds) and by
+the ``cpu_baseline`` leg of bench.py (which times the oracle side as the bounded CPU sample and prints the errors next
+to the throughput line).  Nothing under bitdance_amd/ imports this.
+
+The tiny-model goldens pin the *algorithm*; what they cannot show is that the kernel instantiations picked at
+BitDance-14B dimensions -- the 10-wave adaLN tile, 640-thread row kernels, 40-head attention, GQA group 5 with 56 q/k/v
+slots -- compute the same thing.  Each case here builds a model slice at true width with seeded random weights
+(values bf16-representable, so the CPU oracle and the device see identical parameters), runs
+
+  * the diffusion head: one ``TransEncoder.forward`` (flow_head_parallel_x.py:325-342) of ``depth`` blocks and ``nada``
+    adaLN projections at width D on M = branches*B*P rows  -> x_hat [M, C]
+  * the LLM: one ``Qwen3Model.forward`` decode call (HF modeling_qwen3.py:367-427; t2i_pipeline.py:261-268) of ``layers``
+    layers at true width over P new tokens per sequence against ``past`` cached tokens -> last_hidden_state
+
+on the device through the C ABI (engine.Engine) and on the CPU through oracle.diff_head / oracle.qwen3 under
+``Policy("autocast")``, and returns the error statistics plus the CPU time of the oracle side.
+"""
+from __future__ import annotations
+
+import math
+import time
+
+import torch
+
+from . import diff_head, qwen3, tiny_models as tm
+from .numerics import Policy
+
+HEAD_14B = dict(ch_target=32, ch_cond=5120, ch_latent=5120)           # train/configs/bitdance_14b_64x.yaml:22-33
+QWEN3_14B = dict(hidden_size=5120, num_attention_heads=40, num_key_value_heads=8, head_dim=128,
+                 intermediate_size=17408, vocab_size=64, rms_norm_eps=1e-6, rope_theta=1000000.0)
+
+
+def device_seeded_state(shapes: dict, seed: int, device, gain: float = 1.0) -> dict:
+    """tiny_models.seeded_state's distribution (matrices N(0, gain/sqrt(fan_in)), norm scales 1+0.1N, biases 0.1N, all
+    rounded to bf16) drawn on the device: 0.8 B parameters take seconds instead of minutes.  Returns fp32 tensors on
+    ``device`` holding bf16-representable values."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = {}
+    for name in sorted(shapes):
+        shp = tuple(shapes[name])
+        x = torch.empty(shp, dtype=torch.float32, device=device).normal_(generator=g)
+        if len(shp) >= 2:
+            x = x * (gain / math.sqrt(math.prod(shp[1:])))
+        elif name.endswith("bias"):
+            x = x * 0.1
+        else:
+            x = 1.0 + 0.1 * x
+        out[name] = x.to(torch.bfloat16).to(torch.float32)
+    return out
+
+
+def head_case(device="cuda", *, D=5120, Dz=None, C=32, P=64, B=1, branches=2, depth=2, nada=2, head_dim=128,
+              sigmoid=True, n_steps=3, eval_index=1, seed=101, tune: dict | None = None) -> dict:
+    """One head evaluation at width D: device x_hat vs oracle x_hat.  eval_index > 0 exercises a non-zero timestep
+    embedding; the latent is a fixed random tensor written straight into the engine's state."""
+    from bitdance_amd import engine as E
+    cfgd = dict(ch_target=C, ch_cond=Dz or D, ch_latent=D, depth_latent=depth, depth_adanln=nada)
+    sd_dev = device_seeded_state(tm.head_shapes(cfgd), seed, device)
+    hw = E.HeadWeights.from_state_dict(sd_dev, device, head_dim=head_dim, final_sigmoid=sigmoid)
+    sd = {k: v.cpu() for k, v in sd_dev.items()}
+    del sd_dev
+    eng = E.Engine(hw, None, None, num_images=B, branches=branches, device=device, max_tokens=P, parallel_num=P,
+                   tune=tune)
+    M = branches * B * P
+    g = torch.Generator().manual_seed(seed + 1)
+    z = torch.randn(branches * B, P, cfgd["ch_cond"], generator=g)
+    x = torch.randn(B, P, C, generator=g)
+    eng.set_schedule(n_steps, 3.0, 1)
+    eng.load_noise(torch.zeros(1, n_steps + 1, B, P, C))
+    eng.reset([0] * min(branches * B, 16))
+    eng.set_int("rt.dump_xhat", 1)
+    eng.set_cond(z.to(device))
+    eng.view("head.xt", torch.float32, (B * P, C)).copy_(x.reshape(B * P, C).to(device))
+    eng.head_cond()
+    eng.head_eval(eval_index)
+    torch.cuda.synchronize()
+    xhat = eng.view("head.xhat", torch.float32, (eng.Mpad, C))[:M].cpu().view(branches * B, P, C)
+    t_i = float(eng._sc[eval_index, 0])
+    comb = torch.cat([x] * branches)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref = diff_head.net_forward(sd, comb, torch.full((branches * B,), t_i), z, Policy("autocast"),
+                                    final_sigmoid=sigmoid, head_dim=head_dim).float()
+    t_cpu = time.perf_counter() - t0
+    err = (xhat - ref).abs()
+    cfgs = {n: eng.gemm_config("head." + n) for n in ("ada", "qkv", "wo", "w1", "w2")}
+    macs_per_row = (D * C + D * cfgd["ch_cond"] + (nada * 6 + 2) * D * D + depth * (3 * D * D + D * D + 3 * D * D + 1.5 * D * D) + D * C)
+    return {"max_err": err.max().item(), "mean_err": err.mean().item(), "ref_abs_mean": ref.abs().mean().item(),
+            "finite": bool(torch.isfinite(xhat).all()), "t_cpu_s": t_cpu, "rows": M, "macs_per_row": macs_per_row,
+            "gemm_cfg": {k: {"splitk": s, "nwaves": c & 15} for k, (s, c) in cfgs.items()}, "t": t_i}
+
+
+def llm_case(device="cuda", *, layers=1, P=64, past=(1000, 1017), cfg: dict | None = None, seed=202,
+             tune: dict | None = None) -> dict:
+    """One native decode step (P new tokens per sequence, ragged cache lengths) at Qwen3-14B width vs the oracle.
+    The K/V cache is filled with seeded random post-RoPE keys / values on both sides."""
+    from bitdance_amd import engine as E
+    c = dict(cfg or QWEN3_14B, num_hidden_layers=layers)
+    D, nh, nkv, hd = c["hidden_size"], c["num_attention_heads"], c["num_key_value_heads"], c["head_dim"]
+    sd_dev = {k: v.to(torch.bfloat16) for k, v in device_seeded_state(tm.llm_shapes(c), seed, device).items()}
+    lw = E.LlmWeights.from_state_dict(sd_dev, c, device, keep_for_prefill=False)
+    w = {k: v.cpu() for k, v in sd_dev.items()}
+    del sd_dev
+    nseq = len(past)
+    eng = E.Engine(None, None, lw, num_images=nseq, branches=1, device=device, max_tokens=P, max_kv=max(past) + 2 * P,
+                   parallel_num=P, tune=tune)
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(nseq, P, D, generator=g)
+    kc = eng.ws["llm.k_cache"].view(torch.bfloat16).view(layers, nseq, nkv, eng.Lmax, hd)
+    vc = eng.ws["llm.vt_cache"].view(torch.bfloat16).view(layers, nseq, nkv, hd, eng.Lmax)
+    caches = []
+    for b, L in enumerate(past):
+        per = []
+        for li in range(layers):
+            k = torch.randn(1, nkv, L, hd, generator=g).to(torch.bfloat16)
+            v = torch.randn(1, nkv, L, hd, generator=g).to(torch.bfloat16)
+            kc[li, b, :, :L] = k[0].to(device)
+            vc[li, b, :, :, :L] = v[0].transpose(1, 2).to(device)
+            per.append([k, v])
+        caches.append(per)
+    eng.set_int("rt.emit_cond", 0)
+    eng.reset(list(past))
+    eng.residual()[: nseq * P].copy_(x.reshape(nseq * P, D).to(device))
+    eng.llm_step()
+    torch.cuda.synchronize()
+    got = eng.hidden().cpu().view(nseq, P, D)
+    pol = Policy("autocast")
+    t0 = time.perf_counter()
+    refs = []
+    with torch.no_grad():
+        for b, L in enumerate(past):
+            ones = torch.ones(1, 1, P, L + P, dtype=torch.bool)
+            o, _ = qwen3.model_forward(w, c, x[b:b + 1], caches[b], ones, pol)
+            refs.append(o.float())
+    t_cpu = time.perf_counter() - t0
+    ref = torch.cat(refs)
+    err = (got - ref).abs()
+    cfgs = {n: eng.gemm_config("llm." + n) for n in ("qkv", "o", "gu", "down")}
+    return {"max_err": err.max().item(), "mean_err": err.mean().item(), "ref_abs_mean": ref.abs().mean().item(),
+            "finite": bool(torch.isfinite(got).all()), "t_cpu_s": t_cpu, "rows": nseq * P, "layers": layers,
+            "gemm_cfg": {k: {"splitk": s, "nwaves": c_ & 15} for k, (s, c_) in cfgs.items()}}
