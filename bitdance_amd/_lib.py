@@ -31,12 +31,15 @@ _PROTOS = {
     "bd_gemm_partial": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bd_gemm_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                              C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bd_gemm_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                            C.c_void_p, C.c_void_p]),
     "bd_gemm_swiglu": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bd_ctx_create": (C.c_void_p, []),
     "bd_ctx_destroy": (None, [C.c_void_p]),
     "bd_ctx_set_int": (C.c_int, [C.c_void_p, C.c_char_p, C.c_longlong]),
     "bd_ctx_set_float": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "bd_ctx_set_ptr": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
+    "bd_ctx_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bd_ctx_finalize": (C.c_int, [C.c_void_p]),
     "bd_ctx_ws_count": (C.c_int, [C.c_void_p]),
     "bd_ctx_ws_name": (C.c_char_p, [C.c_void_p, C.c_int]),
@@ -57,6 +60,20 @@ _PROTOS = {
     "bd_gfq_indices": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "bd_gfq_codes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "bd_probe_read": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p]),
+    "bd_comm_create": (C.c_void_p, [C.c_int, C.c_int, C.c_longlong]),
+    "bd_comm_destroy": (None, [C.c_void_p]),
+    "bd_comm_ipc_handles": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bd_comm_open_peer": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "bd_comm_set_peer_ptrs": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "bd_comm_local_data": (C.c_void_p, [C.c_void_p]),
+    "bd_comm_local_flags": (C.c_void_p, [C.c_void_p]),
+    "bd_comm_set_rccl": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bd_comm_set_timeout": (C.c_int, [C.c_void_p, C.c_double]),
+    "bd_comm_error": (C.c_int, [C.c_void_p]),
+    "bd_comm_exchanges": (C.c_longlong, [C.c_void_p]),
+    "bd_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                  C.POINTER(C.c_int), C.c_void_p]),
+    "bd_comm_copy_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]),
     "bd_gemm_config": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
 

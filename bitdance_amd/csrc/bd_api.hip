@@ -15,6 +15,7 @@
 
 static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return -1; }
+void bdk_set_error(const std::string& m) { g_err = m; }      // bd_comm.hip reports through the same bd_last_error()
 
 #define BD_TRY(expr)                                                                     \
     do {                                                                                 \
@@ -22,7 +23,9 @@ static int fail(const std::string& m) { g_err = m; return -1; }
         if (_r != 0) return fail(std::string(#expr) + " failed with " + std::to_string(_r)); \
     } while (0)
 
-struct GemmCfg { int S = 1, nw = 4, ring = 2; int code() const { return nw + 16 * ring; } };
+// nw = waves per workgroup, kw = waves sharing one 32-column panel (split-K inside the workgroup, bd_gemm.hip), ring = K
+// stages in flight per wave, S = split-K over the grid
+struct GemmCfg { int S = 1, nw = 4, ring = 2, kw = 1; int code() const { return nw + 16 * ring + 256 * (kw - 1); } };
 
 struct bd_ctx {
     std::map<std::string, long long> I;
@@ -44,6 +47,16 @@ struct bd_ctx {
     int lD = 0, lL = 0, lnh = 0, lnkv = 0, lF = 0, lLmax = 0, lsplits = 8, lNqkv = 0;
     int ldh = 128, lvariant = 0;          // lvariant 1: imagenet transformer (head_dim 64, MHA, 2-D RoPE, bf16 residual)
     bool has_head = false, has_llm = false, has_proj = false;
+    // tensor parallelism: weights arrive pre-sliced (engine.py); every dim below with an `l` suffix is this rank's
+    bd_comm* comm = nullptr;
+    int tp = 1, tpr = 0;
+    int hDl = 0, hHl = 0, lnhl = 0, lnkvl = 0, lFl = 0;
+
+    const GemmCfg& cfg(const char* name) const {
+        auto it = g.find(name);
+        if (it == g.end()) throw std::runtime_error(std::string("no launch config for GEMM '") + name + "'");
+        return it->second;
+    }
 
     long long geti(const std::string& k) const {
         auto it = I.find(k);
@@ -63,33 +76,92 @@ struct bd_ctx {
 
 static int pad_rows(int m) { return m <= 32 ? 32 : (m <= 64 ? 64 : ((m + 127) / 128) * 128); }
 
-// Launch heuristics from the (nwaves, ring, split-K) sweeps on MI355X (tools/gemm_sweep.py, profiles/r01_gemm_sweep*):
+// Launch heuristics from the (nwaves, ring, split-K) sweeps on MI355X (tools/gemm_sweep.py, profiles/r0*_gemm_sweep*):
 //  * 8 waves (256 output columns per workgroup: the A tile is re-read half as often) for wide N or deep K, else 4;
 //  * split-K so that ~180-240 workgroups exist (<= one wave of workgroups over 256 CUs);
-//  * SwiGLU: fused epilogue (S = 1) when the grid fills the chip, otherwise split-K slabs + swiglu_rows.
-static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K, bool swiglu) {
+//  * SwiGLU: fused epilogue (S = 1) when the grid fills the chip, otherwise split-K slabs + swiglu_rows;
+//  * 128-row passes with K % 128 == 0: 2 panels x 2 K-parts per workgroup (64-column tiles at 4 waves, bd_gemm.hip): the
+//    N = 15360 shapes become 240 single-slice tiles, the N = 5120 shapes 80 tiles x 3 slices reduced in the launch.
+// `reduce3`: the caller needs ONE finished tensor (a tensor-parallel rank's fp32 partial): at most 3 grid slices.
+static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K, bool swiglu, bool reduce3 = false) {
     GemmCfg g;
     const bool two_images = (c->Mpad % 256 == 0);      // 256-row passes (MB = 8) need the 8-wave variant for occupancy
-    const int nst = K / 64;
     g.nw = (N % 256 == 0 && (N >= 8192 || K >= 16384 || two_images)) ? 8 : ((N % 128 == 0) ? 4 : 2);
     // one workgroup per CU and a single wave of workgroups: 10-wave tiles when that lands N/320 just under 256 tiles
     if (!two_images && c->Mpad % 128 == 0 && N % 320 == 0 && N / 320 > 200 && N / 320 <= 256) g.nw = 10;
     // ~120 tiles of 128 columns: two splits give 240 workgroups and only TWO slabs for the consumer to re-read
     if (!two_images && N % 128 == 0 && N / 128 >= 100 && N / 128 <= 128 && K <= 8192) g.nw = 4;
-    const int ntiles = N / (32 * g.nw);
+    int ntiles = N / (32 * g.nw);
     int S = (int)std::lround((g.nw >= 8 ? 180.0 : 240.0) / ntiles);
     if (S < 1) S = 1;
     if (ntiles >= 260 && !swiglu) S = 3;               // > 1 wave of workgroups: split for tail balance
     if (swiglu && ntiles >= 130) S = 1;
+    const bool kw2_ok = !two_images && K % 128 == 0 && N % 64 == 0 && g.nw != 10 && c->geti("tune.kw2", 1) != 0;
+    if (kw2_ok) {
+        const int t64 = N / 64;                        // 64-column tiles: 2 panels x 2 K-parts
+        int s64 = (int)std::lround(240.0 / t64);
+        if (s64 < 1) s64 = 1;
+        if (t64 * s64 <= 256 && t64 * s64 >= 200 && s64 <= 3) { g.nw = 4; g.kw = 2; S = s64; ntiles = t64; }
+    }
+    if (reduce3 && S > 3) {
+        // narrower tiles instead of more slices: 64 columns (2 waves, or 2 x 2 when K allows), then 32
+        if (N % 64 == 0) { g.nw = (kw2_ok ? 4 : 2); g.kw = kw2_ok ? 2 : 1; ntiles = N / 64; }
+        S = (int)std::lround(240.0 / ntiles);
+        if (S > 3) S = 3;
+        if (S < 1) S = 1;
+    }
     g.S = S;
     g.ring = 2;                                        // K stages in flight per wave; deeper rings measured no gain
     g.S = (int)c->geti("tune." + name + ".S", g.S);
     g.nw = (int)c->geti("tune." + name + ".nw", g.nw);
+    g.kw = (int)c->geti("tune." + name + ".kw", g.kw);
     g.ring = (int)c->geti("tune." + name + ".ring", g.ring);
-    if (N % (32 * g.nw)) g.nw = (N % 128 == 0) ? 4 : 2;
+    if (g.kw < 1 || g.kw > 2 || g.nw % g.kw || K % (64 * g.kw)) g.kw = 1;
+    if (N % (32 * (g.nw / g.kw))) { g.kw = 1; g.nw = (N % 128 == 0) ? 4 : 2; }
+    const int nst = K / (64 * g.kw);
     if (g.S > nst) g.S = nst;
     while (g.S > 1 && (g.S - 1) * ((nst + g.S - 1) / g.S) >= nst) --g.S;      // no empty split
     return g;
+}
+
+static const char* const kIntKeys[] = {
+    "B", "branches", "P", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid",
+    "proj.D", "proj.C", "proj.hid", "proj.variant", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
+    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.ada_async"};
+static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
+                                         "llm.qkv", "llm.o", "llm.gu", "llm.down"};
+static bool known_int_key(const std::string& k) {
+    for (const char* n : kIntKeys) if (k == n) return true;
+    if (k.rfind("tune.", 0) == 0) {                    // tune.<gemm>.{S,nw,kw,ring}
+        for (const char* gname : kGemmNames)
+            for (const char* f : {".S", ".nw", ".kw", ".ring"})
+                if (k == std::string("tune.") + gname + f) return true;
+    }
+    return false;
+}
+static const char* const kPtrKeys[] = {
+    "head.cond_w", "head.cond_b", "head.in_w", "head.in_b", "head.ada_w", "head.ada_b", "head.lin_w", "head.lin_b", "head.temb",
+    "head.noise", "head.tok_all", "proj.w1", "proj.b1", "proj.w2", "proj.b2", "llm.final_norm", "llm.emb_norm", "llm.rope2d",
+    "llm.cos", "llm.sin", "pos",
+    // workspaces (the caller allocates them after bd_ctx_finalize; a head-/projector-only context may borrow another's)
+    "state", "gemm.cnt", "head.cond_frag", "head.cond_part", "head.xt", "head.y_frag", "head.X", "head.ada_bf", "head.cemb",
+    "head.h_frag", "head.qkv_part", "head.qkv_bf", "head.br_bf", "head.attn_frag", "head.br_part", "head.act_frag", "head.w1_part",
+    "head.pred", "head.tok_cur", "head.xhat", "head.tp_part", "proj.h_frag", "proj.part", "proj.out_bf", "llm.R", "llm.a_frag", "llm.qkv_part",
+    "llm.qkv_bf", "llm.br_bf", "llm.gu_part", "llm.q", "llm.k_cache", "llm.vt_cache", "llm.attn_opart", "llm.attn_ml",
+    "llm.attn_frag", "llm.br_part", "llm.act_frag", "llm.hidden", "llm.tp_part"};
+static bool known_ptr_key(const std::string& k) {
+    for (const char* n : kPtrKeys) if (k == n) return true;
+    auto indexed = [&](const char* prefix, std::initializer_list<const char*> fields) {
+        const size_t L = std::strlen(prefix);
+        if (k.rfind(prefix, 0) != 0) return false;
+        size_t i = L;
+        while (i < k.size() && k[i] >= '0' && k[i] <= '9') ++i;
+        if (i == L || i >= k.size() || k[i] != '.') return false;
+        for (const char* f : fields) if (k.compare(i + 1, std::string::npos, f) == 0) return true;
+        return false;
+    };
+    return indexed("head.blk", {"ln1_w", "ln1_b", "ln2_w", "ln2_b", "wqkv", "bqkv", "wo", "bo", "w1", "b1", "w2", "b2"}) ||
+           indexed("llm.l", {"in_norm", "post_norm", "q_norm", "k_norm", "wqkv", "wo", "wgu", "wdown"});
 }
 
 extern "C" {
@@ -139,6 +211,11 @@ int bd_gemm_bf16(const void* a, int RB, const void* w, const void* bias, int N, 
     BD_TRY(bdk_gemm(a, RB, w, N, K, S, nw, BD_EPI_BF16, scratch, out_bf16, bias, counters, (hipStream_t)stream));
     return 0;
 }
+int bd_gemm_f32(const void* a, int RB, const void* w, int N, int K, int S, int nw, float* scratch, int* counters, float* out_f32,
+                void* stream) {
+    BD_TRY(bdk_gemm(a, RB, w, N, K, S, nw, BD_EPI_F32, scratch, out_f32, nullptr, counters, (hipStream_t)stream));
+    return 0;
+}
 int bd_gemm_swiglu(const void* a, int RB, const void* w, const void* bias, int N2, int K, int nw, void* act, void* stream) {
     BD_TRY(bdk_gemm(a, RB, w, N2, K, 1, nw, BD_EPI_SWIGLU, nullptr, act, bias, nullptr, (hipStream_t)stream));
     return 0;
@@ -153,9 +230,30 @@ void bd_ctx_destroy(bd_ctx* c) {
     }
     delete c;
 }
-int bd_ctx_set_int(bd_ctx* c, const char* k, long long v) { c->I[k] = v; return 0; }
-int bd_ctx_set_float(bd_ctx* c, const char* k, double v) { c->F[k] = v; return 0; }
-int bd_ctx_set_ptr(bd_ctx* c, const char* k, const void* p) { c->P[k] = p; return 0; }
+// unknown keys are rejected: a typo must not silently fall back to a default (keys: DESIGN.md / the tables above)
+int bd_ctx_set_int(bd_ctx* c, const char* k, long long v) {
+    if (!c || !k || !known_int_key(k)) return fail(std::string("bd_ctx_set_int: unknown key '") + (k ? k : "(null)") + "'");
+    c->I[k] = v;
+    return 0;
+}
+int bd_ctx_set_float(bd_ctx* c, const char* k, double v) {
+    if (!c || !k || std::string(k) != "llm.eps") return fail(std::string("bd_ctx_set_float: unknown key '") + (k ? k : "(null)") + "'");
+    c->F[k] = v;
+    return 0;
+}
+int bd_ctx_set_ptr(bd_ctx* c, const char* k, const void* p) {
+    if (!c || !k || !known_ptr_key(k)) return fail(std::string("bd_ctx_set_ptr: unknown key '") + (k ? k : "(null)") + "'");
+    c->P[k] = p;
+    return 0;
+}
+/* tensor parallelism: this context is rank bd_comm.rank of bd_comm.size; call before bd_ctx_finalize, weights pre-sliced */
+int bd_ctx_set_comm(bd_ctx* c, bd_comm* comm) {
+    if (!c || c->finalized) return fail("bd_ctx_set_comm: call before bd_ctx_finalize");
+    c->comm = comm;
+    c->tp = bdk_comm_size(comm);
+    c->tpr = bdk_comm_rank(comm);
+    return 0;
+}
 
 int bd_ctx_finalize(bd_ctx* c) {
     try {
@@ -188,32 +286,37 @@ int bd_ctx_finalize(bd_ctx* c) {
             if (c->hD % 128 || c->hH % 64 || c->hDz % 64) return fail("head dims must be multiples of 128/64");
             if (c->hNB % c->hNA) return fail("head.nblocks must be divisible by head.nada");
             c->hNada = c->hNA * 6 * c->hD + 2 * c->hD;
+            const int dh = (int)c->geti("head.dh", 128), tp = c->tp;
+            if ((c->hD / dh) % tp || (c->hH / tp) % 64 || (c->hD / tp) % 64)
+                return fail("head: attention heads and the SwiGLU width must divide by the tensor-parallel size (64-column units)");
+            c->hDl = c->hD / tp; c->hHl = c->hH / tp;      // this rank's attention columns / SwiGLU features
             c->g["head.cond"] = choose_cfg(c, "head.cond", c->hD, c->hDz, false);
             c->g["head.ada"] = choose_cfg(c, "head.ada", c->hNada, c->hD, false);
             c->g["head.ada"].S = 1;                            // bf16(+bias) epilogue: 13 consumers read 2 B, not S x 4 B
-            c->g["head.qkv"] = choose_cfg(c, "head.qkv", 3 * c->hD, c->hD, false);
-            c->g["head.wo"] = choose_cfg(c, "head.wo", c->hD, c->hD, false);
-            c->g["head.w1"] = choose_cfg(c, "head.w1", 2 * c->hH, c->hD, true);
-            c->g["head.w2"] = choose_cfg(c, "head.w2", c->hD, c->hH, false);
-            const int sbr = std::max(c->g["head.wo"].S, c->g["head.w2"].S);
+            c->g["head.qkv"] = choose_cfg(c, "head.qkv", 3 * c->hDl, c->hD, false);
+            c->g["head.wo"] = choose_cfg(c, "head.wo", c->hD, c->hDl, false, tp > 1);
+            c->g["head.w1"] = choose_cfg(c, "head.w1", 2 * c->hHl, c->hD, true);
+            c->g["head.w2"] = choose_cfg(c, "head.w2", c->hD, c->hHl, false, tp > 1);
+            const int sbr = std::max(c->cfg("head.wo").S, c->cfg("head.w2").S);
             add("head.cond_frag", Mp * c->hDz * 2);
-            add("head.cond_part", (long long)c->g["head.cond"].S * Mp * c->hD * 4);
+            add("head.cond_part", (long long)c->cfg("head.cond").S * Mp * c->hD * 4);
             add("head.xt", (long long)c->BP * c->hC * 4);
             add("head.y_frag", Mp * c->hD * 2);
             add("head.X", Mp * c->hD * 2);
-            add("head.ada_bf", Mp * c->hNada * 2);
+            add("head.ada_bf", Mp * c->hNada * 2 * (c->geti("tune.ada_async", 0) ? 2 : 1));
             add("head.cemb", Mp * c->hD * 2);
             add("head.h_frag", Mp * c->hD * 2);
-            add("head.qkv_part", (long long)c->g["head.qkv"].S * Mp * 3 * c->hD * 4);
-            add("head.qkv_bf", Mp * 3 * c->hD * 2);
+            add("head.qkv_part", (long long)c->cfg("head.qkv").S * Mp * 3 * c->hDl * 4);
+            add("head.qkv_bf", Mp * 3 * c->hDl * 2);
             add("head.br_bf", Mp * c->hD * 2);
-            add("head.attn_frag", Mp * c->hD * 2);
+            add("head.attn_frag", Mp * c->hDl * 2);
             add("head.br_part", (long long)sbr * Mp * c->hD * 4);
-            add("head.act_frag", Mp * c->hH * 2);
-            add("head.w1_part", (long long)c->g["head.w1"].S * Mp * 2 * c->hH * 4);
+            add("head.act_frag", Mp * c->hHl * 2);
+            add("head.w1_part", (long long)c->cfg("head.w1").S * Mp * 2 * c->hHl * 4);
             add("head.pred", (long long)c->BP * c->hC * 4);
             add("head.tok_cur", (long long)c->BP * c->hC * 4);
             add("head.xhat", Mp * c->hC * 4);
+            if (tp > 1) add("head.tp_part", Mp * c->hD * 4);   // this rank's fp32 partial of a row-split Linear (wo / w2)
         }
         if (c->has_proj) {
             const int D = (int)c->geti("proj.D");
@@ -221,7 +324,7 @@ int bd_ctx_finalize(bd_ctx* c) {
             if (hk % 64) return fail("proj hidden width must be a multiple of 64");
             c->g["proj.fc2"] = choose_cfg(c, "proj.fc2", D, hk, false);
             add("proj.h_frag", (long long)c->BPpad * hk * 2);
-            add("proj.part", (long long)c->g["proj.fc2"].S * c->BPpad * D * 4);
+            add("proj.part", (long long)c->cfg("proj.fc2").S * c->BPpad * D * 4);
             add("proj.out_bf", (long long)c->BPpad * D * 2);
         }
         if (c->has_llm) {
@@ -233,38 +336,48 @@ int bd_ctx_finalize(bd_ctx* c) {
             if (!((c->ldh == 128 && c->lvariant == 0) || (c->ldh == 64 && c->lvariant == 1 && c->lnkv == c->lnh && c->Pn == 16)))
                 return fail("llm: head_dim 128 (Qwen3) or head_dim 64 + variant 1 (imagenet transformer, MHA, P = 16)");
             if (c->lLmax % 64) return fail("llm.Lmax must be a multiple of 64");
-            c->lNqkv = (c->lnh + 2 * c->lnkv) * c->ldh;
+            const int tp = c->tp;
+            if (tp > 1 && (c->lvariant != 0 || c->lnh % tp || c->lnkv % tp || (c->lF / tp) % 64 || c->lF % tp))
+                return fail("llm: q heads, kv heads and the FFN width must divide by the tensor-parallel size (Qwen3 path only)");
+            c->lnhl = c->lnh / tp; c->lnkvl = c->lnkv / tp; c->lFl = c->lF / tp;
+            c->lNqkv = (c->lnhl + 2 * c->lnkvl) * c->ldh;
             if (c->lD % 64 || c->lF % 64) return fail("llm dims must be multiples of 64");
             c->g["llm.qkv"] = choose_cfg(c, "llm.qkv", c->lNqkv, c->lD, false);
-            c->g["llm.o"] = choose_cfg(c, "llm.o", c->lD, c->lnh * c->ldh, false);
-            c->g["llm.gu"] = choose_cfg(c, "llm.gu", 2 * c->lF, c->lD, true);
-
-            c->g["llm.down"] = choose_cfg(c, "llm.down", c->lD, c->lF, false);
+            c->g["llm.o"] = choose_cfg(c, "llm.o", c->lD, c->lnhl * c->ldh, false, tp > 1);
+            c->g["llm.gu"] = choose_cfg(c, "llm.gu", 2 * c->lFl, c->lD, true);
+            c->g["llm.down"] = choose_cfg(c, "llm.down", c->lD, c->lFl, false, tp > 1);
             const int nseq = c->branches * c->B, G = c->lnh / c->lnkv;
-            const int sbr = std::max(c->g["llm.o"].S, c->g["llm.down"].S);
+            const int sbr = std::max(c->cfg("llm.o").S, c->cfg("llm.down").S);
             add("llm.R", Mp * c->lD * 4);
             add("llm.a_frag", Mp * c->lD * 2);
-            add("llm.qkv_part", (long long)c->g["llm.qkv"].S * Mp * c->lNqkv * 4);
+            add("llm.qkv_part", (long long)c->cfg("llm.qkv").S * Mp * c->lNqkv * 4);
             add("llm.qkv_bf", Mp * c->lNqkv * 2);
             add("llm.br_bf", Mp * c->lD * 2);
-            add("llm.gu_part", (long long)c->g["llm.gu"].S * Mp * 2 * c->lF * 4);
-            add("llm.q", Mp * c->lnh * c->ldh * 2);
-            add("llm.k_cache", (long long)c->lL * nseq * c->lnkv * c->lLmax * c->ldh * 2);
-            add("llm.vt_cache", (long long)c->lL * nseq * c->lnkv * c->lLmax * c->ldh * 2);
-            add("llm.attn_opart", (long long)nseq * c->lnkv * c->lsplits * G * c->Pn * 128 * 4);
-            add("llm.attn_ml", (long long)nseq * c->lnkv * c->lsplits * G * c->Pn * 2 * 4);
-            add("llm.attn_frag", Mp * c->lnh * c->ldh * 2);
+            add("llm.gu_part", (long long)c->cfg("llm.gu").S * Mp * 2 * c->lFl * 4);
+            add("llm.q", Mp * c->lnhl * c->ldh * 2);
+            add("llm.k_cache", (long long)c->lL * nseq * c->lnkvl * c->lLmax * c->ldh * 2);
+            add("llm.vt_cache", (long long)c->lL * nseq * c->lnkvl * c->lLmax * c->ldh * 2);
+            add("llm.attn_opart", (long long)nseq * c->lnkvl * c->lsplits * G * c->Pn * 128 * 4);
+            add("llm.attn_ml", (long long)nseq * c->lnkvl * c->lsplits * G * c->Pn * 2 * 4);
+            add("llm.attn_frag", Mp * c->lnhl * c->ldh * 2);
             add("llm.br_part", (long long)sbr * Mp * c->lD * 4);
-            add("llm.act_frag", Mp * c->lF * 2);
+            add("llm.act_frag", Mp * c->lFl * 2);
             add("llm.hidden", Mp * c->lD * 4);
+            if (tp > 1) add("llm.tp_part", Mp * c->lD * 4);
         }
         c->finalized = true;
         return 0;
     } catch (const std::exception& e) { return fail(e.what()); }
 }
 int bd_ctx_ws_count(bd_ctx* c) { return (int)c->ws.size(); }
-const char* bd_ctx_ws_name(bd_ctx* c, int i) { return c->ws[i].first.c_str(); }
-long long bd_ctx_ws_bytes(bd_ctx* c, int i) { return c->ws[i].second; }
+const char* bd_ctx_ws_name(bd_ctx* c, int i) {
+    if (!c || i < 0 || i >= (int)c->ws.size()) { fail("bd_ctx_ws_name: index out of range"); return nullptr; }
+    return c->ws[i].first.c_str();
+}
+long long bd_ctx_ws_bytes(bd_ctx* c, int i) {
+    if (!c || i < 0 || i >= (int)c->ws.size()) { fail("bd_ctx_ws_bytes: index out of range"); return -1; }
+    return c->ws[i].second;
+}
 int bd_ctx_bind(bd_ctx* c) {
     if (!c->finalized) return fail("bd_ctx_bind before bd_ctx_finalize");
     for (auto& w : c->ws)
@@ -298,7 +411,7 @@ static int gemm(bd_ctx* c, const char* name, const void* A, int RB, const void* 
         hipEventCreate(&r.e0); hipEventCreate(&r.e1);
         hipEventRecord(r.e0, st);
     }
-    int* cnt = (epi != BD_EPI_PARTIAL && S > 1) ? (int*)c->wptr("gemm.cnt") : nullptr;
+    int* cnt = (epi != BD_EPI_PARTIAL && S > 1) ? (int*)c->wptr("gemm.cnt") : nullptr;   // in-launch reduction tickets
     const int rc = bdk_gemm(A, RB, W, N, K, S, nw, epi, out, act, bias, cnt, st);
     if (c->prof_on) { hipEventRecord(r.e1, st); c->prof.push_back(r); }
     return rc;
@@ -330,8 +443,21 @@ static int linear(bd_ctx* c, const char* name, const void* A, int RB, const void
     return 0;
 }
 
+// A ROW-split Linear under tensor parallelism (wo / w2 / o_proj / down_proj): this rank multiplies its K-slice into ONE
+// finished fp32 partial (grid slices, if any, reduced inside the launch), then the exchange kernel sums the ranks' partials,
+// adds the bias and rounds once (bd_comm.hip).  With one rank it is the plain Linear above.
+static int linear_rowsplit(bd_ctx* c, const char* name, const void* A, int RB, const void* W, int N, int Klocal, const GemmCfg& g,
+                           const char* scratch_ws, const char* out_ws, const char* tp_ws, const void* bias, int Mpad, int rows,
+                           Partial* res, hipStream_t st) {
+    if (c->tp <= 1) return linear(c, name, A, RB, W, N, Klocal, g, scratch_ws, out_ws, bias, Mpad, res, st);
+    if (g.S > 3) return fail(std::string(name) + ": a tensor-parallel partial needs at most 3 grid slices");
+    BD_TRY(gemm(c, name, A, RB, W, N, Klocal, g.S, g.code(), BD_EPI_F32, (float*)c->wptr(scratch_ws), c->wptr(tp_ws), nullptr, st));
+    BD_TRY(bdk_tp_allreduce(c->comm, (const float*)c->ptr(tp_ws), bias, rows, N, res, st));
+    return 0;
+}
+
 static int head_cond(bd_ctx* c, hipStream_t st) {   // cond_embed(c) is constant over the N+1 evals of this AR step
-    const GemmCfg& g = c->g["head.cond"];
+    const GemmCfg& g = c->cfg("head.cond");
     Partial unused;
     BD_TRY(linear(c, "head.cond", c->ptr("head.cond_frag"), c->RB, c->ptr("head.cond_w"), c->hD, c->hDz, g, "head.cond_part",
                   "head.cemb", c->ptr("head.cond_b"), c->Mpad, &unused, st, /*force_reduce=*/true));
@@ -340,7 +466,8 @@ static int head_cond(bd_ctx* c, hipStream_t st) {   // cond_embed(c) is constant
 
 static int head_eval(bd_ctx* c, int i, hipStream_t st) {
     if (i < 0 || i >= (int)c->sched.size()) return fail("bd_head_eval: eval index outside the schedule");
-    const int D = c->hD, H = c->hH, Mp = c->Mpad, RB = c->RB, M = c->M;
+    const int D = c->hD, Mp = c->Mpad, RB = c->RB, M = c->M;
+    const int Dl = c->hDl, Hl = c->hHl;                       // this rank's attention columns / SwiGLU features (== D, H at tp = 1)
     const int n_steps = (int)c->sched.size() - 1;
     const BdStepState* state = (const BdStepState*)c->ptr("state");
     HeadPrologueArgs pa;
@@ -352,12 +479,12 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
     pa.M = M; pa.BP = c->BP; pa.D = D; pa.C = c->hC; pa.RB = RB;
     BD_TRY(bdk_head_prologue(pa, st));
 
-    const GemmCfg& ga = c->g["head.ada"];
+    const GemmCfg& ga = c->cfg("head.ada");
     BD_TRY(gemm(c, "head.ada", c->ptr("head.y_frag"), RB, c->ptr("head.ada_w"), c->hNada, D, 1, ga.code(), BD_EPI_BF16,
                 nullptr, c->wptr("head.ada_bf"), c->ptr("head.ada_b"), st));
     const void* ada = c->ptr("head.ada_bf");
     const int sw = c->hNB / c->hNA;
-    const GemmCfg &gq = c->g["head.qkv"], &go = c->g["head.wo"], &g1 = c->g["head.w1"], &g2 = c->g["head.w2"];
+    const GemmCfg &gq = c->cfg("head.qkv"), &go = c->cfg("head.wo"), &g1 = c->cfg("head.w1"), &g2 = c->cfg("head.w2");
     Partial br{nullptr, nullptr, 0, 0, 0};                    // pending gated branch output (wo / w2)
     for (int b = 0; b < c->hNB; ++b) {
         const std::string pre = "head.blk" + std::to_string(b) + ".";
@@ -372,13 +499,13 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
         l1.h_frag = c->wptr("head.h_frag"); l1.M = M; l1.D = D; l1.RB = RB; l1.eps = 1e-6f;
         BD_TRY(bdk_ln_mod(l1, st));
         HeadAttnArgs at;
-        BD_TRY(linear(c, "head.qkv", c->ptr("head.h_frag"), RB, c->ptr(pre + "wqkv"), 3 * D, D, gq, "head.qkv_part", "head.qkv_bf",
+        BD_TRY(linear(c, "head.qkv", c->ptr("head.h_frag"), RB, c->ptr(pre + "wqkv"), 3 * Dl, D, gq, "head.qkv_part", "head.qkv_bf",
                       c->ptr(pre + "bqkv"), Mp, &at.qkv, st));
-        at.o_frag = c->wptr("head.attn_frag"); at.nseq = M / c->Pn; at.dh = (int)c->geti("head.dh", 128); at.nhead = D / at.dh; at.D = D; at.RB = RB; at.P = c->Pn;
+        at.o_frag = c->wptr("head.attn_frag"); at.nseq = M / c->Pn; at.dh = (int)c->geti("head.dh", 128); at.nhead = Dl / at.dh; at.D = Dl; at.RB = RB; at.P = c->Pn;
         BD_TRY(bdk_head_attn(at, st));
         LnModArgs l2 = l1;
-        BD_TRY(linear(c, "head.wo", c->ptr("head.attn_frag"), RB, c->ptr(pre + "wo"), D, D, go, "head.br_part", "head.br_bf",
-                      c->ptr(pre + "bo"), Mp, &l2.pend, st));
+        BD_TRY(linear_rowsplit(c, "head.wo", c->ptr("head.attn_frag"), RB, c->ptr(pre + "wo"), D, Dl, go, "head.br_part", "head.br_bf",
+                               "head.tp_part", c->ptr(pre + "bo"), Mp, M, &l2.pend, st));
         l2.gate_off = base + 2 * D; l2.scale_off = base + 3 * D; l2.shift_off = base + 4 * D;
         l2.ln_w = (const float*)c->ptr(pre + "ln2_w"); l2.ln_b = (const float*)c->ptr(pre + "ln2_b");
         BD_TRY(bdk_ln_mod(l2, st));
@@ -386,18 +513,18 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
         // operand: 46.9 + 22.9 us (w1 + w2) against 40.8 + 9.5 + 26.0 us for slabs + swiglu_rows on the same MI355X
         // (tune.w1_fused = 0 selects the latter).
         if (g1.S == 1 || c->geti("tune.w1_fused", (c->Mpad % 256 == 0) ? 0 : 1)) {
-            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * H, D, g1.S, g1.code(), BD_EPI_SWIGLU,
+            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * Hl, D, g1.S, g1.code(), BD_EPI_SWIGLU,
                         (float*)c->wptr("head.w1_part"), c->wptr("head.act_frag"), c->ptr(pre + "b1"), st));
         } else {
-            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * H, D, g1.S, g1.code(), BD_EPI_PARTIAL,
+            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * Hl, D, g1.S, g1.code(), BD_EPI_PARTIAL,
                         (float*)c->wptr("head.w1_part"), nullptr, nullptr, st));
             SwigluArgs sw_;
-            sw_.up = part(c, "head.w1_part", c->ptr(pre + "b1"), g1.S, 2 * H, Mp);
-            sw_.act_frag = c->wptr("head.act_frag"); sw_.M = M; sw_.F = H; sw_.RB = RB; sw_.interleaved = 1;
+            sw_.up = part(c, "head.w1_part", c->ptr(pre + "b1"), g1.S, 2 * Hl, Mp);
+            sw_.act_frag = c->wptr("head.act_frag"); sw_.M = M; sw_.F = Hl; sw_.RB = RB; sw_.interleaved = 1;
             BD_TRY(bdk_swiglu_rows(sw_, st));
         }
-        BD_TRY(linear(c, "head.w2", c->ptr("head.act_frag"), RB, c->ptr(pre + "w2"), D, H, g2, "head.br_part", "head.br_bf",
-                      c->ptr(pre + "b2"), Mp, &br, st));
+        BD_TRY(linear_rowsplit(c, "head.w2", c->ptr("head.act_frag"), RB, c->ptr(pre + "w2"), D, Hl, g2, "head.br_part", "head.br_bf",
+                               "head.tp_part", c->ptr(pre + "b2"), Mp, M, &br, st));
     }
     HeadFinalArgs fa;
     fa.X = c->ptr("head.X");
@@ -437,7 +564,7 @@ static int projector_in(bd_ctx* c, hipStream_t st) {
     InProjFc1Args f1{(const float*)c->ptr("head.tok_cur"), c->ptr("proj.w1"), c->ptr("proj.b1"), c->wptr("proj.h_frag"),
                      c->BP, hid, (int)c->geti("proj.C"), c->RBp};
     BD_TRY(bdk_in_proj_fc1(f1, st));
-    const GemmCfg& g = c->g["proj.fc2"];
+    const GemmCfg& g = c->cfg("proj.fc2");
     InRmsArgs e;
     BD_TRY(linear(c, "proj.fc2", c->ptr("proj.h_frag"), c->RBp, c->ptr("proj.w2"), D, hid, g, "proj.part", "proj.out_bf",
                   c->ptr("proj.b2"), c->BPpad, &e.pend, st));
@@ -455,7 +582,7 @@ static int projector(bd_ctx* c, hipStream_t st) {
     ProjFc1Args f1{(const float*)c->ptr("head.tok_cur"), c->ptr("proj.w1"), c->ptr("proj.b1"), c->wptr("proj.h_frag"),
                    c->BP, D, (int)c->geti("proj.C"), c->RBp};
     BD_TRY(bdk_proj_fc1(f1, st));
-    const GemmCfg& g = c->g["proj.fc2"];
+    const GemmCfg& g = c->cfg("proj.fc2");
     Partial fc2;
     BD_TRY(linear(c, "proj.fc2", c->ptr("proj.h_frag"), c->RBp, c->ptr("proj.w2"), D, D, g, "proj.part", "proj.out_bf",
                   c->ptr("proj.b2"), c->BPpad, &fc2, st));
@@ -473,7 +600,7 @@ static int llm_step_in(bd_ctx* c, hipStream_t st) {
     const int nseq = c->branches * c->B;
     const float eps = (float)c->getf("llm.eps", 1e-6);
     BdStepState* state = (BdStepState*)c->wptr("state");
-    const GemmCfg &gq = c->g["llm.qkv"], &go = c->g["llm.o"], &gg = c->g["llm.gu"], &gd = c->g["llm.down"];
+    const GemmCfg &gq = c->cfg("llm.qkv"), &go = c->cfg("llm.o"), &gg = c->cfg("llm.gu"), &gd = c->cfg("llm.down");
     const size_t layer_elems = (size_t)nseq * nh * c->lLmax * 64;
     Partial br{nullptr, nullptr, 0, 0, 0};
     InRmsArgs r1;
@@ -519,11 +646,12 @@ static int llm_step_in(bd_ctx* c, hipStream_t st) {
 
 static int llm_step(bd_ctx* c, hipStream_t st) {
     if (c->lvariant == 1) return llm_step_in(c, st);
-    const int D = c->lD, F = c->lF, Mp = c->Mpad, RB = c->RB, M = c->M, nh = c->lnh, nkv = c->lnkv;
+    // nh / nkv / F: this rank's q heads, kv heads and FFN features (the full counts at tp = 1)
+    const int D = c->lD, F = c->lFl, Mp = c->Mpad, RB = c->RB, M = c->M, nh = c->lnhl, nkv = c->lnkvl;
     const int nseq = c->branches * c->B;
     const float eps = (float)c->getf("llm.eps", 1e-6);
     BdStepState* state = (BdStepState*)c->wptr("state");
-    const GemmCfg &gq = c->g["llm.qkv"], &go = c->g["llm.o"], &gg = c->g["llm.gu"], &gd = c->g["llm.down"];
+    const GemmCfg &gq = c->cfg("llm.qkv"), &go = c->cfg("llm.o"), &gg = c->cfg("llm.gu"), &gd = c->cfg("llm.down");
     const size_t layer_elems = (size_t)nseq * nkv * c->lLmax * 128;
     Partial br{nullptr, nullptr, 0, 0, 0};                    // pending branch output (o_proj / down_proj)
     for (int l = 0; l < c->lL; ++l) {
@@ -554,14 +682,14 @@ static int llm_step(bd_ctx* c, hipStream_t st) {
         BD_TRY(bdk_llm_attn(aa, st));
 
         RmsArgs r2 = r1;
-        BD_TRY(linear(c, "llm.o", c->ptr("llm.attn_frag"), RB, c->ptr(pre + "wo"), D, nh * 128, go, "llm.br_part", "llm.br_bf",
-                      nullptr, Mp, &r2.pend, st));
+        BD_TRY(linear_rowsplit(c, "llm.o", c->ptr("llm.attn_frag"), RB, c->ptr(pre + "wo"), D, nh * 128, go, "llm.br_part", "llm.br_bf",
+                               "llm.tp_part", nullptr, Mp, M, &r2.pend, st));
         r2.w = c->ptr(pre + "post_norm");
         BD_TRY(bdk_rms(r2, st));
         BD_TRY(gemm(c, "llm.gu", c->ptr("llm.a_frag"), RB, c->ptr(pre + "wgu"), 2 * F, D, gg.S, gg.code(), BD_EPI_SWIGLU,
                         (float*)c->wptr("llm.gu_part"), c->wptr("llm.act_frag"), nullptr, st));
-        BD_TRY(linear(c, "llm.down", c->ptr("llm.act_frag"), RB, c->ptr(pre + "wdown"), D, F, gd, "llm.br_part", "llm.br_bf",
-                      nullptr, Mp, &br, st));
+        BD_TRY(linear_rowsplit(c, "llm.down", c->ptr("llm.act_frag"), RB, c->ptr(pre + "wdown"), D, F, gd, "llm.br_part", "llm.br_bf",
+                               "llm.tp_part", nullptr, Mp, M, &br, st));
     }
     StepAdvanceArgs sa{state, nseq, c->Pn};
     BD_TRY(bdk_step_advance(sa, st));                       // step+1 / kv_len += P: the next patch's position

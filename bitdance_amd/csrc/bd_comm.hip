@@ -1,0 +1,311 @@
+// Tensor-parallel exchange for the BitDance step on one xGMI node: the all-reduce after every
+// row-split Linear (head wo / w2, LLM o_proj / down_proj) as ONE hand-written kernel per exchange, captured inside the
+// AR-step hipGraph with the GEMMs around it.
+//
+// One process per GPU.  Every rank owns one exported allocation {staging [tp][slice] fp32 | result [rows][N] bf16} and a
+// small flag block; the peers' allocations are mapped with hipIpcOpenMemHandle (or handed over as plain pointers when
+// the "ranks" are contexts of one process -- the single-GPU protocol test).  xGMI is point to point, so the exchange is
+// two-shot and PUSH-only (posted writes, no read round trips over the links):
+//
+//   phase 1 (reduce-scatter by push)  rank r writes, for every peer p, the slice p of its fp32 partial [rows][N] into
+//                                     p's staging area [r]                -> one link per peer, (tp-1)/tp of 4*rows*N B out
+//   phase 2 (all-gather by push)      rank r sums the tp staged copies of slice r IN RANK ORDER (every rank computes each
+//                                     element exactly once, so the replicated result is bit-identical everywhere), adds
+//                                     the Linear's bias, rounds once to bf16 (what F.linear returns under autocast) and
+//                                     writes the rows into every rank's result buffer
+//
+// Synchronisation is per (block b of rank r) <-> (block b of every peer): after its pushes a block drains its stores,
+// fences at system scope and writes an epoch number into the peers' flag blocks; it polls its OWN flag block (remote
+// writes, local polls).  Epochs only grow, so there is no reset and the same kernel node replays in a graph.  All remote
+// traffic and all reads of remotely written memory are system-scope (sc0 sc1) accesses: the XCD L2s would otherwise serve
+// stale lines.  Every spin is bounded by a wall-clock budget; on expiry the kernel sets an error word and returns, the
+// host raises (bd_comm_error).
+//
+// RCCL (the library `torch.distributed`'s "nccl" backend drives) is used for bootstrap (handle exchange), for the
+// once-per-image prefill, and as a drop-in fallback / baseline for this kernel: mode 1 calls ncclAllReduce on the fp32
+// partial through a function pointer handed over by the host (bd_comm_set_rccl), also graph-capturable.
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "bd_common.h"
+#include "bd_kernels.h"
+#include "../../include/bitdance_hip.h"
+
+#define BD_TP_MAX 8
+#define BD_TP_GMAX 64
+
+struct bd_comm {
+    int rank = 0, size = 1, mode = 0;
+    long long max_elems = 0;                 // rows * N capacity of one exchange
+    char* data = nullptr;                    // local: staging fp32 [max_elems] | result bf16 [max_elems]
+    int* flags = nullptr;                    // local: A [tp][GMAX] | B [tp][GMAX] | err | epoch [GMAX]
+    bool own = false;
+    char* peer_data[BD_TP_MAX] = {};
+    int* peer_flags[BD_TP_MAX] = {};
+    bool ipc_open[BD_TP_MAX] = {};
+    void* nccl_comm = nullptr;
+    int (*nccl_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    double timeout_s = 20.0;
+    long long n_exchanges = 0;               // launches issued (graph captures count once): reporting only
+};
+
+void bdk_set_error(const std::string& m);    // bd_api.hip
+
+static int cfail(const std::string& m) { bdk_set_error(m); return -1; }
+
+struct ArArgs {
+    const float* part;          // this rank's partial [rows][N] fp32
+    const bf16_t* bias;         // [N] or null
+    char* peer_data[BD_TP_MAX];
+    int* peer_flags[BD_TP_MAX];
+    int* flags;                 // local flag block
+    long long stage_bytes;      // offset of the result buffer inside a data allocation
+    long long timeout_ticks;    // wall_clock64 ticks (100 MHz)
+    int rank, size, G, U, Us, N8;
+};
+
+BD_DEV void st_sys64(void* p, unsigned long long v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+BD_DEV unsigned long long ld_sys64(const void* p) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// all of this block's pushes are at their destination, then the epoch goes to every peer's flag row of this rank
+BD_DEV void tp_signal(const ArArgs& a, int base, int b, int e) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < a.size && t != a.rank) {
+        __threadfence_system();
+        __hip_atomic_store(a.peer_flags[t] + base + a.rank * BD_TP_GMAX + b, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+BD_DEV void tp_wait(const ArArgs& a, int base, int b, int e, int err_index) {
+    const int t = threadIdx.x;
+    if (t < a.size && t != a.rank) {
+        const int* f = a.flags + base + t * BD_TP_GMAX + b;
+        const long long t0 = wall_clock64();
+        while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > a.timeout_ticks) {
+                __hip_atomic_fetch_or(a.flags + err_index, 1 << t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+        __threadfence_system();
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void tp_allreduce_kernel(ArArgs a) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int FA = 0, FB = BD_TP_MAX * BD_TP_GMAX, ERR = 2 * BD_TP_MAX * BD_TP_GMAX, EP = ERR + 1;
+    const int e = a.flags[EP + b] + 1;                       // only this block ever writes its epoch word
+    const int Ub = (a.Us + a.G - 1) / a.G;
+    const int c0 = b * Ub, c1 = min(a.Us, c0 + Ub);
+    // ---- phase 1: push my partial of every peer's slice into that peer's staging row [rank]
+    for (int p = 0; p < a.size; ++p) {
+        if (p == a.rank) continue;
+        float* dst = reinterpret_cast<float*>(a.peer_data[p]) + (size_t)a.rank * a.Us * 8;
+        for (int u = c0 + tid; u < c1; u += 256) {
+            const int gu = p * a.Us + u;
+            if (gu >= a.U) break;
+            const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.part + (size_t)gu * 8);
+            const unsigned long long v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+            unsigned long long* d = reinterpret_cast<unsigned long long*>(dst + (size_t)u * 8);
+            st_sys64(d, v0); st_sys64(d + 1, v1); st_sys64(d + 2, v2); st_sys64(d + 3, v3);
+        }
+    }
+    tp_signal(a, FA, b, e);
+    tp_wait(a, FA, b, e, ERR);
+    // ---- phase 2: reduce my slice in rank order, bias, one rounding to bf16, push the rows to every rank
+    const float* stage = reinterpret_cast<const float*>(a.peer_data[a.rank]);
+    for (int u = c0 + tid; u < c1; u += 256) {
+        const int gu = a.rank * a.Us + u;
+        if (gu >= a.U) break;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int p = 0; p < a.size; ++p) {
+            unsigned long long v[4];
+            if (p == a.rank) {
+                const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.part + (size_t)gu * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = src[j];
+            } else {
+                const float* src = stage + ((size_t)p * a.Us + u) * 8;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ld_sys64(src + 2 * j);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[2 * j] += __uint_as_float((unsigned)(v[j] & 0xffffffffull));
+                acc[2 * j + 1] += __uint_as_float((unsigned)(v[j] >> 32));
+            }
+        }
+        if (a.bias) {
+            const int col = (gu % a.N8) * 8;
+            const u32x4 bq = *reinterpret_cast<const u32x4*>(a.bias + col);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[2 * j] += bf2f((bf16_t)(bq[j] & 0xffff));
+                acc[2 * j + 1] += bf2f((bf16_t)(bq[j] >> 16));
+            }
+        }
+        const unsigned long long o0 = (unsigned long long)pack2(acc[0], acc[1]) | ((unsigned long long)pack2(acc[2], acc[3]) << 32);
+        const unsigned long long o1 = (unsigned long long)pack2(acc[4], acc[5]) | ((unsigned long long)pack2(acc[6], acc[7]) << 32);
+        for (int q = 0; q < a.size; ++q) {
+            unsigned long long* d = reinterpret_cast<unsigned long long*>(a.peer_data[q] + a.stage_bytes) + (size_t)gu * 2;
+            st_sys64(d, o0); st_sys64(d + 1, o1);
+        }
+    }
+    tp_signal(a, FB, b, e);
+    tp_wait(a, FB, b, e, ERR);
+    if (tid == 0) a.flags[EP + b] = e;
+}
+
+// after an RCCL all-reduce the fp32 sums sit in the staging area: the consumer adds bias and rounds (Partial with S = 1)
+int bdk_tp_allreduce(bd_comm* c, const float* part, const void* bias, int rows, int N, Partial* res, hipStream_t st) {
+    if (!c || c->size < 2) return -2;
+    if (N % 8) return -3;
+    {
+        const long long U = (long long)rows * (N / 8), Us = (U + c->size - 1) / c->size;
+        if (Us * c->size * 8 > c->max_elems) return -3;         // staging rows [size][Us] must fit in front of the result
+    }
+    const int Mpad = rows <= 32 ? 32 : (rows <= 64 ? 64 : ((rows + 127) / 128) * 128);
+    c->n_exchanges++;
+    if (c->mode == 1) {
+        if (!c->nccl_allreduce || !c->nccl_comm) return -4;
+        float* sum = reinterpret_cast<float*>(c->data);
+        const int rc = c->nccl_allreduce(part, sum, (size_t)rows * N, /*ncclFloat32*/ 7, /*ncclSum*/ 0, c->nccl_comm, st);
+        if (rc != 0) return -5;
+        *res = Partial{sum, bias, 1, N, Mpad};
+        return 0;
+    }
+    for (int p = 0; p < c->size; ++p)
+        if (!c->peer_data[p] || !c->peer_flags[p]) return -6;
+    ArArgs a;
+    a.part = part; a.bias = (const bf16_t*)bias; a.flags = c->flags;
+    for (int p = 0; p < BD_TP_MAX; ++p) { a.peer_data[p] = c->peer_data[p]; a.peer_flags[p] = c->peer_flags[p]; }
+    a.stage_bytes = c->max_elems * 4;
+    a.timeout_ticks = (long long)(c->timeout_s * 1e8);
+    a.rank = c->rank; a.size = c->size;
+    a.U = rows * (N / 8); a.Us = (a.U + c->size - 1) / c->size; a.N8 = N / 8;
+    a.G = (a.Us + 255) / 256;
+    if (a.G > BD_TP_GMAX) a.G = BD_TP_GMAX;
+    if (a.G < 1) a.G = 1;
+    BD_LAUNCH(tp_allreduce_kernel, dim3(a.G), dim3(256), 0, st, a);
+    if (bd_launch_status() != 0) return -1;
+    Partial r{reinterpret_cast<const float*>(c->data + a.stage_bytes), nullptr, 0, N, Mpad};
+    r.sys = 1;                                               // remotely written: system-scope loads in the consumer
+    *res = r;
+    return 0;
+}
+
+int bdk_comm_rank(const bd_comm* c) { return c ? c->rank : 0; }
+int bdk_comm_size(const bd_comm* c) { return c ? c->size : 1; }
+
+extern "C" {
+
+bd_comm* bd_comm_create(int rank, int size, long long max_elems) {
+    if (size < 1 || size > BD_TP_MAX || rank < 0 || rank >= size || max_elems < 8) { bdk_set_error("bd_comm_create: bad rank/size/capacity"); return nullptr; }
+    bd_comm* c = new bd_comm();
+    c->rank = rank; c->size = size;
+    c->max_elems = (max_elems + 7) / 8 * 8 + 8 * BD_TP_MAX;     // slices are ceil(units / size): up to one 8-element unit of slack per rank
+    const size_t dbytes = (size_t)c->max_elems * 6, fbytes = (size_t)(2 * BD_TP_MAX * BD_TP_GMAX + 1 + BD_TP_GMAX) * sizeof(int);
+    if (hipMalloc((void**)&c->data, dbytes) != hipSuccess) { delete c; bdk_set_error("bd_comm_create: hipMalloc failed"); return nullptr; }
+    // flags: uncached (fine-grained) so a peer's write is seen by the polling loads; plain device memory + system-scope
+    // atomics if this runtime refuses the flag
+    if (hipExtMallocWithFlags((void**)&c->flags, fbytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipMalloc((void**)&c->flags, fbytes) != hipSuccess) { hipFree(c->data); delete c; bdk_set_error("bd_comm_create: flag allocation failed"); return nullptr; }
+    }
+    hipMemset(c->data, 0, dbytes);
+    hipMemset(c->flags, 0, fbytes);
+    hipDeviceSynchronize();
+    c->own = true;
+    c->peer_data[rank] = c->data;
+    c->peer_flags[rank] = c->flags;
+    return c;
+}
+
+void bd_comm_destroy(bd_comm* c) {
+    if (!c) return;
+    for (int p = 0; p < BD_TP_MAX; ++p)
+        if (c->ipc_open[p]) { hipIpcCloseMemHandle(c->peer_data[p]); hipIpcCloseMemHandle(c->peer_flags[p]); }
+    if (c->own) { hipFree(c->data); hipFree(c->flags); }
+    delete c;
+}
+
+/* 2 x hipIpcMemHandle_t (64 B each): data, flags */
+int bd_comm_ipc_handles(bd_comm* c, void* out128) {
+    hipIpcMemHandle_t h[2];
+    if (hipIpcGetMemHandle(&h[0], c->data) != hipSuccess) return cfail(std::string("hipIpcGetMemHandle(data): ") + hipGetErrorString(hipGetLastError()));
+    if (hipIpcGetMemHandle(&h[1], c->flags) != hipSuccess) return cfail(std::string("hipIpcGetMemHandle(flags): ") + hipGetErrorString(hipGetLastError()));
+    std::memcpy(out128, h, sizeof(h));
+    return 0;
+}
+
+int bd_comm_open_peer(bd_comm* c, int peer, const void* handles128) {
+    if (peer < 0 || peer >= c->size || peer == c->rank) return cfail("bd_comm_open_peer: bad peer");
+    hipIpcMemHandle_t h[2];
+    std::memcpy(h, handles128, sizeof(h));
+    void *d = nullptr, *f = nullptr;
+    if (hipIpcOpenMemHandle(&d, h[0], hipIpcMemLazyEnablePeerAccess) != hipSuccess)
+        return cfail(std::string("hipIpcOpenMemHandle(data): ") + hipGetErrorString(hipGetLastError()));
+    if (hipIpcOpenMemHandle(&f, h[1], hipIpcMemLazyEnablePeerAccess) != hipSuccess)
+        return cfail(std::string("hipIpcOpenMemHandle(flags): ") + hipGetErrorString(hipGetLastError()));
+    c->peer_data[peer] = (char*)d; c->peer_flags[peer] = (int*)f; c->ipc_open[peer] = true;
+    return 0;
+}
+
+/* peers that live in this process (several contexts on one device: the protocol test) */
+int bd_comm_set_peer_ptrs(bd_comm* c, int peer, void* data, void* flags) {
+    if (peer < 0 || peer >= c->size || peer == c->rank) return cfail("bd_comm_set_peer_ptrs: bad peer");
+    c->peer_data[peer] = (char*)data; c->peer_flags[peer] = (int*)flags;
+    return 0;
+}
+void* bd_comm_local_data(bd_comm* c) { return c->data; }
+void* bd_comm_local_flags(bd_comm* c) { return c->flags; }
+
+int bd_comm_set_rccl(bd_comm* c, void* nccl_comm, void* nccl_allreduce_fn) {
+    c->nccl_comm = nccl_comm;
+    c->nccl_allreduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(nccl_allreduce_fn);
+    c->mode = (nccl_comm && nccl_allreduce_fn) ? 1 : 0;
+    return 0;
+}
+int bd_comm_set_timeout(bd_comm* c, double seconds) { c->timeout_s = seconds; return 0; }
+long long bd_comm_exchanges(bd_comm* c) { return c->n_exchanges; }
+
+/* host-side check after a stream sync: bit p set = the wait for peer p ran out of its time budget */
+int bd_comm_error(bd_comm* c) {
+    int e = 0;
+    if (hipMemcpy(&e, c->flags + 2 * BD_TP_MAX * BD_TP_GMAX, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return e;
+}
+
+/* standalone exchange (tests, micro-benchmarks): out = bf16(sum over ranks of part + bias), [rows][N];
+ * *out_ptr receives the address of the result (this rank's copy), *out_is_fp32 says whether the consumer still has to
+ * add the bias and round (RCCL mode) */
+int bd_comm_allreduce(bd_comm* c, const float* part, const void* bias_bf16, int rows, int N, void** out_ptr, int* out_is_fp32,
+                      void* stream) {
+    Partial r;
+    const int rc = bdk_tp_allreduce(c, part, bias_bf16, rows, N, &r, (hipStream_t)stream);
+    if (rc != 0) return cfail("bd_comm_allreduce failed with " + std::to_string(rc));
+    *out_ptr = const_cast<float*>(r.p);
+    *out_is_fp32 = r.S != 0;
+    return 0;
+}
+
+/* copy `bytes` of this rank's exchange buffer (offset from its base: 0 = fp32 staging, max_elems*4 = bf16 result) into a
+ * caller-owned device buffer -- how tests read a standalone exchange back */
+int bd_comm_copy_out(bd_comm* c, void* dst, long long bytes, int from_result, void* stream) {
+    const long long off = from_result ? c->max_elems * 4 : 0;
+    if (bytes < 0 || off + bytes > c->max_elems * 6) return cfail("bd_comm_copy_out: range");
+    return hipMemcpyAsync(dst, c->data + off, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess
+               ? 0 : cfail("bd_comm_copy_out: hipMemcpyAsync failed");
+}
+
+}  // extern "C"

@@ -95,20 +95,20 @@ struct GemmP {
     size_t PS, SS;       // packed-W strides in 16 B units: panel stride, 64-deep-K-stage stride
 };
 
-// R = depth of the per-wave W register ring = number of 64-deep K stages a wave keeps in flight.  The A stage is
+// R = depth of the per-wave W register ring = number of K stages a wave keeps in flight.  The A stage is
 // prefetched equally far ahead (R-1 register slots, then one ds_write into the double-buffered LDS tile): vmcnt retires
 // in order, so an A load issued late would force every older W load to complete with it.
 // hipcc's s_waitcnt placement is exact inside a straight-line body but drains the whole queue at the first use after
 // a loop back-edge; U (8 or 12) phases per iteration make that one drain in U.
-// NPW = 32-column panels per wave.  1: the HBM-bound 128-row passes (one A fragment feeds one MFMA: 1 KiB of LDS per MFMA
-// is fine while the matrix pipe idles).  2: the 256-row passes, where 32 MFMAs per wave and k-step would otherwise be
-// bound by LDS reads; each A fragment now feeds two MFMAs, the accumulators (MB x 2 x 16 = 256) live in AGPRs, one
-// wave per SIMD, and the next k-step's fragments are fetched from LDS while the current one multiplies.
-template <int NW, int MB, int EPI, int R, bool RED, int NPW = 1>
-__global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
-    static_assert(NPW == 1 || !RED, "in-launch reduction is only built for one panel per wave");
-    constexpr int NT = NW * 64;
-    constexpr int UNITS = MB * 256;                       // 16 B units per 64-deep A stage
+// NP x KW waves per workgroup: NP 32-column panels, each streamed by KW waves that split every (64*KW)-deep K stage between
+// them (wave kg takes the kg-th 64-deep part) and add their accumulators through LDS at the end -- split-K INSIDE the
+// workgroup.  KW = 2 halves the tile width at the same number of waves and bytes in flight per CU, so the N = 15360 shapes
+// fill 240 CUs with no cross-workgroup split at all (no slabs, no tickets) and the N = 5120 shapes need 3 slices
+// instead of 6 (half the slab traffic, in-launch reduction applies).
+template <int NP, int KW, int MB, int EPI, int R, bool RED>
+__global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
+    constexpr int NW = NP * KW, NT = NW * 64;
+    constexpr int UNITS = MB * 256 * KW;                  // 16 B units per (64*KW)-deep A stage
     constexpr int XL = (UNITS + NT - 1) / NT;             // A loads per thread per stage
     constexpr int XR = R - 1;                             // A register-ring slots
     constexpr int U = (R == 2) ? 8 : 12;
@@ -117,40 +117,37 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
     u32x4* const lds = reinterpret_cast<u32x4*>(smem);    // two A-stage buffers of UNITS each
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pw = wave % NP, kg = wave / NP;              // panel / K-part of this wave
     const int S = p.S;
     const int s = blockIdx.x % S, nt = blockIdx.x / S, mt = blockIdx.y;
-    const int nb = (nt * NW + wave) * NPW;                 // first panel of this wave
-    const int KS = p.K >> 4;
-    const int nst_total = p.K >> 6;
+    const int nb = nt * NP + pw;                           // panel of this wave
+    const int nst_total = p.K / (64 * KW);
     const int q = (nst_total + S - 1) / S;
     const int st0 = s * q;
     const int nst = min(q, nst_total - st0);
 
-    const u32x4* Wp = p.W + (size_t)nb * p.PS + (size_t)st0 * p.SS + lane;
-    const size_t w_stage = p.SS;
-    // A: unit u of a stage = chunk (ksl = (u>>6)/MB, mb = (u>>6)%MB), lane u&63
+    const u32x4* Wp = p.W + (size_t)nb * p.PS + (size_t)(st0 * KW + kg) * p.SS + lane;
+    const size_t w_stage = p.SS * KW;
+    // A: unit u of a stage = chunk (ksl = (u>>6)/MB in [0, 4*KW), mb = (u>>6)%MB), lane u&63
     size_t a_off[XL];
 #pragma unroll
     for (int j = 0; j < XL; ++j) {
         const int u = tid + j * NT;
         const int c = u >> 6;
-        a_off[j] = (((size_t)(st0 * 4 + c / MB) * p.RB) + mt * MB + (c % MB)) * 64 + (u & 63);
+        a_off[j] = (((size_t)(st0 * 4 * KW + c / MB) * p.RB) + mt * MB + (c % MB)) * 64 + (u & 63);
     }
-    const size_t a_stage = (size_t)4 * p.RB * 64;
+    const size_t a_stage = (size_t)4 * KW * p.RB * 64;
 
-    u32x4 w[R][NPW * 4], xr[XR][XL];
-    f32x16 acc[MB * NPW];                                  // [m * NPW + pn]
+    u32x4 w[R][4], xr[XR][XL];
+    f32x16 acc[MB];
 #pragma unroll
-    for (int m = 0; m < MB * NPW; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-    auto load_w = [&](u32x4(&wr)[NPW * 4], int i) {
+    auto load_w = [&](u32x4(&wr)[4], int i) {
 #pragma unroll
-        for (int pn = 0; pn < NPW; ++pn)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                wr[pn * 4 + j] = __builtin_nontemporal_load(Wp + (size_t)pn * p.PS + (size_t)i * w_stage + j * 64);
+        for (int j = 0; j < 4; ++j) wr[j] = __builtin_nontemporal_load(Wp + (size_t)i * w_stage + j * 64);
     };
     auto load_x = [&](u32x4(&x)[XL], int i) {
 #pragma unroll
@@ -162,43 +159,24 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
         for (int j = 0; j < XL; ++j)
             if (UNITS % NT == 0 || tid + j * NT < UNITS) buf[tid + j * NT] = x[j];
     };
-    // The whole A stage goes LDS -> registers in one burst (16 ds_read_b128 for 128 rows), then the MFMAs issue back to
-    // back: with the reads interleaved two-at-a-time the matrix pipe idled on LDS latency (the loop was bound by the
-    // ds_read -> MFMA chain, not by HBM).  For 256-row passes only half a stage fits the register budget.
+    // This wave's 64-deep part of the A stage goes LDS -> registers in one burst (16 ds_read_b128 for 128 rows), then the
+    // MFMAs issue back to back: with the reads interleaved two-at-a-time the matrix pipe idled on LDS latency (the loop
+    // was bound by the ds_read -> MFMA chain, not by HBM).
     constexpr int KG = (MB <= 4 && NW <= 8) ? 4 : 1;      // k-steps whose A fragments are resident at once (VGPR budget)
-    auto compute = [&](const u32x4* buf, const u32x4(&wr)[NPW * 4]) {
-        if constexpr (NPW == 1) {
+    auto compute = [&](const u32x4* stage, const u32x4(&wr)[4]) {
+        const u32x4* buf = stage + kg * MB * 256;
 #pragma unroll
-            for (int k0 = 0; k0 < 4; k0 += KG) {
-                u32x4 xf[KG][MB];
+        for (int k0 = 0; k0 < 4; k0 += KG) {
+            u32x4 xf[KG][MB];
 #pragma unroll
-                for (int kk = 0; kk < KG; ++kk)
+            for (int kk = 0; kk < KG; ++kk)
 #pragma unroll
-                    for (int m = 0; m < MB; ++m) xf[kk][m] = buf[((k0 + kk) * MB + m) * 64 + lane];
-                if constexpr (KG > 1) __builtin_amdgcn_sched_barrier(0);   // keep the burst: hipcc otherwise re-interleaves 2 reads / 2 MFMAs
+                for (int m = 0; m < MB; ++m) xf[kk][m] = buf[((k0 + kk) * MB + m) * 64 + lane];
+            if constexpr (KG > 1) __builtin_amdgcn_sched_barrier(0);   // keep the burst: hipcc otherwise re-interleaves 2 reads / 2 MFMAs
 #pragma unroll
-                for (int kk = 0; kk < KG; ++kk)
+            for (int kk = 0; kk < KG; ++kk)
 #pragma unroll
-                    for (int m = 0; m < MB; ++m) acc[m] = mfma32(xf[kk][m], wr[k0 + kk], acc[m]);
-            }
-        } else {
-            u32x4 xf[2][MB];
-#pragma unroll
-            for (int m = 0; m < MB; ++m) xf[0][m] = buf[m * 64 + lane];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (k < 3) {                          // next k-step's fragments land while this one's 2*MB MFMAs run
-#pragma unroll
-                    for (int m = 0; m < MB; ++m) xf[(k + 1) & 1][m] = buf[((k + 1) * MB + m) * 64 + lane];
-                }
-                __builtin_amdgcn_sched_barrier(0);    // hipcc otherwise collapses the prefetch to one fragment ahead
-#pragma unroll
-                for (int m = 0; m < MB; ++m)
-#pragma unroll
-                    for (int pn = 0; pn < NPW; ++pn)
-                        acc[m * NPW + pn] = mfma32(xf[k & 1][m], wr[pn * 4 + k], acc[m * NPW + pn]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                for (int m = 0; m < MB; ++m) acc[m] = mfma32(xf[kk][m], wr[k0 + kk], acc[m]);
         }
     };
 
@@ -237,29 +215,56 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
         }
     }
 
-    // ---- epilogue.  D layout of the 32x32 MFMA: lane -> column (lane&31), reg r -> row (r&3)+8(r>>2)+4(lane>>5)
-    const int col = nb * 32 + (lane & 31);                 // panel pn of this wave: + pn * 32
-    float bias_pn[NPW];
+    // ---- K parts of one panel meet in LDS: parts 1..KW-1 park their accumulators, part 0 adds them in order
+    if constexpr (KW > 1) {
+        __syncthreads();                                                  // every wave is done with the A tiles
+        f32x4* const red = reinterpret_cast<f32x4*>(smem);                // [(kg-1)*NP + pw][m][r4][lane]: lane-linear 16 B
+        if (kg > 0) {
 #pragma unroll
-    for (int pn = 0; pn < NPW; ++pn) bias_pn[pn] = (EPI != BD_EPI_PARTIAL && p.bias) ? bf2f(p.bias[col + pn * 32]) : 0.f;
-    const float bias_col = bias_pn[0];
-    (void)bias_col;
-    auto finalize_pn = [&](int m, int pn) {
-        const f32x16& a = acc[m * NPW + pn];
-        const int colp = col + pn * 32;
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+                    red[((((kg - 1) * NP + pw) * MB + m) * 4 + r4) * 64 + lane] =
+                        (f32x4){acc[m][4 * r4], acc[m][4 * r4 + 1], acc[m][4 * r4 + 2], acc[m][4 * r4 + 3]};
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int g = 1; g < KW; ++g)
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 v = red[((((g - 1) * NP + pw) * MB + m) * 4 + r4) * 64 + lane];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[m][4 * r4 + j] += v[j];
+                    }
+        }
+    }
+    const bool owner = (kg == 0);                                          // the wave that holds the tile's sums
+
+    // ---- epilogue.  D layout of the 32x32 MFMA: lane -> column (lane&31), reg r -> row (r&3)+8(r>>2)+4(lane>>5)
+    const int col = nb * 32 + (lane & 31);
+    const float bias_col = ((EPI == BD_EPI_BF16 || EPI == BD_EPI_SWIGLU) && p.bias) ? bf2f(p.bias[col]) : 0.f;
+    auto finalize = [&](int m) {
+        const f32x16& a = acc[m];
         if (EPI == BD_EPI_PARTIAL) {
-            float* o = p.out + ((size_t)s * p.Mpad + (size_t)(mt * MB + m) * 32) * p.N + colp;
+            float* o = p.out + ((size_t)s * p.Mpad + (size_t)(mt * MB + m) * 32) * p.N + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = a[r];
+        } else if (EPI == BD_EPI_F32) {    // the finished fp32 sum (no bias, no rounding): one rank's partial of a row-split Linear
+            float* o = reinterpret_cast<float*>(p.act) + (size_t)(mt * MB + m) * 32 * p.N + col;
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = a[r];
         } else if (EPI == BD_EPI_BF16) {   // Linear output rounded once to bf16 (what autocast's F.linear returns)
-            bf16_t* o = p.act + (size_t)(mt * MB + m) * 32 * p.N + colp;
+            bf16_t* o = p.act + (size_t)(mt * MB + m) * 32 * p.N + col;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = f2bf(a[r] + bias_pn[pn]);
+            for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = f2bf(a[r] + bias_col);
         } else {  // BD_EPI_SWIGLU: lanes (l&16)==0 hold gate feature f, lanes (l&16)!=0 the matching up feature
-            const int f = (nb + pn) * 16 + (lane & 15);
+            const int f = nb * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = bfr(a[r] + bias_pn[pn]);              // Linear output rounded to bf16
+                const float v = bfr(a[r] + bias_col);                     // Linear output rounded to bf16
                 const float other = __shfl_xor(v, 16);
                 if ((lane & 16) == 0) {
                     const int row = (mt * MB + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -268,35 +273,39 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
             }
         }
     };
-    auto finalize = [&](int m) {
-#pragma unroll
-        for (int pn = 0; pn < NPW; ++pn) finalize_pn(m, pn);
-    };
     if constexpr (RED) {
         // In-launch split-K reduction ("last arriver reduces"): every K-slice parks its fp32 slab and takes a ticket on
         // the tile's counter; the slice that draws S-1 re-reads ALL slabs in slice order (a fixed summation order: the
         // result does not depend on which slice happened to arrive last) and runs the real epilogue, so the consumers
-        // read ONE finished bf16 tensor instead of S fp32 slabs.
+        // read ONE finished tensor instead of S fp32 slabs.
         // The XCD L2s are not coherent with each other, so the slab traffic is agent-scope relaxed atomics: `sc1`
         // write-through stores, drained by vmcnt(0) before the ticket, and `sc1` loads on the reducing side
         // (MI355X_MICROARCH.md "publish-large": 3.0 vs 8.2 us for plain stores + release fence; the fence form also
-        // writes back / invalidates the whole L2 under the other workgroups' A-operand reuse).
+        // writes back / invalidates the whole L2 under the other workgroups' A-operand reuse).  This relies on gfx950's
+        // sc1 semantics (write-through to the memory side, L2-bypassing loads) rather than on a release/acquire edge of the
+        // memory model: the static_assert below keeps it from being compiled for any other target, and
+        // tests/test_gpu_parity.py::test_gemm_in_launch_splitk_reduction checks determinism and values on the hardware.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+        static_assert(!RED, "the relaxed sc1 slab hand-off is validated for gfx950 only");
+#endif
         float* o = p.out + ((size_t)s * p.Mpad + (size_t)mt * MB * 32) * p.N + col;
+        if (owner) {
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
+            for (int m = 0; m < MB; ++m) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                __hip_atomic_store(o + (size_t)(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N, acc[m][r],
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_sched_barrier(0);                            // one row-block of addresses live at a time
+                for (int r = 0; r < 16; ++r)
+                    __hip_atomic_store(o + (size_t)(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N, acc[m][r],
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_sched_barrier(0);                            // one row-block of addresses live at a time
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every storing wave drains its write-throughs
         __syncthreads();                                                  // (also: all waves are done with the LDS tiles)
         int* const flag = reinterpret_cast<int*>(smem);
-        int* const ticket = p.cnt + (mt * (p.N / (32 * NW)) + nt);
+        int* const ticket = p.cnt + (mt * (p.N / (32 * NP)) + nt);
         if (tid == 0) flag[0] = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        if (flag[0] != S - 1) return;                                     // not the last slice of this tile
+        if (flag[0] != S - 1 || !owner) return;                           // not the last slice of this tile / nothing to store
         if (S == 2) {
             // two slices: own + other == other + own bit for bit, so the last arriver keeps its accumulators and
             // fetches only the other slab, four row-blocks (64 loads per lane) in flight at once
@@ -341,8 +350,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(GemmP p) {
         if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
         return;
     }
+    if (owner) {
 #pragma unroll
-    for (int m = 0; m < MB; ++m) finalize(m);
+        for (int m = 0; m < MB; ++m) finalize(m);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -523,58 +534,74 @@ static int launch_gemm_wide(const GemmP& p, int epi, hipStream_t st) {
     return bd_launch_status();
 }
 
-template <int NW, int MB, int R, bool RED, int NPW = 1>
-static int launch_gemm_r(const GemmP& p, int epi, hipStream_t st) {
-    const int ntiles = p.N / (32 * NW * NPW);
+template <int NP, int KW, int MB, int EPI, int R, bool RED>
+static int launch_one(const GemmP& p, hipStream_t st) {
+    const int ntiles = p.N / (32 * NP);
     dim3 grid(ntiles * p.S, p.RB / MB);
-    const size_t lds = (size_t)2 * MB * 256 * 16;
-    if (epi == BD_EPI_PARTIAL)
-        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_PARTIAL, R, false, NPW>), grid, dim3(NW * 64), lds, st, p);
-    else if (epi == BD_EPI_BF16)
-        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_BF16, R, RED, NPW>), grid, dim3(NW * 64), lds, st, p);
-    else
-        BD_LAUNCH((gemm_kernel<NW, MB, BD_EPI_SWIGLU, R, RED, NPW>), grid, dim3(NW * 64), lds, st, p);
+    // two A-stage buffers; with KW > 1 the same LDS is re-used for the accumulators of K parts 1..KW-1
+    constexpr size_t lds_a = (size_t)2 * MB * 256 * KW * 16, lds_r = (size_t)(KW - 1) * NP * MB * 4096;
+    constexpr size_t lds = lds_a > lds_r ? lds_a : lds_r;
+    if constexpr (lds > 64 * 1024) {                               // beyond 64 KiB of dynamic LDS needs the opt-in
+        static const bool ok = hipFuncSetAttribute((const void*)gemm_kernel<NP, KW, MB, EPI, R, RED>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        if (!ok) return -8;
+    }
+    BD_LAUNCH((gemm_kernel<NP, KW, MB, EPI, R, RED>), grid, dim3(NP * KW * 64), lds, st, p);
     return bd_launch_status();
 }
 
-// A: fragment-major bf16, RB row blocks (RB must be 1, 2 or a multiple of 4).  W: packed.  N % (32*nw) == 0, K % 64 == 0.
-template <int NW, int MB, int R>
-static int launch_gemm(const GemmP& p, int epi, hipStream_t st) {
-    if constexpr (NW == 10) return launch_gemm_r<NW, MB, R, false>(p, epi, st);          // single-slice tiles only
-    else return (p.S > 1 && epi != BD_EPI_PARTIAL) ? launch_gemm_r<NW, MB, R, true>(p, epi, st)
-                                                   : launch_gemm_r<NW, MB, R, false>(p, epi, st);
+template <int NP, int KW, int MB, int R, bool RED>
+static int launch_gemm_r(const GemmP& p, int epi, hipStream_t st) {
+    if (epi == BD_EPI_PARTIAL) return launch_one<NP, KW, MB, BD_EPI_PARTIAL, R, false>(p, st);
+    if (epi == BD_EPI_BF16) return launch_one<NP, KW, MB, BD_EPI_BF16, R, RED>(p, st);
+    if (epi == BD_EPI_F32) return launch_one<NP, KW, MB, BD_EPI_F32, R, RED>(p, st);
+    return launch_one<NP, KW, MB, BD_EPI_SWIGLU, R, RED>(p, st);
 }
 
-// `nw_ring` = waves per workgroup (2, 4, 8) + 16 * ring, ring in {0 (=2), 3, 4}: stages of W/A a wave keeps in flight.
+// A: fragment-major bf16, RB row-blocks (RB must be 1, 2 or a multiple of 4).  W: packed.  N % (32*NP) == 0, K % (64*KW) == 0.
+template <int NP, int KW, int MB, int R>
+static int launch_gemm(const GemmP& p, int epi, hipStream_t st) {
+    if constexpr (NP * KW == 10 && KW == 1) return launch_gemm_r<NP, KW, MB, R, false>(p, epi, st);   // single-slice tiles only
+    else return (p.S > 1 && epi != BD_EPI_PARTIAL) ? launch_gemm_r<NP, KW, MB, R, true>(p, epi, st)
+                                                   : launch_gemm_r<NP, KW, MB, R, false>(p, epi, st);
+}
+
+// `nw_ring` = waves per workgroup (2, 4, 8, 10) + 16 * ring + 256 * (kw - 1): ring in {0 (=2), 3, 4} = stages of W/A a wave
+// keeps in flight, kw in {1, 2} = waves that share one 32-column panel and split each K stage (NP = waves / kw panels per tile).
 int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_ring, int epi,
              float* out_partial, void* out_act, const void* bias, int* cnt, hipStream_t st) {
     const int nw = nw_ring & 15;
-    int ring = nw_ring >> 4;
+    int ring = (nw_ring >> 4) & 15;
+    const int kw = ((nw_ring >> 8) & 3) + 1;
     if (ring == 0) ring = 2;
-    if (ring < 2 || ring > 4) return -7;
-    if (K % 64 || N % (32 * nw) || S < 1) return -2;
-    const int nst_total = K / 64, q = (nst_total + S - 1) / S;
+    if (ring < 2 || ring > 4 || kw > 2 || nw % kw) return -7;
+    const int np = nw / kw;
+    if (K % (64 * kw) || N % (32 * np) || S < 1) return -2;
+    const int nst_total = K / (64 * kw), q = (nst_total + S - 1) / S;
     if ((S - 1) * q >= nst_total) return -3;                       // an empty split
-    if (epi != BD_EPI_PARTIAL && S != 1 && (out_partial == nullptr || cnt == nullptr || nw == 10)) return -4;   // needs slab scratch + counters
+    if (epi != BD_EPI_PARTIAL && S != 1 && (out_partial == nullptr || cnt == nullptr || (nw == 10 && kw == 1))) return -4;   // needs slab scratch + counters
     size_t PS, SS;
     bdk_w_strides(N / 32, K, &PS, &SS);
     GemmP p{(const u32x4*)A, (const u32x4*)W, out_partial, (bf16_t*)out_act, (const bf16_t*)bias, cnt, RB, N, K, S, RB * 32, PS, SS};
     // rows per pass over the weights: 256 (two images with CFG: W streamed once for both) when the row count allows,
     // else 128 / 64 / 32
-    const int MB = (RB % 8 == 0 && nw >= 4) ? 8 : ((RB % 4 == 0) ? 4 : RB);
+    const int MB = (RB % 8 == 0 && nw >= 4 && kw == 1) ? 8 : ((RB % 4 == 0) ? 4 : RB);
     if (MB != 8 && MB != 4 && MB != 2 && MB != 1) return -5;
-    if (MB == 8 || nw == 2 || nw == 10) ring = 2;                  // register budget
-    // 256-row passes over 256-column tiles: 4 waves x 2 panels (MFMA-friendly, see NPW) instead of 8 waves x 1 panel;
+    if (MB == 8 || nw == 2 || nw == 10 || kw == 2) ring = 2;       // register budget
+    // 256-row passes over 256-column tiles: 4 waves x 2 panels (MFMA-friendly) instead of 8 waves x 1 panel;
     // same grid.  BD_GEMM_WIDE=0 keeps the 8-wave form (A/B switch for measurements).
     static const bool wide = [] { const char* e = getenv("BD_GEMM_WIDE"); return !(e && e[0] == '0'); }();
-    if (wide && MB == 8 && nw == 8 && !(S > 1 && epi != BD_EPI_PARTIAL)) return launch_gemm_wide(p, epi, st);
-#define BD_CASE(NWV, MBV, RV) if (nw == NWV && MB == MBV && ring == RV) return launch_gemm<NWV, MBV, RV>(p, epi, st);
+    if (wide && MB == 8 && nw == 8 && epi != BD_EPI_F32 && !(S > 1 && epi != BD_EPI_PARTIAL)) return launch_gemm_wide(p, epi, st);
+#define BD_CASE(NPV, KWV, MBV, RV) if (np == NPV && kw == KWV && MB == MBV && ring == RV) return launch_gemm<NPV, KWV, MBV, RV>(p, epi, st);
     if (MB <= 2 && ring == 3) ring = 4;
     if (MB == 1) ring = 2;
-    BD_CASE(4, 8, 2) BD_CASE(8, 8, 2) BD_CASE(10, 4, 2)
-    BD_CASE(2, 4, 2) BD_CASE(4, 4, 2) BD_CASE(8, 4, 2) BD_CASE(4, 4, 3) BD_CASE(8, 4, 3) BD_CASE(4, 4, 4) BD_CASE(8, 4, 4)
-    BD_CASE(2, 2, 2) BD_CASE(4, 2, 2) BD_CASE(8, 2, 2) BD_CASE(4, 2, 4) BD_CASE(8, 2, 4)
-    BD_CASE(2, 1, 2) BD_CASE(4, 1, 2) BD_CASE(8, 1, 2)
+    BD_CASE(4, 1, 8, 2) BD_CASE(8, 1, 8, 2) BD_CASE(10, 1, 4, 2)
+    BD_CASE(2, 1, 4, 2) BD_CASE(4, 1, 4, 2) BD_CASE(8, 1, 4, 2) BD_CASE(4, 1, 4, 3) BD_CASE(8, 1, 4, 3) BD_CASE(4, 1, 4, 4) BD_CASE(8, 1, 4, 4)
+    BD_CASE(2, 1, 2, 2) BD_CASE(4, 1, 2, 2) BD_CASE(8, 1, 2, 2) BD_CASE(4, 1, 2, 4) BD_CASE(8, 1, 2, 4)
+    BD_CASE(2, 1, 1, 2) BD_CASE(4, 1, 1, 2) BD_CASE(8, 1, 1, 2)
+    BD_CASE(1, 2, 4, 2) BD_CASE(2, 2, 4, 2) BD_CASE(4, 2, 4, 2) BD_CASE(5, 2, 4, 2)
+    BD_CASE(1, 2, 2, 2) BD_CASE(2, 2, 2, 2) BD_CASE(4, 2, 2, 2)
+    BD_CASE(1, 2, 1, 2) BD_CASE(2, 2, 1, 2) BD_CASE(4, 2, 1, 2)
 #undef BD_CASE
     return -6;
 }

@@ -10,7 +10,8 @@ static inline int bd_launch_status() { return hipGetLastError() == hipSuccess ? 
 
 #define BD_EPI_PARTIAL 0
 #define BD_EPI_SWIGLU 1
-#define BD_EPI_BF16 2       // out bf16 row-major [Mpad][N] = bf16(acc + bias), split-K must be 1
+#define BD_EPI_BF16 2       // out bf16 row-major [Mpad][N] = bf16(acc + bias); split-K > 1: reduced inside the launch
+#define BD_EPI_F32 3        // out fp32 row-major [Mpad][N] = the finished K sum, no bias / rounding (a tensor-parallel rank's partial)
 
 struct BdStepState;
 
@@ -29,7 +30,8 @@ struct Partial {            // a Linear output as the consumer sees it:
     const float* p;         //   S >= 1: split-K slabs [S][Mpad][N] fp32 (+ optional bf16 bias[N]) to be summed and rounded
     const void* bias;       //   S == 0: p is a FINISHED bf16 row-major [Mpad][N] tensor (bias added, rounded) -- the
     int S, N, Mpad;         //           GEMM reduced its own K-slices (last-arriver epilogue)
-};
+    int sys = 0;            //   1 (with S == 0): the tensor was written by OTHER GPUs over xGMI (tensor-parallel all-reduce,
+};                          //           bd_comm.hip): read it with system-scope loads, the L2 may hold stale lines
 
 // diffusion head
 struct HeadPrologueArgs {   // y = silu(t_emb + cond_embed(c)) ; x0 = input_proj(x_t)      flow_head:326-330
@@ -201,6 +203,12 @@ int bdk_step_advance(const StepAdvanceArgs& a, hipStream_t st);
 
 int bdk_gfq_indices(const float* z, int* idx, int ntok, int ncb, int bits, hipStream_t st);
 int bdk_gfq_codes(const int* idx, float* code, int ntok, int ncb, int bits, hipStream_t st);
+
+// ---- bd_comm.hip : tensor-parallel exchange (all-reduce of a row-split Linear's fp32 partials, bias, one bf16 rounding)
+struct bd_comm;
+int bdk_tp_allreduce(bd_comm* c, const float* part, const void* bias, int rows, int N, Partial* res, hipStream_t st);
+int bdk_comm_rank(const bd_comm* c);
+int bdk_comm_size(const bd_comm* c);
 
 // ---- bd_attn.hip
 struct HeadAttnArgs {       // DiT attention over one patch (seq = P = 64 or 16), non-causal      flow_head:192-220

@@ -40,7 +40,14 @@ BD_DEV u32x4 pack8(const float* v) {
 // Linear output of 8 consecutive columns: bf16( sum of split-K slabs + bias )
 BD_DEV void slab8(const Partial& q, int row, int col, float* v) {
     if (q.S == 0) {                                     // finished bf16 tensor (the GEMM reduced its own K-slices)
-        ld_bf16x8((const bf16_t*)q.p + (size_t)row * q.N + col, v);
+        const bf16_t* src = (const bf16_t*)q.p + (size_t)row * q.N + col;
+        if (q.sys) {                                    // pushed into this GPU's memory by the tensor-parallel peers
+            const unsigned long long lo = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long hi = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(src) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            unpack8((u32x4){(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)}, v);
+        } else {
+            ld_bf16x8(src, v);
+        }
         return;
     }
     const float* p = q.p + (size_t)row * q.N + col;

@@ -72,13 +72,19 @@ class HeadWeights:
     head_dim: int = 128                             # 128: T2I heads (flow_head_parallel_x.py:227); 64: imagenet (diff_head_parallel.py:207)
     final_sigmoid: bool = True                      # 2*sigmoid(out)-1 (flow_head_parallel_x.py:342); imagenet head: identity
     ptrs: dict = field(default_factory=dict)        # name -> tensor (kept alive)
+    tp_size: int = 1
     time_w0: torch.Tensor = None
     time_b0: torch.Tensor = None
     time_w2: torch.Tensor = None
     time_b2: torch.Tensor = None
 
     @staticmethod
-    def from_state_dict(sd: dict, device, head_dim: int = 128, final_sigmoid: bool = True) -> "HeadWeights":
+    def from_state_dict(sd: dict, device, head_dim: int = 128, final_sigmoid: bool = True, tp_rank: int = 0,
+                        tp_size: int = 1) -> "HeadWeights":
+        """``tp_size`` > 1: pack this rank's slices (tp.shard_head_state); D / H below stay the FULL widths."""
+        if tp_size > 1:
+            from .tp import shard_head_state
+            sd = shard_head_state(sd, tp_rank, tp_size, head_dim)
         g = lambda k: sd[k]
         D, C = g("net.input_proj.weight").shape
         Dz = g("net.cond_embed.weight").shape[1]
@@ -86,10 +92,11 @@ class HeadWeights:
         na = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("net.ada_ln_blocks."))
         if "net.res_blocks.0.w1.weight" not in sd:
             raise BitDanceHipError("native head requires the SwiGLU variant (use_swiglu=True)")
-        H = g("net.res_blocks.0.w2.weight").shape[1]
+        H = g("net.res_blocks.0.w2.weight").shape[1]             # this rank's SwiGLU features
         if head_dim not in (64, 128) or D % head_dim:
             raise BitDanceHipError(f"native head: head_dim {head_dim} unsupported for D={D}")
-        hw = HeadWeights(D=D, C=C, Dz=Dz, H=H, nblocks=nb, nada=na, head_dim=head_dim, final_sigmoid=final_sigmoid)
+        hw = HeadWeights(D=D, C=C, Dz=Dz, H=H * tp_size, nblocks=nb, nada=na, head_dim=head_dim, final_sigmoid=final_sigmoid)
+        hw.tp_size = tp_size
         p = hw.ptrs
         p["head.cond_w"] = pack_linear([g("net.cond_embed.weight")], device)
         p["head.cond_b"] = _bf16(g("net.cond_embed.bias"), device)
@@ -168,10 +175,18 @@ class LlmWeights:
     cfg: dict
     ptrs: dict = field(default_factory=dict)
     sd: dict = field(default_factory=dict)          # original-layout bf16 tensors on device (prefill)
+    tp_size: int = 1
+    tp_rank: int = 0
 
     @staticmethod
-    def from_state_dict(sd: dict, cfg: dict, device, keep_for_prefill: bool = True) -> "LlmWeights":
+    def from_state_dict(sd: dict, cfg: dict, device, keep_for_prefill: bool = True, tp_rank: int = 0,
+                        tp_size: int = 1) -> "LlmWeights":
+        """``tp_size`` > 1: pack (and keep, for the prefill) this rank's slices (tp.shard_llm_state); ``cfg`` stays the full model's."""
+        if tp_size > 1:
+            from .tp import shard_llm_state
+            sd = shard_llm_state(sd, cfg, tp_rank, tp_size)
         lw = LlmWeights(cfg=dict(cfg))
+        lw.tp_size, lw.tp_rank = tp_size, tp_rank
         p = lw.ptrs
         if cfg["head_dim"] != 128:
             raise BitDanceHipError("native LLM path requires head_dim == 128 (Qwen3)")
@@ -240,8 +255,14 @@ class Engine:
 
     def __init__(self, head: HeadWeights | None, proj: ProjWeights | None, llm: LlmWeights | None, *,
                  num_images: int, branches: int, device, max_tokens: int = 64, max_kv: int = 256,
-                 attn_splits: int = 8, tune: dict | None = None, parallel_num: int = 64):
+                 attn_splits: int = 8, tune: dict | None = None, parallel_num: int = 64, comm=None):
+        """``comm``: a tp.TPComm -- this engine is then rank comm.rank of a tensor-parallel group and ``head`` / ``llm`` must
+        have been packed with the same (tp_rank, tp_size)."""
         self.l = lib()
+        self.comm = comm if (comm is not None and comm.size > 1) else None
+        for w in (head, llm):
+            if w is not None and getattr(w, "tp_size", 1) != (self.comm.size if self.comm else 1):
+                raise BitDanceHipError("weights were packed for a different tensor-parallel size than the engine's communicator")
         self.device = torch.device(device)
         self.head, self.proj, self.llm = head, proj, llm
         if parallel_num not in (16, 64):
@@ -273,6 +294,8 @@ class Engine:
             if w is not None:
                 for k, t in w.ptrs.items():
                     self.set_ptr(k, t)
+        if self.comm is not None:
+            check(self.l.bd_ctx_set_comm(self.ctx, self.comm.h), "bd_ctx_set_comm")
         check(self.l.bd_ctx_finalize(self.ctx), "bd_ctx_finalize")
         self.ws: dict[str, torch.Tensor] = {}
         for i in range(self.l.bd_ctx_ws_count(self.ctx)):

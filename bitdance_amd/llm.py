@@ -33,8 +33,10 @@ def prefill_block(eng: Engine, lw: LlmWeights, x: torch.Tensor, seq0: int, past:
     causal=True: standard causal mask (t2i_pipeline.py:199-203); False: every query sees all past+T keys
     (the all-True mask of :206-218).  Appends K/V to the engine cache, returns last_hidden_state (bf16)."""
     c = lw.cfg
-    L, nh, nkv, hd, eps = (c["num_hidden_layers"], c["num_attention_heads"], c["num_key_value_heads"],
+    tp = getattr(lw, "tp_size", 1)                      # tensor parallel: this rank's heads / FFN slice, partial sums all-reduced
+    L, nh, nkv, hd, eps = (c["num_hidden_layers"], c["num_attention_heads"] // tp, c["num_key_value_heads"] // tp,
                            c["head_dim"], c["rms_norm_eps"])
+    reduce_ = eng.comm.all_reduce_ if (tp > 1 and eng.comm is not None) else (lambda t: t)
     B, T, _ = x.shape
     nseq = eng.branches * eng.B
     kc = eng.ws["llm.k_cache"].view(BF16).view(L, nseq, nkv, eng.Lmax, hd)
@@ -70,10 +72,10 @@ def prefill_block(eng: Engine, lw: LlmWeights, x: torch.Tensor, seq0: int, past:
         else:
             o = F.scaled_dot_product_attention(q, kk, vv)
         o = o.transpose(1, 2).reshape(B, T, nh * hd)
-        h = r + F.linear(o, sd[p + "self_attn.o_proj.weight"])
+        h = r + reduce_(F.linear(o, sd[p + "self_attn.o_proj.weight"]))
         r = h
         a = _rms(h, sd[p + "post_attention_layernorm.weight"], eps)
         g = F.linear(a, sd[p + "mlp.gate_proj.weight"])
         u = F.linear(a, sd[p + "mlp.up_proj.weight"])
-        h = r + F.linear(F.silu(g) * u, sd[p + "mlp.down_proj.weight"])
+        h = r + reduce_(F.linear(F.silu(g) * u, sd[p + "mlp.down_proj.weight"]))
     return _rms(h, sd["model.norm.weight"], eps)

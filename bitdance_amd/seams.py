@@ -37,7 +37,7 @@ class NativeDiffHead:
         key = (B, mult, P)
         if key not in self._eng:
             self._eng[key] = Engine(pipe.head_w, None, None, num_images=B, branches=mult, device=pipe.device,
-                                    max_tokens=P, parallel_num=P)
+                                    max_tokens=P, parallel_num=P, comm=getattr(pipe, "tp", None))
         eng = self._eng[key]
         eng.set_schedule(num_sampling_steps, cfg, 1, time_shift=float(pipe.vision_head_config.get("time_shift", 1.0)))
         eng.draw_noise(1)                                   # randn + N x randn_like, the reference's RNG order
@@ -74,7 +74,7 @@ class NativeConnector:
         eng = self._eng[B]
         eng.set_ptr("head.tok_cur", t)
         eng.pos.zero_()
-        eng.reset([0] * B)
+        eng.reset([0] * min(B, 16))                         # the projector reads only the step counter
         eng.projector()
         return eng._R[:n].to(torch.bfloat16).view(*lead, -1)     # values are exact bf16 (pos == 0)
 
@@ -111,7 +111,7 @@ class NativeQwen3Model:
         P = pipe.parallel_num
         if past_key_values is None:
             eng = Engine(None, None, pipe.llm_w, num_images=B, branches=1, device=pipe.device, max_kv=self.max_kv,
-                         max_tokens=P, parallel_num=P)
+                         max_tokens=P, parallel_num=P, comm=getattr(pipe, "tp", None))
             eng.set_int("rt.emit_cond", 0)
             cache = NativeKVCache(eng, B, 0)
         else:

@@ -60,38 +60,50 @@ def _llm_cfg_from_json(cfg: dict) -> dict:
     return out
 
 
+def load_model_dir(model_path: str) -> dict:
+    """Everything ``BitDanceT2IPipeline.__init__`` reads from a released model directory (t2i_pipeline.py:45-75): the HF
+    tokenizer + ``config.json`` (Qwen3) + ``model*.safetensors`` (single file or the sharded index), ``ae_config.json`` /
+    ``ae.safetensors``, ``vision_head_config.json`` / ``vision_head.safetensors``, ``projector.safetensors``.  Pure host
+    code (no GPU), so the checkpoint-loading contract is testable on CPU (tests/test_host_cpu.py)."""
+    from transformers import AutoTokenizer
+    tokenizer = AutoTokenizer.from_pretrained(model_path)
+    with open(os.path.join(model_path, "config.json")) as f:
+        llm_cfg = _llm_cfg_from_json(json.load(f))
+    with open(os.path.join(model_path, "ae_config.json")) as f:
+        ae_config = json.load(f)
+    with open(os.path.join(model_path, "vision_head_config.json")) as f:
+        head_config = json.load(f)
+    return dict(tokenizer=tokenizer, llm_cfg=llm_cfg, llm_sd=_load_llm_state(model_path), ae_config=ae_config,
+                ae_sd=_load_sft(os.path.join(model_path, "ae.safetensors")), head_config=head_config,
+                head_sd=_load_sft(os.path.join(model_path, "vision_head.safetensors")),
+                proj_sd=_load_sft(os.path.join(model_path, "projector.safetensors")))
+
+
 class BitDanceT2IPipeline:
-    def __init__(self, model_path, device="cuda"):
-        from transformers import AutoTokenizer
+    def __init__(self, model_path, device="cuda", tp=None):
+        """``tp``: a ``bitdance_amd.tp.TPComm`` -- this process is then one rank of a tensor-parallel group (every rank
+        constructs the pipeline on its own GPU and makes the same calls with the same seed); None = one GPU."""
         self.device = device
-        tokenizer = AutoTokenizer.from_pretrained(model_path)
-        with open(os.path.join(model_path, "config.json")) as f:
-            llm_cfg = _llm_cfg_from_json(json.load(f))
-        with open(os.path.join(model_path, "ae_config.json")) as f:
-            ae_config = json.load(f)
-        with open(os.path.join(model_path, "vision_head_config.json")) as f:
-            head_config = json.load(f)
-        self._init_from(tokenizer, llm_cfg, _load_llm_state(model_path), ae_config,
-                        _load_sft(os.path.join(model_path, "ae.safetensors")), head_config,
-                        _load_sft(os.path.join(model_path, "vision_head.safetensors")),
-                        _load_sft(os.path.join(model_path, "projector.safetensors")), device)
+        self._init_from(**load_model_dir(model_path), device=device, tp=tp)
 
     @classmethod
     def from_components(cls, *, tokenizer, llm_cfg, llm_sd, ae_config, ae_sd, head_config, head_sd, proj_sd,
-                        device="cuda"):
+                        device="cuda", tp=None):
         """Same object from in-memory state dicts (tests, synthetic-weight benchmarks)."""
         self = object.__new__(cls)
-        self._init_from(tokenizer, llm_cfg, llm_sd, ae_config, ae_sd, head_config, head_sd, proj_sd, device)
+        self._init_from(tokenizer, llm_cfg, llm_sd, ae_config, ae_sd, head_config, head_sd, proj_sd, device, tp=tp)
         return self
 
-    def _init_from(self, tokenizer, llm_cfg, llm_sd, ae_config, ae_sd, head_config, head_sd, proj_sd, device):
+    def _init_from(self, tokenizer, llm_cfg, llm_sd, ae_config, ae_sd, head_config, head_sd, proj_sd, device, tp=None):
         if not torch.cuda.is_available():
             raise RuntimeError("BitDanceT2IPipeline (bitdance_amd) needs a ROCm GPU; there is no CPU fallback")
         self.device = device
+        self.tp = tp if (tp is not None and tp.size > 1) else None
+        tpr, tps = (self.tp.rank, self.tp.size) if self.tp else (0, 1)
         self.tokenizer = tokenizer
         self.llm_config = SimpleNamespace(**llm_cfg)
         self.hidden_size = llm_cfg["hidden_size"]
-        self.llm_w = LlmWeights.from_state_dict(llm_sd, llm_cfg, device)
+        self.llm_w = LlmWeights.from_state_dict(llm_sd, llm_cfg, device, tp_rank=tpr, tp_size=tps)
         self.ae_config = ae_config
         self.ae = VQModel(**ae_config).eval()
         if ae_sd is not None:
@@ -99,7 +111,7 @@ class BitDanceT2IPipeline:
         self.ae.to(device)
         self.vae_patch_size = 2 ** (len(ae_config["ddconfig"]["ch_mult"]) - 1)
         self.vision_head_config = head_config
-        self.head_w = HeadWeights.from_state_dict(head_sd, device)
+        self.head_w = HeadWeights.from_state_dict(head_sd, device, tp_rank=tpr, tp_size=tps)
         self.parallel_num = head_config["parallel_num"]
         if self.parallel_num not in (16, 64):
             raise NotImplementedError("the native path implements the 64x and 16x models (parallel_num 64 / 16)")
@@ -162,7 +174,7 @@ class BitDanceT2IPipeline:
             torch.cuda.empty_cache()
             self._engines[key] = Engine(self.head_w, self.proj_w, self.llm_w, num_images=num_images,
                                         branches=branches, device=self.device, max_tokens=tokens, max_kv=lmax,
-                                        tune=getattr(self, "tune", None), parallel_num=self.parallel_num)
+                                        tune=getattr(self, "tune", None), parallel_num=self.parallel_num, comm=self.tp)
         return self._engines[key]
 
     def _prompt_ids(self, cond_prompt, uncond_prompt, image_size, cfg_on):
@@ -184,6 +196,11 @@ class BitDanceT2IPipeline:
         cfg_on = guidance_scale > 1.0
         branches = 2 if cfg_on else 1
         h, w = image_size[0] // self.vae_patch_size, image_size[1] // self.vae_patch_size
+        # the reference fails in its pos-embed slice / final rearrange when the token budget and the grid disagree
+        # (t2i_pipeline.py:244,279-281); here the engine's token / position / noise buffers are sized from h*w
+        if max_length != h * w or max_length % P:
+            raise ValueError(f"max_length={max_length} must equal (H/{self.vae_patch_size})*(W/{self.vae_patch_size})={h * w} "
+                             f"and be a multiple of parallel_num={P}")
         cond_ids, uncond_ids = self._prompt_ids(cond_prompt, uncond_prompt, image_size, cfg_on)
         kv_need = max(len(cond_ids), len(uncond_ids or [])) + num_steps * P + P
         eng = self._engine(num_images, branches, h * w, kv_need)
@@ -219,6 +236,9 @@ class BitDanceT2IPipeline:
                 if num_steps > 1:
                     eng.capture(1)
             ev[1].record(st)
+            if self.tp is not None:                        # ranks enter the exchange loop together (in-kernel waits are bounded)
+                st.synchronize()
+                self.tp.barrier()
             for step in range(num_steps):
                 if self.use_graph:
                     eng.launch(0)
@@ -230,6 +250,9 @@ class BitDanceT2IPipeline:
                         eng.projector()
                         eng.llm_step()
             ev[2].record(st)
+            if self.tp is not None:
+                st.synchronize()
+                self.tp.check()                            # raises if a peer never arrived
             tokens = eng.tok_all[:, : h * w].clone()
             if return_tokens:
                 out = tokens

@@ -1,0 +1,232 @@
+"""Tensor parallelism of the BitDance step over the xGMI links of one node.
+
+The reference's multi-GPU mode is replicas (eval/eval_dpg.py:25-29); splitting ONE image's generation over 2/4/8 GPUs is
+this framework's own mode, Megatron-style:
+
+  * column-split (by output features / attention heads): head ``wqkv`` and ``w1`` (the SwiGLU pair (h1_f, h2_f) stays on one
+    rank), LLM ``q/k/v`` (by head; a rank's q heads use exactly its kv heads because nkv % tp == 0) and ``gate/up``;
+  * row-split (by input features): head ``wo`` / ``w2``, LLM ``o_proj`` / ``down_proj``; their fp32 partials are summed
+    across ranks by ONE hand-written exchange kernel per Linear (csrc/bd_comm.hip: push-only two-shot over IPC-mapped peer
+    buffers, bias and the single bf16 rounding applied by the reducing rank, result replicated bit-identically), captured
+    in the AR-step hipGraphs;
+  * replicated: residual streams, LayerNorm / RMSNorm, the adaLN projection (its output feeds every rank's LayerNorm rows;
+    it depends only on (t_i, cond) and is the natural candidate for the side stream), projector, sampler, ``sign``, RNG
+    (same seed => same Philox draws on every rank), the conv decoder;
+  * the KV cache is sharded by kv head.
+
+``TPComm`` wraps one rank's ``bd_comm``.  Bootstrap (handle exchange, barriers, the once-per-image prefill's all-reduce)
+goes through ``torch.distributed`` (RCCL on GPUs, gloo in the single-GPU two-process test); ``BD_TP_COMM=rccl`` also routes
+the per-Linear exchange through ``ncclAllReduce`` of the same fp32 partials (fallback and baseline for the kernel).
+
+The ``shard_*`` functions are pure tensor slicing (CPU-testable): ``sum_r rank_r(x) == unsharded(x)`` is checked in
+tests/test_tp_cpu.py, including the q/k/v thirds and the SwiGLU pairs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+from ._lib import BitDanceHipError, check, lib
+
+__all__ = ["TPComm", "shard_head_state", "shard_llm_state", "shard_rows", "shard_cols"]
+
+
+# ----------------------------------------------------------------------------------------------- slicing
+def shard_rows(w: torch.Tensor, rank: int, size: int, groups: int = 1) -> torch.Tensor:
+    """Rows [rank/size) of each of ``groups`` equal row blocks, concatenated (q|k|v thirds, h1|h2 halves)."""
+    n = w.shape[0] // groups
+    if w.shape[0] % groups or n % size:
+        raise BitDanceHipError(f"cannot split {tuple(w.shape)} rows in {groups} groups over {size} ranks")
+    m = n // size
+    return torch.cat([w[g * n + rank * m: g * n + (rank + 1) * m] for g in range(groups)], dim=0).contiguous()
+
+
+def shard_cols(w: torch.Tensor, rank: int, size: int) -> torch.Tensor:
+    k = w.shape[1]
+    if k % size:
+        raise BitDanceHipError(f"cannot split {tuple(w.shape)} columns over {size} ranks")
+    m = k // size
+    return w[:, rank * m:(rank + 1) * m].contiguous()
+
+
+def shard_head_state(sd: dict, rank: int, size: int, head_dim: int = 128) -> dict:
+    """vision_head.safetensors -> this rank's slices (same key names).  wqkv: q,k,v contiguous thirds
+    (flow_head_parallel_x.py:197), split by attention head; w1: h1,h2 halves (:250); wo / w2: input columns; biases of the
+    row-split Linears stay whole (added once, by the exchange)."""
+    if size == 1:
+        return dict(sd)
+    out = {}
+    D = sd["net.input_proj.weight"].shape[0]
+    if (D // head_dim) % size:
+        raise BitDanceHipError(f"{D // head_dim} attention heads do not divide over {size} ranks")
+    for k, v in sd.items():
+        if ".attn.wqkv." in k:
+            out[k] = shard_rows(v, rank, size, groups=3)
+        elif k.endswith(".w1.weight") or k.endswith(".w1.bias"):
+            out[k] = shard_rows(v, rank, size, groups=2)
+        elif k.endswith(".attn.wo.weight") or k.endswith(".w2.weight"):
+            out[k] = shard_cols(v, rank, size)
+        else:
+            out[k] = v
+    return out
+
+
+def shard_llm_state(sd: dict, cfg: dict, rank: int, size: int) -> dict:
+    """HF Qwen3 checkpoint -> this rank's slices: q/k/v rows by head, o_proj columns by q head, gate/up rows, down columns."""
+    if size == 1:
+        return dict(sd)
+    nh, nkv = cfg["num_attention_heads"], cfg["num_key_value_heads"]
+    if nh % size or nkv % size:
+        raise BitDanceHipError(f"{nh} q heads / {nkv} kv heads do not divide over {size} ranks")
+    out = {}
+    for k, v in sd.items():
+        if k.endswith(("q_proj.weight", "k_proj.weight", "v_proj.weight", "gate_proj.weight", "up_proj.weight")):
+            out[k] = shard_rows(v, rank, size)
+        elif k.endswith(("o_proj.weight", "down_proj.weight")):
+            out[k] = shard_cols(v, rank, size)
+        elif k == "lm_head.weight":
+            continue
+        else:
+            out[k] = v
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- communicator
+class _NcclUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+class TPComm:
+    """One rank's exchange state.  ``max_elems`` = rows * N of the largest exchanged tensor (e.g. 512 * 5120)."""
+
+    def __init__(self, rank: int, size: int, max_elems: int, device=None):
+        self.l = lib()
+        self.rank, self.size = rank, size
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        with torch.cuda.device(self.device):
+            self.h = self.l.bd_comm_create(rank, size, int(max_elems))
+        if not self.h:
+            raise BitDanceHipError(f"bd_comm_create failed: {self.l.bd_last_error().decode()}")
+        self.group = None
+        self.backend = "ipc"
+        self._nccl = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.l.bd_comm_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # -- construction ------------------------------------------------------------------------------------
+    @classmethod
+    def from_process_group(cls, max_elems: int, group=None, device=None, backend: str | None = None) -> "TPComm":
+        """One process per GPU: exchange the IPC handles through ``torch.distributed`` and map every peer."""
+        import torch.distributed as dist
+        rank, size = dist.get_rank(group), dist.get_world_size(group)
+        self = cls(rank, size, max_elems, device)
+        self.group = group
+        backend = backend or os.environ.get("BD_TP_COMM", "ipc")
+        if size > 1:
+            buf = C.create_string_buffer(128)
+            check(self.l.bd_comm_ipc_handles(self.h, buf), "bd_comm_ipc_handles")
+            handles = [None] * size
+            dist.all_gather_object(handles, bytes(buf.raw), group=group)
+            for p in range(size):
+                if p != rank:
+                    check(self.l.bd_comm_open_peer(self.h, p, C.create_string_buffer(handles[p], 128)), "bd_comm_open_peer")
+            if backend == "rccl":
+                self._init_rccl(dist, group)
+            dist.barrier(group=group)
+        self.backend = backend if size > 1 else "none"
+        return self
+
+    @classmethod
+    def in_process(cls, size: int, max_elems: int, device=None) -> list:
+        """``size`` ranks as contexts of THIS process on one device, linked by plain pointers: the exchange protocol can then
+        be exercised on a single GPU with one stream per rank (tests/test_gpu_tp.py)."""
+        comms = [cls(r, size, max_elems, device) for r in range(size)]
+        for a in comms:
+            for b in comms:
+                if a is not b:
+                    check(a.l.bd_comm_set_peer_ptrs(a.h, b.rank, a.l.bd_comm_local_data(b.h), a.l.bd_comm_local_flags(b.h)))
+        return comms
+
+    def _init_rccl(self, dist, group) -> None:
+        """ncclCommInitRank on the librccl torch itself uses; the per-Linear exchange then is ncclAllReduce(fp32 partials)."""
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        n = C.CDLL(path)
+        uid = _NcclUniqueId()
+        if self.rank == 0:
+            n.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
+            if n.ncclGetUniqueId(C.byref(uid)) != 0:
+                raise BitDanceHipError("ncclGetUniqueId failed")
+        box = [bytes(uid.internal)] if self.rank == 0 else [None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        C.memmove(C.byref(uid), box[0], 128)
+        comm = C.c_void_p()
+        n.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+        with torch.cuda.device(self.device):
+            if n.ncclCommInitRank(C.byref(comm), self.size, uid, self.rank) != 0:
+                raise BitDanceHipError("ncclCommInitRank failed")
+        fn = C.cast(n.ncclAllReduce, C.c_void_p).value
+        check(self.l.bd_comm_set_rccl(self.h, comm, fn), "bd_comm_set_rccl")
+        self._nccl = (n, comm)
+
+    # -- host-side collectives for the once-per-image prefill -------------------------------------------------
+    def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place sum over the ranks on the current stream (RCCL); through the host when the group is gloo."""
+        if self.size > 1:
+            import torch.distributed as dist
+            if dist.get_backend(self.group) == "gloo" and t.is_cuda:
+                h = t.float().cpu()
+                dist.all_reduce(h, group=self.group)
+                t.copy_(h.to(t.dtype))
+            else:
+                dist.all_reduce(t, group=self.group)
+        return t
+
+    def barrier(self) -> None:
+        if self.size > 1 and _dist_ready():
+            import torch.distributed as dist
+            dist.barrier(group=self.group)
+
+    # -- status -------------------------------------------------------------------------------------------------
+    def check(self) -> None:
+        """After a stream sync: raise if any in-kernel wait ran out of its budget."""
+        e = self.l.bd_comm_error(self.h)
+        if e != 0:
+            peers = [p for p in range(self.size) if e & (1 << p)] if e > 0 else "?"
+            raise BitDanceHipError(f"tensor-parallel exchange timed out on rank {self.rank} waiting for peers {peers}")
+
+    def exchanges(self) -> int:
+        return int(self.l.bd_comm_exchanges(self.h))
+
+    def set_timeout(self, seconds: float) -> None:
+        check(self.l.bd_comm_set_timeout(self.h, float(seconds)))
+
+    def allreduce(self, part: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+        """Standalone exchange of one fp32 partial [rows, N] (tests / micro-benchmarks) on the current stream: returns this
+        rank's copy of bf16(sum over ranks + bias)."""
+        rows, N = part.shape
+        out, is32 = C.c_void_p(), C.c_int()
+        st = torch.cuda.current_stream().cuda_stream
+        check(self.l.bd_comm_allreduce(self.h, part.data_ptr(), bias.data_ptr() if bias is not None else None, rows, N,
+                                       C.byref(out), C.byref(is32), st), "bd_comm_allreduce")
+        if is32.value:                                   # RCCL mode: fp32 sums; bias + rounding are the consumer's
+            t = torch.empty(rows, N, dtype=torch.float32, device=part.device)
+            check(self.l.bd_comm_copy_out(self.h, t.data_ptr(), t.numel() * 4, 0, st), "bd_comm_copy_out")
+            if bias is not None:
+                t = t + bias.float()
+            return t.to(torch.bfloat16)
+        t = torch.empty(rows, N, dtype=torch.bfloat16, device=part.device)
+        check(self.l.bd_comm_copy_out(self.h, t.data_ptr(), t.numel() * 2, 1, st), "bd_comm_copy_out")
+        return t
+
+
+def _dist_ready() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()

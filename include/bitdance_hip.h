@@ -15,6 +15,7 @@ extern "C" {
 #endif
 
 typedef struct bd_ctx bd_ctx;
+typedef struct bd_comm bd_comm;      /* tensor-parallel exchange state of one rank (below) */
 
 int bd_version(void);
 const char* bd_last_error(void);
@@ -38,16 +39,24 @@ int bd_gemm_partial(const void* a_frag, int row_blocks, const void* w_packed, in
  * under autocast.  scratch: [splitk][rows][N] fp32; counters: one int per output tile, zero on entry, zero on exit. */
 int bd_gemm_bf16(const void* a_frag, int row_blocks, const void* w_packed, const void* bias_bf16, int N, int K, int splitk,
                  int nwaves, float* scratch, int* counters, void* out_bf16, void* stream);
+/* The same with a finished fp32 result and no bias / rounding: one tensor-parallel rank's partial of a row-split Linear
+ * (the reference has no tensor parallelism; this is the Megatron-style split SURVEY.md 8e prescribes for wo / w2 / o_proj /
+ * down_proj).  nwaves may carry + 256 for the 2-panels x 2-K-parts workgroup shape (bd_gemm.hip). */
+int bd_gemm_f32(const void* a_frag, int row_blocks, const void* w_packed, int N, int K, int splitk, int nwaves, float* scratch,
+                int* counters, float* out_f32, void* stream);
 /* Linear -> chunk(2) -> silu(h1)*h2 (flow_head:250-251) / down_proj input act_fn(gate)*up (HF:82) */
 int bd_gemm_swiglu(const void* a_frag, int row_blocks, const void* w_packed_pairs, const void* bias_packed, int N2, int K,
                    int nwaves, void* act_frag, void* stream);
 
-/* ---- context: named ints / floats / device pointers, then finalize.  Keys are listed in DESIGN.md. */
+/* ---- context: named ints / floats / device pointers, then finalize.  Keys are listed in DESIGN.md; an unknown key is an
+ *      error (-1, text in bd_last_error()), never a silent default. */
 bd_ctx* bd_ctx_create(void);
 void bd_ctx_destroy(bd_ctx* c);
 int bd_ctx_set_int(bd_ctx* c, const char* key, long long v);
 int bd_ctx_set_float(bd_ctx* c, const char* key, double v);
 int bd_ctx_set_ptr(bd_ctx* c, const char* key, const void* device_ptr);
+int bd_ctx_set_comm(bd_ctx* c, bd_comm* comm);        /* before finalize: this context is rank comm.rank of comm.size;
+                                                         weights handed over are this rank's slices (engine.py) */
 int bd_ctx_finalize(bd_ctx* c);                       /* validates dims, plans the workspaces */
 int bd_ctx_ws_count(bd_ctx* c);                       /* workspaces the caller must allocate (zero-filled) ... */
 const char* bd_ctx_ws_name(bd_ctx* c, int i);         /* ... and hand back with bd_ctx_set_ptr(name, ptr) */
@@ -73,6 +82,30 @@ int bd_llm_step(bd_ctx* c, void* stream);
 int bd_graph_capture(bd_ctx* c, int phase, void* stream);
 int bd_graph_launch(bd_ctx* c, int phase, void* stream);
 int bd_step_reset(bd_ctx* c, const int* kv_len, int nseq, void* stream);   /* step = 0, kv_len[] after prefill */
+
+/* ---- tensor parallelism over xGMI (no counterpart in the reference, whose multi-GPU mode is replicas,
+ *      eval/eval_dpg.py:25-29).  One bd_comm per process/GPU.  bd_comm_create allocates (once, not on the hot path) the
+ *      exported staging/result buffer for exchanges of up to max_elems = rows*N elements and an uncached flag block;
+ *      handles travel through the host's process group (128 bytes per rank); peers are mapped with bd_comm_open_peer.
+ *      The exchange itself -- all-reduce of the ranks' fp32 partials [rows][N], + bias, one rounding to bf16, result
+ *      replicated bit-identically on every rank -- is one kernel launch inside bd_head_eval / bd_llm_step (captured in the
+ *      step graphs), or standalone through bd_comm_allreduce.  bd_comm_set_rccl switches the exchange to ncclAllReduce of
+ *      the same fp32 partials (host passes the RCCL communicator and the address of ncclAllReduce): fallback and baseline. */
+bd_comm* bd_comm_create(int rank, int size, long long max_elems);
+void bd_comm_destroy(bd_comm* c);
+int bd_comm_ipc_handles(bd_comm* c, void* out128);                   /* 2 x hipIpcMemHandle_t: data, flags */
+int bd_comm_open_peer(bd_comm* c, int peer, const void* handles128);
+int bd_comm_set_peer_ptrs(bd_comm* c, int peer, void* data, void* flags);   /* peers inside this process (protocol tests) */
+void* bd_comm_local_data(bd_comm* c);
+void* bd_comm_local_flags(bd_comm* c);
+int bd_comm_set_rccl(bd_comm* c, void* nccl_comm, void* nccl_allreduce_fn);
+int bd_comm_set_timeout(bd_comm* c, double seconds);                 /* budget of every in-kernel wait (default 20 s) */
+int bd_comm_error(bd_comm* c);                                       /* after a sync: bit p set = waiting for peer p timed out */
+long long bd_comm_exchanges(bd_comm* c);                             /* exchange launches issued so far (reporting) */
+int bd_comm_allreduce(bd_comm* c, const float* part, const void* bias_bf16, int rows, int N, void** out_ptr, int* out_is_fp32,
+                      void* stream);
+
+int bd_comm_copy_out(bd_comm* c, void* dst, long long bytes, int from_result, void* stream);   /* read a standalone exchange back */
 
 /* ---- GFQ bit <-> index math of the ImageNet tokenizer (imagenet_gen/src/gfq.py:152-160,217-239): integer, bit exact.
  *      z/codes: [ntok][ncodebooks*bits] fp32 channels-last; idx: [ntok][ncodebooks] int32 (LSB = first channel). */

@@ -1,6 +1,11 @@
 import os
 import sys
 
+# tests/test_gpu_tp.py runs up to 4 tensor-parallel "ranks" as streams of ONE process whose kernels wait for each other:
+# every such stream needs its own hardware queue (the HIP runtime multiplexes streams onto 4 by default; 32 = one per stream of torch's pool).  Read at HIP
+# initialisation, so it has to be set before the first device call of the test session.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

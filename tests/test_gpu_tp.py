@@ -1,0 +1,312 @@
+"""Tensor-parallel path on ONE MI355X (the driver's GPU box has a single GPU):
+
+  * the exchange protocol itself (csrc/bd_comm.hip) with the ranks as contexts of this process, one HIP stream per rank,
+    peers linked by plain pointers: push / flag / epoch logic, bit-identical replicated results, exact value
+    (fp32 sum in rank order + bias, one bf16 rounding), replay over many epochs;
+  * the sharded engine: every rank packs its slices (tp.shard_*), runs the real step kernels on its own stream and meets
+    the others in the exchange after wo / w2 / o_proj / down_proj: replicated outputs bit-identical across ranks, equal
+    to the unsharded engine up to fp32 summation order, and inside the per-operator bounds against the CPU oracle;
+  * the same through hipIpc handles between TWO PROCESSES sharing the GPU (gloo bootstrap): the IPC plumbing of the real
+    multi-GPU launch, whole tiny pipeline.
+What this cannot show is xGMI itself (remote-memory ordering across links); bd_comm.hip uses system-scope accesses and
+bounded waits throughout and bench.py cross-checks token checksums between ranks on the real node."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda"
+
+from oracle import diff_head, qwen3                                       # noqa: E402
+from oracle import tiny_models as tm                                      # noqa: E402
+from oracle.numerics import Policy                                        # noqa: E402
+from oracle.true_dims import device_seeded_state                          # noqa: E402
+
+
+def _comms(tp, max_elems):
+    from bitdance_amd.tp import TPComm
+    comms = TPComm.in_process(tp, max_elems, DEV)
+    for c in comms:
+        c.set_timeout(8.0)                     # a protocol bug must fail the test in seconds, not hang the box
+    return comms
+
+
+@pytest.mark.parametrize("tp,rows,N", [(2, 128, 5120), (4, 128, 5120), (4, 32, 768), (2, 256, 5120), (4, 50, 24), (3, 64, 136)])
+def test_exchange_in_process(tp, rows, N):
+    comms = _comms(tp, max(rows * N, 4096))
+    streams = [torch.cuda.Stream() for _ in range(tp)]
+    g = torch.Generator(device=DEV).manual_seed(tp * 1000 + rows)
+    parts = [torch.randn(rows, N, device=DEV, generator=g) for _ in range(tp)]
+    bias = (torch.randn(N, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+    torch.cuda.synchronize()
+    for rep in range(4):                                   # epochs advance, buffers are re-used
+        cur = [p * float(rep + 1) for p in parts]
+        torch.cuda.synchronize()
+        outs = []
+        for r in range(tp):
+            with torch.cuda.stream(streams[r]):
+                outs.append(comms[r].allreduce(cur[r], bias if rep % 2 == 0 else None))
+        torch.cuda.synchronize()
+        for c in comms:
+            c.check()
+        acc = torch.zeros(rows, N, device=DEV)
+        for r in range(tp):
+            acc = acc + cur[r]                             # the kernel's order: rank 0, 1, ...
+        if rep % 2 == 0:
+            acc = acc + bias.float()
+        want = acc.to(torch.bfloat16)
+        for r in range(tp):
+            assert torch.equal(outs[r], want), (rep, r, (outs[r].float() - want.float()).abs().max())
+
+
+@pytest.mark.parametrize("M,N,K,S,code", [
+    (128, 5120, 5120, 3, 4 + 32 + 256), (128, 15360, 5120, 1, 4 + 32 + 256), (128, 5120, 2560, 3, 4 + 32 + 256),
+    (128, 5120, 640, 2, 4 + 32 + 256), (128, 5120, 960, 3, 2 + 32), (32, 5120, 5120, 3, 4 + 32 + 256),
+    (64, 1024, 512, 2, 4 + 32 + 256), (128, 5120, 17408, 3, 4 + 32 + 256), (128, 256, 256, 1, 4 + 32), (128, 512, 384, 3, 8 + 32)])
+def test_gemm_f32_partial_of_a_rank(M, N, K, S, code):
+    """The row-split Linear of one rank: finished fp32 K-sum, grid slices reduced inside the launch, no bias / rounding;
+    code + 256 = 2 panels x 2 K-parts per workgroup."""
+    from bitdance_amd import engine as E
+    from bitdance_amd._lib import check, lib
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)
+    rb = E.row_blocks(M)
+    xf = torch.zeros(rb * 32 * K, dtype=torch.bfloat16, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib().bd_rows_to_frag(xf.data_ptr(), x.data_ptr(), 1, M, K, rb, st))
+    wp = E.pack_linear([w], DEV)
+    scratch = torch.zeros(S, rb * 32, N, device=DEV)
+    cnt = torch.zeros(16384, dtype=torch.int32, device=DEV)
+    out = torch.full((rb * 32, N), float("nan"), device=DEV)
+    for _ in range(2):                                     # counters re-arm
+        check(lib().bd_gemm_f32(xf.data_ptr(), rb, wp.data_ptr(), N, K, S, code, scratch.data_ptr(), cnt.data_ptr(),
+                                out.data_ptr(), st), "bd_gemm_f32")
+    torch.cuda.synchronize()
+    ref = x.to(torch.bfloat16).double() @ w.double().t()
+    err = (out[:M].double() - ref).abs().max().item()
+    assert err <= 2e-5 * K ** 0.5 + 1e-5, err
+    assert int(cnt.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("M,N,K,S", [(128, 15360, 5120, 1), (128, 5120, 5120, 3), (128, 7168, 5120, 2), (64, 512, 256, 1), (32, 5120, 7680, 3)])
+def test_gemm_kw2_bf16_and_swiglu(M, N, K, S):
+    """2 panels x 2 K-parts per workgroup through the bf16(+bias) epilogue (in-launch reduced when S > 1) and the fused
+    SwiGLU epilogue: same values as the one-wave-per-panel kernel (tests/test_gpu_parity.py bounds)."""
+    from bitdance_amd import engine as E
+    from bitdance_amd._lib import check, lib
+    code = 4 + 32 + 256
+    g = torch.Generator(device=DEV).manual_seed(N + K + S)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = (torch.randn(N, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+    rb = E.row_blocks(M)
+    st = torch.cuda.current_stream().cuda_stream
+    xf = torch.zeros(rb * 32 * K, dtype=torch.bfloat16, device=DEV)
+    check(lib().bd_rows_to_frag(xf.data_ptr(), x.data_ptr(), 1, M, K, rb, st))
+    wp = E.pack_linear([w], DEV)
+    scratch = torch.zeros(S, rb * 32, N, device=DEV)
+    cnt = torch.zeros(16384, dtype=torch.int32, device=DEV)
+    out = torch.zeros(rb * 32, N, dtype=torch.bfloat16, device=DEV)
+    check(lib().bd_gemm_bf16(xf.data_ptr(), rb, wp.data_ptr(), b.data_ptr(), N, K, S, code, scratch.data_ptr(), cnt.data_ptr(),
+                             out.data_ptr(), st), "bd_gemm_bf16")
+    ref = (x.to(torch.bfloat16).float() @ w.float().t() + b.float())
+    d = (out[:M].float() - ref).abs()
+    assert d.max() <= 0.04 * max(1.0, ref.abs().max().item()), d.max()          # one bf16 rounding
+    assert (out[:M] != ref.to(torch.bfloat16)).float().mean() <= 0.02           # <= 1 ulp flips from summation order
+    if S == 1 and N % 64 == 0:
+        F_ = N // 2
+        wp2 = E.pack_swiglu(w[:F_], w[F_:], DEV)
+        bp = E.pack_swiglu_bias(b[:F_], b[F_:], DEV)
+        act = torch.zeros(rb * 32 * F_, dtype=torch.bfloat16, device=DEV)
+        check(lib().bd_gemm_swiglu(xf.data_ptr(), rb, wp2.data_ptr(), bp.data_ptr(), N, K, code, act.data_ptr(), st))
+        h = ref.to(torch.bfloat16)
+        want = torch.nn.functional.silu(h[:, :F_]) * h[:, F_:]
+        a = act.view(F_ // 16, rb, 2, 32, 8).permute(1, 3, 0, 2, 4).reshape(rb * 32, F_)[:M]
+        dd = (a.float() - want.float()).abs()
+        assert (dd > 0).float().mean() <= 0.02 and dd.max() <= 0.07, ((dd > 0).float().mean(), dd.max())
+
+
+# ----------------------------------------------------------------------------------------------- sharded engines
+HEAD8 = dict(ch_target=32, ch_cond=1024, ch_latent=1024, depth_latent=2, depth_adanln=1)     # 8 heads of 128, H = 1536
+
+
+def _head_run(eng, z, x, n_steps=3, eval_index=1):
+    B, P, C = x.shape
+    eng.set_schedule(n_steps, 3.0, 1)
+    eng.load_noise(torch.zeros(1, n_steps + 1, B, P, C))
+    eng.reset([0] * min(eng.branches * B, 16))
+    eng.set_int("rt.dump_xhat", 1)
+    eng.set_cond(z.to(DEV))
+    eng.view("head.xt", torch.float32, (B * P, C)).copy_(x.reshape(B * P, C).to(DEV))
+    eng.head_cond()
+    eng.head_eval(eval_index)
+
+
+@pytest.mark.parametrize("tp,P", [(2, 64), (4, 64), (4, 16)])
+def test_head_eval_tensor_parallel(tp, P):
+    from bitdance_amd import engine as E
+    sd_dev = device_seeded_state(tm.head_shapes(HEAD8), 301, DEV)
+    sd = {k: v.cpu() for k, v in sd_dev.items()}
+    B, br, C = 1, 2, 32
+    g = torch.Generator().manual_seed(302)
+    z = torch.randn(br * B, P, 1024, generator=g)
+    x = torch.randn(B, P, C, generator=g)
+    # unsharded engine
+    e1 = E.Engine(E.HeadWeights.from_state_dict(sd_dev, DEV), None, None, num_images=B, branches=br, device=DEV, max_tokens=P,
+                  parallel_num=P)
+    _head_run(e1, z, x)
+    torch.cuda.synchronize()
+    M = br * B * P
+    x1 = e1.view("head.xhat", torch.float32, (e1.Mpad, C))[:M].clone()
+    # tp ranks, one stream each
+    comms = _comms(tp, e1.Mpad * 1024)
+    streams = [torch.cuda.Stream() for _ in range(tp)]
+    engs = []
+    for r in range(tp):
+        hw = E.HeadWeights.from_state_dict(sd_dev, DEV, tp_rank=r, tp_size=tp)
+        engs.append(E.Engine(hw, None, None, num_images=B, branches=br, device=DEV, max_tokens=P, parallel_num=P, comm=comms[r]))
+    torch.cuda.synchronize()
+    for r in range(tp):
+        with torch.cuda.stream(streams[r]):
+            _head_run(engs[r], z, x)
+    torch.cuda.synchronize()
+    for c in comms:
+        c.check()
+    xs = [e.view("head.xhat", torch.float32, (e.Mpad, C))[:M].clone() for e in engs]
+    for r in range(1, tp):
+        assert torch.equal(xs[r], xs[0]), f"rank {r} diverged from rank 0"        # replicated state stays bit-identical
+    d1 = (xs[0] - x1).abs()
+    assert d1.max() <= 4e-2 and d1.mean() <= 4e-3, (d1.max(), d1.mean())           # vs unsharded: summation order only
+    t_i = float(e1._sc[1, 0])
+    ref = diff_head.net_forward(sd, torch.cat([x] * br), torch.full((br * B,), t_i), z, Policy("autocast")).float().view(M, C)
+    err = (xs[0].cpu() - ref).abs()
+    assert err.max() <= 5e-2 and err.mean() <= 6e-3, (err.max(), err.mean())       # the tiny-test bounds, vs the oracle
+    assert comms[0].exchanges() == 2 * HEAD8["depth_latent"]                       # one exchange per wo / w2
+
+
+def test_llm_step_tensor_parallel():
+    """tiny Qwen3 (4 q heads / 2 kv heads, 2 layers) on 2 ranks: kv cache sharded by kv head, o_proj / down_proj exchanged."""
+    from bitdance_amd import engine as E
+    tp, P = 2, 64
+    c = tm.TINY_LLM
+    sd = {k: v.to(torch.bfloat16) for k, v in tm.seeded_state(tm.llm_shapes(c), seed=22).items()}
+    L, nkv, hd, D = c["num_hidden_layers"], c["num_key_value_heads"], c["head_dim"], c["hidden_size"]
+    past = (75, 40)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, P, D, generator=g)
+    caches = [[[torch.randn(1, nkv, Lp, hd, generator=g).to(torch.bfloat16), torch.randn(1, nkv, Lp, hd, generator=g).to(torch.bfloat16)]
+               for _ in range(L)] for Lp in past]
+
+    def run(eng, r, size):
+        n = nkv // size
+        kc = eng.ws["llm.k_cache"].view(torch.bfloat16).view(L, 2, n, eng.Lmax, hd)
+        vc = eng.ws["llm.vt_cache"].view(torch.bfloat16).view(L, 2, n, hd, eng.Lmax)
+        for b, Lp in enumerate(past):
+            for li in range(L):
+                k, v = caches[b][li]
+                kc[li, b, :, :Lp] = k[0, r * n:(r + 1) * n].to(DEV)
+                vc[li, b, :, :, :Lp] = v[0, r * n:(r + 1) * n].transpose(1, 2).to(DEV)
+        eng.set_int("rt.emit_cond", 0)
+        eng.reset(list(past))
+        eng.residual()[:2 * P].copy_(x.reshape(2 * P, D).to(DEV))
+        eng.llm_step()
+
+    e1 = E.Engine(None, None, E.LlmWeights.from_state_dict(sd, c, DEV, keep_for_prefill=False), num_images=2, branches=1,
+                  device=DEV, max_tokens=P, max_kv=256)
+    run(e1, 0, 1)
+    torch.cuda.synchronize()
+    h1 = e1.hidden().clone()
+    comms = _comms(tp, e1.Mpad * D)
+    streams = [torch.cuda.Stream() for _ in range(tp)]
+    engs = [E.Engine(None, None, E.LlmWeights.from_state_dict(sd, c, DEV, keep_for_prefill=False, tp_rank=r, tp_size=tp),
+                     num_images=2, branches=1, device=DEV, max_tokens=P, max_kv=256, comm=comms[r]) for r in range(tp)]
+    torch.cuda.synchronize()
+    for r in range(tp):
+        with torch.cuda.stream(streams[r]):
+            run(engs[r], r, tp)
+    torch.cuda.synchronize()
+    for cm in comms:
+        cm.check()
+    hs = [e.hidden().clone() for e in engs]
+    assert torch.equal(hs[0], hs[1])
+    d = (hs[0] - h1).abs()
+    assert d.max() <= 0.08 and d.mean() <= 6e-3, (d.max(), d.mean())
+    pol = Policy("autocast")
+    refs = []
+    for b, Lp in enumerate(past):
+        o, _ = qwen3.model_forward(sd, c, x[b:b + 1], [[k.clone(), v.clone()] for k, v in caches[b]],
+                                   torch.ones(1, 1, P, Lp + P, dtype=torch.bool), pol)
+        refs.append(o.float())
+    e = (hs[0].cpu().view(2, P, D) - torch.cat(refs)).abs()
+    assert e.max() <= 0.12 and e.mean() <= 1e-2, (e.max(), e.mean())
+    assert comms[0].exchanges() == 2 * L
+
+
+# ----------------------------------------------------------------------------------------------- two processes, one GPU
+def _proc(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from bitdance_amd.autoencoder import VQModel
+        from bitdance_amd.t2i_pipeline import BitDanceT2IPipeline
+        from bitdance_amd.tp import TPComm
+        comm = TPComm.from_process_group(256 * 256, device="cuda:0", backend="ipc")
+        comm.set_timeout(15.0)
+        llm_sd = {k: v.to(torch.bfloat16) for k, v in tm.seeded_state(tm.llm_shapes(tm.TINY_LLM), seed=22).items()}
+        ae_shapes = {k: tuple(v.shape) for k, v in VQModel(**tm.TINY_AE).state_dict().items()}
+        kw = dict(tokenizer=tm.FakeTokenizer(), llm_cfg=tm.TINY_LLM, llm_sd=llm_sd, ae_config=tm.TINY_AE,
+                  ae_sd=tm.seeded_state(ae_shapes, seed=44, gain=1.4), head_config=dict(tm.TINY_HEAD),
+                  head_sd=tm.seeded_state(tm.head_shapes(tm.TINY_HEAD), seed=11),
+                  proj_sd=tm.seeded_state(tm.proj_shapes(32, 256), seed=33), device="cuda:0")
+        pipe = BitDanceT2IPipeline.from_components(**kw, tp=comm)
+        n, steps = 3, 2
+        noise = torch.randn(steps, n + 1, 1, 64, 32, generator=torch.Generator().manual_seed(7))
+        args = dict(guidance_scale=3.0, num_sampling_steps=n, max_length=128, num_images=1, image_size=[256, 128], noise=noise)
+        tok = pipe.gen_image("a red fox", "<|", return_tokens=True, **args).cpu()
+        tok2 = pipe.gen_image("a red fox", "<|", return_tokens=True, **args).cpu()     # graph replay, epochs keep counting
+        img = pipe.gen_image("a red fox", "<|", **args).cpu()
+        single = None
+        if rank == 0:
+            single = BitDanceT2IPipeline.from_components(**kw).gen_image("a red fox", "<|", return_tokens=True, **args).cpu()
+        dist.barrier()
+        q.put((rank, tok.numpy(), bool(torch.equal(tok, tok2)), tuple(img.shape), bool(torch.isfinite(img).all()),
+               None if single is None else single.numpy(), comm.exchanges()))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:                                  # surface the failure instead of a silent timeout
+        import traceback
+        q.put((rank, "error", traceback.format_exc(), None, None, None, None))
+        raise
+
+
+def test_two_process_ipc_pipeline():
+    import numpy as np
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 2000
+    procs = [ctx.Process(target=_proc, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+    for r in res:
+        assert not (isinstance(r[1], str) and r[1] == "error"), r[2]
+    (r0, t0, same0, shp0, fin0, single, nx0), (r1, t1, same1, shp1, fin1, _, nx1) = res
+    assert np.array_equal(t0, t1)                                     # every rank holds the same tokens
+    assert same0 and same1                                            # replay is deterministic
+    assert shp0 == (1, 3, 256, 128) and fin0 and fin1
+    assert set(np.unique(t0).tolist()) <= {-1.0, 0.0, 1.0}
+    agree0 = float((t0[:, :64] == single[:, :64]).mean())
+    assert agree0 >= 0.93, agree0                                     # first patch vs the single-GPU run (summation order only)
+    assert nx0 == nx1 and nx0 > 0
