@@ -1,20 +1,29 @@
 #!/usr/bin/env python
-"""Benchmark: images/sec at 1024 px, BitDance-14B-64x shapes, on N MI355X (BASELINE.json metric).
+"""Benchmark of the BitDance generation hot path on N MI355X (BASELINE.json metric: images/sec @1024px BitDance-14B-64x).
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 A "step" is one whole pass of the hot path: one ``gen_image`` call (prefill, 64 AR steps x [51 diffusion-head
 evaluations + sign + projector + cond/uncond LLM forward], AE decode) for ``--num-images`` images on synthetic
-(random-weight, true-shape) models with inputs resident in HBM.  N > 1 runs one replica per GPU over disjoint
-images (what the reference's own multi-GPU evaluation does, eval/eval_dpg.py:25-29): weak scaling, no data-path
-collective; value = images of all ranks / max-over-ranks time.
+(random-weight, true-shape) models with inputs resident in HBM.
+
+N > 1, ``--parallel tp`` (default, the north star's mode): ONE job, the 14B model tensor-parallel over the N GPUs
+(bitdance_amd/tp.py: column/row-split Linears, kv cache by head, one hand-written xGMI exchange per row-split Linear inside
+the step graphs); value = images / max-over-ranks time, "scaling": "strong".  ``--parallel replicas``: one full replica per
+GPU over disjoint images (what the reference's own multi-GPU evaluation does, eval/eval_dpg.py:25-29): "scaling": "weak".
+
+``--workload`` selects the other BASELINE configs: ``14b-16x-512`` (config 3: BitDance-14B-16x, 512 px) and
+``imagenet-b16x`` (config 2: class-conditional BitDance-B-16x, 256 px, batch 384, 100 sampling steps, linear CFG 6.1,
+imagenet_gen/sample_ddp_parallel.py:199-214); each prints its own metric name -- only the default is the headline.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  "roofline"     : achieved HBM GB/s of the dominant kernel family (the weight-streaming GEMM), measured live
-                   with HIP events on the pipeline's stream, vs the 8 TB/s HBM3E peak
-  "cpu_baseline" : the CPU oracle (a port of the reference algorithm) timed on this box's host cores on a bounded
-                   sample (one head evaluation + one LLM layer step at true shapes), extrapolated to one image
+  "roofline"     : the dominant kernel family (the weight-streaming / MFMA GEMM), measured live with HIP events on the
+                   pipeline's stream: achieved HBM GB/s vs the 8 TB/s peak (M <= 256 rows) or TFLOP/s vs 2.5 PFLOP/s
+  "cpu_baseline" : the CPU oracle (a port of the reference algorithm) timed on this box's host cores on a bounded sample at
+                   TRUE dimensions (oracle/true_dims.py: a 2-block head evaluation with the full adaLN projection + one
+                   Qwen3-14B layer step), extrapolated to one image -- and, from the same sample, "parity": the max / mean
+                   error of the HIP path against that oracle output on identical inputs
 """
 from __future__ import annotations
 
@@ -30,6 +39,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_PEAK_TFS = 2500.0         # dense bf16 MFMA peak
+
+WORKLOADS = {
+    # name: (pipeline size, height, width, metric)
+    "14b-64x-1024": ("14b-64x", 1024, 1024, "images/sec @1024px BitDance-14B-64x"),
+    "14b-16x-512": ("14b-16x", 512, 512, "images/sec @512px BitDance-14B-16x"),
+    "tiny": ("tiny", 256, 256, "images/sec (tiny smoke config)"),
+    "imagenet-b16x": (None, 256, 256, "images/sec @256px ImageNet BitDance-B-16x"),
+}
 
 
 def parse():
@@ -37,175 +55,218 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", default="14b-64x", choices=["14b-64x", "tiny"])
-    ap.add_argument("--height", type=int, default=1024)
-    ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--num-images", type=int, default=1)
-    ap.add_argument("--sampling-steps", type=int, default=50)
-    ap.add_argument("--guidance", type=float, default=7.5)
+    ap.add_argument("--workload", default=None, choices=list(WORKLOADS))
+    ap.add_argument("--size", default=None, choices=["14b-64x", "tiny"], help="(old spelling of --workload)")
+    ap.add_argument("--parallel", default="tp", choices=["tp", "replicas"], help="N > 1: tensor parallel (one job) or replicas")
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--num-images", type=int, default=None, help="images per gen_image call (imagenet: classes per sample call, default 384)")
+    ap.add_argument("--sampling-steps", type=int, default=None)
+    ap.add_argument("--guidance", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--tune", default="", help="comma list name.S=4,name.nw=2 overriding GEMM launch configs")
-    return ap.parse_args()
+    ap.add_argument("--no-decode", action="store_true", help="imagenet: skip the conv decoder (MIOpen) in the timed pass")
+    ap.add_argument("--tune", default="", help="comma list name.S=4,name.nw=2,kw2=0 overriding GEMM launch configs")
+    a = ap.parse_args()
+    if a.workload is None:
+        a.workload = "tiny" if a.size == "tiny" else "14b-64x-1024"
+    return a
 
 
 # ---------------------------------------------------------------------------------------------------------
-def gemm_roofline(pipe) -> dict:
-    """In-situ roofline of the dominant kernel family (the weight-streaming GEMM, bd_gemm.hip): one extra AR step is
-    run eagerly on the pipeline's stream with every GEMM launch bracketed by HIP events (bd_prof_*), so weights are
-    NOT cache-resident between launches.  achieved = algorithmic weight bytes (N*K*2 per launch) / event time."""
-    eng = next(iter(pipe._engines.values()))
-    st = pipe._stream
-    with torch.cuda.stream(st):
-        prof = eng.profile_gemms(lambda: (eng.head_sample(), eng.projector(), eng.llm_step()))
+def gemm_roofline(eng, run, rows: int) -> dict:
+    """In-situ roofline of the dominant kernel family (the GEMMs of bd_gemm.hip): ``run`` (one AR step's worth of eager
+    launches) is executed with every GEMM launch bracketed by HIP events on the launch stream (bd_prof_*), so weights are
+    NOT cache-resident between launches.  rows <= 256: HBM weight streaming bounds the launch (arithmetic intensity = rows
+    FLOP/B, under the ~310 FLOP/B ridge): achieved = algorithmic weight bytes (N*K*2 per launch) / event time.  More rows
+    (several images / the imagenet batch): the MFMA roofline bounds it: achieved = 2*rows*N*K / event time."""
+    prof = eng.profile_gemms(run)
     tot_b = sum(r["bytes"] for r in prof.values())
     tot_ms = sum(r["ms"] for r in prof.values())
     n_launch = sum(r["count"] for r in prof.values())
-    ach = tot_b / tot_ms / 1e6
     per = []
     for name, r in sorted(prof.items()):
         S, nw = eng.gemm_config(name)
         per.append({"name": name, "launches": r["count"], "avg_us": round(r["ms"] / r["count"] * 1e3, 2),
-                    "GBs": round(r["bytes"] / r["ms"] / 1e6, 1), "splitk": S, "nwaves": nw & 15, "ring": nw >> 4})
-    # HBM bytes per launch from the PMC pass (rocprofv3 --pmc FETCH_SIZE in its own run, x2 gfx950 correction:
-    # tools/pmc_gemm_traffic.py -> profiles/r01_pmc_gemm_traffic.json), weighted by this step's launch mix; only
-    # valid for the shapes / launch configs that pass measured, else null
+                    "GBs": round(r["bytes"] / r["ms"] / 1e6, 1), "splitk": S, "nwaves": nw & 15, "ring": (nw >> 4) & 15,
+                    "kparts": ((nw >> 8) & 3) + 1})
+    common = {"kernel": "gemm_kernel<NP,KW,MB,EPI,R,RED> / gemm_wide_kernel (bd_gemm.hip): every GEMM launch of one AR step, in situ",
+              "launches": n_launch, "avg_launch_us": round(tot_ms / n_launch * 1e3, 2), "per_gemm": per}
+    if rows > 256:
+        ach = tot_b * rows / tot_ms / 1e9                      # 2*rows*N*K flop = bytes * rows
+        return {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_PEAK_TFS, 4), "traffic": None, "rows": rows,
+                "flop_per_launch": int(tot_b * rows / n_launch), **common}
+    ach = tot_b / tot_ms / 1e6
+    # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs, gfx950 x2
+    # wide-read correction: tools/pmc_gemm_traffic.py -> profiles/r0*_pmc_gemm_traffic.json), weighted by this step's
+    # launch mix; only valid for the shapes / launch configs that pass measured, else null
     traffic, traffic_src = None, None
-    pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_gemm_traffic.json")
-    if os.path.exists(pj) and eng.M == 128:
+    for fn in ("r02_pmc_gemm_traffic.json", "r01_pmc_gemm_traffic.json"):
+        pj = os.path.join(ROOT, "profiles", fn)
+        if not os.path.exists(pj) or rows != 128:
+            continue
         pm = json.load(open(pj))["gemms"]
         cfgs = {q["name"]: q for q in per}
         if all(n in pm and pm[n]["splitk"] == cfgs[n]["splitk"] and pm[n]["nwaves"] == cfgs[n]["nwaves"] and
+               pm[n].get("kparts", 1) == cfgs[n]["kparts"] and
                pm[n]["N"] * pm[n]["K"] * 2 * r["count"] == int(r["bytes"]) for n, r in prof.items()):
-            traffic = int(sum(pm[n]["hbm_read_bytes"] * r["count"] for n, r in prof.items()) / n_launch)
-            traffic_src = "profiles/r01_pmc_gemm_traffic.json (FETCH_SIZE, read bytes per launch, launch-mix weighted)"
+            traffic = int(sum((pm[n]["hbm_read_bytes"] + pm[n].get("hbm_write_bytes", 0)) * r["count"] for n, r in prof.items()) / n_launch)
+            traffic_src = f"profiles/{fn} (FETCH_SIZE{' + WRITE_SIZE' if any('hbm_write_bytes' in v for v in pm.values()) else ''}, bytes per launch, launch-mix weighted)"
+            break
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "gemm_kernel<NW,MB,EPI> (bd_gemm.hip): every weight-streaming GEMM launch of one AR step, in situ",
-            "launches": n_launch, "bytes_per_launch": int(tot_b / n_launch),
-            "avg_launch_us": round(tot_ms / n_launch * 1e3, 2), "per_gemm": per}
+            "bytes_per_launch": int(tot_b / n_launch), **common}
 
 
 # ---------------------------------------------------------------------------------------------------------
-def cpu_baseline(args) -> dict:
-    """The CPU oracle (port of the reference algorithm, oracle/) on the host cores, bounded sample (~20 s): ONE of the
-    head's 6 transformer blocks + the stacked adaLN Linear (M = 128 rows) and ONE LLM decoder layer over a 2 x 64-token
-    block with 1k cached tokens, all at true 14B shapes; extrapolated to one image:
-    T = AR * (N+1) * (nblocks * t_block + t_ada) + (AR-1) * L * t_layer   (prefill, final layer, AE decode excluded)."""
-    from oracle import diff_head, qwen3
-    from oracle.numerics import Policy
-    from bitdance_amd import synthetic as syn
+def cpu_baseline_t2i(args, P: int, ar_steps: int, n_eval: int) -> dict:
+    """The CPU oracle (port of the reference algorithm, oracle/) on the host cores at TRUE 14B dimensions, bounded sample:
+    a 2-block / 2-adaLN head evaluation (M = 2*P rows) and one Qwen3-14B layer step over 2 x P tokens against ~1k cached
+    tokens (oracle/true_dims.py).  The same inputs go through the HIP path; the differences are reported as "parity".
+    Extrapolation: T = AR * (N+1) * t_head * (full head MACs / sample MACs) + (AR-1) * 40 * t_layer
+    (prefill, AE decode excluded)."""
+    from oracle.true_dims import head_case, llm_case
     torch.set_num_threads(os.cpu_count() or 1)
-    big = args.size == "14b-64x"
-    hc, lc = (syn.HEAD_14B_64X, syn.QWEN3_14B) if big else (syn.TINY_HEAD, syn.TINY_LLM)
-    pol = Policy("autocast")
-    D = hc["ch_latent"]
-    H = int(D * 1.5)
-    bf = torch.bfloat16
-    cw = lambda *s: torch.full(s, 0.01, dtype=bf)
-    w = {}
-    p = "net.res_blocks.0."
-    for nn_ in ("norm1", "norm2"):
-        w[p + nn_ + ".weight"], w[p + nn_ + ".bias"] = torch.ones(D), torch.zeros(D)
-    for nme, n, k in [("attn.wqkv", 3 * D, D), ("attn.wo", D, D), ("w1", 2 * H, D), ("w2", D, H)]:
-        w[p + nme + ".weight"], w[p + nme + ".bias"] = cw(n, k), cw(n)
-    nada = hc["depth_adanln"] * 6 * D + 2 * D
-    w_ada, b_ada = cw(nada, D), cw(nada)
-    x = torch.randn(2, 64, D).to(bf)
-    y = torch.randn(2, 64, D).to(bf)
-    mods = [torch.randn(2, 64, D).to(bf) * 0.1 for _ in range(6)]
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        diff_head.trans_block(w, 0, x, mods, D // 128, pol)
-        t_block = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        pol.linear(y, w_ada, b_ada)
-        t_ada = time.perf_counter() - t0
-    del w, w_ada
-    one = dict(lc, num_hidden_layers=1)
-    Dl, nh, nkv, hd, ff = lc["hidden_size"], lc["num_attention_heads"], lc["num_key_value_heads"], lc["head_dim"], lc["intermediate_size"]
-    lw = {"model.norm.weight": torch.ones(Dl, dtype=bf)}
-    p = "model.layers.0."
-    for nme, n, k in [("self_attn.q_proj", nh * hd, Dl), ("self_attn.k_proj", nkv * hd, Dl), ("self_attn.v_proj", nkv * hd, Dl),
-                      ("self_attn.o_proj", Dl, nh * hd), ("mlp.gate_proj", ff, Dl), ("mlp.up_proj", ff, Dl), ("mlp.down_proj", Dl, ff)]:
-        lw[p + nme + ".weight"] = cw(n, k)
-    for nme, n in [("self_attn.q_norm", hd), ("self_attn.k_norm", hd), ("input_layernorm", Dl), ("post_attention_layernorm", Dl)]:
-        lw[p + nme + ".weight"] = torch.ones(n, dtype=bf)
-    past = 1024 if big else 128
-    cache = [[torch.randn(2, nkv, past, hd).to(bf), torch.randn(2, nkv, past, hd).to(bf)]]
-    xin = torch.randn(2, 64, Dl)
-    ones = torch.ones(2, 1, 64, past + 64, dtype=torch.bool)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        qwen3.model_forward(lw, one, xin, cache, ones, pol)
-    t_layer = time.perf_counter() - t0
-    ar = (args.height // 16) * (args.width // 16) // 64
-    n_ev = args.sampling_steps + 1
-    L = lc["num_hidden_layers"]
-    t_head = hc["depth_latent"] * t_block + t_ada
-    t_img = ar * n_ev * t_head + (ar - 1) * L * t_layer
+    tiny = args.workload == "tiny"
+    if tiny:
+        h = head_case(D=256, P=P, B=1, branches=2, depth=2, nada=2)
+        from oracle.tiny_models import TINY_LLM
+        l = llm_case(layers=1, P=P, past=(100, 117), cfg=TINY_LLM)
+        D, nblk, nada, L = 256, 4, 2, 2
+    else:
+        h = head_case(D=5120, P=P, B=1, branches=2, depth=2, nada=2)
+        l = llm_case(layers=1, P=P, past=(1000, 1017))
+        D, nblk, nada, L = 5120, 6, 2, 40
+    C = 32
+    full_macs = D * C + D * D + (nada * 6 + 2) * D * D + nblk * 8.5 * D * D + D * C
+    t_head = h["t_cpu_s"] * full_macs / h["macs_per_row"]
+    t_img = ar_steps * n_eval * t_head + (ar_steps - 1) * L * l["t_cpu_s"]
     return {"value": round(1.0 / t_img, 8), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle (CPU port), {'true 14B' if big else 'tiny'} shapes, M=128 rows: 1 head block ({t_block:.2f} s) + adaLN Linear "
-                      f"({t_ada:.2f} s) + 1 LLM layer step 2x64 tokens / {past} cached ({t_layer:.2f} s); extrapolated "
-                      f"x{ar * n_ev} evals, x{(ar - 1) * L} layer steps; excludes prefill, final layer, AE decode"}
+            "sample": f"oracle (CPU port) at {'tiny' if tiny else 'true 14B'} dimensions: one head evaluation of 2 blocks + the full adaLN "
+                      f"projection, M = {h['rows']} rows ({h['t_cpu_s']:.2f} s, scaled x{full_macs / h['macs_per_row']:.2f} to the {nblk}-block head) + "
+                      f"1 LLM layer step {l['rows']} tokens / ~1k cached ({l['t_cpu_s']:.2f} s); extrapolated x{ar_steps * n_eval} evals, "
+                      f"x{(ar_steps - 1) * L} layer steps; excludes prefill, AE decode",
+            "parity": {"head_xhat_max_err": round(h["max_err"], 5), "head_xhat_mean_err": round(h["mean_err"], 6),
+                       "head_gemm_cfg": h["gemm_cfg"], "llm_hidden_max_err": round(l["max_err"], 5),
+                       "llm_hidden_mean_err": round(l["mean_err"], 6), "llm_gemm_cfg": l["gemm_cfg"],
+                       "bounds": "head x_hat in [-1,1]: max 5e-2 / mean 6e-3; LLM hidden: max 0.12 / mean 1e-2 (tests/test_gpu_true_dims.py)",
+                       "within_bounds": bool(h["max_err"] <= 5e-2 and h["mean_err"] <= 6e-3 and l["max_err"] <= 0.12 and l["mean_err"] <= 1e-2)}}
+
+
+def cpu_baseline_imagenet(n_eval: int, ar_steps: int) -> dict:
+    """BitDance-B head at its real dimensions on the host cores (one evaluation of the full 6-block head on 256 rows = 8
+    images with CFG); extrapolated by rows and evaluation count; the transformer (5 % of the FLOPs) and the VAE excluded."""
+    from oracle.true_dims import head_case
+    torch.set_num_threads(os.cpu_count() or 1)
+    h = head_case(D=768, Dz=768, C=32, P=16, B=8, branches=2, depth=6, nada=2, head_dim=64, sigmoid=False, seed=109)
+    t_img = h["t_cpu_s"] / 8 * n_eval * ar_steps
+    return {"value": round(1.0 / t_img, 6), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (CPU port): one evaluation of the BitDance-B head (6 blocks, width 768) on 256 rows = 8 images with CFG "
+                      f"({h['t_cpu_s']:.2f} s); extrapolated x{n_eval * ar_steps} evaluations per image; transformer and VAE excluded",
+            "parity": {"head_out_max_err": round(h["max_err"], 5), "head_out_mean_err": round(h["mean_err"], 6),
+                       "ref_abs_mean": round(h["ref_abs_mean"], 4)}}
 
 
 # ---------------------------------------------------------------------------------------------------------
-def main():
-    args = parse()
+def setup_dist():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        # RCCL ("nccl") on a real node.  BD_BENCH_BACKEND=gloo: several ranks sharing one GPU (functional check of the
+        # tensor-parallel path on a single-GPU box; RCCL refuses two ranks on one device)
+        backend = os.environ.get("BD_BENCH_BACKEND", "nccl")
+        local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
-        dist = None
+        local = 0
         torch.cuda.set_device(0)
+    return dist, world, rank, f"cuda:{local}"
+
+
+def tokens_agree(dist, tokens: torch.Tensor, dev) -> bool:
+    """Tensor parallel: the replicated state must be bit-identical on every rank -- compare two checksums of the tokens."""
+    t = tokens.double()
+    w = torch.arange(1, t.numel() + 1, device=t.device, dtype=torch.float64)
+    mine = torch.stack([t.sum(), (t.flatten() * w).sum()])
+    if dist.get_backend() == "gloo":
+        mine = mine.cpu()
+    allv = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(allv, mine)
+    return all(torch.equal(v, allv[0]) for v in allv)
+
+
+def main():
+    args = parse()
+    dist, world, rank, dev = setup_dist()
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    dev = f"cuda:{local if world > 1 else 0}"
-
     from bitdance_amd import synthetic as syn
     from bitdance_amd.build import build
+    from bitdance_amd.dist_util import max_over_ranks, rank_seed
     build(verbose=False)
-    t0 = time.perf_counter()
-    pipe = syn.build_pipeline(args.size, dev, with_ae=True)
     tune = {}
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
         tune[k] = int(v)
-    pipe.tune = tune or None
-    pipe.use_graph = not args.no_graph
-    if rank == 0:
-        print(f"[bench] model built in {time.perf_counter() - t0:.1f} s", file=sys.stderr)
-    if args.size == "tiny":
-        args.height, args.width = min(args.height, 256), min(args.width, 256)
-    prompt = "A close-up portrait in a cinematic photography style, capturing a girl-next-door look on a sunny daytime urban street."
-    kw = dict(cond_prompt=f"<|im_start|>user\n{prompt}<|im_end|>\n<|im_start|>assistant\n",
-              uncond_prompt="<|im_start|>assistant\n", guidance_scale=args.guidance,
-              num_sampling_steps=args.sampling_steps, num_images=args.num_images,
-              image_size=[args.height, args.width], max_length=(args.height // 16) * (args.width // 16))
-
-    from bitdance_amd.dist_util import job_throughput, max_over_ranks, rank_seed
-
-    def one_pass(i):
-        torch.manual_seed(rank_seed(1234, rank, i))
-        with torch.amp.autocast("cuda", enabled=True, dtype=torch.bfloat16):
-            img = pipe.gen_image(**kw)
-        return img
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    size, H0, W0, metric = WORKLOADS[args.workload]
+    if args.workload == "imagenet-b16x":
+        return bench_imagenet(args, dist, world, rank, dev, metric, barrier, max_over_ranks, rank_seed)
+
+    # ---------------------------------------------------------------- T2I workloads
+    H, W = args.height or H0, args.width or W0
+    if size == "tiny":
+        H, W = min(H, 256), min(W, 256)
+    num_images = args.num_images or 1
+    n_sampling = args.sampling_steps or 50
+    guidance = args.guidance if args.guidance is not None else 7.5
+    tp_mode = world > 1 and args.parallel == "tp"
+    comm = None
+    t0 = time.perf_counter()
+    if tp_mode:
+        from bitdance_amd.tp import TPComm
+        rows_max = 2 * num_images * 64
+        comm = TPComm.from_process_group(max(rows_max, 128) * 5120, device=dev)
+    pipe = syn.build_pipeline(size, dev, with_ae=True, tp=comm)
+    pipe.tune = tune or None
+    pipe.use_graph = not args.no_graph
+    if rank == 0:
+        print(f"[bench] model built in {time.perf_counter() - t0:.1f} s"
+              + (f" (tensor parallel x{world}, exchange backend {comm.backend})" if tp_mode else ""), file=sys.stderr)
+    P = pipe.parallel_num
+    prompt = "A close-up portrait in a cinematic photography style, capturing a girl-next-door look on a sunny daytime urban street."
+    kw = dict(cond_prompt=f"<|im_start|>user\n{prompt}<|im_end|>\n<|im_start|>assistant\n",
+              uncond_prompt="<|im_start|>assistant\n", guidance_scale=guidance,
+              num_sampling_steps=n_sampling, num_images=num_images,
+              image_size=[H, W], max_length=(H // 16) * (W // 16))
+
+    def one_pass(i):
+        torch.manual_seed(rank_seed(1234, 0 if tp_mode else rank, i))       # tensor parallel: every rank draws the same noise
+        with torch.amp.autocast("cuda", enabled=True, dtype=torch.bfloat16):
+            return pipe.gen_image(**kw)
+
     for i in range(args.warmup):
         one_pass(i)
+        if tp_mode and i == 0:
+            eng = next(iter(pipe._engines.values()))
+            if not tokens_agree(dist, eng.tok_all, dev):
+                raise RuntimeError("tensor-parallel ranks diverged: token checksums differ between ranks")
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -213,29 +274,95 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     assert torch.isfinite(img).all()
-    dt = max_over_ranks(dt, dist, dev)
+    if tp_mode:
+        eng = next(iter(pipe._engines.values()))
+        assert tokens_agree(dist, eng.tok_all, dev), "tensor-parallel ranks diverged in the timed region"
+    dt = max_over_ranks(dt, dist, "cpu" if (dist is not None and dist.get_backend() == "gloo") else dev)
 
-    out = None
     if rank == 0:
         n = world
-        images = n * args.num_images * args.steps
-        assert abs(images / dt - job_throughput(args.num_images, args.steps, dt, n)) < 1e-9
+        images = (1 if tp_mode else n) * num_images * args.steps
+        ar_steps = kw["max_length"] // P
+        eng = next(iter(pipe._engines.values()))
         out = {
-            "metric": "images/sec @1024px BitDance-14B-64x" if args.size == "14b-64x" else "images/sec (tiny smoke config)",
-            "value": round(images / dt, 5), "unit": "images/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random weights at true shapes, fixed token ids)",
-            "config": {"workload": f"BitDance-14B-64x T2I {args.height}x{args.width}, {args.sampling_steps} sampling steps, "
-                                   f"cfg {args.guidance}, num_images={args.num_images} per GPU"
-                                   if args.size == "14b-64x" else "tiny",
-                       "ar_steps": kw["max_length"] // 64, "parallelism": f"replicas x{n}" if n > 1 else "single GPU",
+            "metric": metric, "value": round(images / dt, 5), "unit": "images/s", "n_gpus": n, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "strong" if tp_mode else "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic (random weights at true shapes, fixed token ids)",
+            "config": {"workload": f"BitDance-{size.upper()} T2I {H}x{W}, {n_sampling} sampling steps, cfg {guidance}, "
+                                   f"num_images={num_images} per {'job' if tp_mode else 'GPU'}" if size != "tiny" else "tiny",
+                       "ar_steps": ar_steps, "rows_per_pass": eng.M,
+                       "parallelism": (f"tp{n}" if tp_mode else f"replicas x{n}") if n > 1 else "single GPU",
                        "hipgraph": pipe.use_graph},
             "phases_ms_last_step": {k: round(v, 1) for k, v in pipe.timings().items()},
         }
+        if tp_mode:
+            wbytes = sum(t.numel() * t.element_size() for w_ in (pipe.head_w, pipe.llm_w, pipe.proj_w) for t in w_.ptrs.values())
+            nblk, L = pipe.head_w.nblocks, pipe.llm_w.cfg["num_hidden_layers"]
+            n_x = ar_steps * (n_sampling + 1) * 2 * nblk + (ar_steps - 1) * 2 * L
+            out["tp"] = {"size": n, "exchange_backend": comm.backend, "weight_bytes_per_rank": int(wbytes),
+                         "exchanges_per_image": n_x, "exchange_payload_bytes_per_rank": int(eng.M * 5120 * 6 * (n - 1) / n),
+                         "ranks_bit_identical": True}
         if not args.no_roofline:
-            out["roofline"] = gemm_roofline(pipe)
+            st = pipe._stream
+            with torch.cuda.stream(st):
+                out["roofline"] = gemm_roofline(eng, lambda: (eng.head_sample(), eng.projector(), eng.llm_step()), eng.M)
+            if tp_mode:
+                out["roofline"]["note"] = "rank 0's launches: per-rank slices of the weights"
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            del pipe
+            out["cpu_baseline"] = cpu_baseline_t2i(args, P, ar_steps, n_sampling + 1)
+        print(json.dumps(out), flush=True)
+    elif tp_mode and not args.no_roofline:
+        # rank 0's eager profiling pass launches exchanges: every rank has to take part in them
+        eng = next(iter(pipe._engines.values()))
+        with torch.cuda.stream(pipe._stream):
+            eng.head_sample(); eng.projector(); eng.llm_step()
+        torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_imagenet(args, dist, world, rank, dev, metric, barrier, max_over_ranks, rank_seed):
+    """BASELINE config 2: one ``BitDance.sample`` call over ``--num-images`` (default 384) classes, 100 sampling steps,
+    linear CFG 6.1, VAE decode in chunks; N > 1 = replicas over disjoint class batches (what sample_ddp_parallel.py does)."""
+    from bitdance_amd import synthetic as syn
+    n_cls = args.num_images or 384
+    n_sampling = args.sampling_steps or 100
+    guidance = args.guidance if args.guidance is not None else 6.1
+    m = syn.build_imagenet(dev, with_vae=not args.no_decode)
+    ids = (torch.arange(n_cls) + rank * n_cls) % 1000
+
+    def one_pass(i):
+        torch.manual_seed(rank_seed(99, rank, i))
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return m.sample(ids, n_sampling, cfg_scale=guidance, cfg_schedule="linear", chunk_size=48)
+
+    for i in range(args.warmup):
+        one_pass(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out_img = one_pass(args.warmup + i)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, dist, "cpu" if (dist is not None and dist.get_backend() == "gloo") else dev)
+    assert torch.isfinite(out_img.float()).all()
+    if rank == 0:
+        images = world * n_cls * args.steps
+        ar_steps = (256 // 16) ** 2 // 16
+        out = {"metric": metric, "value": round(images / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random weights at true shapes, class ids arange % 1000)",
+               "config": {"workload": f"imagenet_gen BitDance-B-16x 256x256, batch {n_cls} classes per call, {n_sampling} sampling steps, "
+                                      f"linear CFG {guidance}, VAE decode {'off' if args.no_decode else 'on (chunks of 48)'}",
+                          "ar_steps": ar_steps, "rows_per_pass": 2 * n_cls * 16,
+                          "parallelism": f"replicas x{world}" if world > 1 else "single GPU", "hipgraph": False}}
+        if not args.no_roofline:
+            eng = m._eng[(n_cls, 2)]
+            out["roofline"] = gemm_roofline(eng, eng.head_sample, eng.M)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_imagenet(n_sampling + 1, ar_steps)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

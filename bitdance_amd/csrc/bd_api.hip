@@ -96,7 +96,8 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
     if (S < 1) S = 1;
     if (ntiles >= 260 && !swiglu) S = 3;               // > 1 wave of workgroups: split for tail balance
     if (swiglu && ntiles >= 130) S = 1;
-    const bool kw2_ok = !two_images && K % 128 == 0 && N % 64 == 0 && g.nw != 10 && c->geti("tune.kw2", 1) != 0;
+    const bool kw2_shape = !two_images && K % 128 == 0 && N % 64 == 0 && g.nw != 10;
+    const bool kw2_ok = kw2_shape && c->geti("tune.kw2", 0) != 0;          // measured slower at tp = 1 (profiles/r02_gemm_sweep2.log)
     if (kw2_ok) {
         const int t64 = N / 64;                        // 64-column tiles: 2 panels x 2 K-parts
         int s64 = (int)std::lround(240.0 / t64);
@@ -105,7 +106,7 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
     }
     if (reduce3 && S > 3) {
         // narrower tiles instead of more slices: 64 columns (2 waves, or 2 x 2 when K allows), then 32
-        if (N % 64 == 0) { g.nw = (kw2_ok ? 4 : 2); g.kw = kw2_ok ? 2 : 1; ntiles = N / 64; }
+        if (N % 64 == 0) { g.nw = (kw2_shape ? 4 : 2); g.kw = kw2_shape ? 2 : 1; ntiles = N / 64; }
         S = (int)std::lround(240.0 / ntiles);
         if (S > 3) S = 3;
         if (S < 1) S = 1;

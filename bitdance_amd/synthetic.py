@@ -18,6 +18,11 @@ QWEN3_14B = dict(hidden_size=5120, num_hidden_layers=40, num_attention_heads=40,
 HEAD_14B_64X = dict(ch_target=32, ch_cond=5120, ch_latent=5120, depth_latent=6, depth_adanln=2, parallel_num=64,
                     use_swiglu=True, time_shift=1.0, time_schedule="logit_normal", P_mean=-0.8, P_std=0.8,
                     diff_batch_mul=1)                      # train/configs/bitdance_14b_64x.yaml:22-33
+HEAD_14B_16X = dict(HEAD_14B_64X, parallel_num=16)          # BitDance-14B-16x: 16-token patches (README.md:77-78)
+# imagenet_gen BitDance-B-16x (model_parallel.py:456-465): 24 layers, width 768, 12 heads of 64, head 6 blocks / 2 adaLN
+IMAGENET_B_16X = dict(dim=768, n_layer=24, n_head=12, diff_layers=6, diff_dim=768, diff_adanln_layers=2, latent_dim=32,
+                      down_size=16, patch_size=1, resolution=256, cls_token_num=64, num_classes=1000, parallel_num=16,
+                      time_shift=1.0)
 AE_D16C32 = dict(ddconfig=dict(double_z=False, z_channels=32, in_channels=3, out_ch=3, ch=256, ch_mult=[1, 1, 2, 2, 4],
                                num_res_blocks=4), gan_decoder=False)      # bitdance_14b_64x.yaml:9-16
 
@@ -108,6 +113,53 @@ def random_ae_state(ae_config: dict, device, seed: int = 3) -> dict:
     return sd
 
 
+def random_imagenet_state(cfg: dict, device, seed: int = 4, std: float = 0.02) -> dict:
+    """state_dict() of imagenet_gen's BitDance minus ``vae.*`` (model_parallel.py:104-196) with random values: transformer
+    (``layers.{i}.attention.wqkv / wo``, ``feed_forward.w1 / w2`` with find_multiple(2*4*dim/3, 256) hidden features,
+    RMSNorm scales), ``proj_in`` SwiGLU connector, class / query / position embeddings and the ``head.net.*`` diffusion head."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    D, L = cfg["dim"], cfg["latent_dim"] * cfg["patch_size"] ** 2
+    hid = int(D * 1.5)
+    ff = int(2 * 4.0 * D / 3)
+    ff = ff if ff % 256 == 0 else ff + 256 - ff % 256
+    hw = cfg["resolution"] // (cfg["down_size"] * cfg["patch_size"])
+    f32 = torch.float32
+    sd = {"query_token": _normal((1, cfg["parallel_num"] - 1, D), std, g, device, f32),
+          "cls_embedding.weight": _normal((cfg["num_classes"] + 1, D * cfg["cls_token_num"]), std, g, device, f32),
+          "proj_in.w1.weight": _normal((2 * hid, L), 1.0 / math.sqrt(L), g, device, f32),
+          "proj_in.w1.bias": _normal((2 * hid,), std, g, device, f32),
+          "proj_in.w2.weight": _normal((D, hid), 1.0 / math.sqrt(hid), g, device, f32),
+          "proj_in.w2.bias": _normal((D,), std, g, device, f32),
+          "emb_norm.weight": torch.ones(D, device=device), "norm.weight": torch.ones(D, device=device),
+          "pos_for_diff.weight": _normal((hw * hw, D), std, g, device, f32)}
+    for i in range(cfg["n_layer"]):
+        p = f"layers.{i}."
+        sd[p + "attention.wqkv.weight"] = _normal((3 * D, D), 1.0 / math.sqrt(D), g, device, f32)
+        sd[p + "attention.wo.weight"] = _normal((D, D), 1.0 / math.sqrt(D), g, device, f32)
+        sd[p + "feed_forward.w1.weight"] = _normal((2 * ff, D), 1.0 / math.sqrt(D), g, device, f32)
+        sd[p + "feed_forward.w2.weight"] = _normal((D, ff), 1.0 / math.sqrt(ff), g, device, f32)
+        sd[p + "attention_norm.weight"] = torch.ones(D, device=device)
+        sd[p + "ffn_norm.weight"] = torch.ones(D, device=device)
+    hcfg = dict(ch_target=L, ch_cond=D, ch_latent=cfg["diff_dim"], depth_latent=cfg["diff_layers"],
+                depth_adanln=cfg["diff_adanln_layers"])
+    for k, v in random_head_state(hcfg, device, seed=seed + 1, std=1.0 / math.sqrt(cfg["diff_dim"])).items():
+        sd["head." + k] = v.float()
+    return sd
+
+
+def build_imagenet(device: str = "cuda", cfg: dict | None = None, with_vae: bool = True):
+    """BitDance-B-16x (class-conditional ImageNet, 256 px) on random weights, optionally with the ae_d16c32 decoder."""
+    from .autoencoder import VQModel
+    from .imagenet import BitDance
+    cfg = dict(cfg or IMAGENET_B_16X)
+    vae = None
+    if with_vae:
+        vae = VQModel(**AE_D16C32).eval()
+        vae.load_state_dict(random_ae_state(AE_D16C32, device), strict=True, assign=True)
+        vae.to(device)
+    return BitDance(random_imagenet_state(cfg, device), device=device, vae=vae, **cfg)
+
+
 class SyntheticTokenizer:
     """Fixed-length stand-in for the HF tokenizer: no tokenizer files exist offline.  ``encode`` maps a prompt to
     a deterministic id list (77 ids for a user prompt, 3 for the bare assistant prefix)."""
@@ -130,11 +182,14 @@ class SyntheticTokenizer:
         raise KeyError(tok)
 
 
-def build_pipeline(size: str = "14b-64x", device: str = "cuda", with_ae: bool = True):
-    """A BitDanceT2IPipeline on random weights: ``14b-64x`` (BitDance-14B-64x shapes) or ``tiny``."""
+def build_pipeline(size: str = "14b-64x", device: str = "cuda", with_ae: bool = True, tp=None):
+    """A BitDanceT2IPipeline on random weights: ``14b-64x`` / ``14b-16x`` (BitDance-14B shapes) or ``tiny``.  ``tp``: a
+    tp.TPComm -- every rank draws the SAME full model from the same seeds and keeps its slices."""
     from .t2i_pipeline import BitDanceT2IPipeline
     if size == "14b-64x":
         lc, hc, ac = QWEN3_14B, HEAD_14B_64X, AE_D16C32
+    elif size == "14b-16x":
+        lc, hc, ac = QWEN3_14B, HEAD_14B_16X, AE_D16C32
     elif size == "tiny":
         lc, hc, ac = TINY_LLM, TINY_HEAD, TINY_AE
     else:
@@ -144,5 +199,5 @@ def build_pipeline(size: str = "14b-64x", device: str = "cuda", with_ae: bool = 
         tokenizer=SyntheticTokenizer(lc["vocab_size"]), llm_cfg=lc, llm_sd=random_llm_state(lc, device),
         ae_config=ac, ae_sd=random_ae_state(ac, device) if with_ae else None, head_config=head_cfg,
         head_sd=random_head_state(hc, device), proj_sd=random_proj_state(hc["ch_target"], lc["hidden_size"], device),
-        device=device)
+        device=device, tp=tp)
     return pipe

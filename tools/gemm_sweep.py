@@ -31,15 +31,18 @@ def main():
         check(lib().bd_rows_to_frag(xf.data_ptr(), x.data_ptr(), 1, M, K, RB, st))
         out = torch.empty(16 * M * N if not swiglu else M * N, dtype=torch.float32, device=DEV)
         Ss = [1] if swiglu else [1, 2, 3, 4, 6, 8, 12]
-        for nw, ring in ([(2, 2), (4, 2), (4, 3), (8, 2), (8, 3), (8, 4)] if M == 128 else [(4, 2), (8, 2)]):
-            if N % (32 * nw):
+        kws = "--kw" in sys.argv
+        cfgs = ([(4, 2, 1), (8, 2, 1), (4, 2, 2), (8, 2, 2), (10, 2, 2)] if kws else
+                [(2, 2, 1), (4, 2, 1), (4, 3, 1), (8, 2, 1), (8, 3, 1), (8, 4, 1)]) if M == 128 else [(4, 2, 1), (8, 2, 1)]
+        for nw, ring, kw in cfgs:
+            if N % (32 * nw // kw) or K % (64 * kw):
                 continue
-            code = nw + 16 * ring
+            code = nw + 16 * ring + 256 * (kw - 1)
             for S in Ss:
-                nst = K // 64
+                nst = K // (64 * kw)
                 if S > nst or (S > 1 and (S - 1) * ((nst + S - 1) // S) >= nst):
                     continue
-                blocks = N // (32 * nw) * S
+                blocks = N // (32 * nw // kw) * S
                 blocks *= max(1, M // 256)
                 if blocks < 100 or blocks > 1300:
                     continue
@@ -61,8 +64,8 @@ def main():
                 us = e0.elapsed_time(e1) * 1e3 / reps
                 gbs = N * K * 2 / us / 1e3
                 tfs = 2.0 * M * N * K / us / 1e6
-                res.append(dict(name=name, N=N, K=K, nw=nw, ring=ring, S=S, blocks=blocks, us=round(us, 1), GBs=round(gbs)))
-                print(f"{name:9s} N={N:6d} K={K:6d} nw={nw} R={ring} S={S:2d} blocks={blocks:5d}  {us:8.1f} us  {gbs:7.0f} GB/s  {tfs:6.0f} TFLOP/s", flush=True)
+                res.append(dict(name=name, N=N, K=K, nw=nw, ring=ring, kw=kw, S=S, blocks=blocks, us=round(us, 1), GBs=round(gbs)))
+                print(f"{name:9s} N={N:6d} K={K:6d} nw={nw} kw={kw} R={ring} S={S:2d} blocks={blocks:5d}  {us:8.1f} us  {gbs:7.0f} GB/s  {tfs:6.0f} TFLOP/s", flush=True)
         del wp
     best = {}
     for r in res:
