@@ -105,7 +105,11 @@ struct GemmP {
 // workgroup.  KW = 2 halves the tile width at the same number of waves and bytes in flight per CU, so the N = 15360 shapes
 // fill 240 CUs with no cross-workgroup split at all (no slabs, no tickets) and the N = 5120 shapes need 3 slices
 // instead of 6 (half the slab traffic, in-launch reduction applies).
-template <int NP, int KW, int MB, int EPI, int R, bool RED>
+// PIPE: the LDS reads of stage j+1 are issued BEFORE the MFMAs of stage j (whose fragments were read one phase earlier), so
+// the matrix pipe never waits on ds_read latency and a phase costs max(MFMA, LDS, HBM) instead of their sum; the A tile of
+// stage j+2 is written over stage j's buffer in the same phase (its reads drained at the previous barrier).  One more A
+// stage of lookahead, 64 more VGPRs for the second fragment set (4-wave workgroups: one wave per SIMD, 512 registers).
+template <int NP, int KW, int MB, int EPI, int R, bool RED, bool PIPE = false>
 __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
     constexpr int NW = NP * KW, NT = NW * 64;
     constexpr int UNITS = MB * 256 * KW;                  // 16 B units per (64*KW)-deep A stage
@@ -180,6 +184,59 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
         }
     };
 
+  if constexpr (PIPE) {
+    static_assert(R == 2 && KG == 4, "pipelined loop: two W stages in flight, whole-stage fragment sets");
+    u32x4 xf[2][4][MB];
+    auto read_stage = [&](u32x4(&x)[4][MB], const u32x4* stage) {
+        const u32x4* buf = stage + kg * MB * 256;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int m = 0; m < MB; ++m) x[kk][m] = buf[(kk * MB + m) * 64 + lane];
+    };
+    auto mma_stage = [&](const u32x4(&x)[4][MB], const u32x4(&wr)[4]) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int m = 0; m < MB; ++m) acc[m] = mfma32(x[kk][m], wr[kk], acc[m]);
+    };
+    // prologue: A stages 0 and 1 in LDS, stage 2 in registers; W stages 0 and 1 in registers; fragments of stage 0 read
+    load_x(xr[0], 0);
+    load_w(w[0], 0);
+    store_x(lds, xr[0]);
+    if (1 < nst) { load_x(xr[0], 1); load_w(w[1], 1); store_x(lds + UNITS, xr[0]); }
+    if (2 < nst) load_x(xr[0], 2);
+    __syncthreads();
+    read_stage(xf[0], lds);
+    int i = 0;
+    for (; i + U + 2 < nst; i += U) {
+#pragma unroll
+        for (int ph = 0; ph < U; ++ph) {
+            read_stage(xf[(ph + 1) & 1], lds + ((ph + 1) & 1) * UNITS);       // stage j+1 (stored during phase ph-1)
+            __builtin_amdgcn_sched_barrier(0);
+            mma_stage(xf[ph & 1], w[ph & 1]);                                 // stage j
+            store_x(lds + (ph & 1) * UNITS, xr[0]);                           // stage j+2 over stage j's tile
+            load_x(xr[0], i + ph + 3);
+            load_w(w[ph & 1], i + ph + 2);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int ph = 0; ph < U + 2; ++ph) {
+        const int j = i + ph;
+        if (j < nst) {
+            if (j + 1 < nst) read_stage(xf[(ph + 1) & 1], lds + ((ph + 1) & 1) * UNITS);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_stage(xf[ph & 1], w[ph & 1]);
+            if (j + 2 < nst) {
+                store_x(lds + (ph & 1) * UNITS, xr[0]);
+                if (j + 3 < nst) load_x(xr[0], j + 3);
+                load_w(w[ph & 1], j + 2);
+            }
+            if (j + 1 < nst) __syncthreads();
+        }
+    }
+  } else {
     // prologue: stages 0..R-1 of A and W in flight; stage q of A lives in ring slot q % XR
     load_x(xr[0], 0);
     load_w(w[0], 0);
@@ -214,6 +271,7 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
             }
         }
     }
+  }
 
     // ---- K parts of one panel meet in LDS: parts 1..KW-1 park their accumulators, part 0 adds them in order
     if constexpr (KW > 1) {
@@ -534,7 +592,7 @@ static int launch_gemm_wide(const GemmP& p, int epi, hipStream_t st) {
     return bd_launch_status();
 }
 
-template <int NP, int KW, int MB, int EPI, int R, bool RED>
+template <int NP, int KW, int MB, int EPI, int R, bool RED, bool PIPE = false>
 static int launch_one(const GemmP& p, hipStream_t st) {
     const int ntiles = p.N / (32 * NP);
     dim3 grid(ntiles * p.S, p.RB / MB);
@@ -542,37 +600,39 @@ static int launch_one(const GemmP& p, hipStream_t st) {
     constexpr size_t lds_a = (size_t)2 * MB * 256 * KW * 16, lds_r = (size_t)(KW - 1) * NP * MB * 4096;
     constexpr size_t lds = lds_a > lds_r ? lds_a : lds_r;
     if constexpr (lds > 64 * 1024) {                               // beyond 64 KiB of dynamic LDS needs the opt-in
-        static const bool ok = hipFuncSetAttribute((const void*)gemm_kernel<NP, KW, MB, EPI, R, RED>,
+        static const bool ok = hipFuncSetAttribute((const void*)gemm_kernel<NP, KW, MB, EPI, R, RED, PIPE>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
         if (!ok) return -8;
     }
-    BD_LAUNCH((gemm_kernel<NP, KW, MB, EPI, R, RED>), grid, dim3(NP * KW * 64), lds, st, p);
+    BD_LAUNCH((gemm_kernel<NP, KW, MB, EPI, R, RED, PIPE>), grid, dim3(NP * KW * 64), lds, st, p);
     return bd_launch_status();
 }
 
-template <int NP, int KW, int MB, int R, bool RED>
+template <int NP, int KW, int MB, int R, bool RED, bool PIPE = false>
 static int launch_gemm_r(const GemmP& p, int epi, hipStream_t st) {
-    if (epi == BD_EPI_PARTIAL) return launch_one<NP, KW, MB, BD_EPI_PARTIAL, R, false>(p, st);
-    if (epi == BD_EPI_BF16) return launch_one<NP, KW, MB, BD_EPI_BF16, R, RED>(p, st);
-    if (epi == BD_EPI_F32) return launch_one<NP, KW, MB, BD_EPI_F32, R, RED>(p, st);
-    return launch_one<NP, KW, MB, BD_EPI_SWIGLU, R, RED>(p, st);
+    if (epi == BD_EPI_PARTIAL) return launch_one<NP, KW, MB, BD_EPI_PARTIAL, R, false, PIPE>(p, st);
+    if (epi == BD_EPI_BF16) return launch_one<NP, KW, MB, BD_EPI_BF16, R, RED, PIPE>(p, st);
+    if (epi == BD_EPI_F32) return launch_one<NP, KW, MB, BD_EPI_F32, R, RED, PIPE>(p, st);
+    return launch_one<NP, KW, MB, BD_EPI_SWIGLU, R, RED, PIPE>(p, st);
 }
 
 // A: fragment-major bf16, RB row-blocks (RB must be 1, 2 or a multiple of 4).  W: packed.  N % (32*NP) == 0, K % (64*KW) == 0.
-template <int NP, int KW, int MB, int R>
+template <int NP, int KW, int MB, int R, bool PIPE = false>
 static int launch_gemm(const GemmP& p, int epi, hipStream_t st) {
     if constexpr (NP * KW == 10 && KW == 1) return launch_gemm_r<NP, KW, MB, R, false>(p, epi, st);   // single-slice tiles only
-    else return (p.S > 1 && epi != BD_EPI_PARTIAL) ? launch_gemm_r<NP, KW, MB, R, true>(p, epi, st)
-                                                   : launch_gemm_r<NP, KW, MB, R, false>(p, epi, st);
+    else return (p.S > 1 && epi != BD_EPI_PARTIAL) ? launch_gemm_r<NP, KW, MB, R, true, PIPE>(p, epi, st)
+                                                   : launch_gemm_r<NP, KW, MB, R, false, PIPE>(p, epi, st);
 }
 
-// `nw_ring` = waves per workgroup (2, 4, 8, 10) + 16 * ring + 256 * (kw - 1): ring in {0 (=2), 3, 4} = stages of W/A a wave
-// keeps in flight, kw in {1, 2} = waves that share one 32-column panel and split each K stage (NP = waves / kw panels per tile).
+// `nw_ring` = waves per workgroup (2, 4, 8, 10) + 16 * ring + 256 * (kw - 1) + 2048 * pipe: ring in {0 (=2), 3, 4} = stages of
+// W/A a wave keeps in flight, kw in {1, 2} = waves that share one 32-column panel and split each K stage (NP = waves / kw
+// panels per tile), pipe = LDS reads one stage ahead of the MFMAs (falls back to the plain loop where not instantiated).
 int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_ring, int epi,
              float* out_partial, void* out_act, const void* bias, int* cnt, hipStream_t st) {
     const int nw = nw_ring & 15;
     int ring = (nw_ring >> 4) & 15;
     const int kw = ((nw_ring >> 8) & 3) + 1;
+    const bool pipe = (nw_ring >> 11) & 1;             // + 2048: software-pipelined LDS reads (4-wave workgroups, ring 2)
     if (ring == 0) ring = 2;
     if (ring < 2 || ring > 4 || kw > 2 || nw % kw) return -7;
     const int np = nw / kw;
@@ -593,6 +653,9 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
     static const bool wide = [] { const char* e = getenv("BD_GEMM_WIDE"); return !(e && e[0] == '0'); }();
     if (wide && MB == 8 && nw == 8 && epi != BD_EPI_F32 && !(S > 1 && epi != BD_EPI_PARTIAL)) return launch_gemm_wide(p, epi, st);
 #define BD_CASE(NPV, KWV, MBV, RV) if (np == NPV && kw == KWV && MB == MBV && ring == RV) return launch_gemm<NPV, KWV, MBV, RV>(p, epi, st);
+#define BD_CASE_PIPE(NPV, KWV, MBV) if (pipe && np == NPV && kw == KWV && MB == MBV) return launch_gemm<NPV, KWV, MBV, 2, true>(p, epi, st);
+    BD_CASE_PIPE(4, 1, 4) BD_CASE_PIPE(2, 1, 4) BD_CASE_PIPE(2, 2, 4) BD_CASE_PIPE(4, 1, 2) BD_CASE_PIPE(4, 1, 1)
+#undef BD_CASE_PIPE
     if (MB <= 2 && ring == 3) ring = 4;
     if (MB == 1) ring = 2;
     BD_CASE(4, 1, 8, 2) BD_CASE(8, 1, 8, 2) BD_CASE(10, 1, 4, 2)

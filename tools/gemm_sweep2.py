@@ -45,30 +45,36 @@ def main():
         for nw, kw, S, form in CANDS[name]:
             if N % (32 * nw // kw) or K % (64 * kw):
                 continue
-            code = nw + 32 + 256 * (kw - 1)
-
-            def launch(i):
-                if form == "p":
-                    return lib().bd_gemm_partial(xf.data_ptr(), RB, wps[i % rot].data_ptr(), N, K, S, code, scratch.data_ptr(), st)
-                return lib().bd_gemm_bf16(xf.data_ptr(), RB, wps[i % rot].data_ptr(), None, N, K, S, code, scratch.data_ptr(),
-                                          cnt.data_ptr(), outb.data_ptr(), st)
-            if launch(0) != 0:
-                print(f"{name:9s} nw={nw} kw={kw} S={S} {form}: rejected ({lib().bd_last_error().decode()})")
-                continue
-            for i in range(3):
-                launch(i)
-            reps = 40
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for i in range(reps):
-                launch(i)
-            e1.record()
-            e1.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / reps
-            blocks = N // (32 * nw // kw) * S
-            print(f"{name:9s} N={N:6d} K={K:6d} waves={nw:2d} kparts={kw} S={S:2d} {'slabs' if form == 'p' else 'reduced'} blocks={blocks:4d} "
-                  f"{us:7.1f} us {N * K * 2 / us / 1e3:6.0f} GB/s", flush=True)
+            for pipe in (0, 1):
+              if pipe and nw > 4:
+                  continue
+              code = nw + 32 + 256 * (kw - 1) + 2048 * pipe
+              bench_one(name, N, K, nw, kw, S, form, code, pipe, xf, wps, rot, scratch, outb, cnt, RB, st)
         del wps
+
+
+def bench_one(name, N, K, nw, kw, S, form, code, pipe, xf, wps, rot, scratch, outb, cnt, RB, st):
+    def launch(i):
+        if form == "p":
+            return lib().bd_gemm_partial(xf.data_ptr(), RB, wps[i % rot].data_ptr(), N, K, S, code, scratch.data_ptr(), st)
+        return lib().bd_gemm_bf16(xf.data_ptr(), RB, wps[i % rot].data_ptr(), None, N, K, S, code, scratch.data_ptr(),
+                                  cnt.data_ptr(), outb.data_ptr(), st)
+    if launch(0) != 0:
+        print(f"{name:9s} nw={nw} kw={kw} S={S} {form}: rejected ({lib().bd_last_error().decode()})")
+        return
+    for i in range(3):
+        launch(i)
+    reps = 40
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(reps):
+        launch(i)
+    e1.record()
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    blocks = N // (32 * nw // kw) * S
+    print(f"{name:9s} N={N:6d} K={K:6d} waves={nw:2d} kparts={kw} pipe={pipe} S={S:2d} {'slabs' if form == 'p' else 'reduced'} blocks={blocks:4d} "
+          f"{us:7.1f} us {N * K * 2 / us / 1e3:6.0f} GB/s", flush=True)
 
 
 if __name__ == "__main__":
