@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="imagenet: skip the conv decoder (MIOpen) in the timed pass")
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: streamed Linear weights as e4m3 + per-channel scales (BASELINE config 5; a separate precision mode)")
     ap.add_argument("--tune", default="", help="comma list name.S=4,name.nw=2,kw2=0 overriding GEMM launch configs")
     a = ap.parse_args()
     if a.workload is None:
@@ -243,7 +245,9 @@ def main():
         from bitdance_amd.tp import TPComm
         rows_max = 2 * num_images * 64
         comm = TPComm.from_process_group(max(rows_max, 128) * 5120, device=dev)
-    pipe = syn.build_pipeline(size, dev, with_ae=True, tp=comm)
+    pipe = syn.build_pipeline(size, dev, with_ae=True, tp=comm, weights=args.weights)
+    if args.weights == "fp8":
+        metric += " (fp8-e4m3 weights)"
     pipe.tune = tune or None
     pipe.use_graph = not args.no_graph
     if rank == 0:
@@ -287,7 +291,8 @@ def main():
         out = {
             "metric": metric, "value": round(images / dt, 5), "unit": "images/s", "n_gpus": n, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "strong" if tp_mode else "weak", "vs_baseline": None, "dtype": "bf16",
+            "scaling": "strong" if tp_mode else "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.weights == "bf16" else "bf16 activations / fp32 accumulate, fp8-e4m3 weights (per-channel scales)",
             "data": "synthetic (random weights at true shapes, fixed token ids)",
             "config": {"workload": f"BitDance-{size.upper()} T2I {H}x{W}, {n_sampling} sampling steps, cfg {guidance}, "
                                    f"num_images={num_images} per {'job' if tp_mode else 'GPU'}" if size != "tiny" else "tiny",

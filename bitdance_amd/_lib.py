@@ -33,6 +33,10 @@ _PROTOS = {
                              C.c_void_p, C.c_void_p, C.c_void_p]),
     "bd_gemm_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                             C.c_void_p, C.c_void_p]),
+    "bd_pack_weight8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "bd_pack_weight8_swiglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "bd_gemm_w8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bd_gemm_swiglu": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bd_ctx_create": (C.c_void_p, []),
     "bd_ctx_destroy": (None, [C.c_void_p]),

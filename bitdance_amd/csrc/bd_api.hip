@@ -49,6 +49,7 @@ struct bd_ctx {
     bool has_head = false, has_llm = false, has_proj = false;
     // tensor parallelism: weights arrive pre-sliced (engine.py); every dim below with an `l` suffix is this rank's
     bd_comm* comm = nullptr;
+    bool wfp8 = false;                    // "wdtype" = 1: every streamed weight is fp8-e4m3 + "<key>_s" scales (bd_gemm8.hip)
     int tp = 1, tpr = 0;
     int hDl = 0, hHl = 0, lnhl = 0, lnkvl = 0, lFl = 0;
 
@@ -126,7 +127,7 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
 }
 
 static const char* const kIntKeys[] = {
-    "B", "branches", "P", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid",
+    "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
     "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.ada_async"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
@@ -161,8 +162,11 @@ static bool known_ptr_key(const std::string& k) {
         for (const char* f : fields) if (k.compare(i + 1, std::string::npos, f) == 0) return true;
         return false;
     };
-    return indexed("head.blk", {"ln1_w", "ln1_b", "ln2_w", "ln2_b", "wqkv", "bqkv", "wo", "bo", "w1", "b1", "w2", "b2"}) ||
-           indexed("llm.l", {"in_norm", "post_norm", "q_norm", "k_norm", "wqkv", "wo", "wgu", "wdown"});
+    for (const char* n : {"head.cond_w_s", "head.ada_w_s", "proj.w2_s"}) if (k == n) return true;      // fp8 scales
+    return indexed("head.blk", {"ln1_w", "ln1_b", "ln2_w", "ln2_b", "wqkv", "bqkv", "wo", "bo", "w1", "b1", "w2", "b2",
+                                "wqkv_s", "wo_s", "w1_s", "w2_s"}) ||
+           indexed("llm.l", {"in_norm", "post_norm", "q_norm", "k_norm", "wqkv", "wo", "wgu", "wdown",
+                             "wqkv_s", "wo_s", "wgu_s", "wdown_s"});
 }
 
 extern "C" {
@@ -215,6 +219,25 @@ int bd_gemm_bf16(const void* a, int RB, const void* w, const void* bias, int N, 
 int bd_gemm_f32(const void* a, int RB, const void* w, int N, int K, int S, int nw, float* scratch, int* counters, float* out_f32,
                 void* stream) {
     BD_TRY(bdk_gemm(a, RB, w, N, K, S, nw, BD_EPI_F32, scratch, out_f32, nullptr, counters, (hipStream_t)stream));
+    return 0;
+}
+int bd_pack_weight8(void* dst, const void* src_fp8, int rows, int K, int dst_row0, int dst_rows_total, void* stream) {
+    if (rows % 32 || dst_row0 % 32 || dst_rows_total % 32 || dst_row0 + rows > dst_rows_total)
+        return fail("bd_pack_weight8: rows, dst_row0, dst_rows_total must be multiples of 32 and nest");
+    BD_TRY(bdk_pack_w8(dst, src_fp8, nullptr, rows / 32, K, dst_row0 / 32, dst_rows_total / 32, 0, (hipStream_t)stream));
+    return 0;
+}
+int bd_pack_weight8_swiglu(void* dst, const void* gate_fp8, const void* up_fp8, int F, int K, void* stream) {
+    if (F % 16) return fail("bd_pack_weight8_swiglu: F must be a multiple of 16");
+    BD_TRY(bdk_pack_w8(dst, gate_fp8, up_fp8, F / 16, K, 0, F / 16, 1, (hipStream_t)stream));
+    return 0;
+}
+int bd_gemm_w8(const void* a, int RB, const void* w8, const float* wscale, const void* bias, int N, int K, int S, int nw, int epi,
+               float* scratch, int* counters, void* out, void* stream) {
+    if (!wscale) return fail("bd_gemm_w8: scales required");
+    if (epi < 0 || epi > 3) return fail("bd_gemm_w8: epi 0 = fp32 slabs, 1 = SwiGLU, 2 = bf16(+bias), 3 = fp32 sum");
+    BD_TRY(bdk_gemm(a, RB, w8, N, K, S, nw, epi, epi == BD_EPI_PARTIAL ? (float*)out : scratch, epi == BD_EPI_PARTIAL ? nullptr : out,
+                    bias, counters, (hipStream_t)stream, wscale));
     return 0;
 }
 int bd_gemm_swiglu(const void* a, int RB, const void* w, const void* bias, int N2, int K, int nw, void* act, void* stream) {
@@ -271,6 +294,7 @@ int bd_ctx_finalize(bd_ctx* c) {
         c->has_head = c->I.count("head.D") > 0;
         c->has_llm = c->I.count("llm.D") > 0;
         c->has_proj = c->I.count("proj.D") > 0;
+        c->wfp8 = c->geti("wdtype", 0) == 1;
         // the step state has 16 per-sequence KV-length slots: a limit of the Qwen3 decode path only (prompts differ in
         // length); head-only contexts read just the step counter, imagenet sequences all share slot 0
         if (c->branches * c->B > 16 && c->has_llm && c->geti("llm.variant", 0) == 0)
@@ -404,16 +428,24 @@ int bd_head_set_schedule(bd_ctx* c, int n_steps, const float* s, float cfg) {
 // ------------------------------------------------------------------------------------------------
 // every weight-streaming GEMM of the step goes through here; with profiling on (eager mode only) each launch is
 // bracketed by HIP events on the launch stream so bench.py can report in-situ per-launch durations.
-static int gemm(bd_ctx* c, const char* name, const void* A, int RB, const void* W, int N, int K, int S, int nw, int epi,
+// a streamed weight: packed bf16, or packed fp8-e4m3 + per-output-channel fp32 scales ("<key>_s") when the context is fp8
+struct WRef { const void* w; const float* s; };
+static WRef wref(const bd_ctx* c, const std::string& key) {
+    WRef r{c->ptr(key), nullptr};
+    if (c->wfp8) r.s = (const float*)c->ptr(key + "_s");
+    return r;
+}
+
+static int gemm(bd_ctx* c, const char* name, const void* A, int RB, WRef W, int N, int K, int S, int nw, int epi,
                 float* out, void* act, const void* bias, hipStream_t st) {
     bd_ctx::ProfRec r;
     if (c->prof_on) {
-        r.name = name; r.bytes = (double)N * K * 2;
+        r.name = name; r.bytes = (double)N * K * (W.s ? 1 : 2);
         hipEventCreate(&r.e0); hipEventCreate(&r.e1);
         hipEventRecord(r.e0, st);
     }
     int* cnt = (epi != BD_EPI_PARTIAL && S > 1) ? (int*)c->wptr("gemm.cnt") : nullptr;   // in-launch reduction tickets
-    const int rc = bdk_gemm(A, RB, W, N, K, S, nw, epi, out, act, bias, cnt, st);
+    const int rc = bdk_gemm(A, RB, W.w, N, K, S, nw, epi, out, act, bias, cnt, st, W.s);
     if (c->prof_on) { hipEventRecord(r.e1, st); c->prof.push_back(r); }
     return rc;
 }
@@ -429,7 +461,7 @@ static Partial done(const bd_ctx* c, const std::string& ws, int N, int Mpad) {  
 // A Linear whose output the consumer reads as bf16(sum + bias).  Few K-slices: the GEMM reduces them in the launch
 // (last-arriver epilogue) and the consumer reads one bf16 tensor.  Many K-slices: the serial tail of a single reducing
 // workgroup (S x 64-128 KiB through one CU) costs more than it saves, so the slabs stay and the consumer sums them.
-static int linear(bd_ctx* c, const char* name, const void* A, int RB, const void* W, int N, int K, const GemmCfg& g,
+static int linear(bd_ctx* c, const char* name, const void* A, int RB, WRef W, int N, int K, const GemmCfg& g,
                   const char* scratch_ws, const char* out_ws, const void* bias, int Mpad, Partial* res, hipStream_t st,
                   bool force_reduce = false) {
     // 256-row passes run the 4-wave x 2-panel kernel, which has no in-launch reduction: slabs for the consumer there
@@ -447,7 +479,7 @@ static int linear(bd_ctx* c, const char* name, const void* A, int RB, const void
 // A ROW-split Linear under tensor parallelism (wo / w2 / o_proj / down_proj): this rank multiplies its K-slice into ONE
 // finished fp32 partial (grid slices, if any, reduced inside the launch), then the exchange kernel sums the ranks' partials,
 // adds the bias and rounds once (bd_comm.hip).  With one rank it is the plain Linear above.
-static int linear_rowsplit(bd_ctx* c, const char* name, const void* A, int RB, const void* W, int N, int Klocal, const GemmCfg& g,
+static int linear_rowsplit(bd_ctx* c, const char* name, const void* A, int RB, WRef W, int N, int Klocal, const GemmCfg& g,
                            const char* scratch_ws, const char* out_ws, const char* tp_ws, const void* bias, int Mpad, int rows,
                            Partial* res, hipStream_t st) {
     if (c->tp <= 1) return linear(c, name, A, RB, W, N, Klocal, g, scratch_ws, out_ws, bias, Mpad, res, st);
@@ -460,7 +492,7 @@ static int linear_rowsplit(bd_ctx* c, const char* name, const void* A, int RB, c
 static int head_cond(bd_ctx* c, hipStream_t st) {   // cond_embed(c) is constant over the N+1 evals of this AR step
     const GemmCfg& g = c->cfg("head.cond");
     Partial unused;
-    BD_TRY(linear(c, "head.cond", c->ptr("head.cond_frag"), c->RB, c->ptr("head.cond_w"), c->hD, c->hDz, g, "head.cond_part",
+    BD_TRY(linear(c, "head.cond", c->ptr("head.cond_frag"), c->RB, wref(c, "head.cond_w"), c->hD, c->hDz, g, "head.cond_part",
                   "head.cemb", c->ptr("head.cond_b"), c->Mpad, &unused, st, /*force_reduce=*/true));
     return 0;
 }
@@ -481,7 +513,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
     BD_TRY(bdk_head_prologue(pa, st));
 
     const GemmCfg& ga = c->cfg("head.ada");
-    BD_TRY(gemm(c, "head.ada", c->ptr("head.y_frag"), RB, c->ptr("head.ada_w"), c->hNada, D, 1, ga.code(), BD_EPI_BF16,
+    BD_TRY(gemm(c, "head.ada", c->ptr("head.y_frag"), RB, wref(c, "head.ada_w"), c->hNada, D, 1, ga.code(), BD_EPI_BF16,
                 nullptr, c->wptr("head.ada_bf"), c->ptr("head.ada_b"), st));
     const void* ada = c->ptr("head.ada_bf");
     const int sw = c->hNB / c->hNA;
@@ -500,12 +532,12 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
         l1.h_frag = c->wptr("head.h_frag"); l1.M = M; l1.D = D; l1.RB = RB; l1.eps = 1e-6f;
         BD_TRY(bdk_ln_mod(l1, st));
         HeadAttnArgs at;
-        BD_TRY(linear(c, "head.qkv", c->ptr("head.h_frag"), RB, c->ptr(pre + "wqkv"), 3 * Dl, D, gq, "head.qkv_part", "head.qkv_bf",
+        BD_TRY(linear(c, "head.qkv", c->ptr("head.h_frag"), RB, wref(c, pre + "wqkv"), 3 * Dl, D, gq, "head.qkv_part", "head.qkv_bf",
                       c->ptr(pre + "bqkv"), Mp, &at.qkv, st));
         at.o_frag = c->wptr("head.attn_frag"); at.nseq = M / c->Pn; at.dh = (int)c->geti("head.dh", 128); at.nhead = Dl / at.dh; at.D = Dl; at.RB = RB; at.P = c->Pn;
         BD_TRY(bdk_head_attn(at, st));
         LnModArgs l2 = l1;
-        BD_TRY(linear_rowsplit(c, "head.wo", c->ptr("head.attn_frag"), RB, c->ptr(pre + "wo"), D, Dl, go, "head.br_part", "head.br_bf",
+        BD_TRY(linear_rowsplit(c, "head.wo", c->ptr("head.attn_frag"), RB, wref(c, pre + "wo"), D, Dl, go, "head.br_part", "head.br_bf",
                                "head.tp_part", c->ptr(pre + "bo"), Mp, M, &l2.pend, st));
         l2.gate_off = base + 2 * D; l2.scale_off = base + 3 * D; l2.shift_off = base + 4 * D;
         l2.ln_w = (const float*)c->ptr(pre + "ln2_w"); l2.ln_b = (const float*)c->ptr(pre + "ln2_b");
@@ -514,17 +546,17 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
         // operand: 46.9 + 22.9 us (w1 + w2) against 40.8 + 9.5 + 26.0 us for slabs + swiglu_rows on the same MI355X
         // (tune.w1_fused = 0 selects the latter).
         if (g1.S == 1 || c->geti("tune.w1_fused", (c->Mpad % 256 == 0) ? 0 : 1)) {
-            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * Hl, D, g1.S, g1.code(), BD_EPI_SWIGLU,
+            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, wref(c, pre + "w1"), 2 * Hl, D, g1.S, g1.code(), BD_EPI_SWIGLU,
                         (float*)c->wptr("head.w1_part"), c->wptr("head.act_frag"), c->ptr(pre + "b1"), st));
         } else {
-            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, c->ptr(pre + "w1"), 2 * Hl, D, g1.S, g1.code(), BD_EPI_PARTIAL,
+            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, wref(c, pre + "w1"), 2 * Hl, D, g1.S, g1.code(), BD_EPI_PARTIAL,
                         (float*)c->wptr("head.w1_part"), nullptr, nullptr, st));
             SwigluArgs sw_;
             sw_.up = part(c, "head.w1_part", c->ptr(pre + "b1"), g1.S, 2 * Hl, Mp);
             sw_.act_frag = c->wptr("head.act_frag"); sw_.M = M; sw_.F = Hl; sw_.RB = RB; sw_.interleaved = 1;
             BD_TRY(bdk_swiglu_rows(sw_, st));
         }
-        BD_TRY(linear_rowsplit(c, "head.w2", c->ptr("head.act_frag"), RB, c->ptr(pre + "w2"), D, Hl, g2, "head.br_part", "head.br_bf",
+        BD_TRY(linear_rowsplit(c, "head.w2", c->ptr("head.act_frag"), RB, wref(c, pre + "w2"), D, Hl, g2, "head.br_part", "head.br_bf",
                                "head.tp_part", c->ptr(pre + "b2"), Mp, M, &br, st));
     }
     HeadFinalArgs fa;
@@ -567,7 +599,7 @@ static int projector_in(bd_ctx* c, hipStream_t st) {
     BD_TRY(bdk_in_proj_fc1(f1, st));
     const GemmCfg& g = c->cfg("proj.fc2");
     InRmsArgs e;
-    BD_TRY(linear(c, "proj.fc2", c->ptr("proj.h_frag"), c->RBp, c->ptr("proj.w2"), D, hid, g, "proj.part", "proj.out_bf",
+    BD_TRY(linear(c, "proj.fc2", c->ptr("proj.h_frag"), c->RBp, wref(c, "proj.w2"), D, hid, g, "proj.part", "proj.out_bf",
                   c->ptr("proj.b2"), c->BPpad, &e.pend, st));
     e.R = (float*)c->wptr("llm.R"); e.init_from_pend = 1; e.renorm_to_R = 1; e.w = (const float*)c->ptr("llm.emb_norm");
     e.a_frag = nullptr; e.hidden_out = nullptr; e.cond_frag = nullptr; e.pos = nullptr;
@@ -585,7 +617,7 @@ static int projector(bd_ctx* c, hipStream_t st) {
     BD_TRY(bdk_proj_fc1(f1, st));
     const GemmCfg& g = c->cfg("proj.fc2");
     Partial fc2;
-    BD_TRY(linear(c, "proj.fc2", c->ptr("proj.h_frag"), c->RBp, c->ptr("proj.w2"), D, D, g, "proj.part", "proj.out_bf",
+    BD_TRY(linear(c, "proj.fc2", c->ptr("proj.h_frag"), c->RBp, wref(c, "proj.w2"), D, D, g, "proj.part", "proj.out_bf",
                   c->ptr("proj.b2"), c->BPpad, &fc2, st));
     EmbedFinalizeArgs ef;
     ef.fc2 = fc2;
@@ -614,7 +646,7 @@ static int llm_step_in(bd_ctx* c, hipStream_t st) {
         r1.w = (const float*)c->ptr(pre + "in_norm");
         BD_TRY(bdk_in_rms(r1, st));
         InQkvPostArgs qa;
-        BD_TRY(linear(c, "llm.qkv", c->ptr("llm.a_frag"), RB, c->ptr(pre + "wqkv"), c->lNqkv, D, gq, "llm.qkv_part", "llm.qkv_bf",
+        BD_TRY(linear(c, "llm.qkv", c->ptr("llm.a_frag"), RB, wref(c, pre + "wqkv"), c->lNqkv, D, gq, "llm.qkv_part", "llm.qkv_bf",
                       nullptr, Mp, &qa.qkv, st));
         qa.rope = (const float*)c->ptr("llm.rope2d"); qa.q_out = c->wptr("llm.q");
         qa.k_cache = (bf16_t*)c->wptr("llm.k_cache") + l * layer_elems;
@@ -624,13 +656,13 @@ static int llm_step_in(bd_ctx* c, hipStream_t st) {
         InAttnArgs aa{c->ptr("llm.q"), qa.k_cache, qa.v_cache, c->wptr("llm.attn_frag"), state, nseq, c->Pn, nh, c->lLmax, RB};
         BD_TRY(bdk_in_attn(aa, st));
         InRmsArgs r2 = r1;
-        BD_TRY(linear(c, "llm.o", c->ptr("llm.attn_frag"), RB, c->ptr(pre + "wo"), D, D, go, "llm.br_part", "llm.br_bf",
+        BD_TRY(linear(c, "llm.o", c->ptr("llm.attn_frag"), RB, wref(c, pre + "wo"), D, D, go, "llm.br_part", "llm.br_bf",
                       nullptr, Mp, &r2.pend, st));
         r2.w = (const float*)c->ptr(pre + "post_norm");
         BD_TRY(bdk_in_rms(r2, st));
-        BD_TRY(gemm(c, "llm.gu", c->ptr("llm.a_frag"), RB, c->ptr(pre + "wgu"), 2 * F, D, gg.S, gg.code(), BD_EPI_SWIGLU,
+        BD_TRY(gemm(c, "llm.gu", c->ptr("llm.a_frag"), RB, wref(c, pre + "wgu"), 2 * F, D, gg.S, gg.code(), BD_EPI_SWIGLU,
                     (float*)c->wptr("llm.gu_part"), c->wptr("llm.act_frag"), nullptr, st));
-        BD_TRY(linear(c, "llm.down", c->ptr("llm.act_frag"), RB, c->ptr(pre + "wdown"), D, F, gd, "llm.br_part", "llm.br_bf",
+        BD_TRY(linear(c, "llm.down", c->ptr("llm.act_frag"), RB, wref(c, pre + "wdown"), D, F, gd, "llm.br_part", "llm.br_bf",
                       nullptr, Mp, &br, st));
     }
     StepAdvanceArgs sa{state, nseq < 16 ? nseq : 16, c->Pn};
@@ -666,7 +698,7 @@ static int llm_step(bd_ctx* c, hipStream_t st) {
         BD_TRY(bdk_rms(r1, st));
 
         QkvPostArgs qa;
-        BD_TRY(linear(c, "llm.qkv", c->ptr("llm.a_frag"), RB, c->ptr(pre + "wqkv"), c->lNqkv, D, gq, "llm.qkv_part", "llm.qkv_bf",
+        BD_TRY(linear(c, "llm.qkv", c->ptr("llm.a_frag"), RB, wref(c, pre + "wqkv"), c->lNqkv, D, gq, "llm.qkv_part", "llm.qkv_bf",
                       nullptr, Mp, &qa.qkv, st));
         qa.qn_w = c->ptr(pre + "q_norm"); qa.kn_w = c->ptr(pre + "k_norm");
         qa.cos = (const float*)c->ptr("llm.cos"); qa.sin = (const float*)c->ptr("llm.sin");
@@ -683,13 +715,13 @@ static int llm_step(bd_ctx* c, hipStream_t st) {
         BD_TRY(bdk_llm_attn(aa, st));
 
         RmsArgs r2 = r1;
-        BD_TRY(linear_rowsplit(c, "llm.o", c->ptr("llm.attn_frag"), RB, c->ptr(pre + "wo"), D, nh * 128, go, "llm.br_part", "llm.br_bf",
+        BD_TRY(linear_rowsplit(c, "llm.o", c->ptr("llm.attn_frag"), RB, wref(c, pre + "wo"), D, nh * 128, go, "llm.br_part", "llm.br_bf",
                                "llm.tp_part", nullptr, Mp, M, &r2.pend, st));
         r2.w = c->ptr(pre + "post_norm");
         BD_TRY(bdk_rms(r2, st));
-        BD_TRY(gemm(c, "llm.gu", c->ptr("llm.a_frag"), RB, c->ptr(pre + "wgu"), 2 * F, D, gg.S, gg.code(), BD_EPI_SWIGLU,
+        BD_TRY(gemm(c, "llm.gu", c->ptr("llm.a_frag"), RB, wref(c, pre + "wgu"), 2 * F, D, gg.S, gg.code(), BD_EPI_SWIGLU,
                         (float*)c->wptr("llm.gu_part"), c->wptr("llm.act_frag"), nullptr, st));
-        BD_TRY(linear_rowsplit(c, "llm.down", c->ptr("llm.act_frag"), RB, c->ptr(pre + "wdown"), D, F, gd, "llm.br_part", "llm.br_bf",
+        BD_TRY(linear_rowsplit(c, "llm.down", c->ptr("llm.act_frag"), RB, wref(c, pre + "wdown"), D, F, gd, "llm.br_part", "llm.br_bf",
                                "llm.tp_part", nullptr, Mp, M, &br, st));
     }
     StepAdvanceArgs sa{state, nseq, c->Pn};

@@ -17,17 +17,7 @@
 //    to fp32 slabs that the consumer row-kernels reduce in their prologue (bd_rows.hip) -- no extra launch.
 //  * fused SwiGLU epilogue (gate/up rows interleaved 16/16 inside each packed panel so the partner value is
 //    one cross-lane exchange away) writes the bf16 activation in fragment-major order for the next GEMM.
-#include <cstdlib>
-#include <type_traits>
-#include "bd_common.h"
-#include "bd_kernels.h"
-
-typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
-
-BD_DEV f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mfma_bf16x8, a),
-                                                   __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
-}
+#include "bd_gemm_kernel.h"
 
 // Packed-weight order in HBM.  0 = panel-major  [panel][K/64 stages][4 k-steps][64 lanes]: every wave walks its own
 // contiguous 32-column panel.  1 = stage-major [K/64 stages][panel][4 k-steps][64 lanes]: the waves of the whole grid,
@@ -84,336 +74,6 @@ __global__ void rows_to_afrag_kernel(bf16_t* __restrict__ dst, const float* __re
 // ---------------------------------------------------------------------------------------------------
 // the GEMM
 // ---------------------------------------------------------------------------------------------------
-struct GemmP {
-    const u32x4* A;      // fragment-major activations, RB row-blocks
-    const u32x4* W;      // packed weights
-    float* out;          // EPI_PARTIAL: [S][Mpad][N] fp32
-    bf16_t* act;         // EPI_SWIGLU : fragment-major bf16 [Mpad][N/2];  EPI_BF16: row-major bf16 [Mpad][N]
-    const bf16_t* bias;  // EPI_SWIGLU : [N] in PACKED row order (or null); EPI_BF16: [N] (or null)
-    int* cnt;            // EPI_BF16 / EPI_SWIGLU with S > 1: one arrival counter per output tile (zero between launches)
-    int RB, N, K, S, Mpad;
-    size_t PS, SS;       // packed-W strides in 16 B units: panel stride, 64-deep-K-stage stride
-};
-
-// R = depth of the per-wave W register ring = number of K stages a wave keeps in flight.  The A stage is
-// prefetched equally far ahead (R-1 register slots, then one ds_write into the double-buffered LDS tile): vmcnt retires
-// in order, so an A load issued late would force every older W load to complete with it.
-// hipcc's s_waitcnt placement is exact inside a straight-line body but drains the whole queue at the first use after
-// a loop back-edge; U (8 or 12) phases per iteration make that one drain in U.
-// NP x KW waves per workgroup: NP 32-column panels, each streamed by KW waves that split every (64*KW)-deep K stage between
-// them (wave kg takes the kg-th 64-deep part) and add their accumulators through LDS at the end -- split-K INSIDE the
-// workgroup.  KW = 2 halves the tile width at the same number of waves and bytes in flight per CU, so the N = 15360 shapes
-// fill 240 CUs with no cross-workgroup split at all (no slabs, no tickets) and the N = 5120 shapes need 3 slices
-// instead of 6 (half the slab traffic, in-launch reduction applies).
-// PIPE: the LDS reads of stage j+1 are issued BEFORE the MFMAs of stage j (whose fragments were read one phase earlier), so
-// the matrix pipe never waits on ds_read latency and a phase costs max(MFMA, LDS, HBM) instead of their sum; the A tile of
-// stage j+2 is written over stage j's buffer in the same phase (its reads drained at the previous barrier).  One more A
-// stage of lookahead, 64 more VGPRs for the second fragment set (4-wave workgroups: one wave per SIMD, 512 registers).
-template <int NP, int KW, int MB, int EPI, int R, bool RED, bool PIPE = false>
-__global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
-    constexpr int NW = NP * KW, NT = NW * 64;
-    constexpr int UNITS = MB * 256 * KW;                  // 16 B units per (64*KW)-deep A stage
-    constexpr int XL = (UNITS + NT - 1) / NT;             // A loads per thread per stage
-    constexpr int XR = R - 1;                             // A register-ring slots
-    constexpr int U = (R == 2) ? 8 : 12;
-    static_assert(U % R == 0 && U % XR == 0 && U % 2 == 0, "static ring/buffer indices");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    u32x4* const lds = reinterpret_cast<u32x4*>(smem);    // two A-stage buffers of UNITS each
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pw = wave % NP, kg = wave / NP;              // panel / K-part of this wave
-    const int S = p.S;
-    const int s = blockIdx.x % S, nt = blockIdx.x / S, mt = blockIdx.y;
-    const int nb = nt * NP + pw;                           // panel of this wave
-    const int nst_total = p.K / (64 * KW);
-    const int q = (nst_total + S - 1) / S;
-    const int st0 = s * q;
-    const int nst = min(q, nst_total - st0);
-
-    const u32x4* Wp = p.W + (size_t)nb * p.PS + (size_t)(st0 * KW + kg) * p.SS + lane;
-    const size_t w_stage = p.SS * KW;
-    // A: unit u of a stage = chunk (ksl = (u>>6)/MB in [0, 4*KW), mb = (u>>6)%MB), lane u&63
-    size_t a_off[XL];
-#pragma unroll
-    for (int j = 0; j < XL; ++j) {
-        const int u = tid + j * NT;
-        const int c = u >> 6;
-        a_off[j] = (((size_t)(st0 * 4 * KW + c / MB) * p.RB) + mt * MB + (c % MB)) * 64 + (u & 63);
-    }
-    const size_t a_stage = (size_t)4 * KW * p.RB * 64;
-
-    u32x4 w[R][4], xr[XR][XL];
-    f32x16 acc[MB];
-#pragma unroll
-    for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-
-    auto load_w = [&](u32x4(&wr)[4], int i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wr[j] = __builtin_nontemporal_load(Wp + (size_t)i * w_stage + j * 64);
-    };
-    auto load_x = [&](u32x4(&x)[XL], int i) {
-#pragma unroll
-        for (int j = 0; j < XL; ++j)
-            if (UNITS % NT == 0 || tid + j * NT < UNITS) x[j] = p.A[a_off[j] + (size_t)i * a_stage];
-    };
-    auto store_x = [&](u32x4* buf, const u32x4(&x)[XL]) {
-#pragma unroll
-        for (int j = 0; j < XL; ++j)
-            if (UNITS % NT == 0 || tid + j * NT < UNITS) buf[tid + j * NT] = x[j];
-    };
-    // This wave's 64-deep part of the A stage goes LDS -> registers in one burst (16 ds_read_b128 for 128 rows), then the
-    // MFMAs issue back to back: with the reads interleaved two-at-a-time the matrix pipe idled on LDS latency (the loop
-    // was bound by the ds_read -> MFMA chain, not by HBM).
-    constexpr int KG = (MB <= 4 && NW <= 8) ? 4 : 1;      // k-steps whose A fragments are resident at once (VGPR budget)
-    auto compute = [&](const u32x4* stage, const u32x4(&wr)[4]) {
-        const u32x4* buf = stage + kg * MB * 256;
-#pragma unroll
-        for (int k0 = 0; k0 < 4; k0 += KG) {
-            u32x4 xf[KG][MB];
-#pragma unroll
-            for (int kk = 0; kk < KG; ++kk)
-#pragma unroll
-                for (int m = 0; m < MB; ++m) xf[kk][m] = buf[((k0 + kk) * MB + m) * 64 + lane];
-            if constexpr (KG > 1) __builtin_amdgcn_sched_barrier(0);   // keep the burst: hipcc otherwise re-interleaves 2 reads / 2 MFMAs
-#pragma unroll
-            for (int kk = 0; kk < KG; ++kk)
-#pragma unroll
-                for (int m = 0; m < MB; ++m) acc[m] = mfma32(xf[kk][m], wr[k0 + kk], acc[m]);
-        }
-    };
-
-  if constexpr (PIPE) {
-    static_assert(R == 2 && KG == 4, "pipelined loop: two W stages in flight, whole-stage fragment sets");
-    u32x4 xf[2][4][MB];
-    auto read_stage = [&](u32x4(&x)[4][MB], const u32x4* stage) {
-        const u32x4* buf = stage + kg * MB * 256;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int m = 0; m < MB; ++m) x[kk][m] = buf[(kk * MB + m) * 64 + lane];
-    };
-    auto mma_stage = [&](const u32x4(&x)[4][MB], const u32x4(&wr)[4]) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int m = 0; m < MB; ++m) acc[m] = mfma32(x[kk][m], wr[kk], acc[m]);
-    };
-    // prologue: A stages 0 and 1 in LDS, stage 2 in registers; W stages 0 and 1 in registers; fragments of stage 0 read
-    load_x(xr[0], 0);
-    load_w(w[0], 0);
-    store_x(lds, xr[0]);
-    if (1 < nst) { load_x(xr[0], 1); load_w(w[1], 1); store_x(lds + UNITS, xr[0]); }
-    if (2 < nst) load_x(xr[0], 2);
-    __syncthreads();
-    read_stage(xf[0], lds);
-    int i = 0;
-    for (; i + U + 2 < nst; i += U) {
-#pragma unroll
-        for (int ph = 0; ph < U; ++ph) {
-            read_stage(xf[(ph + 1) & 1], lds + ((ph + 1) & 1) * UNITS);       // stage j+1 (stored during phase ph-1)
-            __builtin_amdgcn_sched_barrier(0);
-            mma_stage(xf[ph & 1], w[ph & 1]);                                 // stage j
-            store_x(lds + (ph & 1) * UNITS, xr[0]);                           // stage j+2 over stage j's tile
-            load_x(xr[0], i + ph + 3);
-            load_w(w[ph & 1], i + ph + 2);
-            __syncthreads();
-        }
-    }
-#pragma unroll
-    for (int ph = 0; ph < U + 2; ++ph) {
-        const int j = i + ph;
-        if (j < nst) {
-            if (j + 1 < nst) read_stage(xf[(ph + 1) & 1], lds + ((ph + 1) & 1) * UNITS);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_stage(xf[ph & 1], w[ph & 1]);
-            if (j + 2 < nst) {
-                store_x(lds + (ph & 1) * UNITS, xr[0]);
-                if (j + 3 < nst) load_x(xr[0], j + 3);
-                load_w(w[ph & 1], j + 2);
-            }
-            if (j + 1 < nst) __syncthreads();
-        }
-    }
-  } else {
-    // prologue: stages 0..R-1 of A and W in flight; stage q of A lives in ring slot q % XR
-    load_x(xr[0], 0);
-    load_w(w[0], 0);
-    store_x(lds, xr[0]);
-#pragma unroll
-    for (int r = 1; r < R; ++r)
-        if (r < nst) { load_x(xr[r % XR], r); load_w(w[r], r); }
-    __syncthreads();
-
-    int i = 0;
-    // steady state: stage j = i + ph; every ring / buffer index below is a compile-time constant
-    for (; i + U + R - 1 < nst; i += U) {
-#pragma unroll
-        for (int ph = 0; ph < U; ++ph) {
-            compute(lds + (ph & 1) * UNITS, w[ph % R]);
-            store_x(lds + ((ph + 1) & 1) * UNITS, xr[(ph + 1) % XR]);
-            load_x(xr[(ph + 1) % XR], i + ph + R);          // same slot: (ph + R) % XR == (ph + 1) % XR
-            load_w(w[ph % R], i + ph + R);
-            __syncthreads();
-        }
-    }
-    // tail: at most U + R - 1 stages, guarded (block-uniform conditions)
-#pragma unroll
-    for (int ph = 0; ph < U + R - 1; ++ph) {
-        const int j = i + ph;
-        if (j < nst) {
-            compute(lds + (ph & 1) * UNITS, w[ph % R]);
-            if (j + 1 < nst) {
-                store_x(lds + ((ph + 1) & 1) * UNITS, xr[(ph + 1) % XR]);
-                if (j + R < nst) { load_x(xr[(ph + 1) % XR], j + R); load_w(w[ph % R], j + R); }
-                __syncthreads();
-            }
-        }
-    }
-  }
-
-    // ---- K parts of one panel meet in LDS: parts 1..KW-1 park their accumulators, part 0 adds them in order
-    if constexpr (KW > 1) {
-        __syncthreads();                                                  // every wave is done with the A tiles
-        f32x4* const red = reinterpret_cast<f32x4*>(smem);                // [(kg-1)*NP + pw][m][r4][lane]: lane-linear 16 B
-        if (kg > 0) {
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4)
-                    red[((((kg - 1) * NP + pw) * MB + m) * 4 + r4) * 64 + lane] =
-                        (f32x4){acc[m][4 * r4], acc[m][4 * r4 + 1], acc[m][4 * r4 + 2], acc[m][4 * r4 + 3]};
-        }
-        __syncthreads();
-        if (kg == 0) {
-#pragma unroll
-            for (int g = 1; g < KW; ++g)
-#pragma unroll
-                for (int m = 0; m < MB; ++m)
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        const f32x4 v = red[((((g - 1) * NP + pw) * MB + m) * 4 + r4) * 64 + lane];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[m][4 * r4 + j] += v[j];
-                    }
-        }
-    }
-    const bool owner = (kg == 0);                                          // the wave that holds the tile's sums
-
-    // ---- epilogue.  D layout of the 32x32 MFMA: lane -> column (lane&31), reg r -> row (r&3)+8(r>>2)+4(lane>>5)
-    const int col = nb * 32 + (lane & 31);
-    const float bias_col = ((EPI == BD_EPI_BF16 || EPI == BD_EPI_SWIGLU) && p.bias) ? bf2f(p.bias[col]) : 0.f;
-    auto finalize = [&](int m) {
-        const f32x16& a = acc[m];
-        if (EPI == BD_EPI_PARTIAL) {
-            float* o = p.out + ((size_t)s * p.Mpad + (size_t)(mt * MB + m) * 32) * p.N + col;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = a[r];
-        } else if (EPI == BD_EPI_F32) {    // the finished fp32 sum (no bias, no rounding): one rank's partial of a row-split Linear
-            float* o = reinterpret_cast<float*>(p.act) + (size_t)(mt * MB + m) * 32 * p.N + col;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = a[r];
-        } else if (EPI == BD_EPI_BF16) {   // Linear output rounded once to bf16 (what autocast's F.linear returns)
-            bf16_t* o = p.act + (size_t)(mt * MB + m) * 32 * p.N + col;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = f2bf(a[r] + bias_col);
-        } else {  // BD_EPI_SWIGLU: lanes (l&16)==0 hold gate feature f, lanes (l&16)!=0 the matching up feature
-            const int f = nb * 16 + (lane & 15);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = bfr(a[r] + bias_col);                     // Linear output rounded to bf16
-                const float other = __shfl_xor(v, 16);
-                if ((lane & 16) == 0) {
-                    const int row = (mt * MB + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    p.act[afrag_off(row, f, p.RB)] = f2bf(silu_bf(v) * other);   // silu -> bf16, product -> bf16
-                }
-            }
-        }
-    };
-    if constexpr (RED) {
-        // In-launch split-K reduction ("last arriver reduces"): every K-slice parks its fp32 slab and takes a ticket on
-        // the tile's counter; the slice that draws S-1 re-reads ALL slabs in slice order (a fixed summation order: the
-        // result does not depend on which slice happened to arrive last) and runs the real epilogue, so the consumers
-        // read ONE finished tensor instead of S fp32 slabs.
-        // The XCD L2s are not coherent with each other, so the slab traffic is agent-scope relaxed atomics: `sc1`
-        // write-through stores, drained by vmcnt(0) before the ticket, and `sc1` loads on the reducing side
-        // (MI355X_MICROARCH.md "publish-large": 3.0 vs 8.2 us for plain stores + release fence; the fence form also
-        // writes back / invalidates the whole L2 under the other workgroups' A-operand reuse).  This relies on gfx950's
-        // sc1 semantics (write-through to the memory side, L2-bypassing loads) rather than on a release/acquire edge of the
-        // memory model: the static_assert below keeps it from being compiled for any other target, and
-        // tests/test_gpu_parity.py::test_gemm_in_launch_splitk_reduction checks determinism and values on the hardware.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
-        static_assert(!RED, "the relaxed sc1 slab hand-off is validated for gfx950 only");
-#endif
-        float* o = p.out + ((size_t)s * p.Mpad + (size_t)mt * MB * 32) * p.N + col;
-        if (owner) {
-#pragma unroll
-            for (int m = 0; m < MB; ++m) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    __hip_atomic_store(o + (size_t)(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N, acc[m][r],
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_sched_barrier(0);                            // one row-block of addresses live at a time
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every storing wave drains its write-throughs
-        __syncthreads();                                                  // (also: all waves are done with the LDS tiles)
-        int* const flag = reinterpret_cast<int*>(smem);
-        int* const ticket = p.cnt + (mt * (p.N / (32 * NP)) + nt);
-        if (tid == 0) flag[0] = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (flag[0] != S - 1 || !owner) return;                           // not the last slice of this tile / nothing to store
-        if (S == 2) {
-            // two slices: own + other == other + own bit for bit, so the last arriver keeps its accumulators and
-            // fetches only the other slab, four row-blocks (64 loads per lane) in flight at once
-            const float* q2 = p.out + ((size_t)(1 - s) * p.Mpad + (size_t)mt * MB * 32) * p.N + col;
-            constexpr int MG = (NW >= 8) ? 1 : (MB < 4 ? MB : 4);     // 16 * MG loads per lane in flight (VGPR budget)
-#pragma unroll
-            for (int m0 = 0; m0 < MB; m0 += MG) {
-                float v[MG][16];
-#pragma unroll
-                for (int m = 0; m < MG; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        v[m][r] = __hip_atomic_load(q2 + (size_t)((m0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N,
-                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int m = 0; m < MG; ++m) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m0 + m][r] += v[m][r];
-                    finalize(m0 + m);
-                }
-            }
-            if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-            for (int s2 = 0; s2 < S; ++s2) {
-                const float* q2 = p.out + ((size_t)s2 * p.Mpad + (size_t)(mt * MB + m) * 32) * p.N + col;
-                float v[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    v[r] = __hip_atomic_load(q2 + (size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N,
-                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][r] += v[r];
-            }
-            finalize(m);                                                  // row-block by row-block: short live ranges
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
-        return;
-    }
-    if (owner) {
-#pragma unroll
-        for (int m = 0; m < MB; ++m) finalize(m);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------
 // 256-row passes (two images with CFG, or 4 as two row tiles): the matrix pipe, not HBM, is the scarce unit here
 // (256 FLOP per weight byte), so this variant is organised around keeping MFMAs issuing back to back:
@@ -592,43 +252,12 @@ static int launch_gemm_wide(const GemmP& p, int epi, hipStream_t st) {
     return bd_launch_status();
 }
 
-template <int NP, int KW, int MB, int EPI, int R, bool RED, bool PIPE = false>
-static int launch_one(const GemmP& p, hipStream_t st) {
-    const int ntiles = p.N / (32 * NP);
-    dim3 grid(ntiles * p.S, p.RB / MB);
-    // two A-stage buffers; with KW > 1 the same LDS is re-used for the accumulators of K parts 1..KW-1
-    constexpr size_t lds_a = (size_t)2 * MB * 256 * KW * 16, lds_r = (size_t)(KW - 1) * NP * MB * 4096;
-    constexpr size_t lds = lds_a > lds_r ? lds_a : lds_r;
-    if constexpr (lds > 64 * 1024) {                               // beyond 64 KiB of dynamic LDS needs the opt-in
-        static const bool ok = hipFuncSetAttribute((const void*)gemm_kernel<NP, KW, MB, EPI, R, RED, PIPE>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-        if (!ok) return -8;
-    }
-    BD_LAUNCH((gemm_kernel<NP, KW, MB, EPI, R, RED, PIPE>), grid, dim3(NP * KW * 64), lds, st, p);
-    return bd_launch_status();
-}
-
-template <int NP, int KW, int MB, int R, bool RED, bool PIPE = false>
-static int launch_gemm_r(const GemmP& p, int epi, hipStream_t st) {
-    if (epi == BD_EPI_PARTIAL) return launch_one<NP, KW, MB, BD_EPI_PARTIAL, R, false, PIPE>(p, st);
-    if (epi == BD_EPI_BF16) return launch_one<NP, KW, MB, BD_EPI_BF16, R, RED, PIPE>(p, st);
-    if (epi == BD_EPI_F32) return launch_one<NP, KW, MB, BD_EPI_F32, R, RED, PIPE>(p, st);
-    return launch_one<NP, KW, MB, BD_EPI_SWIGLU, R, RED, PIPE>(p, st);
-}
-
-// A: fragment-major bf16, RB row-blocks (RB must be 1, 2 or a multiple of 4).  W: packed.  N % (32*NP) == 0, K % (64*KW) == 0.
-template <int NP, int KW, int MB, int R, bool PIPE = false>
-static int launch_gemm(const GemmP& p, int epi, hipStream_t st) {
-    if constexpr (NP * KW == 10 && KW == 1) return launch_gemm_r<NP, KW, MB, R, false>(p, epi, st);   // single-slice tiles only
-    else return (p.S > 1 && epi != BD_EPI_PARTIAL) ? launch_gemm_r<NP, KW, MB, R, true, PIPE>(p, epi, st)
-                                                   : launch_gemm_r<NP, KW, MB, R, false, PIPE>(p, epi, st);
-}
-
 // `nw_ring` = waves per workgroup (2, 4, 8, 10) + 16 * ring + 256 * (kw - 1) + 2048 * pipe: ring in {0 (=2), 3, 4} = stages of
 // W/A a wave keeps in flight, kw in {1, 2} = waves that share one 32-column panel and split each K stage (NP = waves / kw
 // panels per tile), pipe = LDS reads one stage ahead of the MFMAs (falls back to the plain loop where not instantiated).
 int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_ring, int epi,
-             float* out_partial, void* out_act, const void* bias, int* cnt, hipStream_t st) {
+             float* out_partial, void* out_act, const void* bias, int* cnt, hipStream_t st, const float* wscale) {
+    if (wscale) return bdk_gemm8(A, RB, W, wscale, N, K, S, nw_ring, epi, out_partial, out_act, bias, cnt, st);   // fp8 weights: bd_gemm8.hip
     const int nw = nw_ring & 15;
     int ring = (nw_ring >> 4) & 15;
     const int kw = ((nw_ring >> 8) & 3) + 1;
@@ -642,7 +271,7 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
     if (epi != BD_EPI_PARTIAL && S != 1 && (out_partial == nullptr || cnt == nullptr || (nw == 10 && kw == 1))) return -4;   // needs slab scratch + counters
     size_t PS, SS;
     bdk_w_strides(N / 32, K, &PS, &SS);
-    GemmP p{(const u32x4*)A, (const u32x4*)W, out_partial, (bf16_t*)out_act, (const bf16_t*)bias, cnt, RB, N, K, S, RB * 32, PS, SS};
+    GemmP p{(const u32x4*)A, (const u32x4*)W, out_partial, (bf16_t*)out_act, (const bf16_t*)bias, cnt, nullptr, RB, N, K, S, RB * 32, PS, SS};
     // rows per pass over the weights: 256 (two images with CFG: W streamed once for both) when the row count allows,
     // else 128 / 64 / 32
     const int MB = (RB % 8 == 0 && nw >= 4 && kw == 1) ? 8 : ((RB % 4 == 0) ? 4 : RB);

@@ -16,8 +16,13 @@ static inline int bd_launch_status() { return hipGetLastError() == hipSuccess ? 
 struct BdStepState;
 
 // ---- bd_gemm.hip
+// wscale != nullptr: W holds fp8-e4m3 weights (bdk_pack_w8) with per-packed-row fp32 scales
 int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw, int epi,
-             float* out_partial, void* out_act, const void* bias, int* tile_counters, hipStream_t st);
+             float* out_partial, void* out_act, const void* bias, int* tile_counters, hipStream_t st, const float* wscale = nullptr);
+// ---- bd_gemm8.hip : the same GEMM on fp8-e4m3 weights
+int bdk_gemm8(const void* A, int RB, const void* W8, const float* wscale, int N, int K, int S, int nw, int epi,
+              float* out_partial, void* out_act, const void* bias, int* tile_counters, hipStream_t st);
+int bdk_pack_w8(void* dst, const void* src_fp8, const void* src2_fp8, int panels, int K, int nb0, int panels_total, int mode, hipStream_t st);
 int bdk_pack_w(void* dst, const void* src, const void* src2, int panels, int K, int nb0, int panels_total, int mode, hipStream_t st);
 void bdk_set_w_layout(int v);
 int bdk_get_w_layout();

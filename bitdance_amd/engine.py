@@ -51,8 +51,71 @@ def pack_swiglu(gate: torch.Tensor, up: torch.Tensor, device) -> torch.Tensor:
     return out
 
 
+FP8_MAX = 448.0                                      # largest finite OCP e4m3 value
+
+
+def quantize_rows_fp8(w: torch.Tensor):
+    """Per-output-channel symmetric quantisation to OCP e4m3: scale[n] = max|W[n, :]| / 448, q = fp8(W / scale).  Returns
+    (uint8 view of the fp8 bytes [N, K], fp32 scales [N]).  The scale is computed from the bf16 weight values in fp32."""
+    wf = w.detach().to(torch.bfloat16).float()
+    s = (wf.abs().amax(dim=1) / FP8_MAX).clamp_min(1e-12)
+    q = (wf / s[:, None]).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).contiguous(), s.contiguous()
+
+
+def pack_linear_fp8(ws: list[torch.Tensor], device):
+    """pack_linear for the fp8 weight path: (packed e4m3 bytes, fp32 scales [N]) (csrc/bd_gemm8.hip)."""
+    K = ws[0].shape[1]
+    n = sum(w.shape[0] for w in ws)
+    if K % 64 or any(w.shape[0] % 32 for w in ws):
+        raise BitDanceHipError(f"pack_linear_fp8: unsupported shape N={[w.shape[0] for w in ws]} K={K}")
+    out = torch.empty(n * K, dtype=torch.uint8, device=device)
+    scales = []
+    row = 0
+    for w in ws:
+        q, s_ = quantize_rows_fp8(w.to(device))
+        check(lib().bd_pack_weight8(out.data_ptr(), q.data_ptr(), q.shape[0], K, row, n, _stream()), "bd_pack_weight8")
+        scales.append(s_)
+        row += q.shape[0]
+    torch.cuda.current_stream().synchronize()
+    return out, torch.cat(scales).contiguous()
+
+
+def pack_swiglu_fp8(gate: torch.Tensor, up: torch.Tensor, device):
+    F_, K = gate.shape
+    if K % 64 or F_ % 32:
+        raise BitDanceHipError(f"pack_swiglu_fp8: unsupported shape F={F_} K={K}")
+    qg, sg = quantize_rows_fp8(gate.to(device))
+    qu, su = quantize_rows_fp8(up.to(device))
+    out = torch.empty(2 * F_ * K, dtype=torch.uint8, device=device)
+    check(lib().bd_pack_weight8_swiglu(out.data_ptr(), qg.data_ptr(), qu.data_ptr(), F_, K, _stream()), "bd_pack_weight8_swiglu")
+    torch.cuda.current_stream().synchronize()
+    scales = torch.stack([sg.view(-1, 16), su.view(-1, 16)], dim=1).reshape(-1).contiguous()      # packed row order
+    return out, scales
+
+
+def _put_linear(p: dict, key: str, ws: list, device, fp8: bool) -> None:
+    if fp8:
+        p[key], p[key + "_s"] = pack_linear_fp8(ws, device)
+    else:
+        p[key] = pack_linear(ws, device)
+
+
+def _put_swiglu(p: dict, key: str, gate, up, device, fp8: bool) -> None:
+    if fp8:
+        p[key], p[key + "_s"] = pack_swiglu_fp8(gate, up, device)
+    else:
+        p[key] = pack_swiglu(gate, up, device)
+
+
 def pack_swiglu_bias(bg: torch.Tensor, bu: torch.Tensor, device) -> torch.Tensor:
     return torch.stack([_bf16(bg, device).view(-1, 16), _bf16(bu, device).view(-1, 16)], dim=1).reshape(-1).contiguous()
+
+
+def _fp8_flag(weights: str) -> bool:
+    if weights not in ("bf16", "fp8"):
+        raise BitDanceHipError(f"weights must be 'bf16' or 'fp8', not {weights!r}")
+    return weights == "fp8"
 
 
 def row_blocks(m: int) -> int:
@@ -73,6 +136,7 @@ class HeadWeights:
     final_sigmoid: bool = True                      # 2*sigmoid(out)-1 (flow_head_parallel_x.py:342); imagenet head: identity
     ptrs: dict = field(default_factory=dict)        # name -> tensor (kept alive)
     tp_size: int = 1
+    wdtype: int = 0                                 # 1: fp8-e4m3 streamed weights
     time_w0: torch.Tensor = None
     time_b0: torch.Tensor = None
     time_w2: torch.Tensor = None
@@ -80,8 +144,10 @@ class HeadWeights:
 
     @staticmethod
     def from_state_dict(sd: dict, device, head_dim: int = 128, final_sigmoid: bool = True, tp_rank: int = 0,
-                        tp_size: int = 1) -> "HeadWeights":
-        """``tp_size`` > 1: pack this rank's slices (tp.shard_head_state); D / H below stay the FULL widths."""
+                        tp_size: int = 1, weights: str = "bf16") -> "HeadWeights":
+        """``tp_size`` > 1: pack this rank's slices (tp.shard_head_state); D / H below stay the FULL widths.
+        ``weights`` = "fp8": the streamed Linears (cond_embed, adaLN, wqkv, wo, w1, w2) are stored e4m3 + per-channel scales."""
+        fp8 = _fp8_flag(weights)
         if tp_size > 1:
             from .tp import shard_head_state
             sd = shard_head_state(sd, tp_rank, tp_size, head_dim)
@@ -97,28 +163,29 @@ class HeadWeights:
             raise BitDanceHipError(f"native head: head_dim {head_dim} unsupported for D={D}")
         hw = HeadWeights(D=D, C=C, Dz=Dz, H=H * tp_size, nblocks=nb, nada=na, head_dim=head_dim, final_sigmoid=final_sigmoid)
         hw.tp_size = tp_size
+        hw.wdtype = int(fp8)
         p = hw.ptrs
-        p["head.cond_w"] = pack_linear([g("net.cond_embed.weight")], device)
+        _put_linear(p, "head.cond_w", [g("net.cond_embed.weight")], device, fp8)
         p["head.cond_b"] = _bf16(g("net.cond_embed.bias"), device)
         p["head.in_w"] = _bf16(g("net.input_proj.weight"), device)
         p["head.in_b"] = _bf16(g("net.input_proj.bias"), device)
         ada_w = [g(f"net.ada_ln_blocks.{j}.weight") for j in range(na)] + [g("net.final_layer.ada_ln_modulation.weight")]
         ada_b = [g(f"net.ada_ln_blocks.{j}.bias") for j in range(na)] + [g("net.final_layer.ada_ln_modulation.bias")]
-        p["head.ada_w"] = pack_linear(ada_w, device)
+        _put_linear(p, "head.ada_w", ada_w, device, fp8)
         p["head.ada_b"] = torch.cat([_bf16(b, device) for b in ada_b]).contiguous()
         for i in range(nb):
             s, d = f"net.res_blocks.{i}.", f"head.blk{i}."
             for n in ("1", "2"):
                 p[d + f"ln{n}_w"] = g(s + f"norm{n}.weight").detach().to(device, torch.float32).contiguous()
                 p[d + f"ln{n}_b"] = g(s + f"norm{n}.bias").detach().to(device, torch.float32).contiguous()
-            p[d + "wqkv"] = pack_linear([g(s + "attn.wqkv.weight")], device)
+            _put_linear(p, d + "wqkv", [g(s + "attn.wqkv.weight")], device, fp8)
             p[d + "bqkv"] = _bf16(g(s + "attn.wqkv.bias"), device)
-            p[d + "wo"] = pack_linear([g(s + "attn.wo.weight")], device)
+            _put_linear(p, d + "wo", [g(s + "attn.wo.weight")], device, fp8)
             p[d + "bo"] = _bf16(g(s + "attn.wo.bias"), device)
             w1, b1 = g(s + "w1.weight"), g(s + "w1.bias")
-            p[d + "w1"] = pack_swiglu(w1[:H], w1[H:], device)
+            _put_swiglu(p, d + "w1", w1[:H], w1[H:], device, fp8)
             p[d + "b1"] = pack_swiglu_bias(b1[:H], b1[H:], device)
-            p[d + "w2"] = pack_linear([g(s + "w2.weight")], device)
+            _put_linear(p, d + "w2", [g(s + "w2.weight")], device, fp8)
             p[d + "b2"] = _bf16(g(s + "w2.bias"), device)
         p["head.lin_w"] = _bf16(g("net.final_layer.linear.weight"), device)
         p["head.lin_b"] = _bf16(g("net.final_layer.linear.bias"), device)
@@ -153,14 +220,16 @@ class ProjWeights:
     D: int
     C: int
     ptrs: dict = field(default_factory=dict)
+    wdtype: int = 0
 
     @staticmethod
-    def from_state_dict(sd: dict, device) -> "ProjWeights":
+    def from_state_dict(sd: dict, device, weights: str = "bf16") -> "ProjWeights":
         D, C_ = sd["fc1.weight"].shape
         pw = ProjWeights(D=D, C=C_)
+        pw.wdtype = int(_fp8_flag(weights))
         pw.ptrs["proj.w1"] = _bf16(sd["fc1.weight"], device)
         pw.ptrs["proj.b1"] = _bf16(sd["fc1.bias"], device)
-        pw.ptrs["proj.w2"] = pack_linear([sd["fc2.weight"]], device)
+        _put_linear(pw.ptrs, "proj.w2", [sd["fc2.weight"]], device, bool(pw.wdtype))
         pw.ptrs["proj.b2"] = _bf16(sd["fc2.bias"], device)
         return pw
 
@@ -177,26 +246,29 @@ class LlmWeights:
     sd: dict = field(default_factory=dict)          # original-layout bf16 tensors on device (prefill)
     tp_size: int = 1
     tp_rank: int = 0
+    wdtype: int = 0
 
     @staticmethod
     def from_state_dict(sd: dict, cfg: dict, device, keep_for_prefill: bool = True, tp_rank: int = 0,
-                        tp_size: int = 1) -> "LlmWeights":
+                        tp_size: int = 1, weights: str = "bf16") -> "LlmWeights":
         """``tp_size`` > 1: pack (and keep, for the prefill) this rank's slices (tp.shard_llm_state); ``cfg`` stays the full model's."""
         if tp_size > 1:
             from .tp import shard_llm_state
             sd = shard_llm_state(sd, cfg, tp_rank, tp_size)
         lw = LlmWeights(cfg=dict(cfg))
         lw.tp_size, lw.tp_rank = tp_size, tp_rank
+        fp8 = _fp8_flag(weights)
+        lw.wdtype = int(fp8)
         p = lw.ptrs
         if cfg["head_dim"] != 128:
             raise BitDanceHipError("native LLM path requires head_dim == 128 (Qwen3)")
         for i in range(cfg["num_hidden_layers"]):
             s, d = f"model.layers.{i}.", f"llm.l{i}."
             q, k, v = (sd[s + f"self_attn.{n}_proj.weight"] for n in "qkv")
-            p[d + "wqkv"] = pack_linear([q, k, v], device)
-            p[d + "wo"] = pack_linear([sd[s + "self_attn.o_proj.weight"]], device)
-            p[d + "wgu"] = pack_swiglu(sd[s + "mlp.gate_proj.weight"], sd[s + "mlp.up_proj.weight"], device)
-            p[d + "wdown"] = pack_linear([sd[s + "mlp.down_proj.weight"]], device)
+            _put_linear(p, d + "wqkv", [q, k, v], device, fp8)
+            _put_linear(p, d + "wo", [sd[s + "self_attn.o_proj.weight"]], device, fp8)
+            _put_swiglu(p, d + "wgu", sd[s + "mlp.gate_proj.weight"], sd[s + "mlp.up_proj.weight"], device, fp8)
+            _put_linear(p, d + "wdown", [sd[s + "mlp.down_proj.weight"]], device, fp8)
             p[d + "in_norm"] = _bf16(sd[s + "input_layernorm.weight"], device)
             p[d + "post_norm"] = _bf16(sd[s + "post_attention_layernorm.weight"], device)
             p[d + "q_norm"] = _bf16(sd[s + "self_attn.q_norm.weight"], device)
@@ -275,8 +347,12 @@ class Engine:
         self._keep: dict[str, torch.Tensor] = {}
         self._sched_key = None
         self._captured: set = set()
+        wd = {getattr(w, "wdtype", 0) for w in (head, proj, llm) if w is not None}
+        if len(wd) > 1:
+            raise BitDanceHipError("head / projector / LLM weights must all be bf16 or all be fp8")
+        self.wdtype = wd.pop() if wd else 0
         self.ctx = self.l.bd_ctx_create()
-        ints = {"B": self.B, "branches": self.branches, "P": self.P}
+        ints = {"B": self.B, "branches": self.branches, "P": self.P, "wdtype": self.wdtype}
         if head is not None:
             ints.update(head.ints())
             ints["head.T"] = max_tokens

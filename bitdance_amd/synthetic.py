@@ -182,7 +182,7 @@ class SyntheticTokenizer:
         raise KeyError(tok)
 
 
-def build_pipeline(size: str = "14b-64x", device: str = "cuda", with_ae: bool = True, tp=None):
+def build_pipeline(size: str = "14b-64x", device: str = "cuda", with_ae: bool = True, tp=None, weights: str = "bf16"):
     """A BitDanceT2IPipeline on random weights: ``14b-64x`` / ``14b-16x`` (BitDance-14B shapes) or ``tiny``.  ``tp``: a
     tp.TPComm -- every rank draws the SAME full model from the same seeds and keeps its slices."""
     from .t2i_pipeline import BitDanceT2IPipeline
@@ -199,5 +199,5 @@ def build_pipeline(size: str = "14b-64x", device: str = "cuda", with_ae: bool = 
         tokenizer=SyntheticTokenizer(lc["vocab_size"]), llm_cfg=lc, llm_sd=random_llm_state(lc, device),
         ae_config=ac, ae_sd=random_ae_state(ac, device) if with_ae else None, head_config=head_cfg,
         head_sd=random_head_state(hc, device), proj_sd=random_proj_state(hc["ch_target"], lc["hidden_size"], device),
-        device=device, tp=tp)
+        device=device, tp=tp, weights=weights)
     return pipe

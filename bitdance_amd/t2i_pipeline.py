@@ -80,21 +80,25 @@ def load_model_dir(model_path: str) -> dict:
 
 
 class BitDanceT2IPipeline:
-    def __init__(self, model_path, device="cuda", tp=None):
+    def __init__(self, model_path, device="cuda", tp=None, weights: str = "bf16"):
         """``tp``: a ``bitdance_amd.tp.TPComm`` -- this process is then one rank of a tensor-parallel group (every rank
         constructs the pipeline on its own GPU and makes the same calls with the same seed); None = one GPU."""
         self.device = device
-        self._init_from(**load_model_dir(model_path), device=device, tp=tp)
+        self._init_from(**load_model_dir(model_path), device=device, tp=tp, weights=weights)
 
     @classmethod
     def from_components(cls, *, tokenizer, llm_cfg, llm_sd, ae_config, ae_sd, head_config, head_sd, proj_sd,
-                        device="cuda", tp=None):
+                        device="cuda", tp=None, weights: str = "bf16"):
         """Same object from in-memory state dicts (tests, synthetic-weight benchmarks)."""
         self = object.__new__(cls)
-        self._init_from(tokenizer, llm_cfg, llm_sd, ae_config, ae_sd, head_config, head_sd, proj_sd, device, tp=tp)
+        self._init_from(tokenizer, llm_cfg, llm_sd, ae_config, ae_sd, head_config, head_sd, proj_sd, device, tp=tp, weights=weights)
         return self
 
-    def _init_from(self, tokenizer, llm_cfg, llm_sd, ae_config, ae_sd, head_config, head_sd, proj_sd, device, tp=None):
+    def _init_from(self, tokenizer, llm_cfg, llm_sd, ae_config, ae_sd, head_config, head_sd, proj_sd, device, tp=None,
+                   weights: str = "bf16"):
+        """``weights`` = "fp8": the streamed Linears are stored e4m3 + per-channel scales (a separate precision mode, BASELINE
+        config 5; the once-per-image prefill keeps bf16 copies)."""
+        self.weights = weights
         if not torch.cuda.is_available():
             raise RuntimeError("BitDanceT2IPipeline (bitdance_amd) needs a ROCm GPU; there is no CPU fallback")
         self.device = device
@@ -103,7 +107,7 @@ class BitDanceT2IPipeline:
         self.tokenizer = tokenizer
         self.llm_config = SimpleNamespace(**llm_cfg)
         self.hidden_size = llm_cfg["hidden_size"]
-        self.llm_w = LlmWeights.from_state_dict(llm_sd, llm_cfg, device, tp_rank=tpr, tp_size=tps)
+        self.llm_w = LlmWeights.from_state_dict(llm_sd, llm_cfg, device, tp_rank=tpr, tp_size=tps, weights=weights)
         self.ae_config = ae_config
         self.ae = VQModel(**ae_config).eval()
         if ae_sd is not None:
@@ -111,12 +115,12 @@ class BitDanceT2IPipeline:
         self.ae.to(device)
         self.vae_patch_size = 2 ** (len(ae_config["ddconfig"]["ch_mult"]) - 1)
         self.vision_head_config = head_config
-        self.head_w = HeadWeights.from_state_dict(head_sd, device, tp_rank=tpr, tp_size=tps)
+        self.head_w = HeadWeights.from_state_dict(head_sd, device, tp_rank=tpr, tp_size=tps, weights=weights)
         self.parallel_num = head_config["parallel_num"]
         if self.parallel_num not in (16, 64):
             raise NotImplementedError("the native path implements the 64x and 16x models (parallel_num 64 / 16)")
         self.ps = int(self.parallel_num ** 0.5)
-        self.proj_w = ProjWeights.from_state_dict(proj_sd, device)
+        self.proj_w = ProjWeights.from_state_dict(proj_sd, device, weights=weights)
         # the reference's operator seams (same attribute names), each backed by the native engine
         self.llm_model = SimpleNamespace(model=NativeQwen3Model(self))
         self.vision_head = NativeDiffHead(self)

@@ -48,6 +48,16 @@ int bd_gemm_f32(const void* a_frag, int row_blocks, const void* w_packed, int N,
 int bd_gemm_swiglu(const void* a_frag, int row_blocks, const void* w_packed_pairs, const void* bias_packed, int N2, int K,
                    int nwaves, void* act_frag, void* stream);
 
+/* ---- fp8-e4m3 weight storage (BASELINE config 5; a separate precision mode).  src: OCP e4m3 bytes [rows][K] row-major,
+ *      already divided by the per-output-channel scale; the GEMM converts to bf16 in registers and multiplies the fp32 scale
+ *      (wscale[N], packed row order) into the accumulator.  epi: 0 fp32 slabs [splitk][rows][N] into out, 1 fused SwiGLU
+ *      (out = activation fragments), 2 bf16(+bias), 3 finished fp32 sum.  Context form: int "wdtype" = 1 and a "<weight key>_s"
+ *      scale pointer next to every streamed weight. */
+int bd_pack_weight8(void* dst_packed, const void* src_fp8, int rows, int K, int dst_row0, int dst_rows_total, void* stream);
+int bd_pack_weight8_swiglu(void* dst_packed, const void* gate_fp8, const void* up_fp8, int F, int K, void* stream);
+int bd_gemm_w8(const void* a_frag, int row_blocks, const void* w8_packed, const float* wscale, const void* bias_bf16, int N, int K,
+               int splitk, int nwaves, int epi, float* scratch, int* counters, void* out, void* stream);
+
 /* ---- context: named ints / floats / device pointers, then finalize.  Keys are listed in DESIGN.md; an unknown key is an
  *      error (-1, text in bd_last_error()), never a silent default. */
 bd_ctx* bd_ctx_create(void);

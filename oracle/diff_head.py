@@ -36,9 +36,9 @@ def timestep_features(t: torch.Tensor, dim: int = 256, max_period: float = 10000
 def time_embed(w: dict, t: torch.Tensor, pol: Policy) -> torch.Tensor:
     """TimestepEmbedder.forward :140-143 (Linear -> SiLU -> Linear)."""
     f = timestep_features(t, w["net.time_embed.mlp.0.weight"].shape[1])
-    h = pol.linear(f, w["net.time_embed.mlp.0.weight"], w["net.time_embed.mlp.0.bias"])
+    h = pol.linear(f, w["net.time_embed.mlp.0.weight"], w["net.time_embed.mlp.0.bias"], quant=False)
     h = F.silu(h)
-    return pol.linear(h, w["net.time_embed.mlp.2.weight"], w["net.time_embed.mlp.2.bias"])
+    return pol.linear(h, w["net.time_embed.mlp.2.weight"], w["net.time_embed.mlp.2.bias"], quant=False)
 
 
 def attention(w: dict, pre: str, x: torch.Tensor, n_head: int, pol: Policy) -> torch.Tensor:
@@ -101,7 +101,7 @@ def net_forward(w: dict, x: torch.Tensor, t: torch.Tensor, c: torch.Tensor, pol:
     switch = max(1, n_blocks // n_ada)
     dim = w["net.input_proj.weight"].shape[0]
     n_head = dim // head_dim                  # TransBlock.__init__ :227 (128); imagenet diff_head_parallel.py:207 (64)
-    x = pol.linear(x, w["net.input_proj.weight"], w["net.input_proj.bias"])
+    x = pol.linear(x, w["net.input_proj.weight"], w["net.input_proj.bias"], quant=False)
     te = time_embed(w, t, pol).unsqueeze(1)
     ce = pol.linear(c, w["net.cond_embed.weight"], w["net.cond_embed.bias"])
     y = F.silu(te + ce)
@@ -118,7 +118,7 @@ def net_forward(w: dict, x: torch.Tensor, t: torch.Tensor, c: torch.Tensor, pol:
     scale, shift = pol.linear(y, w["net.final_layer.ada_ln_modulation.weight"],
                               w["net.final_layer.ada_ln_modulation.bias"]).chunk(2, dim=-1)
     h = pol.layer_norm(x, None, None, 1e-6) * (1.0 + scale) + shift
-    out = pol.linear(h, w["net.final_layer.linear.weight"], w["net.final_layer.linear.bias"])
+    out = pol.linear(h, w["net.final_layer.linear.weight"], w["net.final_layer.linear.bias"], quant=False)
     if not final_sigmoid:                     # imagenet variant, diff_head_parallel.py:310
         return out
     return 2 * torch.sigmoid(out) - 1

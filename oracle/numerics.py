@@ -14,6 +14,13 @@ rounding points are visible and run identically on any CPU:
                               in fp32 (autocast's fp32 list); everything else follows
                               normal type promotion of its operands.
 
+  * ``Policy("fp8w")``     -- the framework's own fp8 weight mode (BASELINE config 5; no counterpart in the reference):
+                              the autocast flow with the STREAMED Linear weights stored as OCP e4m3 with one fp32 scale per
+                              output channel (scale = max|row| / 448, computed from the bf16 weights): products of bf16
+                              activations with the exactly-converted e4m3 values accumulate in fp32, the scale multiplies
+                              the fp32 sum, then bias and the single bf16 rounding.  Small Linears the product keeps in bf16
+                              (time embedding, input_proj, final Linear, projector fc1) pass ``quant=False``.
+
 Elementwise bf16 ops on CPU tensors (compute in fp32, round to bf16) follow the same
 eager semantics as on the GPU, so the oracle keeps real ``torch.bfloat16`` tensors
 where the reference would and lets torch's type promotion do the rest.
@@ -29,21 +36,26 @@ F32 = torch.float32
 
 class Policy:
     def __init__(self, name: str = "autocast"):
-        if name not in ("fp32", "autocast"):
+        if name not in ("fp32", "autocast", "fp8w"):
             raise ValueError(f"unknown policy {name!r}")
         self.name = name
 
     @property
     def amp(self) -> bool:
-        return self.name == "autocast"
+        return self.name in ("autocast", "fp8w")
 
     # -- F.linear under the policy -------------------------------------------------
-    def linear(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None = None) -> torch.Tensor:
+    def linear(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None = None, quant: bool = True) -> torch.Tensor:
         if not self.amp:
             return F.linear(x, w, b)
         xb = x.to(BF16).to(F32)
         wb = w.to(BF16).to(F32)
-        acc = xb @ wb.t()
+        if self.name == "fp8w" and quant:
+            s = (wb.abs().amax(dim=1) / 448.0).clamp_min(1e-12)
+            q = (wb / s[:, None]).to(torch.float8_e4m3fn).to(F32)
+            acc = (xb @ q.t()) * s
+        else:
+            acc = xb @ wb.t()
         if b is not None:
             acc = acc + b.to(BF16).to(F32)
         return acc.to(BF16)

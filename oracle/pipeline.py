@@ -38,7 +38,7 @@ def pos_embed_2d(table: torch.Tensor, h: int, w: int, ps: int) -> torch.Tensor:
 
 def projector(w: dict, x: torch.Tensor, pol: Policy) -> torch.Tensor:
     """MLPconnector.forward utils.py:16-20 with ``gelu_pytorch_tanh``."""
-    h = pol.linear(x, w["fc1.weight"], w["fc1.bias"])
+    h = pol.linear(x, w["fc1.weight"], w["fc1.bias"], quant=False)
     h = F.gelu(h, approximate="tanh")
     return pol.linear(h, w["fc2.weight"], w["fc2.bias"])
 

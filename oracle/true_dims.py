@@ -52,13 +52,13 @@ def device_seeded_state(shapes: dict, seed: int, device, gain: float = 1.0) -> d
 
 
 def head_case(device="cuda", *, D=5120, Dz=None, C=32, P=64, B=1, branches=2, depth=2, nada=2, head_dim=128,
-              sigmoid=True, n_steps=3, eval_index=1, seed=101, tune: dict | None = None) -> dict:
+              sigmoid=True, n_steps=3, eval_index=1, seed=101, tune: dict | None = None, weights: str = "bf16") -> dict:
     """One head evaluation at width D: device x_hat vs oracle x_hat.  eval_index > 0 exercises a non-zero timestep
     embedding; the latent is a fixed random tensor written straight into the engine's state."""
     from bitdance_amd import engine as E
     cfgd = dict(ch_target=C, ch_cond=Dz or D, ch_latent=D, depth_latent=depth, depth_adanln=nada)
     sd_dev = device_seeded_state(tm.head_shapes(cfgd), seed, device)
-    hw = E.HeadWeights.from_state_dict(sd_dev, device, head_dim=head_dim, final_sigmoid=sigmoid)
+    hw = E.HeadWeights.from_state_dict(sd_dev, device, head_dim=head_dim, final_sigmoid=sigmoid, weights=weights)
     sd = {k: v.cpu() for k, v in sd_dev.items()}
     del sd_dev
     eng = E.Engine(hw, None, None, num_images=B, branches=branches, device=device, max_tokens=P, parallel_num=P,
@@ -81,26 +81,33 @@ def head_case(device="cuda", *, D=5120, Dz=None, C=32, P=64, B=1, branches=2, de
     comb = torch.cat([x] * branches)
     t0 = time.perf_counter()
     with torch.no_grad():
-        ref = diff_head.net_forward(sd, comb, torch.full((branches * B,), t_i), z, Policy("autocast"),
+        ref = diff_head.net_forward(sd, comb, torch.full((branches * B,), t_i), z, Policy("fp8w" if weights == "fp8" else "autocast"),
                                     final_sigmoid=sigmoid, head_dim=head_dim).float()
     t_cpu = time.perf_counter() - t0
     err = (xhat - ref).abs()
+    extra = {}
+    if weights == "fp8":                                    # how far the fp8 mode is from the bf16 reference flow
+        with torch.no_grad():
+            ref16 = diff_head.net_forward(sd, comb, torch.full((branches * B,), t_i), z, Policy("autocast"),
+                                          final_sigmoid=sigmoid, head_dim=head_dim).float()
+        e16 = (xhat - ref16).abs()
+        extra = {"vs_bf16_max": e16.max().item(), "vs_bf16_mean": e16.mean().item()}
     cfgs = {n: eng.gemm_config("head." + n) for n in ("ada", "qkv", "wo", "w1", "w2")}
     macs_per_row = (D * C + D * cfgd["ch_cond"] + (nada * 6 + 2) * D * D + depth * (3 * D * D + D * D + 3 * D * D + 1.5 * D * D) + D * C)
     return {"max_err": err.max().item(), "mean_err": err.mean().item(), "ref_abs_mean": ref.abs().mean().item(),
             "finite": bool(torch.isfinite(xhat).all()), "t_cpu_s": t_cpu, "rows": M, "macs_per_row": macs_per_row,
-            "gemm_cfg": {k: {"splitk": s, "nwaves": c & 15} for k, (s, c) in cfgs.items()}, "t": t_i}
+            "gemm_cfg": {k: {"splitk": s, "nwaves": c & 15} for k, (s, c) in cfgs.items()}, "t": t_i, **extra}
 
 
 def llm_case(device="cuda", *, layers=1, P=64, past=(1000, 1017), cfg: dict | None = None, seed=202,
-             tune: dict | None = None) -> dict:
+             tune: dict | None = None, weights: str = "bf16") -> dict:
     """One native decode step (P new tokens per sequence, ragged cache lengths) at Qwen3-14B width vs the oracle.
     The K/V cache is filled with seeded random post-RoPE keys / values on both sides."""
     from bitdance_amd import engine as E
     c = dict(cfg or QWEN3_14B, num_hidden_layers=layers)
     D, nh, nkv, hd = c["hidden_size"], c["num_attention_heads"], c["num_key_value_heads"], c["head_dim"]
     sd_dev = {k: v.to(torch.bfloat16) for k, v in device_seeded_state(tm.llm_shapes(c), seed, device).items()}
-    lw = E.LlmWeights.from_state_dict(sd_dev, c, device, keep_for_prefill=False)
+    lw = E.LlmWeights.from_state_dict(sd_dev, c, device, keep_for_prefill=False, weights=weights)
     w = {k: v.cpu() for k, v in sd_dev.items()}
     del sd_dev
     nseq = len(past)
@@ -126,7 +133,7 @@ def llm_case(device="cuda", *, layers=1, P=64, past=(1000, 1017), cfg: dict | No
     eng.llm_step()
     torch.cuda.synchronize()
     got = eng.hidden().cpu().view(nseq, P, D)
-    pol = Policy("autocast")
+    pol = Policy("fp8w" if weights == "fp8" else "autocast")
     t0 = time.perf_counter()
     refs = []
     with torch.no_grad():
