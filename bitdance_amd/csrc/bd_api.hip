@@ -105,6 +105,12 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
         if (s64 < 1) s64 = 1;
         if (t64 * s64 <= 256 && t64 * s64 >= 200 && s64 <= 3) { g.nw = 4; g.kw = 2; S = s64; ntiles = t64; }
     }
+    // 128-column tiles whose slices stay with the consumer (S >= 4: the N = 5120 shapes): 8 waves as 4 panels x 2 K-parts --
+    // two waves per SIMD overlap each other's LDS / MFMA latencies at the same tile, grid and slab count
+    // (profiles/r02_gemm_sweep2_pipe.log: wo 16.6 vs 17.8 us, w2 20.2 vs 23.3 us)
+    if (!two_images && g.nw == 4 && g.kw == 1 && S >= 4 && K % 128 == 0 && K <= 8192 && c->geti("tune.kparts8", 1) != 0) {
+        g.nw = 8; g.kw = 2;
+    }
     if (reduce3 && S > 3) {
         // narrower tiles instead of more slices: 64 columns (2 waves, or 2 x 2 when K allows), then 32
         if (N % 64 == 0) { g.nw = (kw2_shape ? 4 : 2); g.kw = kw2_shape ? 2 : 1; ntiles = N / 64; }
@@ -129,7 +135,7 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
 static const char* const kIntKeys[] = {
     "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
-    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.ada_async"};
+    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
                                          "llm.qkv", "llm.o", "llm.gu", "llm.down"};
 static bool known_int_key(const std::string& k) {

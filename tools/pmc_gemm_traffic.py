@@ -1,13 +1,16 @@
-"""HBM traffic of every weight-streaming GEMM shape of one AR step, from the FETCH_SIZE PMC counter.
+"""HBM traffic (read AND write) and matrix-pipe occupancy of every weight-streaming GEMM shape of one AR step, from PMC counters.
 
-  1. on the GPU box, counters in their own pass (MI355X_MICROARCH.md, HBM section):
-       rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc -o p -- python tools/pmc_gemm_traffic.py run
-  2. python tools/pmc_gemm_traffic.py parse /tmp/pmc/p_results.db profiles/r01_pmc_gemm_traffic.json
+  1. on the GPU box, each counter group in its OWN pass (MI355X_MICROARCH.md, HBM / PMC-slot sections; --pmc is never combined
+     with the sys/hip/hsa trace domains):
+       tools/run_pmc_passes.sh            # FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+  2. python tools/pmc_gemm_traffic.py parse out.json fetch.db write.db sq.db
 
-`run` launches each (shape, split-K, waves) exactly as the engine configures it at M = 128, REPS times in a row;
-`parse` takes the gemm_kernel dispatches in order, REPS per shape, and writes per-shape bytes per launch:
-FETCH_SIZE is reported in KiB... of 64 B requests tallied for 128 B on gfx950 wide streaming reads, so the guide's
-correction (x2) is applied and stated in the output.
+`run` launches each (shape, split-K, waves) exactly as the engine configures it at M = 128 -- fp32 slabs where the engine
+leaves the slices to the consumer (split-K > 3), the in-launch reduction to bf16 otherwise -- REPS times in a row, preceded by
+two calibration dispatches of known size (a 256 MiB fill = pure write, a 256 MiB read-reduce = pure read).  `parse` takes the
+gemm dispatches in order, REPS per shape.  FETCH_SIZE on gfx950 tallies a wide (16 B/lane) streaming read's 128 B requests as
+64 B: the guide's x2 correction is applied and cross-checked against the calibration read; WRITE_SIZE is scaled by the
+calibration fill (the guide calls it uncalibrated).
 """
 import json
 import os
@@ -16,11 +19,12 @@ import sys
 
 REPS = 4
 M = 128
-# name, N, K, split-K, waves: the in-situ configuration of bench.py's default workload (roofline.per_gemm)
-SHAPES = [("head.ada", 71680, 5120, 1, 10), ("head.qkv", 15360, 5120, 2, 4), ("head.wo", 5120, 5120, 6, 4),
-          ("head.w1", 15360, 5120, 2, 4), ("head.w2", 5120, 7680, 6, 4), ("head.cond", 5120, 5120, 6, 4),
-          ("proj.fc2", 5120, 5120, 6, 4), ("llm.qkv", 7168, 5120, 4, 4), ("llm.o", 5120, 5120, 6, 4),
-          ("llm.gu", 34816, 5120, 1, 8), ("llm.down", 5120, 17408, 9, 8)]
+CAL_BYTES = 256 << 20
+# name, N, K, split-K, waves, kparts: the in-situ configuration of bench.py's default workload (roofline.per_gemm)
+SHAPES = [("head.ada", 71680, 5120, 1, 10, 1), ("head.qkv", 15360, 5120, 2, 4, 1), ("head.wo", 5120, 5120, 6, 8, 2),
+          ("head.w1", 15360, 5120, 2, 4, 1), ("head.w2", 5120, 7680, 6, 8, 2), ("head.cond", 5120, 5120, 6, 8, 2),
+          ("proj.fc2", 5120, 5120, 6, 8, 2), ("llm.qkv", 7168, 5120, 4, 8, 2), ("llm.o", 5120, 5120, 6, 8, 2),
+          ("llm.gu", 34816, 5120, 1, 8, 1), ("llm.down", 5120, 17408, 9, 8, 1)]
 
 
 def run():
@@ -29,43 +33,100 @@ def run():
     from bitdance_amd import engine as E
     from bitdance_amd._lib import check, lib
     st = torch.cuda.current_stream().cuda_stream
-    for name, N, K, S, nw in SHAPES:
+    cal = torch.empty(CAL_BYTES // 4, dtype=torch.float32, device="cuda")
+    sink = torch.zeros(64, dtype=torch.int32, device="cuda")
+    for _ in range(2):
+        cal.fill_(1.0)                                                                  # calibration: 256 MiB written
+        check(lib().bd_probe_read(cal.data_ptr(), CAL_BYTES, 1024, sink.data_ptr(), st))  # calibration: 256 MiB read (16 B/lane)
+    torch.cuda.synchronize()
+    for name, N, K, S, nw, kw in SHAPES:
         w = (torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16)
         wp = E.pack_linear([w], "cuda")
         del w
         x = torch.randn(M, K, device="cuda")
         xf = torch.zeros(M * K, dtype=torch.bfloat16, device="cuda")
         check(lib().bd_rows_to_frag(xf.data_ptr(), x.data_ptr(), 1, M, K, M // 32, st))
-        out = torch.empty(S * M * N, dtype=torch.float32, device="cuda")
+        out = torch.empty(max(S, 1) * M * N, dtype=torch.float32, device="cuda")
+        outb = torch.empty(M * N, dtype=torch.bfloat16, device="cuda")
+        cnt = torch.zeros(16384, dtype=torch.int32, device="cuda")
+        code = nw + 32 + 256 * (kw - 1)
         for _ in range(REPS):
-            check(lib().bd_gemm_partial(xf.data_ptr(), M // 32, wp.data_ptr(), N, K, S, nw, out.data_ptr(), st))
+            if S > 3 or name == "llm.gu":
+                check(lib().bd_gemm_partial(xf.data_ptr(), M // 32, wp.data_ptr(), N, K, S, code, out.data_ptr(), st))
+            else:
+                check(lib().bd_gemm_bf16(xf.data_ptr(), M // 32, wp.data_ptr(), None, N, K, S, code, out.data_ptr(), cnt.data_ptr(),
+                                         outb.data_ptr(), st))
         torch.cuda.synchronize()
         del wp, out
 
 
-def parse(db_path, out_path):
+def _rows(db_path, counter):
     cur = sqlite3.connect(db_path).cursor()
-    rows = cur.execute("select dispatch_id, name, counter_value, duration from pmc_events where counter_name = 'FETCH_SIZE' "
-                       "order by dispatch_id").fetchall()
-    g = [r for r in rows if "gemm_kernel" in r[1]]
-    assert len(g) == REPS * len(SHAPES), (len(g), REPS * len(SHAPES))
+    # SQ counters come as one row per shader engine: summed per dispatch.  GRBM_GUI_ACTIVE comes once per XCD and every
+    # instance reports the whole kernel: averaged (= busy cycles of the dispatch)
+    agg = "avg" if counter.startswith("GRBM") else "sum"
+    return cur.execute(f"select dispatch_id, name, {agg}(counter_value), max(duration) from pmc_events where counter_name = ? "
+                       "group by dispatch_id, name order by dispatch_id", (counter,)).fetchall()
+
+
+def parse(out_path, fetch_db, write_db=None, sq_db=None):
+    def gemms(rows):
+        g = [r for r in rows if "gemm_kernel" in r[1] or "gemm_wide" in r[1]]
+        assert len(g) == REPS * len(SHAPES), (len(g), REPS * len(SHAPES))
+        return g
+
+    def cal(rows, key):
+        c = [r for r in rows if key in r[1]]
+        return sum(r[2] for r in c[1:]) / max(1, len(c) - 1) if len(c) > 1 else None
+
+    fr = _rows(fetch_db, "FETCH_SIZE")
+    fcal = cal(fr, "probe_read_kernel")
+    fetch_scale = 2.0 * 1024.0
+    note = {"fetch": "FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction)"}
+    if fcal:
+        note["fetch_calibration"] = f"256 MiB probe read reported {fcal:.0f} KiB raw -> x{CAL_BYTES / (fcal * 1024):.3f} would be exact"
+    wr = _rows(write_db, "WRITE_SIZE") if write_db else None
+    wscale = None
+    if wr:
+        fills = sorted(r[2] for r in wr if "FillFunctor" in r[1])
+        wcal = fills[-1] if fills else None                     # the 256 MiB calibration fill is the largest fill of the run
+        wscale = CAL_BYTES / wcal if wcal else 1024.0
+        note["write"] = (f"WRITE_SIZE KiB x {wscale:.1f} (calibration: the 256 MiB fill reported {wcal:.0f} KiB)" if wcal
+                         else "WRITE_SIZE KiB x 1024 (uncalibrated)")
+    sq = {c: _rows(sq_db, c) for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE")} if sq_db else None
+    gf = gemms(fr)
+    gw = gemms(wr) if wr else None
+    gs = {c: gemms(r) for c, r in sq.items() if r} if sq else {}
     res = {}
-    for i, (name, N, K, S, nw) in enumerate(SHAPES):
-        grp = g[i * REPS:(i + 1) * REPS][1:]                 # drop the first launch of each shape (cold TLB / code)
-        kib = sum(r[2] for r in grp) / len(grp)
-        fetched = 2.0 * kib * 1024.0                         # gfx950: FETCH_SIZE tallies 128 B requests as 64 B
+    for i, (name, N, K, S, nw, kw) in enumerate(SHAPES):
+        sl = slice(i * REPS + 1, (i + 1) * REPS)              # drop the first launch of each shape (cold TLB / code)
+        avg = lambda g: sum(r[2] for r in g[sl]) / (REPS - 1)
         alg = N * K * 2
-        res[name] = dict(N=N, K=K, splitk=S, nwaves=nw, fetch_size_kib_raw=round(kib, 1), hbm_read_bytes=round(fetched),
-                         algorithmic_bytes=alg, ratio=round(fetched / alg, 4))
-    out = dict(counter="FETCH_SIZE", unit="KiB raw; x2 gfx950 wide-read correction applied (MI355X_MICROARCH.md, HBM section)",
-               rows_M=M, reps_averaged=REPS - 1, gemms=res)
+        e = dict(N=N, K=K, splitk=S, nwaves=nw, kparts=kw, fetch_size_kib_raw=round(avg(gf), 1), hbm_read_bytes=round(avg(gf) * fetch_scale),
+                 algorithmic_bytes=alg)
+        e["read_ratio"] = round(e["hbm_read_bytes"] / alg, 4)
+        e["avg_ns"] = round(sum(r[3] for r in gf[sl]) / (REPS - 1))
+        if gw:
+            e["hbm_write_bytes"] = round(avg(gw) * wscale)
+            e["traffic_ratio"] = round((e["hbm_read_bytes"] + e["hbm_write_bytes"]) / alg, 4)
+        if gs:
+            mf, gui = avg(gs["SQ_VALU_MFMA_BUSY_CYCLES"]), avg(gs["GRBM_GUI_ACTIVE"])
+            e["mfma_busy_cycles"], e["gui_active_cycles"] = round(mf), round(gui)
+            e["mfma_util"] = round(mf / (gui * 1024.0), 4)    # matrix-pipe busy cycles / (kernel cycles x 256 CUs x 4 SIMDs)
+            e["mfma_util_from_flops"] = round(2.0 * M * N * K / (e["avg_ns"] * 1e-9) / 2.5e15, 4)   # same thing from 2*M*N*K / time / 2.5 PFLOP/s
+            if "SQ_BUSY_CYCLES" in gs:
+                e["sq_busy_cycles"] = round(avg(gs["SQ_BUSY_CYCLES"]))
+        res[name] = e
+    out = dict(counters="FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE (separate rocprofv3 --pmc passes)",
+               notes=note, rows_M=M, reps_averaged=REPS - 1, gemms=res)
     json.dump(out, open(out_path, "w"), indent=1)
     for k, v in res.items():
-        print(f"{k:10s} fetched {v['hbm_read_bytes'] / 1e6:8.1f} MB  algorithmic {v['algorithmic_bytes'] / 1e6:8.1f} MB  x{v['ratio']}")
+        print(f"{k:10s} read {v['hbm_read_bytes'] / 1e6:8.1f} MB  write {v.get('hbm_write_bytes', 0) / 1e6:7.1f} MB  algorithmic "
+              f"{v['algorithmic_bytes'] / 1e6:8.1f} MB  x{v.get('traffic_ratio', v['read_ratio'])}  mfma_util {v.get('mfma_util')}")
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run()
     else:
-        parse(sys.argv[2], sys.argv[3])
+        parse(*sys.argv[2:])
