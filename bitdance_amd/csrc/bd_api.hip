@@ -40,6 +40,12 @@ struct bd_ctx {
     std::vector<ProfRec> prof;
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     hipGraph_t graph[2] = {nullptr, nullptr};
+    // "tune.ada_async": the adaLN projection of evaluation i+1 (a function of (t_{i+1}, cond) only) runs on a second,
+    // low-priority stream beside evaluation i's chain; fork / join through events, also inside the captured graph
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev_ada, ev_done;
+    hipEvent_t ev_fork = nullptr;
+    bool ada_async = false;
 
     // derived
     int B = 1, branches = 2, Pn = 64, BP = 64, M = 128, RB = 4, RBp = 2, Mpad = 128, BPpad = 64;
@@ -74,6 +80,8 @@ struct bd_ctx {
     void* wptr(const std::string& k) const { return const_cast<void*>(ptr(k)); }
     const void* optr(const std::string& k) const { auto it = P.find(k); return it == P.end() ? nullptr : it->second; }
 };
+
+static int async_setup(bd_ctx* c, int n_evals);
 
 static int pad_rows(int m) { return m <= 32 ? 32 : (m <= 64 ? 64 : ((m + 127) / 128) * 128); }
 
@@ -135,7 +143,7 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
 static const char* const kIntKeys[] = {
     "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
-    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async"};
+    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
                                          "llm.qkv", "llm.o", "llm.gu", "llm.down"};
 static bool known_int_key(const std::string& k) {
@@ -258,6 +266,10 @@ void bd_ctx_destroy(bd_ctx* c) {
         if (c->gexec[i]) hipGraphExecDestroy(c->gexec[i]);
         if (c->graph[i]) hipGraphDestroy(c->graph[i]);
     }
+    for (hipEvent_t e : c->ev_ada) hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_done) hipEventDestroy(e);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->side) hipStreamDestroy(c->side);
     delete c;
 }
 // unknown keys are rejected: a typo must not silently fall back to a default (keys: DESIGN.md / the tables above)
@@ -426,6 +438,8 @@ int bd_head_set_schedule(bd_ctx* c, int n_steps, const float* s, float cfg) {
         q.is_final = (i == n_steps); q.cfg_mult = c->branches;
         c->sched.push_back(q);
     }
+    c->ada_async = c->has_head && c->geti("tune.ada_async", 0) != 0;
+    if (c->ada_async && async_setup(c, n_steps + 1) != 0) return -1;
     return 0;
 }
 
@@ -503,25 +517,45 @@ static int head_cond(bd_ctx* c, hipStream_t st) {   // cond_embed(c) is constant
     return 0;
 }
 
-static int head_eval(bd_ctx* c, int i, hipStream_t st) {
+// y = silu(time_embed(t_i) + cond_embed(c)) and the stacked adaLN projection of evaluation i into half `buf` of head.ada_bf
+static int head_ada(bd_ctx* c, int i, int buf, bool light, hipStream_t st) {
+    const int D = c->hD, RB = c->RB;
+    HeadPrologueArgs pa;
+    pa.cemb = c->ptr("head.cemb");
+    pa.temb = (const bf16_t*)c->ptr("head.temb") + (size_t)i * D;
+    pa.xt = nullptr; pa.in_w = nullptr; pa.in_b = nullptr; pa.X = nullptr;
+    pa.y_frag = c->wptr("head.y_frag");
+    pa.M = c->M; pa.BP = c->BP; pa.D = D; pa.C = c->hC; pa.RB = RB;
+    BD_TRY(bdk_head_prologue(pa, st));
+    GemmCfg ga = c->cfg("head.ada");
+    if (light) { ga.nw = 4; ga.kw = 1; ga.ring = 2; }
+    bf16_t* out = (bf16_t*)c->wptr("head.ada_bf") + (size_t)buf * c->Mpad * c->hNada;
+    BD_TRY(gemm(c, "head.ada", c->ptr("head.y_frag"), RB, wref(c, "head.ada_w"), c->hNada, D, 1, ga.code() + (light ? 8192 : 0), BD_EPI_BF16,
+                nullptr, out, c->ptr("head.ada_b"), st));
+    return 0;
+}
+
+// `ada_buf` < 0: compute y and the adaLN projection here, in line (the plain path); >= 0: they were produced ahead of time
+// into that half of head.ada_bf (head_sample with tune.ada_async)
+static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1) {
     if (i < 0 || i >= (int)c->sched.size()) return fail("bd_head_eval: eval index outside the schedule");
     const int D = c->hD, Mp = c->Mpad, RB = c->RB, M = c->M;
     const int Dl = c->hDl, Hl = c->hHl;                       // this rank's attention columns / SwiGLU features (== D, H at tp = 1)
     const int n_steps = (int)c->sched.size() - 1;
     const BdStepState* state = (const BdStepState*)c->ptr("state");
+    if (ada_buf < 0) {
+        BD_TRY(head_ada(c, i, 0, false, st));
+        ada_buf = 0;
+    }
     HeadPrologueArgs pa;
-    pa.cemb = c->ptr("head.cemb");
-    pa.temb = (const bf16_t*)c->ptr("head.temb") + (size_t)i * D;
+    pa.cemb = nullptr; pa.temb = nullptr; pa.y_frag = nullptr;
     pa.xt = (const float*)c->ptr("head.xt");
     pa.in_w = c->ptr("head.in_w"); pa.in_b = c->ptr("head.in_b");
-    pa.y_frag = c->wptr("head.y_frag"); pa.X = c->wptr("head.X");
+    pa.X = c->wptr("head.X");
     pa.M = M; pa.BP = c->BP; pa.D = D; pa.C = c->hC; pa.RB = RB;
     BD_TRY(bdk_head_prologue(pa, st));
 
-    const GemmCfg& ga = c->cfg("head.ada");
-    BD_TRY(gemm(c, "head.ada", c->ptr("head.y_frag"), RB, wref(c, "head.ada_w"), c->hNada, D, 1, ga.code(), BD_EPI_BF16,
-                nullptr, c->wptr("head.ada_bf"), c->ptr("head.ada_b"), st));
-    const void* ada = c->ptr("head.ada_bf");
+    const void* ada = (const bf16_t*)c->ptr("head.ada_bf") + (size_t)ada_buf * Mp * c->hNada;
     const int sw = c->hNB / c->hNA;
     const GemmCfg &gq = c->cfg("head.qkv"), &go = c->cfg("head.wo"), &g1 = c->cfg("head.w1"), &g2 = c->cfg("head.w2");
     Partial br{nullptr, nullptr, 0, 0, 0};                    // pending gated branch output (wo / w2)
@@ -586,6 +620,22 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st) {
     return 0;
 }
 
+static int async_setup(bd_ctx* c, int n_evals) {          // streams / events are created OUTSIDE any capture
+    if (!c->side) {
+        int least = 0, greatest = 0;
+        hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least) != hipSuccess) return fail("side stream creation failed");
+        if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail("event creation failed");
+    }
+    while ((int)c->ev_ada.size() < n_evals) {
+        hipEvent_t a, d;
+        if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d, hipEventDisableTiming) != hipSuccess)
+            return fail("event creation failed");
+        c->ev_ada.push_back(a); c->ev_done.push_back(d);
+    }
+    return 0;
+}
+
 static int head_sample(bd_ctx* c, hipStream_t st) {
     if (c->sched.empty()) return fail("bd_head_sample: no schedule set");
     const int n_steps = (int)c->sched.size() - 1;
@@ -593,7 +643,21 @@ static int head_sample(bd_ctx* c, hipStream_t st) {
                       (long long)(n_steps + 1) * c->BP * c->hC, (const BdStepState*)c->ptr("state"), c->BP * c->hC};
     BD_TRY(bdk_init_latent(ia, st));
     BD_TRY(head_cond(c, st));
-    for (int i = 0; i <= n_steps; ++i) BD_TRY(head_eval(c, i, st));
+    if (!c->ada_async || c->prof_on) {
+        for (int i = 0; i <= n_steps; ++i) BD_TRY(head_eval(c, i, st));
+        return 0;
+    }
+    // fork: the side stream produces y / adaLN(i) into half i & 1 as soon as evaluation i-2 has released it; the chain of
+    // evaluation i waits for adaLN(i) only.  The last side operation is joined by the chain of the last evaluation.
+    if ((int)c->ev_ada.size() <= n_steps || !c->side) return fail("bd_head_sample: async state not set up (bd_head_set_schedule)");
+    if (hipEventRecord(c->ev_fork, st) != hipSuccess || hipStreamWaitEvent(c->side, c->ev_fork, 0) != hipSuccess) return fail("fork failed");
+    for (int i = 0; i <= n_steps; ++i) {
+        if (i >= 2 && hipStreamWaitEvent(c->side, c->ev_done[i - 2], 0) != hipSuccess) return fail("side wait failed");
+        BD_TRY(head_ada(c, i, i & 1, true, c->side));
+        if (hipEventRecord(c->ev_ada[i], c->side) != hipSuccess || hipStreamWaitEvent(st, c->ev_ada[i], 0) != hipSuccess) return fail("join failed");
+        BD_TRY(head_eval(c, i, st, i & 1));
+        if (hipEventRecord(c->ev_done[i], st) != hipSuccess) return fail("event record failed");
+    }
     return 0;
 }
 
@@ -691,6 +755,9 @@ static int llm_step(bd_ctx* c, hipStream_t st) {
     const float eps = (float)c->getf("llm.eps", 1e-6);
     BdStepState* state = (BdStepState*)c->wptr("state");
     const GemmCfg &gq = c->cfg("llm.qkv"), &go = c->cfg("llm.o"), &gg = c->cfg("llm.gu"), &gd = c->cfg("llm.down");
+    // prefill (once per image, eager): the same step over a block of PROMPT tokens -- causal mask, bf16 hidden states
+    // (t2i_pipeline.py:199-217); the host sets the per-sequence cache lengths itself between blocks
+    const int causal = (int)c->geti("rt.llm_causal", 0), bf16s = (int)c->geti("rt.llm_bf16", 0);
     const size_t layer_elems = (size_t)nseq * nkv * c->lLmax * 128;
     Partial br{nullptr, nullptr, 0, 0, 0};                    // pending branch output (o_proj / down_proj)
     for (int l = 0; l < c->lL; ++l) {
@@ -700,7 +767,7 @@ static int llm_step(bd_ctx* c, hipStream_t st) {
         r1.pend = br;                                      // down_proj output of the previous layer (none for layer 0)
         r1.w = c->ptr(pre + "in_norm"); r1.a_frag = c->wptr("llm.a_frag");
         r1.hidden_out = nullptr; r1.cond_frag = nullptr; r1.pos = nullptr; r1.state = state;
-        r1.M = M; r1.D = D; r1.RB = RB; r1.P = c->Pn; r1.eps = eps;
+        r1.M = M; r1.D = D; r1.RB = RB; r1.P = c->Pn; r1.eps = eps; r1.bf16_stream = bf16s;
         BD_TRY(bdk_rms(r1, st));
 
         QkvPostArgs qa;
@@ -711,13 +778,13 @@ static int llm_step(bd_ctx* c, hipStream_t st) {
         qa.q_out = c->wptr("llm.q");
         qa.k_cache = (bf16_t*)c->wptr("llm.k_cache") + l * layer_elems;
         qa.vt_cache = (bf16_t*)c->wptr("llm.vt_cache") + l * layer_elems;
-        qa.state = state; qa.M = M; qa.P = c->Pn; qa.nh = nh; qa.nkv = nkv; qa.Lmax = c->lLmax; qa.eps = eps;
+        qa.state = state; qa.M = M; qa.P = c->Pn; qa.nh = nh; qa.nkv = nkv; qa.Lmax = c->lLmax; qa.eps = eps; qa.rope_bf16 = bf16s;
         BD_TRY(bdk_qkv_post(qa, st));
         LlmAttnArgs aa;
         aa.q = c->ptr("llm.q"); aa.k_cache = qa.k_cache; aa.vt_cache = qa.vt_cache;
         aa.o_part = (float*)c->wptr("llm.attn_opart"); aa.ml_part = (float*)c->wptr("llm.attn_ml");
         aa.o_frag = c->wptr("llm.attn_frag"); aa.state = state;
-        aa.nseq = nseq; aa.P = c->Pn; aa.nh = nh; aa.nkv = nkv; aa.Lmax = c->lLmax; aa.splits = c->lsplits; aa.RB = RB;
+        aa.nseq = nseq; aa.P = c->Pn; aa.nh = nh; aa.nkv = nkv; aa.Lmax = c->lLmax; aa.splits = c->lsplits; aa.RB = RB; aa.causal = causal;
         BD_TRY(bdk_llm_attn(aa, st));
 
         RmsArgs r2 = r1;
@@ -730,8 +797,10 @@ static int llm_step(bd_ctx* c, hipStream_t st) {
         BD_TRY(linear_rowsplit(c, "llm.down", c->ptr("llm.act_frag"), RB, wref(c, pre + "wdown"), D, F, gd, "llm.br_part", "llm.br_bf",
                                "llm.tp_part", nullptr, Mp, M, &br, st));
     }
-    StepAdvanceArgs sa{state, nseq, c->Pn};
-    BD_TRY(bdk_step_advance(sa, st));                       // step+1 / kv_len += P: the next patch's position
+    if (!c->geti("rt.no_advance", 0)) {
+        StepAdvanceArgs sa{state, nseq, c->Pn};
+        BD_TRY(bdk_step_advance(sa, st));                   // step+1 / kv_len += P: the next patch's position
+    }
     RmsArgs rf;
     rf.R = (float*)c->wptr("llm.R");
     rf.pend = br;
@@ -740,7 +809,7 @@ static int llm_step(bd_ctx* c, hipStream_t st) {
     const bool emit = c->geti("rt.emit_cond", 1) != 0 && c->has_head;
     rf.cond_frag = emit ? c->wptr("head.cond_frag") : nullptr;
     rf.pos = emit ? (const float*)c->ptr("pos") : nullptr;
-    rf.state = state; rf.M = M; rf.D = D; rf.RB = RB; rf.P = c->Pn; rf.eps = eps;
+    rf.state = state; rf.M = M; rf.D = D; rf.RB = RB; rf.P = c->Pn; rf.eps = eps; rf.bf16_stream = bf16s;
     BD_TRY(bdk_rms(rf, st));
     return 0;
 }

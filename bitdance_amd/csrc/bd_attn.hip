@@ -353,7 +353,9 @@ __global__ __launch_bounds__(640) void llm_attn_kernel(LlmAttnArgs a) {
     const int qh = wave / halves, half = wave % halves;
     const int head = kvh * G + qh;
     const bool qvalid = half * 32 + (lane & 31) < a.P;
-    const int L = a.state->kv_len[seq] + a.P;                // keys visible to this block of queries
+    const int past = a.state->kv_len[seq];
+    const int L = past + a.P;                                // keys visible to this block of queries
+    const int qlim = a.causal ? past + half * 32 + (lane & 31) : L - 1;   // last key this lane's query may see
     const int ntiles = (L + 63) >> 6;
     const int per = (ntiles + a.splits - 1) / a.splits;
     const int t_beg = split * per, t_end = min(ntiles, t_beg + per);
@@ -405,19 +407,20 @@ __global__ __launch_bounds__(640) void llm_attn_kernel(LlmAttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = key_base + kb * 32 + mfma_row(r, lane);
-                const float s = (key < L) ? sacc[kb][r] : -INFINITY;
+                const float s = (key < L && key <= qlim) ? sacc[kb][r] : -INFINITY;
                 p[kb][r] = s;
                 tmax = fmaxf(tmax, s);
             }
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m_run, tmax);               // finite: every processed tile has a valid key
-        const float alpha = __expf((m_run - m_new) * scale);
+        const float m_new = fmaxf(m_run, tmax);               // -inf only while a causal query has not met a visible key yet
+        const bool none = (m_new == -INFINITY);
+        const float alpha = none ? 1.f : __expf((m_run - m_new) * scale);
         float tsum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { p[kb][r] = __expf((p[kb][r] - m_new) * scale); tsum += p[kb][r]; }
+            for (int r = 0; r < 16; ++r) { p[kb][r] = none ? 0.f : __expf((p[kb][r] - m_new) * scale); tsum += p[kb][r]; }
         tsum += __shfl_xor(tsum, 32);
         l_run = l_run * alpha + tsum;
         m_run = m_new;

@@ -54,10 +54,10 @@ int bdk_gemm8(const void* A, int RB, const void* W8, const float* wscale, int N,
     // ring 2 (two 2 KiB stages per wave in flight).  Ring 4 was measured SLOWER (adaLN 125 vs 97 us, profiles/r02_bench_fp8_v2.json):
     // at 128 rows and half the bytes per weight the workgroup is bound by its LDS-read + MFMA work per stage (256 FLOP per weight
     // byte, at the ridge), not by bytes in flight.
-#define BD_CASE8(NPV, KWV, MBV) if (np == NPV && kw == KWV && MB == MBV) return launch_gemm<NPV, KWV, MBV, 2, false, 1>(p, epi, st);
+#define BD_CASE8(NPV, KWV, MBV) if (np == NPV && kw == KWV && MB == MBV) return launch_gemm<NPV, KWV, MBV, 2, 0, 1>(p, epi, st);
     BD_CASE8(4, 1, 4) BD_CASE8(8, 1, 4) BD_CASE8(10, 1, 4) BD_CASE8(2, 1, 4) BD_CASE8(4, 2, 4) BD_CASE8(2, 2, 4)
-    BD_CASE8(4, 1, 2) BD_CASE8(8, 1, 2) BD_CASE8(2, 1, 2)
-    BD_CASE8(4, 1, 1) BD_CASE8(8, 1, 1) BD_CASE8(2, 1, 1)
+    BD_CASE8(4, 1, 2) BD_CASE8(8, 1, 2) BD_CASE8(2, 1, 2) BD_CASE8(4, 2, 2) BD_CASE8(2, 2, 2)
+    BD_CASE8(4, 1, 1) BD_CASE8(8, 1, 1) BD_CASE8(2, 1, 1) BD_CASE8(4, 2, 1) BD_CASE8(2, 2, 1)
 #undef BD_CASE8
     return -6;
 }

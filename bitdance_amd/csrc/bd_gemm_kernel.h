@@ -53,9 +53,11 @@ struct GemmP {
 // WT = weight storage: 0 bf16 (1 KiB chunk per (panel, k-step of 16)), 1 fp8-e4m3 with per-output-channel scales (1 KiB
 // chunk per (panel, PAIR of k-steps): a lane's 16 B = its 8 weights of k-step 2j, then of 2j+1; converted to bf16 in registers
 // right before the MFMA, the scale multiplied into the accumulator after the K loop): half the bytes per weight.
-template <int NP, int KW, int MB, int EPI, int R, bool RED, bool PIPE = false, int WT = 0>
+template <int NP, int KW, int MB, int EPI, int R, bool RED, int MODE = 0, int WT = 0>
 __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
     constexpr int WL = (WT == 1) ? 2 : 4;                 // 16 B loads per lane and 64-deep stage
+    constexpr bool PIPE = (MODE == 1);                    // MODE 2 ("light"): one k-step of fragments resident at a time -- a
+                                                          // ~170-register wave that fits NEXT to a 300-register one on a SIMD
     constexpr int NW = NP * KW, NT = NW * 64;
     constexpr int UNITS = MB * 256 * KW;                  // 16 B units per (64*KW)-deep A stage
     constexpr int XL = (UNITS + NT - 1) / NT;             // A loads per thread per stage
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
     // This wave's 64-deep part of the A stage goes LDS -> registers in one burst (16 ds_read_b128 for 128 rows), then the
     // MFMAs issue back to back: with the reads interleaved two-at-a-time the matrix pipe idled on LDS latency (the loop
     // was bound by the ds_read -> MFMA chain, not by HBM).
-    constexpr int KG = (MB <= 4 && NW <= 8) ? 4 : 1;      // k-steps whose A fragments are resident at once (VGPR budget)
+    constexpr int KG = (MODE != 2 && MB <= 4 && NW <= 8) ? 4 : 1;      // k-steps whose A fragments are resident at once (VGPR budget)
     auto compute = [&](const u32x4* stage, const u32x4(&wr)[WL]) {
         const u32x4* buf = stage + kg * MB * 256;
 #pragma unroll
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
     }
 }
 
-template <int NP, int KW, int MB, int EPI, int R, bool RED, bool PIPE = false, int WT = 0>
+template <int NP, int KW, int MB, int EPI, int R, bool RED, int MODE = 0, int WT = 0>
 static int launch_one(const GemmP& p, hipStream_t st) {
     const int ntiles = p.N / (32 * NP);
     dim3 grid(ntiles * p.S, p.RB / MB);
@@ -382,27 +384,27 @@ static int launch_one(const GemmP& p, hipStream_t st) {
     constexpr size_t lds_a = (size_t)2 * MB * 256 * KW * 16, lds_r = (size_t)(KW - 1) * NP * MB * 4096;
     constexpr size_t lds = lds_a > lds_r ? lds_a : lds_r;
     if constexpr (lds > 64 * 1024) {                               // beyond 64 KiB of dynamic LDS needs the opt-in
-        static const bool ok = hipFuncSetAttribute((const void*)gemm_kernel<NP, KW, MB, EPI, R, RED, PIPE, WT>,
+        static const bool ok = hipFuncSetAttribute((const void*)gemm_kernel<NP, KW, MB, EPI, R, RED, MODE, WT>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
         if (!ok) return -8;
     }
-    BD_LAUNCH((gemm_kernel<NP, KW, MB, EPI, R, RED, PIPE, WT>), grid, dim3(NP * KW * 64), lds, st, p);
+    BD_LAUNCH((gemm_kernel<NP, KW, MB, EPI, R, RED, MODE, WT>), grid, dim3(NP * KW * 64), lds, st, p);
     return bd_launch_status();
 }
 
-template <int NP, int KW, int MB, int R, bool RED, bool PIPE = false, int WT = 0>
+template <int NP, int KW, int MB, int R, bool RED, int MODE = 0, int WT = 0>
 static int launch_gemm_r(const GemmP& p, int epi, hipStream_t st) {
-    if (epi == BD_EPI_PARTIAL) return launch_one<NP, KW, MB, BD_EPI_PARTIAL, R, false, PIPE, WT>(p, st);
-    if (epi == BD_EPI_BF16) return launch_one<NP, KW, MB, BD_EPI_BF16, R, RED, PIPE, WT>(p, st);
-    if (epi == BD_EPI_F32) return launch_one<NP, KW, MB, BD_EPI_F32, R, RED, PIPE, WT>(p, st);
-    return launch_one<NP, KW, MB, BD_EPI_SWIGLU, R, RED, PIPE, WT>(p, st);
+    if (epi == BD_EPI_PARTIAL) return launch_one<NP, KW, MB, BD_EPI_PARTIAL, R, false, MODE, WT>(p, st);
+    if (epi == BD_EPI_BF16) return launch_one<NP, KW, MB, BD_EPI_BF16, R, RED, MODE, WT>(p, st);
+    if (epi == BD_EPI_F32) return launch_one<NP, KW, MB, BD_EPI_F32, R, RED, MODE, WT>(p, st);
+    return launch_one<NP, KW, MB, BD_EPI_SWIGLU, R, RED, MODE, WT>(p, st);
 }
 
 // A: fragment-major bf16, RB row-blocks (RB must be 1, 2 or a multiple of 4).  W: packed.  N % (32*NP) == 0, K % (64*KW) == 0.
-template <int NP, int KW, int MB, int R, bool PIPE = false, int WT = 0>
+template <int NP, int KW, int MB, int R, int MODE = 0, int WT = 0>
 static int launch_gemm(const GemmP& p, int epi, hipStream_t st) {
-    if constexpr (NP * KW == 10 && KW == 1) return launch_gemm_r<NP, KW, MB, R, false, false, WT>(p, epi, st);   // single-slice tiles only
-    else return (p.S > 1 && epi != BD_EPI_PARTIAL) ? launch_gemm_r<NP, KW, MB, R, true, PIPE, WT>(p, epi, st)
-                                                   : launch_gemm_r<NP, KW, MB, R, false, PIPE, WT>(p, epi, st);
+    if constexpr (NP * KW == 10 && KW == 1) return launch_gemm_r<NP, KW, MB, R, false, 0, WT>(p, epi, st);   // single-slice tiles only
+    else return (p.S > 1 && epi != BD_EPI_PARTIAL) ? launch_gemm_r<NP, KW, MB, R, true, MODE, WT>(p, epi, st)
+                                                   : launch_gemm_r<NP, KW, MB, R, false, MODE, WT>(p, epi, st);
 }
 

@@ -138,6 +138,8 @@ struct RmsArgs {            // R (+= bf16(pending)) ; a = bf16(w * R*rsqrt(mean(
     const BdStepState* state;
     int M, D, RB, P;
     float eps;
+    int bf16_stream = 0;    // 1: prefill -- the residual stream is bf16 (bf16 embeds, no fp32 position table added): the branch add
+                            //    and both RMSNorm products round to bf16 (HF:59-64 with a bf16 input)
 };
 int bdk_rms(const RmsArgs& a, hipStream_t st);
 
@@ -153,6 +155,7 @@ struct QkvPostArgs {        // q/k RMS-norm + RoPE + KV-cache append            
     const BdStepState* state;
     int M, P, nh, nkv, Lmax;
     float eps;
+    int rope_bf16 = 0;      // 1: prefill -- cos / sin cast to the bf16 hidden dtype (HF:137), every RoPE op rounds to bf16
 };
 int bdk_qkv_post(const QkvPostArgs& a, hipStream_t st);
 
@@ -233,5 +236,6 @@ struct LlmAttnArgs {        // block-bidirectional decode attention over the sta
     void* o_frag;           // out fragment-major bf16 [Mpad][nh*128]
     const BdStepState* state;
     int nseq, P, nh, nkv, Lmax, splits, RB;
+    int causal = 0;         // 1: query p sees keys <= kv_len + p (the prompt call, t2i_pipeline.py:199-203); 0: all kv_len + P keys
 };
 int bdk_llm_attn(const LlmAttnArgs& a, hipStream_t st);

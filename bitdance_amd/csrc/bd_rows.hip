@@ -129,21 +129,29 @@ __global__ void head_prologue_kernel(HeadPrologueArgs a) {
     extern __shared__ float sh[];                    // C floats of the latent row (bf16-rounded)
     const int m = blockIdx.x;
     const int src = m % a.BP;                        // cond / uncond rows share the latent (sampling_x.py:71)
-    for (int k = threadIdx.x; k < a.C; k += blockDim.x) sh[k] = bfr(a.xt[(size_t)src * a.C + k]);
-    __syncthreads();
+    if (a.X) {
+        for (int k = threadIdx.x; k < a.C; k += blockDim.x) sh[k] = bfr(a.xt[(size_t)src * a.C + k]);
+        __syncthreads();
+    }
     const int d0 = threadIdx.x * 8;
     if (d0 >= a.D) return;
-    float ce[8], te[8], y[8], x0[8], b[8];
-    ld_bf16x8((const bf16_t*)a.cemb + (size_t)m * a.D + d0, ce);
-    ld_bf16x8((const bf16_t*)a.temb + d0, te);
-    ld_bf16x8((const bf16_t*)a.in_b + d0, b);
+    // either half may be switched off (null output): y depends on (t_i, cond) only and can run ahead of the chain on a
+    // second stream; x0 depends on the latent the previous evaluation produced
+    if (a.y_frag) {
+        float ce[8], te[8], y[8];
+        ld_bf16x8((const bf16_t*)a.cemb + (size_t)m * a.D + d0, ce);
+        ld_bf16x8((const bf16_t*)a.temb + d0, te);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        y[j] = silu_f(bfr(te[j] + ce[j]));           // bf16 + bf16 -> bf16 ; silu -> bf16 (rounded by pack8)
-        x0[j] = small_dot(sh, (const bf16_t*)a.in_w + (size_t)(d0 + j) * a.C, a.C) + b[j];
+        for (int j = 0; j < 8; ++j) y[j] = silu_f(bfr(te[j] + ce[j]));           // bf16 + bf16 -> bf16 ; silu -> bf16 (rounded by pack8)
+        *reinterpret_cast<u32x4*>((bf16_t*)a.y_frag + afrag_off(m, d0, a.RB)) = pack8(y);
     }
-    *reinterpret_cast<u32x4*>((bf16_t*)a.y_frag + afrag_off(m, d0, a.RB)) = pack8(y);
-    *reinterpret_cast<u32x4*>((bf16_t*)a.X + (size_t)m * a.D + d0) = pack8(x0);
+    if (a.X) {
+        float x0[8], b[8];
+        ld_bf16x8((const bf16_t*)a.in_b + d0, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x0[j] = small_dot(sh, (const bf16_t*)a.in_w + (size_t)(d0 + j) * a.C, a.C) + b[j];
+        *reinterpret_cast<u32x4*>((bf16_t*)a.X + (size_t)m * a.D + d0) = pack8(x0);
+    }
 }
 int bdk_head_prologue(const HeadPrologueArgs& a, hipStream_t st) {
     const int t = row_threads(a.D);
@@ -467,7 +475,7 @@ __global__ void rms_kernel(RmsArgs a) {
             float o[8];
             slab8(a.pend, m, d0, o);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] += o[j];             // fp32 residual + bf16 branch -> fp32
+            for (int j = 0; j < 8; ++j) r[j] = a.bf16_stream ? bfr(r[j] + o[j]) : r[j] + o[j];   // fp32 (decode) / bf16 (prefill) residual + bf16 branch
             st_f32x8(a.R + (size_t)m * a.D + d0, r);
         }
 #pragma unroll
@@ -478,7 +486,8 @@ __global__ void rms_kernel(RmsArgs a) {
     float w[8], n[8];
     unpack8(wr, w);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) n[j] = fmul(w[j], fmul(r[j], rs));   // weight * (x * rsqrt(var+eps)), fp32
+    for (int j = 0; j < 8; ++j)                                     // weight * (x * rsqrt(var+eps)).to(input dtype): fp32, or twice-rounded bf16
+        n[j] = a.bf16_stream ? bfr(fmul(w[j], bfr(fmul(r[j], rs)))) : fmul(w[j], fmul(r[j], rs));
     if (a.a_frag) *reinterpret_cast<u32x4*>((bf16_t*)a.a_frag + afrag_off(m, d0, a.RB)) = pack8(n);   // cast by the next Linear
     if (a.hidden_out) st_f32x8(a.hidden_out + (size_t)m * a.D + d0, n);
     if (a.cond_frag) {                                             // cond = hidden + pos (t2i:244-245), cast by cond_embed
@@ -518,10 +527,17 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(QkvPostArgs a) {
             const float rs = rsqrtf(var + a.eps);
             x0 = bfr(bf2f(w[lane]) * bfr(x0 * rs));               // weight * normed.to(bf16)  (bf16*bf16 -> bf16)
             x1 = bfr(bf2f(w[lane + 64]) * bfr(x1 * rs));
-            const float c0 = a.cos[(size_t)pos * 128 + lane], s0 = a.sin[(size_t)pos * 128 + lane];
-            const float c1 = a.cos[(size_t)pos * 128 + lane + 64], s1 = a.sin[(size_t)pos * 128 + lane + 64];
-            const float y0 = fadd(fmul(x0, c0), fmul(-x1, s0));    // q*cos + rotate_half(q)*sin
-            const float y1 = fadd(fmul(x1, c1), fmul(x0, s1));
+            float c0 = a.cos[(size_t)pos * 128 + lane], s0 = a.sin[(size_t)pos * 128 + lane];
+            float c1 = a.cos[(size_t)pos * 128 + lane + 64], s1 = a.sin[(size_t)pos * 128 + lane + 64];
+            float y0, y1;
+            if (a.rope_bf16) {                                     // bf16 hidden states: tables and every op in bf16
+                c0 = bfr(c0); s0 = bfr(s0); c1 = bfr(c1); s1 = bfr(s1);
+                y0 = bfr(bfr(x0 * c0) + bfr(-x1 * s0));
+                y1 = bfr(bfr(x1 * c1) + bfr(x0 * s1));
+            } else {
+                y0 = fadd(fmul(x0, c0), fmul(-x1, s0));            // q*cos + rotate_half(q)*sin
+                y1 = fadd(fmul(x1, c1), fmul(x0, s1));
+            }
             x0 = y0; x1 = y1;
         }
         if (slot < a.nh) {

@@ -1,10 +1,17 @@
-"""Qwen3 decoder for the BitDance loop: native decode step + prefill on hipBLASLt/SDPA.
+"""Qwen3 decoder for the BitDance loop: the prompt passes (prefill).
 
-The decode step (64 new tokens against the KV cache, the part that runs 64x per image) is the HIP path in
-engine.Engine.llm_step.  The prefill (once per image, SURVEY.md section 8f rank 1 = "next") runs here with
-torch ops in exactly the dtype flow HF's Qwen3 has under bf16 autocast with bf16 hidden states
-(HF modeling_qwen3.py:59-64,140-170,241-323), and writes post-RoPE K / V straight into the engine's static
-KV cache (K [seq][kvh][pos][128], V transposed [seq][kvh][128][pos]).
+The decode step (P new tokens against the KV cache, the part that runs 64x per image) is the HIP path in
+engine.Engine.llm_step.  The prefill (once per image: a causal call over the prompt, then one block-bidirectional call over
+the last P tokens, t2i_pipeline.py:199-217) runs
+
+  * natively (``prefill_native`` / ``native_block``, the default): the SAME step kernels over blocks of P prompt tokens with
+    three switches -- causal masking inside the block, a bf16 residual stream and bf16 RoPE tables -- i.e. the dtype flow
+    HF's Qwen3 has with bf16 hidden states (HF modeling_qwen3.py:59-64,137,140-170,294-323).  No second copy of the LLM
+    weights, and under tensor parallelism the row-split Linears use the same in-step exchange as the decode;
+  * or with torch ops (``prefill_block``: hipBLASLt + SDPA on the original-layout weights, kept only when the weights were
+    packed with ``keep_for_prefill=True``): the round-1 path, still used as a cross-check in the tests.
+
+Both write post-RoPE K / V into the engine's static KV cache (K [seq][kvh][pos][128], V transposed [seq][kvh][128][pos]).
 """
 from __future__ import annotations
 
@@ -79,3 +86,60 @@ def prefill_block(eng: Engine, lw: LlmWeights, x: torch.Tensor, seq0: int, past:
         u = F.linear(a, sd[p + "mlp.up_proj.weight"])
         h = r + reduce_(F.linear(F.silu(g) * u, sd[p + "mlp.down_proj.weight"]))
     return _rms(h, sd["model.norm.weight"], eps)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _run_block(eng: Engine, rows: list, kv: list[int], causal: bool) -> torch.Tensor:
+    """One native step over a block of <= P PROMPT tokens per sequence.  rows[i]: [t_i, D] bf16 (t_i <= P) or None; kv[i]: tokens
+    already cached for sequence i.  Rows past t_i are zero padding: their K / V land behind the real tokens and are
+    overwritten by the next block (every later block starts at kv[i] + t_i), causal queries never see them.
+    Returns last_hidden_state of the block [nseq, P, D] (bf16 values in fp32 storage; rows >= t_i are meaningless)."""
+    P, D = eng.P, eng.llm.cfg["hidden_size"]
+    nseq = len(rows)
+    R = eng.residual()
+    R[: nseq * P].zero_()
+    for i, r in enumerate(rows):
+        if r is not None and r.shape[0]:
+            R[i * P: i * P + r.shape[0]].copy_(r)
+    eng.reset(kv)
+    for k, v in (("rt.llm_causal", int(causal)), ("rt.llm_bf16", 1), ("rt.no_advance", 1), ("rt.emit_cond", 0)):
+        eng.set_int(k, v)
+    try:
+        eng.llm_step()
+    finally:
+        for k, v in (("rt.llm_causal", 0), ("rt.llm_bf16", 0), ("rt.no_advance", 0), ("rt.emit_cond", 1)):
+            eng.set_int(k, v)
+    return eng.hidden().view(nseq, P, D).clone()
+
+
+@torch.no_grad()
+def prefill_native(eng: Engine, seq_embeds: list) -> tuple[torch.Tensor, list[int]]:
+    """The reference's two prompt calls for EVERY sequence of the engine at once (sequences may differ in length: cond /
+    uncond prompts): causal over tokens [0, T_i - P), then all-visible over the last P tokens.  seq_embeds[i]: [T_i, D] bf16.
+    Returns (last_hidden_state of the last P tokens [nseq, P, D], cache lengths T_i)."""
+    P = eng.P
+    nseq = eng.branches * eng.B
+    if len(seq_embeds) != nseq or any(e.shape[0] < P for e in seq_embeds):
+        raise ValueError("prefill_native: one [T >= P, D] embedding tensor per sequence")
+    T0 = [e.shape[0] - P for e in seq_embeds]
+    for c in range((max(T0) + P - 1) // P):
+        rows = [e[c * P: min((c + 1) * P, t0)] if c * P < t0 else None for e, t0 in zip(seq_embeds, T0)]
+        _run_block(eng, rows, [min(c * P, t0) for t0 in T0], causal=True)
+    hid = _run_block(eng, [e[t0:] for e, t0 in zip(seq_embeds, T0)], T0, causal=False)
+    return hid, [e.shape[0] for e in seq_embeds]
+
+
+@torch.no_grad()
+def native_block(eng: Engine, x: torch.Tensor, past: int, causal: bool) -> torch.Tensor:
+    """``Qwen3Model.forward`` over x [B, T, D] (bf16) for all B sequences of the engine with ``past`` cached tokens each:
+    causal (any T, in blocks of P) or all-visible (T == P).  Returns last_hidden_state [B, T, D] bf16."""
+    B, T, D = x.shape
+    P = eng.P
+    if not causal and T != P:
+        raise NotImplementedError("an all-visible prompt call must be exactly one block of parallel_num tokens")
+    outs = []
+    for c in range((T + P - 1) // P):
+        t = min(P, T - c * P)
+        h = _run_block(eng, [x[b, c * P: c * P + t] for b in range(B)], [past + c * P] * B, causal)
+        outs.append(h[:, :t])
+    return torch.cat(outs, dim=1).to(BF16)

@@ -18,7 +18,7 @@ import torch
 import torch.nn.functional as F
 
 from .engine import Engine
-from .llm import prefill_block
+from .llm import native_block, prefill_block
 
 
 class NativeDiffHead:
@@ -125,6 +125,9 @@ class NativeQwen3Model:
             hidden = eng.hidden().clone().view(B, P, -1)
         else:
             x = inputs_embeds.to(pipe.device, torch.bfloat16)
-            hidden = prefill_block(eng, pipe.llm_w, x, 0, past, causal=attention_mask is None)
+            if getattr(pipe, "native_prefill", False):
+                hidden = native_block(eng, x, past, causal=attention_mask is None)
+            else:
+                hidden = prefill_block(eng, pipe.llm_w, x, 0, past, causal=attention_mask is None)
         cache.length = past + T
         return SimpleNamespace(last_hidden_state=hidden, past_key_values=cache)

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from .autoencoder import VQModel
 from .engine import Engine, HeadWeights, LlmWeights, ProjWeights
-from .llm import prefill_block
+from .llm import prefill_block, prefill_native
 from .seams import NativeConnector, NativeDiffHead, NativeQwen3Model
 
 IMAGE_SIZE_LIST = [
@@ -80,25 +80,27 @@ def load_model_dir(model_path: str) -> dict:
 
 
 class BitDanceT2IPipeline:
-    def __init__(self, model_path, device="cuda", tp=None, weights: str = "bf16"):
+    def __init__(self, model_path, device="cuda", tp=None, weights: str = "bf16", native_prefill: bool = True):
         """``tp``: a ``bitdance_amd.tp.TPComm`` -- this process is then one rank of a tensor-parallel group (every rank
         constructs the pipeline on its own GPU and makes the same calls with the same seed); None = one GPU."""
         self.device = device
-        self._init_from(**load_model_dir(model_path), device=device, tp=tp, weights=weights)
+        self._init_from(**load_model_dir(model_path), device=device, tp=tp, weights=weights, native_prefill=native_prefill)
 
     @classmethod
     def from_components(cls, *, tokenizer, llm_cfg, llm_sd, ae_config, ae_sd, head_config, head_sd, proj_sd,
-                        device="cuda", tp=None, weights: str = "bf16"):
+                        device="cuda", tp=None, weights: str = "bf16", native_prefill: bool = True):
         """Same object from in-memory state dicts (tests, synthetic-weight benchmarks)."""
         self = object.__new__(cls)
-        self._init_from(tokenizer, llm_cfg, llm_sd, ae_config, ae_sd, head_config, head_sd, proj_sd, device, tp=tp, weights=weights)
+        self._init_from(tokenizer, llm_cfg, llm_sd, ae_config, ae_sd, head_config, head_sd, proj_sd, device, tp=tp, weights=weights,
+                        native_prefill=native_prefill)
         return self
 
     def _init_from(self, tokenizer, llm_cfg, llm_sd, ae_config, ae_sd, head_config, head_sd, proj_sd, device, tp=None,
-                   weights: str = "bf16"):
+                   weights: str = "bf16", native_prefill: bool = True):
         """``weights`` = "fp8": the streamed Linears are stored e4m3 + per-channel scales (a separate precision mode, BASELINE
         config 5; the once-per-image prefill keeps bf16 copies)."""
         self.weights = weights
+        self.native_prefill = native_prefill               # False: torch prefill on a second, original-layout copy of the LLM
         if not torch.cuda.is_available():
             raise RuntimeError("BitDanceT2IPipeline (bitdance_amd) needs a ROCm GPU; there is no CPU fallback")
         self.device = device
@@ -107,7 +109,8 @@ class BitDanceT2IPipeline:
         self.tokenizer = tokenizer
         self.llm_config = SimpleNamespace(**llm_cfg)
         self.hidden_size = llm_cfg["hidden_size"]
-        self.llm_w = LlmWeights.from_state_dict(llm_sd, llm_cfg, device, tp_rank=tpr, tp_size=tps, weights=weights)
+        self.llm_w = LlmWeights.from_state_dict(llm_sd, llm_cfg, device, keep_for_prefill=not native_prefill, tp_rank=tpr, tp_size=tps,
+                                                weights=weights)
         self.ae_config = ae_config
         self.ae = VQModel(**ae_config).eval()
         if ae_sd is not None:
@@ -225,13 +228,21 @@ class BitDanceT2IPipeline:
             ev[0].record(st)
             hid = []
             kv = []
-            for br, ids in enumerate([cond_ids, uncond_ids][:branches]):
-                x = F.embedding(torch.tensor(ids, device=dev, dtype=torch.long), embed)
-                x = x.unsqueeze(0).repeat(num_images, 1, 1)
-                T0 = x.shape[1] - P
-                prefill_block(eng, self.llm_w, x[:, :T0], br * num_images, 0, causal=True)
-                hid.append(prefill_block(eng, self.llm_w, x[:, T0:], br * num_images, T0, causal=False))
-                kv += [x.shape[1]] * num_images
+            if self.native_prefill:
+                embs = []
+                for ids in [cond_ids, uncond_ids][:branches]:
+                    x = F.embedding(torch.tensor(ids, device=dev, dtype=torch.long), embed)
+                    embs += [x] * num_images
+                hid_last, kv = prefill_native(eng, embs)
+                hid = [hid_last.to(torch.bfloat16)]
+            else:
+                for br, ids in enumerate([cond_ids, uncond_ids][:branches]):
+                    x = F.embedding(torch.tensor(ids, device=dev, dtype=torch.long), embed)
+                    x = x.unsqueeze(0).repeat(num_images, 1, 1)
+                    T0 = x.shape[1] - P
+                    prefill_block(eng, self.llm_w, x[:, :T0], br * num_images, 0, causal=True)
+                    hid.append(prefill_block(eng, self.llm_w, x[:, T0:], br * num_images, T0, causal=False))
+                    kv += [x.shape[1]] * num_images
             cond0 = torch.cat(hid, dim=0)[:, -P:] + pos[None, :P]          # bf16 + fp32 -> fp32 (t2i:244-245)
             eng.set_cond(cond0.reshape(eng.M, -1))
             eng.reset(kv)

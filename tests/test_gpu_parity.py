@@ -224,7 +224,7 @@ def test_llm_second_step_uses_appended_kv(eng_mod, golden_dir):
 
 
 # ----------------------------------------------------------------------------------------------- whole loop
-def tiny_pipeline(head_cfg=None):
+def tiny_pipeline(head_cfg=None, native_prefill=False):
     from bitdance_amd.t2i_pipeline import BitDanceT2IPipeline
     from bitdance_amd.autoencoder import VQModel
     llm_sd = {k: v.to(torch.bfloat16) for k, v in tm.seeded_state(tm.llm_shapes(tm.TINY_LLM), seed=22).items()}
@@ -233,7 +233,7 @@ def tiny_pipeline(head_cfg=None):
         tokenizer=tm.FakeTokenizer(), llm_cfg=tm.TINY_LLM, llm_sd=llm_sd, ae_config=tm.TINY_AE,
         ae_sd=tm.seeded_state(ae_shapes, seed=44, gain=1.4), head_config=dict(head_cfg or tm.TINY_HEAD),
         head_sd=tm.seeded_state(tm.head_shapes(tm.TINY_HEAD), seed=11),
-        proj_sd=tm.seeded_state(tm.proj_shapes(32, 256), seed=33), device=DEV)
+        proj_sd=tm.seeded_state(tm.proj_shapes(32, 256), seed=33), device=DEV, native_prefill=native_prefill)
 
 
 def test_gen_image_teacher_forced_vs_reference(golden_dir):
@@ -757,3 +757,84 @@ def test_pipeline_from_model_dir_and_mllm_surface(tmp_path, golden_dir):
     assert img.shape == (1, 3, 256, 128) and torch.isfinite(img).all()
     with pytest.raises(NotImplementedError):
         m.gen_image_full_causal("x")
+
+
+def test_adaln_side_stream_equals_inline(eng_mod, golden_dir):
+    """tune.ada_async: the adaLN projection of evaluation i+1 runs on a second stream beside evaluation i (fork / join by
+    events, double-buffered output, a low-register GEMM variant).  Same arithmetic per output element -> bit-identical
+    samples, eagerly and from the captured graph."""
+    g = load(golden_dir, "head_amp")
+    sd = tm.seeded_state(tm.head_shapes(tm.TINY_HEAD), seed=11)
+    hw = eng_mod.HeadWeights.from_state_dict(sd, DEV)
+    n, cfg = 3, 2.5
+    outs = []
+    side = torch.cuda.Stream()                                   # graphs cannot be captured on the legacy default stream
+    torch.cuda.set_stream(side)
+    for tune in (None, {"ada_async": 1}):
+        eng = eng_mod.Engine(hw, None, None, num_images=2, branches=2, device=DEV, max_tokens=64, tune=tune)
+        eng.set_schedule(n, cfg, 1)
+        eng.load_noise(g["noise"].view(1, n + 1, 2, 64, 32))
+        eng.reset([0, 0, 0, 0])
+        eng.set_cond(g["z"].to(DEV))
+        eng.head_sample()
+        torch.cuda.synchronize()
+        outs.append(eng.pred().clone())
+        if tune:
+            eng.capture(0)
+            eng.reset([0, 0, 0, 0])
+            eng.launch(0)
+            eng.launch(0)                                     # replay twice: events / buffers are re-usable
+            torch.cuda.synchronize()
+            outs.append(eng.pred().clone())
+    torch.cuda.set_stream(torch.cuda.default_stream())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_native_prefill_vs_reference_and_oracle(eng_mod, golden_dir):
+    """The prompt passes on the step kernels (causal block + bf16 hidden-state flow) against the reference's own outputs
+    (golden llm_amp: h1 = causal call over 11 tokens, h2 = all-visible call over the next 64) with the bounds of the torch
+    prefill, then a decode step on top of the natively filled cache (h3); ragged prompts (a 75-token and a 70-token
+    sequence in one engine) against the oracle."""
+    from bitdance_amd.llm import native_block, prefill_native
+    g = load(golden_dir, "llm_amp")
+    sd, lw, eng = tiny_llm(eng_mod)
+    emb = torch.nn.functional.embedding(g["ids"].long().to(DEV), lw.sd["model.embed_tokens.weight"])
+    h1 = native_block(eng, emb, 0, causal=True)
+    h2 = native_block(eng, g["blk"].to(DEV).to(torch.bfloat16), 11, causal=False)
+    for got, ref in ((h1, g["h1"]), (h2, g["h2"])):
+        e = (got.float().cpu() - ref).abs()
+        assert e.max() <= 0.12 and e.mean() <= 1e-2, (e.max(), e.mean())
+    eng.set_int("rt.emit_cond", 0)
+    eng.reset([75, 75])
+    eng.residual()[:128].copy_(g["dec"].reshape(128, 256).to(DEV))
+    eng.llm_step()
+    torch.cuda.synchronize()
+    e = (eng.hidden().cpu().view(2, 64, 256) - g["h3"]).abs()
+    assert e.max() <= 0.12 and e.mean() <= 1e-2, (e.max(), e.mean())
+    # ragged: sequence 0 has 139 prompt tokens (75 causal + 64), sequence 1 has 134 (70 + 64): blocks of 64 with padding
+    w = {k: v.to(torch.bfloat16) for k, v in sd.items()}
+    gen = torch.Generator().manual_seed(3)
+    xs = [(torch.randn(t, 256, generator=gen) * 0.5).to(torch.bfloat16) for t in (139, 134)]
+    hid, kv = prefill_native(eng, [x.to(DEV) for x in xs])
+    assert kv == [139, 134]
+    pol = Policy("autocast")
+    for b, x in enumerate(xs):
+        T0 = x.shape[0] - 64
+        _, cache = qwen3.model_forward(w, tm.TINY_LLM, x[None, :T0], None, None, pol)
+        ref, _ = qwen3.model_forward(w, tm.TINY_LLM, x[None, T0:], cache, torch.ones(1, 1, 64, x.shape[0], dtype=torch.bool), pol)
+        e = (hid[b].float().cpu() - ref[0].float()).abs()
+        assert e.max() <= 0.1 and e.mean() <= 8e-3, (b, e.max(), e.mean())
+
+
+def test_pipeline_native_prefill_matches_torch_prefill():
+    """Whole loop with the native prefill (the default) vs the torch prefill: first-patch tokens agree (the two prefills differ
+    by bf16 summation order only), no second LLM weight copy is kept."""
+    p_nat, p_torch = tiny_pipeline(native_prefill=True), tiny_pipeline(native_prefill=False)
+    assert set(p_nat.llm_w.sd) == {"model.embed_tokens.weight"} and len(p_torch.llm_w.sd) > 10
+    n, steps = 3, 2
+    noise = torch.randn(steps, n + 1, 1, 64, 32, generator=torch.Generator().manual_seed(7))
+    kw = dict(guidance_scale=3.0, num_sampling_steps=n, max_length=128, num_images=1, image_size=[256, 128], noise=noise)
+    a = p_nat.gen_image("a red fox", "<|", return_tokens=True, **kw)
+    b = p_torch.gen_image("a red fox", "<|", return_tokens=True, **kw)
+    assert (a[:, :64] == b[:, :64]).float().mean().item() >= 0.95
+    assert torch.isfinite(p_nat.gen_image("a red fox", "<|", **kw)).all()

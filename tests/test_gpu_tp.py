@@ -27,6 +27,18 @@ from oracle.numerics import Policy                                        # noqa
 from oracle.true_dims import device_seeded_state                          # noqa: E402
 
 
+_RANK_STREAMS: list = []
+
+
+def _streams(n):
+    """One HIP stream per in-process rank, created ONCE for the whole session: the ranks' kernels wait for each other, so two
+    rank streams must never share a hardware queue; streams taken from torch's pool at different times can (the pool wraps
+    around the queues the runtime multiplexes them onto), a batch created together does not."""
+    while len(_RANK_STREAMS) < 4:
+        _RANK_STREAMS.append(torch.cuda.Stream())
+    return _RANK_STREAMS[:n]
+
+
 def _comms(tp, max_elems):
     from bitdance_amd.tp import TPComm
     comms = TPComm.in_process(tp, max_elems, DEV)
@@ -38,7 +50,7 @@ def _comms(tp, max_elems):
 @pytest.mark.parametrize("tp,rows,N", [(2, 128, 5120), (4, 128, 5120), (4, 32, 768), (2, 256, 5120), (4, 50, 24), (3, 64, 136)])
 def test_exchange_in_process(tp, rows, N):
     comms = _comms(tp, max(rows * N, 4096))
-    streams = [torch.cuda.Stream() for _ in range(tp)]
+    streams = _streams(tp)
     g = torch.Generator(device=DEV).manual_seed(tp * 1000 + rows)
     parts = [torch.randn(rows, N, device=DEV, generator=g) for _ in range(tp)]
     bias = (torch.randn(N, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
@@ -165,7 +177,7 @@ def test_head_eval_tensor_parallel(tp, P):
     x1 = e1.view("head.xhat", torch.float32, (e1.Mpad, C))[:M].clone()
     # tp ranks, one stream each
     comms = _comms(tp, e1.Mpad * 1024)
-    streams = [torch.cuda.Stream() for _ in range(tp)]
+    streams = _streams(tp)
     engs = []
     for r in range(tp):
         hw = E.HeadWeights.from_state_dict(sd_dev, DEV, tp_rank=r, tp_size=tp)
@@ -222,7 +234,7 @@ def test_llm_step_tensor_parallel():
     torch.cuda.synchronize()
     h1 = e1.hidden().clone()
     comms = _comms(tp, e1.Mpad * D)
-    streams = [torch.cuda.Stream() for _ in range(tp)]
+    streams = _streams(tp)
     engs = [E.Engine(None, None, E.LlmWeights.from_state_dict(sd, c, DEV, keep_for_prefill=False, tp_rank=r, tp_size=tp),
                      num_images=2, branches=1, device=DEV, max_tokens=P, max_kv=256, comm=comms[r]) for r in range(tp)]
     torch.cuda.synchronize()
