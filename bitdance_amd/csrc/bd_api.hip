@@ -101,9 +101,12 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
     // ~120 tiles of 128 columns: two splits give 240 workgroups and only TWO slabs for the consumer to re-read
     if (!two_images && N % 128 == 0 && N / 128 >= 100 && N / 128 <= 128 && K <= 8192) g.nw = 4;
     int ntiles = N / (32 * g.nw);
-    int S = (int)std::lround((g.nw >= 8 ? 180.0 : 240.0) / ntiles);
+    // row tiles of the grid (256-row passes): a large batch (ImageNet: 12288 rows = 48 row tiles) already fills the chip
+    // with N tiles x row tiles -- splitting K there only multiplies fp32 slab traffic
+    const int row_tiles = two_images ? c->Mpad / 256 : 1;
+    int S = (int)std::lround((g.nw >= 8 ? 180.0 : 240.0) / ((double)ntiles * row_tiles));
     if (S < 1) S = 1;
-    if (ntiles >= 260 && !swiglu) S = 3;               // > 1 wave of workgroups: split for tail balance
+    if (ntiles >= 260 && !swiglu && row_tiles == 1) S = 3;   // > 1 wave of workgroups: split for tail balance
     if (swiglu && ntiles >= 130) S = 1;
     const bool kw2_shape = !two_images && K % 128 == 0 && N % 64 == 0 && g.nw != 10;
     const bool kw2_ok = kw2_shape && c->geti("tune.kw2", 0) != 0;          // measured slower at tp = 1 (profiles/r02_gemm_sweep2.log)
@@ -486,7 +489,7 @@ static int linear(bd_ctx* c, const char* name, const void* A, int RB, WRef W, in
                   bool force_reduce = false) {
     // 256-row passes run the 4-wave x 2-panel kernel, which has no in-launch reduction: slabs for the consumer there
     const int max_s = (int)c->geti("tune.reduce_max_s", (c->Mpad % 256 == 0) ? 0 : 3);
-    if (g.S <= max_s || force_reduce) {
+    if (g.S <= max_s || g.S == 1 || force_reduce) {            // a single slice needs no reduction: bias + rounding in the epilogue
         BD_TRY(gemm(c, name, A, RB, W, N, K, g.S, g.code(), BD_EPI_BF16, (float*)c->wptr(scratch_ws), c->wptr(out_ws), bias, st));
         *res = Partial{(const float*)c->ptr(out_ws), nullptr, 0, N, Mpad};
     } else {

@@ -248,9 +248,99 @@ __global__ __launch_bounds__(256) void head_attn16_kernel(HeadAttnArgs a) {
     }
 }
 
+
+// The same branch for a FINISHED bf16 qkv tensor (the GEMM rounded its own output): one wave per (sequence, head), four
+// heads per workgroup.  q k^T on the matrix pipe straight from global memory (v_mfma_f32_16x16x32_bf16: a lane's 16 B of Q /
+// K are exactly its A / B operand), softmax across the 16 lanes that hold one query row, P and the V tile through a few KiB
+// of LDS, P V on the VALU (16 keys: 256 FMAs per lane).  Rounding points as above.  At the ImageNet batch (768 sequences x
+// 12 heads) the element-wise kernel above took 1.48 ms per call (profiles/r02_kernel_stats_imagenet_b16x_batch384_10steps.md).
+typedef __attribute__((ext_vector_type(8))) __bf16 bd_bf16x8v;
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+template <int DH>
+__global__ __launch_bounds__(256) void head_attn16_mfma_kernel(HeadAttnArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[4][16 * DH];
+    __shared__ float Ps[4][16 * 17];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pair = blockIdx.x * 4 + wave;                       // (sequence, head)
+    if (pair >= a.nseq * a.nhead) return;                         // whole waves only: no barrier below is block-wide
+    const int seq = pair / a.nhead, h = pair % a.nhead;
+    const bf16_t* base = (const bf16_t*)a.qkv.p + (size_t)(seq * 16) * a.qkv.N + h * DH;
+    const float scale = (DH == 64) ? 0.125f : 0.08838834764831845f;
+    // V tile -> LDS (bf16, row-major [key][DH]); lane l: key l >> 2, 16 B pieces (l & 3) + 4 t
+    {
+        const bf16_t* vrow = base + 2 * a.D + (size_t)(lane >> 2) * a.qkv.N;
+#pragma unroll
+        for (int t = 0; t < DH / 32; ++t) {
+            const int pc = (lane & 3) + 4 * t;
+            *reinterpret_cast<u32x4*>(&Vs[wave][(lane >> 2) * DH + pc * 8]) = *reinterpret_cast<const u32x4*>(vrow + pc * 8);
+        }
+    }
+    // scores: S[i][j] = bf16( sum_d bf16(q_i[d] * scale) k_j[d] ); this lane: i = 4 (lane >> 4) + r, j = lane & 15
+    f32x4v sacc = {0.f, 0.f, 0.f, 0.f};
+    {
+        const bf16_t* qrow = base + (size_t)(lane & 15) * a.qkv.N + (lane >> 4) * 8;
+        const bf16_t* krow = qrow + a.D;
+#pragma unroll
+        for (int kk = 0; kk < DH / 32; ++kk) {
+            const u32x4 qraw = *reinterpret_cast<const u32x4*>(qrow + kk * 32);
+            const u32x4 kraw = *reinterpret_cast<const u32x4*>(krow + kk * 32);
+            u32x4 qs;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                qs[j] = pack2(bf2f((bf16_t)(qraw[j] & 0xffff)) * scale, bf2f((bf16_t)(qraw[j] >> 16)) * scale);   // xq * scale (bf16)
+            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bd_bf16x8v, qs), __builtin_bit_cast(bd_bf16x8v, kraw), sacc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float sv = bfr(sacc[r]);                               // matmul output rounded to bf16
+        float m = sv;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        const float e = expf(sv - m);
+        float sum = e;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        Ps[wave][((lane >> 4) * 4 + r) * 17 + (lane & 15)] = bfr(e / sum);        // P cast to bf16 by the second matmul
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the wave's own LDS writes before its own reads
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // out[i][d0 .. d0 + DH/4) = bf16( sum_j p_ij v_j[d] ); lane: i = lane >> 2, quarter lane & 3
+    constexpr int CH = DH / 4;
+    const int i = lane >> 2, d0 = (lane & 3) * CH;
+    float o[CH];
+#pragma unroll
+    for (int t = 0; t < CH; ++t) o[t] = 0.f;
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+        const float pj = Ps[wave][i * 17 + j];
+#pragma unroll
+        for (int g8 = 0; g8 < CH / 8; ++g8) {
+            const u32x4 vq = *reinterpret_cast<const u32x4*>(&Vs[wave][j * DH + d0 + g8 * 8]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                o[g8 * 8 + 2 * t] += pj * bf2f((bf16_t)(vq[t] & 0xffff));
+                o[g8 * 8 + 2 * t + 1] += pj * bf2f((bf16_t)(vq[t] >> 16));
+            }
+        }
+    }
+    bf16_t* O = (bf16_t*)a.o_frag;
+#pragma unroll
+    for (int g8 = 0; g8 < CH / 8; ++g8)
+        *reinterpret_cast<u32x4*>(O + afrag_off(seq * 16 + i, h * DH + d0 + g8 * 8, a.RB)) =
+            (u32x4){pack2(o[g8 * 8], o[g8 * 8 + 1]), pack2(o[g8 * 8 + 2], o[g8 * 8 + 3]), pack2(o[g8 * 8 + 4], o[g8 * 8 + 5]),
+                    pack2(o[g8 * 8 + 6], o[g8 * 8 + 7])};
+}
+
 int bdk_head_attn(const HeadAttnArgs& a, hipStream_t st) {
     if (a.dh != 128 && !(a.dh == 64 && a.P == 16)) return -2;
     if (a.P == 64) BD_LAUNCH(head_attn_kernel, dim3(a.nseq * a.nhead), dim3(256), 0, st, a);
+    else if (a.P == 16 && a.qkv.S == 0 && a.qkv.N % 8 == 0) {       // finished bf16 qkv: matrix-pipe scores, 4 heads per workgroup
+        const int blocks = (a.nseq * a.nhead + 3) / 4;
+        if (a.dh == 64) BD_LAUNCH(head_attn16_mfma_kernel<64>, dim3(blocks), dim3(256), 0, st, a);
+        else BD_LAUNCH(head_attn16_mfma_kernel<128>, dim3(blocks), dim3(256), 0, st, a);
+    }
     else if (a.P == 16) BD_LAUNCH(head_attn16_kernel, dim3(a.nseq * a.nhead), dim3(256), 0, st, a);
     else return -2;
     return bd_launch_status();
