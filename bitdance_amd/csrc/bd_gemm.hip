@@ -94,7 +94,12 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int S = p.S;
-    const int s = blockIdx.x % S, nt = blockIdx.x / S, mt = blockIdx.y;
+    // row tiles fastest: the workgroups that stream the SAME weight slice (one per 256-row tile) are dispatched back to back,
+    // so the slice comes from HBM once and from L2 / Infinity Cache for the others (512 rows = num_images 4: W used to be
+    // streamed twice; 12 288 rows = the ImageNet batch: 48 consumers per slice)
+    const int RT = p.RB / 8;
+    const int mt = blockIdx.x % RT, rest = blockIdx.x / RT;
+    const int s = rest % S, nt = rest / S;
     const int nb = (nt * 4 + wave) * NPW;
     const int nst_total = p.K >> 6;
     const int q = (nst_total + S - 1) / S;
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
 
 static int launch_gemm_wide(const GemmP& p, int epi, hipStream_t st) {
     const int ntiles = p.N / 256;
-    dim3 grid(ntiles * p.S, p.RB / 8);
+    dim3 grid(ntiles * p.S * (p.RB / 8));
     const size_t lds = (size_t)3 * 8 * 256 * 16;
     static const bool lds_ok = [] {                            // 96 KiB of dynamic LDS needs the opt-in
         const int n = 3 * 8 * 256 * 16;
