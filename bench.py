@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--no-decode", action="store_true", help="imagenet: skip the conv decoder (MIOpen) in the timed pass")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: streamed Linear weights as e4m3 + per-channel scales (BASELINE config 5; a separate precision mode)")
+    ap.add_argument("--attn-splits", type=int, default=None, help="KV splits of the LLM decode attention (default 8)")
     ap.add_argument("--tune", default="", help="comma list name.S=4,name.nw=2,kw2=0 overriding GEMM launch configs")
     a = ap.parse_args()
     if a.workload is None:
@@ -249,6 +250,8 @@ def main():
     if args.weights == "fp8":
         metric += " (fp8-e4m3 weights)"
     pipe.tune = tune or None
+    if args.attn_splits:
+        pipe.attn_splits = args.attn_splits
     pipe.use_graph = not args.no_graph
     if rank == 0:
         print(f"[bench] model built in {time.perf_counter() - t0:.1f} s"

@@ -46,6 +46,7 @@ struct bd_ctx {
     std::vector<hipEvent_t> ev_ada, ev_done;
     hipEvent_t ev_fork = nullptr;
     bool ada_async = false;
+    bool y_ready = false;                 // head.y_all holds y_i of every evaluation for the current cond (set by head_cond)
 
     // derived
     int B = 1, branches = 2, Pn = 64, BP = 64, M = 128, RB = 4, RBp = 2, Mpad = 128, BPpad = 64;
@@ -144,9 +145,9 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
 }
 
 static const char* const kIntKeys[] = {
-    "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid",
+    "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid", "head.y_evals",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
-    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async"};
+    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
                                          "llm.qkv", "llm.o", "llm.gu", "llm.down"};
 static bool known_int_key(const std::string& k) {
@@ -160,7 +161,7 @@ static bool known_int_key(const std::string& k) {
 }
 static const char* const kPtrKeys[] = {
     "head.cond_w", "head.cond_b", "head.in_w", "head.in_b", "head.ada_w", "head.ada_b", "head.lin_w", "head.lin_b", "head.temb",
-    "head.noise", "head.tok_all", "proj.w1", "proj.b1", "proj.w2", "proj.b2", "llm.final_norm", "llm.emb_norm", "llm.rope2d",
+    "head.noise", "head.tok_all", "head.y_all", "proj.w1", "proj.b1", "proj.w2", "proj.b2", "llm.final_norm", "llm.emb_norm", "llm.rope2d",
     "llm.cos", "llm.sin", "pos",
     // workspaces (the caller allocates them after bd_ctx_finalize; a head-/projector-only context may borrow another's)
     "state", "gemm.cnt", "head.cond_frag", "head.cond_part", "head.xt", "head.y_frag", "head.X", "head.ada_bf", "head.cemb",
@@ -517,30 +518,44 @@ static int head_cond(bd_ctx* c, hipStream_t st) {   // cond_embed(c) is constant
     Partial unused;
     BD_TRY(linear(c, "head.cond", c->ptr("head.cond_frag"), c->RB, wref(c, "head.cond_w"), c->hD, c->hDz, g, "head.cond_part",
                   "head.cemb", c->ptr("head.cond_b"), c->Mpad, &unused, st, /*force_reduce=*/true));
+    // y_i = silu(time_embed(t_i) + cond_embed(c)) for the whole schedule while cond_embed is hot (the caller provides
+    // head.y_all [head.y_evals][Mpad][D] when it fits; otherwise every evaluation computes its own y)
+    c->y_ready = false;
+    const int n_evals = (int)c->sched.size();
+    if (n_evals > 0 && c->optr("head.y_all") && c->geti("head.y_evals", 0) >= n_evals) {
+        HeadYAllArgs ya{c->ptr("head.cemb"), c->ptr("head.temb"), c->wptr("head.y_all"), c->M, c->hD, c->RB, c->Mpad, n_evals};
+        BD_TRY(bdk_head_y_all(ya, st));
+        c->y_ready = true;
+    }
     return 0;
 }
 
 // y = silu(time_embed(t_i) + cond_embed(c)) and the stacked adaLN projection of evaluation i into half `buf` of head.ada_bf
 static int head_ada(bd_ctx* c, int i, int buf, bool light, hipStream_t st) {
     const int D = c->hD, RB = c->RB;
-    HeadPrologueArgs pa;
-    pa.cemb = c->ptr("head.cemb");
-    pa.temb = (const bf16_t*)c->ptr("head.temb") + (size_t)i * D;
-    pa.xt = nullptr; pa.in_w = nullptr; pa.in_b = nullptr; pa.X = nullptr;
-    pa.y_frag = c->wptr("head.y_frag");
-    pa.M = c->M; pa.BP = c->BP; pa.D = D; pa.C = c->hC; pa.RB = RB;
-    BD_TRY(bdk_head_prologue(pa, st));
+    const void* y = c->ptr("head.y_frag");
+    if (c->y_ready) {                                          // every y_i of this AR step was produced with cond_embed (head_cond)
+        y = (const bf16_t*)c->ptr("head.y_all") + (size_t)i * c->Mpad * D;
+    } else {
+        HeadPrologueArgs pa;
+        pa.cemb = c->ptr("head.cemb");
+        pa.temb = (const bf16_t*)c->ptr("head.temb") + (size_t)i * D;
+        pa.xt = nullptr; pa.in_w = nullptr; pa.in_b = nullptr; pa.X = nullptr;
+        pa.y_frag = c->wptr("head.y_frag");
+        pa.M = c->M; pa.BP = c->BP; pa.D = D; pa.C = c->hC; pa.RB = RB;
+        BD_TRY(bdk_head_prologue(pa, st));
+    }
     GemmCfg ga = c->cfg("head.ada");
     if (light) { ga.nw = 4; ga.kw = 1; ga.ring = 2; }
     bf16_t* out = (bf16_t*)c->wptr("head.ada_bf") + (size_t)buf * c->Mpad * c->hNada;
-    BD_TRY(gemm(c, "head.ada", c->ptr("head.y_frag"), RB, wref(c, "head.ada_w"), c->hNada, D, 1, ga.code() + (light ? 8192 : 0), BD_EPI_BF16,
+    BD_TRY(gemm(c, "head.ada", y, RB, wref(c, "head.ada_w"), c->hNada, D, 1, ga.code() + (light ? 8192 : 0), BD_EPI_BF16,
                 nullptr, out, c->ptr("head.ada_b"), st));
     return 0;
 }
 
 // `ada_buf` < 0: compute y and the adaLN projection here, in line (the plain path); >= 0: they were produced ahead of time
 // into that half of head.ada_bf (head_sample with tune.ada_async)
-static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1) {
+static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0_ready = false, bool chain_next = false) {
     if (i < 0 || i >= (int)c->sched.size()) return fail("bd_head_eval: eval index outside the schedule");
     const int D = c->hD, Mp = c->Mpad, RB = c->RB, M = c->M;
     const int Dl = c->hDl, Hl = c->hHl;                       // this rank's attention columns / SwiGLU features (== D, H at tp = 1)
@@ -550,13 +565,15 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1) {
         BD_TRY(head_ada(c, i, 0, false, st));
         ada_buf = 0;
     }
-    HeadPrologueArgs pa;
-    pa.cemb = nullptr; pa.temb = nullptr; pa.y_frag = nullptr;
-    pa.xt = (const float*)c->ptr("head.xt");
-    pa.in_w = c->ptr("head.in_w"); pa.in_b = c->ptr("head.in_b");
-    pa.X = c->wptr("head.X");
-    pa.M = M; pa.BP = c->BP; pa.D = D; pa.C = c->hC; pa.RB = RB;
-    BD_TRY(bdk_head_prologue(pa, st));
+    if (!x0_ready) {                                           // x0 = input_proj(x_t): the previous evaluation's final kernel wrote it
+        HeadPrologueArgs pa;                                   // when the evaluations run as a chain (head_sample)
+        pa.cemb = nullptr; pa.temb = nullptr; pa.y_frag = nullptr;
+        pa.xt = (const float*)c->ptr("head.xt");
+        pa.in_w = c->ptr("head.in_w"); pa.in_b = c->ptr("head.in_b");
+        pa.X = c->wptr("head.X");
+        pa.M = M; pa.BP = c->BP; pa.D = D; pa.C = c->hC; pa.RB = RB;
+        BD_TRY(bdk_head_prologue(pa, st));
+    }
 
     const void* ada = (const bf16_t*)c->ptr("head.ada_bf") + (size_t)ada_buf * Mp * c->hNada;
     const int sw = c->hNB / c->hNA;
@@ -619,6 +636,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1) {
     fa.xhat_out = c->geti("rt.dump_xhat", 0) ? (float*)c->wptr("head.xhat") : nullptr;
     fa.sc = c->sched[i];
     fa.BP = c->BP; fa.D = D; fa.C = c->hC; fa.M = M; fa.eps_ln = 1e-6f; fa.sigmoid = (int)c->geti("head.sigmoid", 1);
+    if (chain_next) { fa.X_next = c->wptr("head.X"); fa.in_w = c->ptr("head.in_w"); fa.in_b = c->ptr("head.in_b"); }
     BD_TRY(bdk_head_final(fa, st));
     return 0;
 }
@@ -647,7 +665,7 @@ static int head_sample(bd_ctx* c, hipStream_t st) {
     BD_TRY(bdk_init_latent(ia, st));
     BD_TRY(head_cond(c, st));
     if (!c->ada_async || c->prof_on) {
-        for (int i = 0; i <= n_steps; ++i) BD_TRY(head_eval(c, i, st));
+        for (int i = 0; i <= n_steps; ++i) BD_TRY(head_eval(c, i, st, -1, /*x0_ready=*/i > 0, /*chain_next=*/true));
         return 0;
     }
     // fork: the side stream produces y / adaLN(i) into half i & 1 as soon as evaluation i-2 has released it; the chain of
@@ -658,7 +676,7 @@ static int head_sample(bd_ctx* c, hipStream_t st) {
         if (i >= 2 && hipStreamWaitEvent(c->side, c->ev_done[i - 2], 0) != hipSuccess) return fail("side wait failed");
         BD_TRY(head_ada(c, i, i & 1, true, c->side));
         if (hipEventRecord(c->ev_ada[i], c->side) != hipSuccess || hipStreamWaitEvent(st, c->ev_ada[i], 0) != hipSuccess) return fail("join failed");
-        BD_TRY(head_eval(c, i, st, i & 1));
+        BD_TRY(head_eval(c, i, st, i & 1, i > 0, true));
         if (hipEventRecord(c->ev_done[i], st) != hipSuccess) return fail("event record failed");
     }
     return 0;
@@ -830,7 +848,10 @@ extern "C" {
     try { __VA_ARGS__ } catch (const std::exception& e) { return fail(e.what()); }
 
 int bd_head_cond(bd_ctx* c, void* s) { BD_GUARD(return head_cond(c, (hipStream_t)s);) }
-int bd_head_eval(bd_ctx* c, int i, void* s) { BD_GUARD(return head_eval(c, i, (hipStream_t)s);) }
+int bd_head_eval(bd_ctx* c, int i, void* s) {
+    BD_GUARD(const bool chain = c->geti("rt.chain", 0) != 0;      // debugging: drive head_sample's chained form one evaluation at a time
+             return head_eval(c, i, (hipStream_t)s, -1, chain && i > 0, chain);)
+}
 int bd_head_sample(bd_ctx* c, void* s) { BD_GUARD(return head_sample(c, (hipStream_t)s);) }
 int bd_projector(bd_ctx* c, void* s) { BD_GUARD(return projector(c, (hipStream_t)s);) }
 int bd_llm_step(bd_ctx* c, void* s) { BD_GUARD(return llm_step(c, (hipStream_t)s);) }

@@ -91,8 +91,19 @@ struct HeadFinalArgs {      // pending update, final LN-mod, Linear(D->C), 2*sig
     int BP, D, C, M;
     float eps_ln;
     int sigmoid;            // 1: x_hat = 2*sigmoid(out)-1 (flow_head_parallel_x.py:342); 0: x_hat = out (diff_head_parallel.py:310)
+    void* X_next = nullptr; // not null (and not the final step): x0 = input_proj(x_t) of the NEXT evaluation, written over X's rows of this
+    const void* in_w = nullptr;   // workgroup (flow_head:326) -- saves the next evaluation's prologue launch
+    const void* in_b = nullptr;
 };
 int bdk_head_final(const HeadFinalArgs& a, hipStream_t st);
+
+struct HeadYAllArgs {       // y_i = silu(time_embed(t_i) + cond_embed(c)) for EVERY evaluation of the schedule at once: depends on
+    const void* cemb;       // (t_i, cond) only (flow_head:328-330), so it is computed once per AR step, not once per evaluation
+    const void* temb;       // [n_evals][D] bf16
+    void* y_all;            // out: [n_evals] fragment-major bf16 [Mpad][D]
+    int M, D, RB, Mpad, n_evals;
+};
+int bdk_head_y_all(const HeadYAllArgs& a, hipStream_t st);
 
 struct FinalizeRowsArgs { Partial in; void* out; int M, N; };   // bf16 row-major out = bf16(sum of slabs + bias)
 int bdk_finalize_rows(const FinalizeRowsArgs& a, hipStream_t st);

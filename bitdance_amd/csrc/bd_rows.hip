@@ -272,10 +272,28 @@ BD_DEV void block_sum2(float& v0, float& v1, float* red) {
     v0 = t0; v1 = t1;
 }
 
+__global__ void head_y_all_kernel(HeadYAllArgs a) {
+    const int m = blockIdx.x, i = blockIdx.y, d0 = threadIdx.x * 8;
+    if (d0 >= a.D) return;
+    float ce[8], te[8], y[8];
+    ld_bf16x8((const bf16_t*)a.cemb + (size_t)m * a.D + d0, ce);
+    ld_bf16x8((const bf16_t*)a.temb + (size_t)i * a.D + d0, te);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[j] = silu_f(bfr(te[j] + ce[j]));               // bf16 + bf16 -> bf16 ; silu -> bf16 (rounded by pack8)
+    *reinterpret_cast<u32x4*>((bf16_t*)a.y_all + (size_t)i * a.Mpad * a.D + afrag_off(m, d0, a.RB)) = pack8(y);
+}
+int bdk_head_y_all(const HeadYAllArgs& a, hipStream_t st) {
+    const int t = row_threads(a.D);
+    if (t < 0 || a.D % 8) return -2;
+    BD_LAUNCH(head_y_all_kernel, dim3(a.M, a.n_evals), dim3(t), 0, st, a);
+    return bd_launch_status();
+}
+
 __global__ __launch_bounds__(640) void head_final_kernel(HeadFinalArgs a) {
     __shared__ float red[32];
     __shared__ float wsum[16][64];
     __shared__ float xh[64];
+    __shared__ float xnext[32];
     const int bp = blockIdx.x, d0 = threadIdx.x * 8, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwav = blockDim.x >> 6;
     const bool active = d0 < a.D;
@@ -366,6 +384,19 @@ __global__ __launch_bounds__(640) void head_final_kernel(HeadFinalArgs a) {
             }
         }
         a.xt[idx] = xn;
+        xnext[c] = bfr(xn);                                          // what input_proj's autocast cast sees
+    }
+    if (a.X_next && !a.sc.is_final) {                                // block-uniform
+        __syncthreads();
+        if (active) {
+            float x0n[8], b[8];
+            ld_bf16x8((const bf16_t*)a.in_b + d0, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x0n[j] = small_dot(xnext, (const bf16_t*)a.in_w + (size_t)(d0 + j) * a.C, a.C) + b[j];
+            const u32x4 q = pack8(x0n);
+            *reinterpret_cast<u32x4*>((bf16_t*)a.X_next + (size_t)m0 * a.D + d0) = q;       // cond / uncond rows share the latent
+            if (two) *reinterpret_cast<u32x4*>((bf16_t*)a.X_next + (size_t)m1 * a.D + d0) = q;
+        }
     }
 }
 int bdk_head_final(const HeadFinalArgs& a, hipStream_t st) {

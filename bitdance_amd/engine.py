@@ -432,6 +432,14 @@ class Engine:
         self.set_ptr("head.temb", self.temb)
         self.noise = torch.zeros(ar_steps, n_steps + 1, self.BP, self.head.C, dtype=torch.float32, device=self.device)
         self.set_ptr("head.noise", self.noise)
+        # y_i = silu(time_embed(t_i) + cond_embed(c)) of every evaluation, produced once per AR step next to cond_embed
+        y_bytes = (n_steps + 1) * self.Mpad * self.head.D * 2
+        if y_bytes <= (512 << 20):
+            self.y_all = torch.empty(y_bytes // 2, dtype=BF16, device=self.device)
+            self.set_ptr("head.y_all", self.y_all)
+            self.set_int("head.y_evals", n_steps + 1)
+        else:
+            self.set_int("head.y_evals", 0)
         self.n_steps = n_steps
         self._sched_key = key
         self._captured.clear()                       # pointers / scalars are baked into the graphs

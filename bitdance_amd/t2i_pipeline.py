@@ -181,7 +181,8 @@ class BitDanceT2IPipeline:
             torch.cuda.empty_cache()
             self._engines[key] = Engine(self.head_w, self.proj_w, self.llm_w, num_images=num_images,
                                         branches=branches, device=self.device, max_tokens=tokens, max_kv=lmax,
-                                        tune=getattr(self, "tune", None), parallel_num=self.parallel_num, comm=self.tp)
+                                        tune=getattr(self, "tune", None), parallel_num=self.parallel_num, comm=self.tp,
+                                        attn_splits=getattr(self, "attn_splits", 8))
         return self._engines[key]
 
     def _prompt_ids(self, cond_prompt, uncond_prompt, image_size, cfg_on):

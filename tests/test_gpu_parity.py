@@ -838,3 +838,41 @@ def test_pipeline_native_prefill_matches_torch_prefill():
     b = p_torch.gen_image("a red fox", "<|", return_tokens=True, **kw)
     assert (a[:, :64] == b[:, :64]).float().mean().item() >= 0.95
     assert torch.isfinite(p_nat.gen_image("a red fox", "<|", **kw)).all()
+
+
+@pytest.mark.parametrize("B,branches", [(1, 2), (2, 2), (2, 1)])
+def test_head_sample_chain_equals_standalone_evaluations(eng_mod, B, branches):
+    """head_sample runs the evaluations as a chain: y_i of the whole schedule is produced once next to cond_embed, and the final
+    kernel of evaluation i writes x0 = input_proj(x_t) of evaluation i+1 (no prologue launch).  Same arithmetic per element as
+    the standalone evaluations (bd_head_eval: own prologue each): bit-identical latents after every evaluation."""
+    sd = tm.seeded_state(tm.head_shapes(tm.TINY_HEAD), seed=11)
+    hw = eng_mod.HeadWeights.from_state_dict(sd, DEV)
+    n = 3
+    g = torch.Generator().manual_seed(1)
+    noise = torch.randn(1, n + 1, B, 64, 32, generator=g)
+    z = torch.randn(B * branches, 64, 256, generator=g)
+
+    def mk(chain, y_all=True):
+        eng = eng_mod.Engine(hw, None, None, num_images=B, branches=branches, device=DEV, max_tokens=64)
+        eng.set_schedule(n, 2.5 if branches == 2 else 1.0, 1)
+        if not y_all:
+            eng.set_int("head.y_evals", 0)
+        eng.load_noise(noise)
+        eng.reset([0] * (B * branches))
+        eng.set_cond(z.to(DEV))
+        eng.set_int("rt.chain", chain)
+        return eng
+    a, b, c = mk(1), mk(0), mk(0, y_all=False)
+    for e in (a, b, c):
+        e.view("head.xt", torch.float32, (B * 64, 32)).copy_(e.noise[0, 0])
+        e.head_cond()
+    for i in range(n + 1):
+        for e in (a, b, c):
+            e.head_eval(i)
+        torch.cuda.synchronize()
+        xa, xb, xc = (e.view("head.xt", torch.float32, (B * 64, 32)) for e in (a, b, c))
+        assert torch.equal(xa, xb) and torch.equal(xb, xc), i
+    s = mk(0)
+    s.head_sample()
+    torch.cuda.synchronize()
+    assert torch.equal(s.pred(), b.pred())
