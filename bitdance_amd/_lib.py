@@ -44,6 +44,7 @@ _PROTOS = {
     "bd_ctx_set_float": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "bd_ctx_set_ptr": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
     "bd_ctx_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bd_ctx_set_tp": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "bd_ctx_finalize": (C.c_int, [C.c_void_p]),
     "bd_ctx_ws_count": (C.c_int, [C.c_void_p]),
     "bd_ctx_ws_name": (C.c_char_p, [C.c_void_p, C.c_int]),

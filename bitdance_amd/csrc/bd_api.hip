@@ -293,6 +293,12 @@ int bd_ctx_set_ptr(bd_ctx* c, const char* k, const void* p) {
     return 0;
 }
 /* tensor parallelism: this context is rank bd_comm.rank of bd_comm.size; call before bd_ctx_finalize, weights pre-sliced */
+/* plan a rank's context without a communicator (inspection / host-side tests); a step then fails loudly */
+int bd_ctx_set_tp(bd_ctx* c, int rank, int size) {
+    if (!c || c->finalized || size < 1 || size > 8 || rank < 0 || rank >= size) return fail("bd_ctx_set_tp: before finalize, 0 <= rank < size <= 8");
+    c->comm = nullptr; c->tp = size; c->tpr = rank;
+    return 0;
+}
 int bd_ctx_set_comm(bd_ctx* c, bd_comm* comm) {
     if (!c || c->finalized) return fail("bd_ctx_set_comm: call before bd_ctx_finalize");
     c->comm = comm;
@@ -507,6 +513,7 @@ static int linear_rowsplit(bd_ctx* c, const char* name, const void* A, int RB, W
                            const char* scratch_ws, const char* out_ws, const char* tp_ws, const void* bias, int Mpad, int rows,
                            Partial* res, hipStream_t st) {
     if (c->tp <= 1) return linear(c, name, A, RB, W, N, Klocal, g, scratch_ws, out_ws, bias, Mpad, res, st);
+    if (!c->comm) return fail(std::string(name) + ": tensor-parallel context without a communicator (bd_ctx_set_comm)");
     if (g.S > 3) return fail(std::string(name) + ": a tensor-parallel partial needs at most 3 grid slices");
     BD_TRY(gemm(c, name, A, RB, W, N, Klocal, g.S, g.code(), BD_EPI_F32, (float*)c->wptr(scratch_ws), c->wptr(tp_ws), nullptr, st));
     BD_TRY(bdk_tp_allreduce(c->comm, (const float*)c->ptr(tp_ws), bias, rows, N, res, st));

@@ -67,6 +67,7 @@ int bd_ctx_set_float(bd_ctx* c, const char* key, double v);
 int bd_ctx_set_ptr(bd_ctx* c, const char* key, const void* device_ptr);
 int bd_ctx_set_comm(bd_ctx* c, bd_comm* comm);        /* before finalize: this context is rank comm.rank of comm.size;
                                                          weights handed over are this rank's slices (engine.py) */
+int bd_ctx_set_tp(bd_ctx* c, int rank, int size);     /* plan a rank's context WITHOUT a communicator (inspection, host tests) */
 int bd_ctx_finalize(bd_ctx* c);                       /* validates dims, plans the workspaces */
 int bd_ctx_ws_count(bd_ctx* c);                       /* workspaces the caller must allocate (zero-filled) ... */
 const char* bd_ctx_ws_name(bd_ctx* c, int i);         /* ... and hand back with bd_ctx_set_ptr(name, ptr) */

@@ -173,3 +173,70 @@ def test_gen_image_rejects_inconsistent_token_budget():
     for bad in (192, 320, 100):
         with pytest.raises(ValueError):
             p.gen_image("a", "b", guidance_scale=2.0, max_length=bad, image_size=[256, 256])
+
+
+# ---------------------------------------------------------------------------------------------------------
+def _ctx(ints: dict):
+    from bitdance_amd._lib import lib
+    l = lib()
+    c = l.bd_ctx_create()
+    for k, v in ints.items():
+        assert l.bd_ctx_set_int(c, k.encode(), int(v)) == 0, (k, l.bd_last_error())
+    return l, c
+
+
+DIMS_14B = {"B": 1, "branches": 2, "P": 64, "head.D": 5120, "head.C": 32, "head.Dz": 5120, "head.H": 7680, "head.nblocks": 6,
+            "head.nada": 2, "head.T": 4096, "proj.D": 5120, "proj.C": 32, "llm.D": 5120, "llm.L": 40, "llm.nh": 40, "llm.nkv": 8,
+            "llm.F": 17408, "llm.head_dim": 128, "llm.Lmax": 4352, "llm.splits": 8}
+
+
+def _cfg(l, c, name):
+    s, nw = ctypes.c_int(), ctypes.c_int()
+    assert l.bd_gemm_config(c, name.encode(), ctypes.byref(s), ctypes.byref(nw)) == 0
+    return s.value, nw.value & 15, ((nw.value >> 8) & 3) + 1
+
+
+def test_context_planning_is_host_only_and_rejects_unknown_keys():
+    """bd_ctx_* up to bd_ctx_finalize is host code (no GPU): unknown keys are errors, never silent defaults; the launch plan at
+    BitDance-14B-64x dimensions is the one the headline benchmark runs (10-wave adaLN tiles, 2-slice qkv / w1, 6-slice 8-wave
+    N = 5120 shapes) and every workspace has a positive size."""
+    l, c = _ctx(DIMS_14B)
+    assert l.bd_ctx_set_int(c, b"head.Dd", 1) != 0 and b"unknown key" in l.bd_last_error()
+    assert l.bd_ctx_set_ptr(c, b"head.blk0.wqkx", 0) != 0
+    assert l.bd_ctx_set_ptr(c, b"head.blk12.wqkv", 0) == 0 and l.bd_ctx_set_ptr(c, b"llm.l39.wdown_s", 0) == 0
+    assert l.bd_ctx_set_float(c, b"llm.epsilon", 1e-6) != 0 and l.bd_ctx_set_float(c, b"llm.eps", 1e-6) == 0
+    assert l.bd_ctx_set_int(c, b"tune.head.wo.S", 6) == 0 and l.bd_ctx_set_int(c, b"tune.head.wq.S", 6) != 0
+    assert l.bd_ctx_finalize(c) == 0, l.bd_last_error()
+    assert _cfg(l, c, "head.ada") == (1, 10, 1)
+    assert _cfg(l, c, "head.qkv") == (2, 4, 1) and _cfg(l, c, "head.w1") == (2, 4, 1)
+    assert _cfg(l, c, "head.wo") == (6, 8, 2) and _cfg(l, c, "head.w2") == (6, 8, 2) and _cfg(l, c, "llm.o") == (6, 8, 2)
+    n = l.bd_ctx_ws_count(c)
+    names = [l.bd_ctx_ws_name(c, i).decode() for i in range(n)]
+    assert "llm.k_cache" in names and "head.ada_bf" in names and "head.tp_part" not in names
+    assert all(l.bd_ctx_ws_bytes(c, i) > 0 for i in range(n))
+    assert l.bd_ctx_ws_name(c, n) is None and l.bd_ctx_ws_bytes(c, -1) < 0           # bounds-checked
+    assert l.bd_ctx_bind(c) != 0                                                      # workspaces not provided yet
+    l.bd_ctx_destroy(c)
+
+
+@pytest.mark.parametrize("tp", [2, 4, 8])
+def test_context_planning_tensor_parallel(tp):
+    """Per-rank plan of the 14B model (bd_ctx_set_tp: planning needs no communicator): local widths divide, the row-split
+    Linears (wo / w2 / o_proj / down_proj) produce ONE finished partial (at most 3 grid slices, reduced in the launch), the KV
+    cache shrinks with the kv heads, an indivisible size is rejected."""
+    l, c = _ctx(DIMS_14B)
+    assert l.bd_ctx_set_tp(c, tp - 1, tp) == 0
+    assert l.bd_ctx_finalize(c) == 0, l.bd_last_error()
+    for name in ("head.wo", "head.w2", "llm.o", "llm.down"):
+        assert _cfg(l, c, name)[0] <= 3, (name, _cfg(l, c, name))
+    ws = {l.bd_ctx_ws_name(c, i).decode(): l.bd_ctx_ws_bytes(c, i) for i in range(l.bd_ctx_ws_count(c))}
+    assert "head.tp_part" in ws and ws["head.tp_part"] == 128 * 5120 * 4 and "llm.tp_part" in ws
+    l1, c1 = _ctx(DIMS_14B)
+    assert l1.bd_ctx_finalize(c1) == 0
+    ws1 = {l1.bd_ctx_ws_name(c1, i).decode(): l1.bd_ctx_ws_bytes(c1, i) for i in range(l1.bd_ctx_ws_count(c1))}
+    assert ws["llm.k_cache"] * tp == ws1["llm.k_cache"] and ws["head.act_frag"] * tp == ws1["head.act_frag"]
+    l.bd_ctx_destroy(c); l1.bd_ctx_destroy(c1)
+    l3, c3 = _ctx(DIMS_14B)
+    assert l3.bd_ctx_set_tp(c3, 0, 3) == 0 and l3.bd_ctx_finalize(c3) != 0 and b"divide" in l3.bd_last_error()
+    assert l3.bd_ctx_set_tp(c3, 3, 3) != 0
+    l3.bd_ctx_destroy(c3)
