@@ -416,8 +416,124 @@ __global__ __launch_bounds__(256) void in_attn_kernel(InAttnArgs a) {
             make_uint2(pack2(o4[0], o4[1]), pack2(o4[2], o4[3]));
     }
 }
+
+// The same arithmetic on the matrix pipe, one wave per (sequence, head), four pairs per workgroup, all LDS wave-private:
+//   scores: v_mfma_f32_16x16x32_bf16 with Q (16 queries x 64) resident in registers and 16 keys per step read straight from
+//           the cache (a lane's 16 B = its B operand), four steps of loads in flight; bf16(score) parked in LDS;
+//   softmax over the whole row (the reference rounds P = e / sum to bf16 only after the full-row sum): max, sum, then
+//           p = bf16(e / sum) overwrites the score;
+//   P V on the VALU from 64-key V tiles staged in LDS (16 x L x 64 MACs per pair).
+// 12 + 8 KiB of LDS per wave at L <= 384: two workgroups per CU.  ImageNet batch 384: 1027 -> see profiles/.
+__global__ __launch_bounds__(256) void in_attn_mfma_kernel(InAttnArgs a, int LS) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= a.nseq * a.nh) return;                              // wave-private LDS: no block-wide barrier below
+    bf16_t* sc = reinterpret_cast<bf16_t*>(smem_raw) + (size_t)wave * (16 * LS + 64 * 64);   // [16][LS] scores, then P
+    bf16_t* Vs = sc + 16 * LS;                                      // [64 keys][64] V tile
+    const int seq = pair / a.nh, h = pair % a.nh;
+    const int L = a.state->kv_len[0] + a.P;
+    const int D = a.nh * 64;
+    const bf16_t* Q = (const bf16_t*)a.q + (size_t)seq * 16 * D + h * 64;
+    const bf16_t* Kc = a.k_cache + ((size_t)seq * a.nh + h) * a.Lmax * 64;
+    const bf16_t* Vc = a.v_cache + ((size_t)seq * a.nh + h) * a.Lmax * 64;
+    const int r16 = lane & 15, kg = (lane >> 4) * 8;
+    u32x4 qa[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) qa[kk] = *reinterpret_cast<const u32x4*>(Q + (size_t)r16 * D + kk * 32 + kg);
+    // ---- scores
+    for (int t0 = 0; t0 < L; t0 += 64) {
+        u32x4 kb[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int key = t0 + u * 16 + r16;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                kb[u][kk] = (key < L) ? *reinterpret_cast<const u32x4*>(Kc + (size_t)key * 64 + kk * 32 + kg) : (u32x4){0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            f32x4v sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bd_bf16x8v, qa[kk]), __builtin_bit_cast(bd_bf16x8v, kb[u][kk]), sacc, 0, 0, 0);
+            const int key = t0 + u * 16 + r16;                      // D layout: row (query) 4 (lane >> 4) + r, column (key) lane & 15
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[((lane >> 4) * 4 + r) * LS + key] = (key < L) ? f2bf(sacc[r]) : (bf16_t)0xff80;   // -inf pad
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- softmax: 4 lanes per query row
+    const int i = lane >> 2, sub = lane & 3;
+    const int Lp = (L + 63) & ~63;
+    {
+        bf16_t* row = sc + i * LS;
+        float mx = -INFINITY;
+        for (int j = sub; j < L; j += 4) mx = fmaxf(mx, bf2f(row[j]));
+        mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
+        float sum = 0.f;
+        for (int j = sub; j < L; j += 4) sum += expf(bf2f(row[j]) - mx);
+        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
+        for (int j = sub; j < Lp; j += 4) row[j] = (j < L) ? f2bf(expf(bf2f(row[j]) - mx) / sum) : (bf16_t)0;   // P as bf16; pads 0
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- P V: lane -> query i, 16 channels d0..
+    const int d0 = sub * 16;
+    float o[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) o[t] = 0.f;
+    for (int t0 = 0; t0 < L; t0 += 64) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {                               // 64 keys x 8 pieces of 16 B
+            const int u = lane + 64 * t, key = u >> 3, pc = u & 7;
+            *reinterpret_cast<u32x4*>(Vs + key * 64 + pc * 8) =
+                (t0 + key < L) ? *reinterpret_cast<const u32x4*>(Vc + (size_t)(t0 + key) * 64 + pc * 8) : (u32x4){0, 0, 0, 0};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll 2
+        for (int j8 = 0; j8 < 8; ++j8) {
+            const u32x4 pq = *reinterpret_cast<const u32x4*>(sc + i * LS + t0 + j8 * 8);
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const float pj = bf2f((bf16_t)((jj & 1) ? (pq[jj >> 1] >> 16) : (pq[jj >> 1] & 0xffff)));
+                const bf16_t* vrow = Vs + (j8 * 8 + jj) * 64 + d0;
+                const u32x4 v0 = *reinterpret_cast<const u32x4*>(vrow), v1 = *reinterpret_cast<const u32x4*>(vrow + 8);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    o[2 * t] += pj * bf2f((bf16_t)(v0[t] & 0xffff));
+                    o[2 * t + 1] += pj * bf2f((bf16_t)(v0[t] >> 16));
+                    o[8 + 2 * t] += pj * bf2f((bf16_t)(v1[t] & 0xffff));
+                    o[8 + 2 * t + 1] += pj * bf2f((bf16_t)(v1[t] >> 16));
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                            // the tile is consumed before the next one overwrites it
+    }
+    bf16_t* O = (bf16_t*)a.o_frag;
+#pragma unroll
+    for (int g8 = 0; g8 < 2; ++g8)
+        *reinterpret_cast<u32x4*>(O + afrag_off(seq * 16 + i, h * 64 + d0 + g8 * 8, a.RB)) =
+            (u32x4){pack2(o[g8 * 8], o[g8 * 8 + 1]), pack2(o[g8 * 8 + 2], o[g8 * 8 + 3]), pack2(o[g8 * 8 + 4], o[g8 * 8 + 5]),
+                    pack2(o[g8 * 8 + 6], o[g8 * 8 + 7])};
+}
+
 int bdk_in_attn(const InAttnArgs& a, hipStream_t st) {
     if (a.P > 16) return -2;
+    {   // matrix-pipe form: whole 16-token blocks, score rows that fit the per-wave LDS budget
+        const int LS = ((a.Lmax + 64 + 63) & ~63) + 8;             // row stride in bf16: multiple of 8 (16 B reads), off the bank period
+        const size_t lds_m = (size_t)4 * (16 * LS + 64 * 64) * sizeof(bf16_t);
+        static const bool ok = hipFuncSetAttribute((const void*)in_attn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        if (a.P == 16 && ok && lds_m <= 160 * 1024) {
+            BD_LAUNCH(in_attn_mfma_kernel, dim3((a.nseq * a.nh + 3) / 4), dim3(256), lds_m, st, a, LS);
+            return bd_launch_status();
+        }
+    }
     const int Lcap = a.Lmax + 64;
     const size_t lds = (size_t)(16 * 64 + 64 * 65 + 16 * (Lcap + 1)) * sizeof(float);
     if (lds > 160 * 1024) return -3;
