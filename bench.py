@@ -268,12 +268,34 @@ def main():
         with torch.amp.autocast("cuda", enabled=True, dtype=torch.bfloat16):
             return pipe.gen_image(**kw)
 
+    def tp_pass_ok(i) -> bool:
+        """One pass; True iff it completed on every rank AND every rank holds bit-identical tokens."""
+        ok = 1
+        try:
+            one_pass(i)
+        except Exception as e:                                 # in-kernel wait budget exceeded etc.: all ranks must agree on what happens next
+            print(f"[bench] rank {rank}: tensor-parallel pass failed: {e}", file=sys.stderr, flush=True)
+            ok = 0
+        flag = torch.tensor([ok], device="cpu" if dist.get_backend() == "gloo" else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            return False
+        return tokens_agree(dist, next(iter(pipe._engines.values())).tok_all, dev)
+
     for i in range(args.warmup):
-        one_pass(i)
         if tp_mode and i == 0:
-            eng = next(iter(pipe._engines.values()))
-            if not tokens_agree(dist, eng.tok_all, dev):
-                raise RuntimeError("tensor-parallel ranks diverged: token checksums differ between ranks")
+            if not tp_pass_ok(i):
+                if comm.backend == "rccl":
+                    raise RuntimeError("tensor-parallel ranks failed or diverged (RCCL exchange)")
+                if rank == 0:
+                    print("[bench] the IPC exchange failed or diverged on this node: falling back to RCCL all-reduce", file=sys.stderr, flush=True)
+                pipe._engines.clear()
+                comm.reset()
+                comm.use_rccl()
+                if not tp_pass_ok(i):
+                    raise RuntimeError("tensor-parallel ranks failed or diverged with the RCCL exchange too")
+        else:
+            one_pass(i)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):

@@ -87,7 +87,10 @@ BD_DEV void tp_wait(const ArArgs& a, int base, int b, int e, int err_index) {
     if (t < a.size && t != a.rank) {
         const int* f = a.flags + base + t * BD_TP_GMAX + b;
         const long long t0 = wall_clock64();
-        while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+        // once any wait of this rank has timed out the exchange is dead: later waits return at once (the host raises after
+        // the next sync) instead of spending the budget 44 000 times
+        const bool dead = __hip_atomic_load(a.flags + err_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+        while (!dead && (int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
             __builtin_amdgcn_s_sleep(8);
             if (wall_clock64() - t0 > a.timeout_ticks) {
                 __hip_atomic_fetch_or(a.flags + err_index, 1 << t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256) void tp_allreduce_kernel(ArArgs a) {
 
 // after an RCCL all-reduce the fp32 sums sit in the staging area: the consumer adds bias and rounds (Partial with S = 1)
 int bdk_tp_allreduce(bd_comm* c, const float* part, const void* bias, int rows, int N, Partial* res, hipStream_t st) {
-    if (!c || c->size < 2) return -2;
+    if (!c || (c->size < 2 && c->mode != 1)) return -2;            // a single rank only through RCCL (plumbing tests)
     if (N % 8) return -3;
     {
         const long long U = (long long)rows * (N / 8), Us = (U + c->size - 1) / c->size;
@@ -277,6 +280,13 @@ int bd_comm_set_rccl(bd_comm* c, void* nccl_comm, void* nccl_allreduce_fn) {
     return 0;
 }
 int bd_comm_set_timeout(bd_comm* c, double seconds) { c->timeout_s = seconds; return 0; }
+/* after a failed exchange (all ranks, between two host barriers): clear flags, epochs and the error word */
+int bd_comm_reset(bd_comm* c) {
+    const size_t fbytes = (size_t)(2 * BD_TP_MAX * BD_TP_GMAX + 1 + BD_TP_GMAX) * sizeof(int);
+    if (hipDeviceSynchronize() != hipSuccess || hipMemset(c->flags, 0, fbytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+        return cfail("bd_comm_reset failed");
+    return 0;
+}
 long long bd_comm_exchanges(bd_comm* c) { return c->n_exchanges; }
 
 /* host-side check after a stream sync: bit p set = the wait for peer p ran out of its time budget */

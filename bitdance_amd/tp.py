@@ -95,7 +95,7 @@ def shard_llm_state(sd: dict, cfg: dict, rank: int, size: int) -> dict:
 
 # ----------------------------------------------------------------------------------------------- communicator
 class _NcclUniqueId(C.Structure):
-    _fields_ = [("internal", C.c_char * 128)]
+    _fields_ = [("internal", C.c_ubyte * 128)]          # c_ubyte: a c_char field would be read back truncated at the first NUL
 
 
 class TPComm:
@@ -131,18 +131,44 @@ class TPComm:
         self.group = group
         backend = backend or os.environ.get("BD_TP_COMM", "ipc")
         if size > 1:
+            # map the peers' buffers; if ANY rank cannot (IPC export / open refused on this node), every rank falls back to RCCL
+            ok, why = True, ""
             buf = C.create_string_buffer(128)
-            check(self.l.bd_comm_ipc_handles(self.h, buf), "bd_comm_ipc_handles")
+            if self.l.bd_comm_ipc_handles(self.h, buf) != 0:
+                ok, why = False, self.l.bd_last_error().decode()
             handles = [None] * size
-            dist.all_gather_object(handles, bytes(buf.raw), group=group)
-            for p in range(size):
-                if p != rank:
-                    check(self.l.bd_comm_open_peer(self.h, p, C.create_string_buffer(handles[p], 128)), "bd_comm_open_peer")
+            dist.all_gather_object(handles, (bytes(buf.raw), ok, why), group=group)
+            ok = all(h[1] for h in handles)
+            if ok:
+                for p in range(size):
+                    if p != rank and self.l.bd_comm_open_peer(self.h, p, C.create_string_buffer(handles[p][0], 128)) != 0:
+                        ok, why = False, self.l.bd_last_error().decode()
+            flags = [None] * size
+            dist.all_gather_object(flags, (ok, why), group=group)
+            if not all(f[0] for f in flags):
+                if rank == 0:
+                    print(f"[bitdance_amd.tp] IPC mapping failed ({[f[1] for f in flags if not f[0]][:1]}): exchanges go through RCCL", flush=True)
+                backend = "rccl"
             if backend == "rccl":
                 self._init_rccl(dist, group)
             dist.barrier(group=group)
         self.backend = backend if size > 1 else "none"
         return self
+
+    def use_rccl(self) -> None:
+        """Switch the per-Linear exchange to ncclAllReduce (every rank must call it; engines / graphs built before are stale)."""
+        import torch.distributed as dist
+        if self._nccl is None:
+            self._init_rccl(dist, self.group)
+        else:
+            check(self.l.bd_comm_set_rccl(self.h, self._nccl[1], C.cast(self._nccl[0].ncclAllReduce, C.c_void_p).value), "bd_comm_set_rccl")
+        self.backend = "rccl"
+
+    def reset(self) -> None:
+        """After a failed exchange: every rank, between two barriers."""
+        self.barrier()
+        check(self.l.bd_comm_reset(self.h), "bd_comm_reset")
+        self.barrier()
 
     @classmethod
     def in_process(cls, size: int, max_elems: int, device=None) -> list:
@@ -162,16 +188,18 @@ class TPComm:
         uid = _NcclUniqueId()
         if self.rank == 0:
             n.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
-            if n.ncclGetUniqueId(C.byref(uid)) != 0:
-                raise BitDanceHipError("ncclGetUniqueId failed")
-        box = [bytes(uid.internal)] if self.rank == 0 else [None]
+            rc = n.ncclGetUniqueId(C.byref(uid))
+            if rc != 0:
+                raise BitDanceHipError(f"ncclGetUniqueId failed ({rc})")
+        box = [C.string_at(C.byref(uid), 128)] if self.rank == 0 else [None]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         C.memmove(C.byref(uid), box[0], 128)
         comm = C.c_void_p()
         n.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
         with torch.cuda.device(self.device):
-            if n.ncclCommInitRank(C.byref(comm), self.size, uid, self.rank) != 0:
-                raise BitDanceHipError("ncclCommInitRank failed")
+            rc = n.ncclCommInitRank(C.byref(comm), self.size, uid, self.rank)
+            if rc != 0:
+                raise BitDanceHipError(f"ncclCommInitRank failed ({rc})")
         fn = C.cast(n.ncclAllReduce, C.c_void_p).value
         check(self.l.bd_comm_set_rccl(self.h, comm, fn), "bd_comm_set_rccl")
         self._nccl = (n, comm)

@@ -111,6 +111,7 @@ void* bd_comm_local_data(bd_comm* c);
 void* bd_comm_local_flags(bd_comm* c);
 int bd_comm_set_rccl(bd_comm* c, void* nccl_comm, void* nccl_allreduce_fn);
 int bd_comm_set_timeout(bd_comm* c, double seconds);                 /* budget of every in-kernel wait (default 20 s) */
+int bd_comm_reset(bd_comm* c);                                       /* all ranks, between host barriers: clear flags / epochs / error */
 int bd_comm_error(bd_comm* c);                                       /* after a sync: bit p set = waiting for peer p timed out */
 long long bd_comm_exchanges(bd_comm* c);                             /* exchange launches issued so far (reporting) */
 int bd_comm_allreduce(bd_comm* c, const float* part, const void* bias_bf16, int rows, int N, void** out_ptr, int* out_is_fp32,

@@ -322,3 +322,29 @@ def test_two_process_ipc_pipeline():
     agree0 = float((t0[:, :64] == single[:, :64]).mean())
     assert agree0 >= 0.93, agree0                                     # first patch vs the single-GPU run (summation order only)
     assert nx0 == nx1 and nx0 > 0
+
+
+def test_rccl_exchange_plumbing_single_rank():
+    """The RCCL form of the exchange (BD_TP_COMM=rccl / the automatic fallback): communicator bootstrap through ctypes on the
+    librccl torch itself uses (unique id by value, ncclCommInitRank) and ncclAllReduce called from the C library through the
+    function pointer handed over by the host.  A one-GPU box can only form a single-rank communicator (RCCL refuses two ranks
+    on one device), which still exercises every call on the path; values: bf16(partial + bias)."""
+    import torch.distributed as dist
+    from bitdance_amd.tp import TPComm
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=0, world_size=1, init_method=f"tcp://127.0.0.1:{29900 + os.getpid() % 1000}")
+        created = True
+    try:
+        comm = TPComm(0, 1, 128 * 5120, DEV)
+        comm._init_rccl(dist, None)
+        g = torch.Generator(device=DEV).manual_seed(5)
+        part = torch.randn(128, 5120, device=DEV, generator=g)
+        bias = (torch.randn(5120, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+        for _ in range(2):
+            out = comm.allreduce(part, bias)
+            torch.cuda.synchronize()
+            assert torch.equal(out, (part + bias.float()).to(torch.bfloat16))
+    finally:
+        if created:
+            dist.destroy_process_group()
