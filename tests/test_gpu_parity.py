@@ -876,3 +876,29 @@ def test_head_sample_chain_equals_standalone_evaluations(eng_mod, B, branches):
     s.head_sample()
     torch.cuda.synchronize()
     assert torch.equal(s.pred(), b.pred())
+
+
+def test_bench_contract_on_tiny_workload():
+    """bench.py's one-JSON-line contract (driver-facing): run the tiny workload end to end in a subprocess and check the fields
+    the driver and the judge read, incl. roofline and cpu_baseline.parity."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and d["higher_is_better"] is True
+    assert abs(d["value"] - 1000.0 / d["ms_per_step"]) < 1e-2 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert cb["parity"]["within_bounds"] is True
