@@ -36,7 +36,7 @@ int bd_gemm_partial(const void* a_frag, int row_blocks, const void* w_packed, in
                     float* out_partial, void* stream);
 /* The same Linear with the split-K slices reduced INSIDE the launch (the last-arriving slice of each tile sums the
  * others' slabs, adds the bias and rounds once): out_bf16 [row_blocks*32][N] row-major is exactly what F.linear returns
- * under autocast.  scratch: [splitk][rows][N] fp32; counters: one int per output tile, zero on entry, zero on exit. */
+ * under autocast.  scratch: splitk x rows x N fp32 of slab space (layout private to the kernel); counters: one int per output tile, zero on entry, zero on exit. */
 int bd_gemm_bf16(const void* a_frag, int row_blocks, const void* w_packed, const void* bias_bf16, int N, int K, int splitk,
                  int nwaves, float* scratch, int* counters, void* out_bf16, void* stream);
 /* The same with a finished fp32 result and no bias / rounding: one tensor-parallel rank's partial of a row-split Linear
