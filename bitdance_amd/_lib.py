@@ -26,6 +26,7 @@ _PROTOS = {
     "bd_last_error": (C.c_char_p, []),
     "bd_pack_weight": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "bd_set_weight_layout": (C.c_int, [C.c_int]),
+    "bd_set_gemm_option": (C.c_int, [C.c_char_p, C.c_int]),
     "bd_pack_weight_swiglu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "bd_rows_to_frag": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "bd_gemm_partial": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

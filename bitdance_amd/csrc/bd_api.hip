@@ -51,6 +51,7 @@ struct bd_ctx {
     // derived
     int B = 1, branches = 2, Pn = 64, BP = 64, M = 128, RB = 4, RBp = 2, Mpad = 128, BPpad = 64;
     int hD = 0, hC = 0, hDz = 0, hH = 0, hNB = 0, hNA = 0, hNada = 0, hT = 0;
+    int hMlp = 0;                         // "head.variant" = 1: MLP head of the 1x ImageNet models (imagenet_gen/src/diff_head.py), no attention
     int lD = 0, lL = 0, lnh = 0, lnkv = 0, lF = 0, lLmax = 0, lsplits = 8, lNqkv = 0;
     int ldh = 128, lvariant = 0;          // lvariant 1: imagenet transformer (head_dim 64, MHA, 2-D RoPE, bf16 residual)
     bool has_head = false, has_llm = false, has_proj = false;
@@ -101,7 +102,16 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
     if (!two_images && c->Mpad % 128 == 0 && N % 320 == 0 && N / 320 > 200 && N / 320 <= 256) g.nw = 10;
     // ~120 tiles of 128 columns: two splits give 240 workgroups and only TWO slabs for the consumer to re-read
     if (!two_images && N % 128 == 0 && N / 128 >= 100 && N / 128 <= 128 && K <= 8192) g.nw = 4;
-    int ntiles = N / (32 * g.nw);
+    // one wave of workgroups with a RAGGED last tile: N/32 panels over ceil(panels / 9) workgroups of 9 waves when that lands just
+    // under 256 (adaLN: 2240 panels -> 249 workgroups instead of 224 x 10 waves: 131.7 vs 137.5 us isolated, profiles/
+    // r02_gemm_sweep3.log).  The 5-wave form (gate/up: 1088 panels -> 218 workgroups instead of 136 x 8) measured SLOWER (88.1 vs
+    // 82.8 us: fewer bytes in flight per CU), so it stays a tune option.  bf16 weights, 128-row passes (the instantiated shapes).
+    bool ragged = false;
+    if (!two_images && c->Mpad % 128 == 0 && !c->wfp8 && N % 32 == 0 && c->geti("tune.ragged", 1) != 0) {
+        const int npmin = (N / 32 + 255) / 256;
+        if (npmin == 9) { g.nw = npmin; ragged = true; }
+    }
+    int ntiles = (N / 32 + g.nw - 1) / g.nw;
     // row tiles of the grid (256-row passes): a large batch (ImageNet: 12288 rows = 48 row tiles) already fills the chip
     // with N tiles x row tiles -- splitting K there only multiplies fp32 slab traffic
     const int row_tiles = two_images ? c->Mpad / 256 : 1;
@@ -137,7 +147,8 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
     g.kw = (int)c->geti("tune." + name + ".kw", g.kw);
     g.ring = (int)c->geti("tune." + name + ".ring", g.ring);
     if (g.kw < 1 || g.kw > 2 || g.nw % g.kw || K % (64 * g.kw)) g.kw = 1;
-    if (N % (32 * (g.nw / g.kw))) { g.kw = 1; g.nw = (N % 128 == 0) ? 4 : 2; }
+    ragged = ragged || (g.kw == 1 && (g.nw == 5 || g.nw == 9) && !c->wfp8 && c->Mpad % 128 == 0 && !two_images);
+    if (N % (32 * (g.nw / g.kw)) && !ragged) { g.kw = 1; g.nw = (N % 128 == 0) ? 4 : 2; }
     const int nst = K / (64 * g.kw);
     if (g.S > nst) g.S = nst;
     while (g.S > 1 && (g.S - 1) * ((nst + g.S - 1) / g.S) >= nst) --g.S;      // no empty split
@@ -145,9 +156,9 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
 }
 
 static const char* const kIntKeys[] = {
-    "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid", "head.y_evals",
+    "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid", "head.y_evals", "head.variant",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
-    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async"};
+    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async", "tune.ragged"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
                                          "llm.qkv", "llm.o", "llm.gu", "llm.down"};
 static bool known_int_key(const std::string& k) {
@@ -201,6 +212,11 @@ int bd_pack_weight(void* dst, const void* src, int rows, int K, int dst_row0, in
 int bd_set_weight_layout(int stage_major) {
     if (stage_major != 0 && stage_major != 1) return fail("bd_set_weight_layout: 0 (panel-major) or 1 (stage-major)");
     bdk_set_w_layout(stage_major);
+    return 0;
+}
+int bd_set_gemm_option(const char* name, int value) {
+    if (!name || bdk_set_gemm_option(name, value) != 0)
+        return fail(std::string("bd_set_gemm_option: unknown option or value: ") + (name ? name : "(null)"));
     return 0;
 }
 int bd_pack_weight_swiglu(void* dst, const void* gate, const void* up, int F, int K, void* stream) {
@@ -312,7 +328,8 @@ int bd_ctx_finalize(bd_ctx* c) {
         c->B = (int)c->geti("B");
         c->branches = (int)c->geti("branches");
         c->Pn = (int)c->geti("P");
-        if (c->Pn != 64 && c->Pn != 16) return fail("parallel_num must be 64 (64x models) or 16 (16x models)");
+        // tokens per AR step: 64 / 16 (T2I 64x / 16x, ImageNet 16x), 4 (ImageNet 4x), 1 (ImageNet 1x: MLP head, causal transformer)
+        if (c->Pn != 64 && c->Pn != 16 && c->Pn != 4 && c->Pn != 1) return fail("parallel_num must be 64, 16, 4 or 1");
         c->BP = c->B * c->Pn;
         c->M = c->branches * c->BP;
         c->Mpad = pad_rows(c->M);
@@ -327,6 +344,11 @@ int bd_ctx_finalize(bd_ctx* c) {
         // length); head-only contexts read just the step counter, imagenet sequences all share slot 0
         if (c->branches * c->B > 16 && c->has_llm && c->geti("llm.variant", 0) == 0)
             return fail("too many sequences for the Qwen3 decode path (max 16)");
+        if (c->Pn < 16 && c->has_llm && c->geti("llm.variant", 0) == 0)
+            return fail("the Qwen3 decode path takes 64 or 16 tokens per step");
+        c->hMlp = c->has_head ? (int)c->geti("head.variant", 0) : 0;
+        if (c->hMlp != 0 && c->hMlp != 1) return fail("head.variant: 0 (transformer blocks) or 1 (MLP blocks)");
+        if (c->has_head && !c->hMlp && c->Pn == 1) return fail("the transformer head needs at least 4 tokens per step (head.variant = 1 for the 1x models)");
         c->ws.clear();
         auto add = [&](const std::string& n, long long bytes) { c->ws.push_back({n, bytes}); };
         add("state", sizeof(BdStepState));
@@ -338,7 +360,10 @@ int bd_ctx_finalize(bd_ctx* c) {
             c->hT = (int)c->geti("head.T", c->Pn);
             if (c->hD % 128 || c->hH % 64 || c->hDz % 64) return fail("head dims must be multiples of 128/64");
             if (c->hNB % c->hNA) return fail("head.nblocks must be divisible by head.nada");
-            c->hNada = c->hNA * 6 * c->hD + 2 * c->hD;
+            // stacked adaLN projections: per adaLN block 6 chunks (scale1, shift1, gate1, scale2, shift2, gate2; flow_head:331)
+            // or 3 for the MLP head (scale, shift, gate; imagenet diff_head.py:237), then the final layer's (scale, shift)
+            c->hNada = c->hNA * (c->hMlp ? 3 : 6) * c->hD + 2 * c->hD;
+            if (c->hMlp && c->tp > 1) return fail("head.variant = 1 (MLP head) has no tensor-parallel form");
             const int dh = (int)c->geti("head.dh", 128), tp = c->tp;
             if ((c->hD / dh) % tp || (c->hH / tp) % 64 || (c->hD / tp) % 64)
                 return fail("head: attention heads and the SwiGLU width must divide by the tensor-parallel size (64-column units)");
@@ -386,8 +411,8 @@ int bd_ctx_finalize(bd_ctx* c) {
             c->lsplits = (int)c->geti("llm.splits", 8);
             c->ldh = (int)c->geti("llm.head_dim", 128);
             c->lvariant = (int)c->geti("llm.variant", 0);
-            if (!((c->ldh == 128 && c->lvariant == 0) || (c->ldh == 64 && c->lvariant == 1 && c->lnkv == c->lnh && c->Pn == 16)))
-                return fail("llm: head_dim 128 (Qwen3) or head_dim 64 + variant 1 (imagenet transformer, MHA, P = 16)");
+            if (!((c->ldh == 128 && c->lvariant == 0) || (c->ldh == 64 && c->lvariant == 1 && c->lnkv == c->lnh && c->Pn <= 16)))
+                return fail("llm: head_dim 128 (Qwen3) or head_dim 64 + variant 1 (imagenet transformer, MHA, P <= 16)");
             if (c->lLmax % 64) return fail("llm.Lmax must be a multiple of 64");
             const int tp = c->tp;
             if (tp > 1 && (c->lvariant != 0 || c->lnh % tp || c->lnkv % tp || (c->lF / tp) % 64 || c->lF % tp))
@@ -584,29 +609,35 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0
 
     const void* ada = (const bf16_t*)c->ptr("head.ada_bf") + (size_t)ada_buf * Mp * c->hNada;
     const int sw = c->hNB / c->hNA;
+    const bool mlp = c->hMlp != 0;
+    const int nc = mlp ? 3 : 6;                               // adaLN chunks per adaLN block; the block's last gate is chunk nc - 1
     const GemmCfg &gq = c->cfg("head.qkv"), &go = c->cfg("head.wo"), &g1 = c->cfg("head.w1"), &g2 = c->cfg("head.w2");
     Partial br{nullptr, nullptr, 0, 0, 0};                    // pending gated branch output (wo / w2)
     for (int b = 0; b < c->hNB; ++b) {
         const std::string pre = "head.blk" + std::to_string(b) + ".";
-        const int base = (b / sw) * 6 * D;
+        const int base = (b / sw) * nc * D;
         LnModArgs l1;
         l1.X = c->wptr("head.X");
         l1.pend = br;                                      // w2 output of the previous block (none for block 0)
         l1.ada = ada; l1.ada_ld = c->hNada;
-        l1.gate_off = ((b - 1 < 0 ? 0 : b - 1) / sw) * 6 * D + 5 * D;
+        l1.gate_off = ((b - 1 < 0 ? 0 : b - 1) / sw) * nc * D + (nc - 1) * D;
         l1.scale_off = base; l1.shift_off = base + D;
-        l1.ln_w = (const float*)c->ptr(pre + "ln1_w"); l1.ln_b = (const float*)c->ptr(pre + "ln1_b");
         l1.h_frag = c->wptr("head.h_frag"); l1.M = M; l1.D = D; l1.RB = RB; l1.eps = 1e-6f;
-        BD_TRY(bdk_ln_mod(l1, st));
-        HeadAttnArgs at;
-        BD_TRY(linear(c, "head.qkv", c->ptr("head.h_frag"), RB, wref(c, pre + "wqkv"), 3 * Dl, D, gq, "head.qkv_part", "head.qkv_bf",
-                      c->ptr(pre + "bqkv"), Mp, &at.qkv, st));
-        at.o_frag = c->wptr("head.attn_frag"); at.nseq = M / c->Pn; at.dh = (int)c->geti("head.dh", 128); at.nhead = Dl / at.dh; at.D = Dl; at.RB = RB; at.P = c->Pn;
-        BD_TRY(bdk_head_attn(at, st));
         LnModArgs l2 = l1;
-        BD_TRY(linear_rowsplit(c, "head.wo", c->ptr("head.attn_frag"), RB, wref(c, pre + "wo"), D, Dl, go, "head.br_part", "head.br_bf",
-                               "head.tp_part", c->ptr(pre + "bo"), Mp, M, &l2.pend, st));
-        l2.gate_off = base + 2 * D; l2.scale_off = base + 3 * D; l2.shift_off = base + 4 * D;
+        if (!mlp) {
+            l1.ln_w = (const float*)c->ptr(pre + "ln1_w"); l1.ln_b = (const float*)c->ptr(pre + "ln1_b");
+            BD_TRY(bdk_ln_mod(l1, st));
+            HeadAttnArgs at;
+            BD_TRY(linear(c, "head.qkv", c->ptr("head.h_frag"), RB, wref(c, pre + "wqkv"), 3 * Dl, D, gq, "head.qkv_part", "head.qkv_bf",
+                          c->ptr(pre + "bqkv"), Mp, &at.qkv, st));
+            at.o_frag = c->wptr("head.attn_frag"); at.nseq = M / c->Pn; at.dh = (int)c->geti("head.dh", 128); at.nhead = Dl / at.dh; at.D = Dl; at.RB = RB; at.P = c->Pn;
+            BD_TRY(bdk_head_attn(at, st));
+            BD_TRY(linear_rowsplit(c, "head.wo", c->ptr("head.attn_frag"), RB, wref(c, pre + "wo"), D, Dl, go, "head.br_part", "head.br_bf",
+                                   "head.tp_part", c->ptr(pre + "bo"), Mp, M, &l2.pend, st));
+            l2.gate_off = base + 2 * D; l2.scale_off = base + 3 * D; l2.shift_off = base + 4 * D;
+        }
+        // MLP head (diff_head.py:133-137): the block IS the second half -- h = norm(x) * (1 + scale) + shift with the block's
+        // (scale, shift) = chunks 0, 1 and the previous block's gated w2 output still pending, exactly l1's offsets above
         l2.ln_w = (const float*)c->ptr(pre + "ln2_w"); l2.ln_b = (const float*)c->ptr(pre + "ln2_b");
         BD_TRY(bdk_ln_mod(l2, st));
         // Linear -> chunk(2) -> silu(h1)*h2.  Fused epilogue (on the last-arriving K-slice when split) writes the next
@@ -630,8 +661,8 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0
     fa.X = c->ptr("head.X");
     fa.pend = br;
     fa.ada = ada; fa.ada_ld = c->hNada;
-    fa.gate_off = ((c->hNB - 1) / sw) * 6 * D + 5 * D;
-    fa.scale_off = c->hNA * 6 * D; fa.shift_off = c->hNA * 6 * D + D;
+    fa.gate_off = ((c->hNB - 1) / sw) * nc * D + (nc - 1) * D;
+    fa.scale_off = c->hNA * nc * D; fa.shift_off = c->hNA * nc * D + D;
     fa.lin_w = c->ptr("head.lin_w"); fa.lin_b = c->ptr("head.lin_b");
     fa.xt = (float*)c->wptr("head.xt");
     fa.noise = (const float*)c->ptr("head.noise");

@@ -197,21 +197,22 @@ __global__ __launch_bounds__(256) void head_attn16_kernel(HeadAttnArgs a) {
     __shared__ float qs[16 * 132], ks[16 * 132], vs[16 * 132], sc[16 * 17];
     const int seq = blockIdx.x / a.nhead, h = blockIdx.x % a.nhead;
     const int tid = threadIdx.x, D = a.D, dh = a.dh;           // dh = 128 (T2I heads) or 64 (imagenet diff_head_parallel.py:207)
+    const int P = a.P;                                         // tokens per sequence: 16 (16x models) or 4 (ImageNet 4x)
     const Partial& q = a.qkv;
     const bf16_t* bias = (const bf16_t*)q.bias;
     const float scale = (dh == 64) ? 0.125f : 0.08838834764831845f;     // head_dim ** -0.5
-    const bool act = (tid & 15) * 8 < dh;                      // thread -> (row i, 8 channels d0..d0+7)
+    const bool act = (tid & 15) * 8 < dh && (tid >> 4) < P;    // thread -> (row i, 8 channels d0..d0+7)
     if (act) {   // Linear outputs (sum of slabs + bias) rounded to bf16
         const int i = tid >> 4, d0 = (tid & 15) * 8;
         for (int which = 0; which < 3; ++which) {
             const int col = which * D + h * dh + d0;
-            const float* p = q.p + (size_t)(seq * 16 + i) * q.N + col;
+            const float* p = q.p + (size_t)(seq * P + i) * q.N + col;
             float* dst = (which == 0 ? qs : (which == 1 ? ks : vs)) + i * 132 + d0;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float v = 0.f;
                 if (q.S == 0) {
-                    v = bf2f(((const bf16_t*)q.p)[(size_t)(seq * 16 + i) * q.N + col + j]);
+                    v = bf2f(((const bf16_t*)q.p)[(size_t)(seq * P + i) * q.N + col + j]);
                 } else {
                     for (int s_ = 0; s_ < q.S; ++s_) v += p[(size_t)s_ * q.Mpad * q.N + j];
                     v = bfr(v + (bias ? bf2f(bias[col + j]) : 0.f));
@@ -223,27 +224,33 @@ __global__ __launch_bounds__(256) void head_attn16_kernel(HeadAttnArgs a) {
     __syncthreads();
     {   // scores[i][j] = bf16( sum_d q_i[d] k_j[d] )
         const int i = tid >> 4, j = tid & 15;
-        float acc = 0.f;
-        for (int d = 0; d < dh; ++d) acc += qs[i * 132 + d] * ks[j * 132 + d];
-        sc[i * 17 + j] = bfr(acc);
+        if (i < P && j < P) {
+            float acc = 0.f;
+            for (int d = 0; d < dh; ++d) acc += qs[i * 132 + d] * ks[j * 132 + d];
+            sc[i * 17 + j] = bfr(acc);
+        }
     }
     __syncthreads();
     if (act) {   // softmax over j in fp32, then out[i][d0..d0+7] = bf16( sum_j bf16(p_ij) v_j[d] )
         const int i = tid >> 4, d0 = (tid & 15) * 8;
         float m = -INFINITY;
-        for (int j = 0; j < 16; ++j) m = fmaxf(m, sc[i * 17 + j]);
+        for (int j = 0; j < P; ++j) m = fmaxf(m, sc[i * 17 + j]);
         float e[16], sum = 0.f;
-        for (int j = 0; j < 16; ++j) { e[j] = expf(sc[i * 17 + j] - m); sum += e[j]; }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { e[j] = (j < P) ? expf(sc[i * 17 + j] - m) : 0.f; sum += e[j]; }
         float o[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) o[t] = 0.f;
-        for (int j = 0; j < 16; ++j) {
-            const float pj = bfr(e[j] / sum);
 #pragma unroll
-            for (int t = 0; t < 8; ++t) o[t] += pj * vs[j * 132 + d0 + t];
+        for (int j = 0; j < 16; ++j) {
+            if (j < P) {
+                const float pj = bfr(e[j] / sum);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) o[t] += pj * vs[j * 132 + d0 + t];
+            }
         }
         bf16_t* O = (bf16_t*)a.o_frag;
-        *reinterpret_cast<u32x4*>(O + afrag_off(seq * 16 + i, h * dh + d0, a.RB)) =
+        *reinterpret_cast<u32x4*>(O + afrag_off(seq * P + i, h * dh + d0, a.RB)) =
             (u32x4){pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7])};
     }
 }
@@ -334,14 +341,14 @@ __global__ __launch_bounds__(256) void head_attn16_mfma_kernel(HeadAttnArgs a) {
 }
 
 int bdk_head_attn(const HeadAttnArgs& a, hipStream_t st) {
-    if (a.dh != 128 && !(a.dh == 64 && a.P == 16)) return -2;
+    if (a.dh != 128 && !(a.dh == 64 && a.P <= 16)) return -2;
     if (a.P == 64) BD_LAUNCH(head_attn_kernel, dim3(a.nseq * a.nhead), dim3(256), 0, st, a);
     else if (a.P == 16 && a.qkv.S == 0 && a.qkv.N % 8 == 0) {       // finished bf16 qkv: matrix-pipe scores, 4 heads per workgroup
         const int blocks = (a.nseq * a.nhead + 3) / 4;
         if (a.dh == 64) BD_LAUNCH(head_attn16_mfma_kernel<64>, dim3(blocks), dim3(256), 0, st, a);
         else BD_LAUNCH(head_attn16_mfma_kernel<128>, dim3(blocks), dim3(256), 0, st, a);
     }
-    else if (a.P == 16) BD_LAUNCH(head_attn16_kernel, dim3(a.nseq * a.nhead), dim3(256), 0, st, a);
+    else if (a.P <= 16 && a.P >= 2) BD_LAUNCH(head_attn16_kernel, dim3(a.nseq * a.nhead), dim3(256), 0, st, a);   // 16x from slabs; 4x
     else return -2;
     return bd_launch_status();
 }

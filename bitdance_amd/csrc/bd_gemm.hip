@@ -17,6 +17,7 @@
 //    to fp32 slabs that the consumer row-kernels reduce in their prologue (bd_rows.hip) -- no extra launch.
 //  * fused SwiGLU epilogue (gate/up rows interleaved 16/16 inside each packed panel so the partner value is
 //    one cross-lane exchange away) writes the bf16 activation in fragment-major order for the next GEMM.
+#include <string>
 #include "bd_gemm_kernel.h"
 
 // Packed-weight order in HBM.  0 = panel-major  [panel][K/64 stages][4 k-steps][64 lanes]: every wave walks its own
@@ -86,7 +87,11 @@ __global__ void rows_to_afrag_kernel(bf16_t* __restrict__ dst, const float* __re
 //     the MFMA stream (sched_barrier pins the order), not in a block between stages;
 //   * loads past the last stage are clamped to it instead of branched around: every phase issues the same number of
 //     loads, which keeps hipcc's s_waitcnt counts exact (the redundant lines are L2 hits).
-template <int EPI>
+//   * WR = W stages a wave keeps in flight in registers.  A W stage is consumed one 2048-cycle phase after the previous one,
+//     so WR = 2 hides only ~0.85 us of HBM latency behind the MFMAs; WR = 3 doubles that for 32 more VGPRs.
+//   * XCD = 1: the row tiles that stream the same weight slice are placed on the SAME XCD (blocks b and b + 8): the second
+//     reader hits that XCD's L2 instead of making the fabric deliver the slice to two L2s.
+template <int EPI, int WR, bool XCD>
 __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
     constexpr int MB = 8, NPW = 2, NT = 256, UNITS = MB * 256, XL = UNITS / NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -98,7 +103,23 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
     // so the slice comes from HBM once and from L2 / Infinity Cache for the others (512 rows = num_images 4: W used to be
     // streamed twice; 12 288 rows = the ImageNet batch: 48 consumers per slice)
     const int RT = p.RB / 8;
-    const int mt = blockIdx.x % RT, rest = blockIdx.x / RT;
+    int mt, rest;
+    if constexpr (XCD) {
+        // blocks are dealt round-robin to the 8 XCDs: within a group of 8 * RT blocks, block j runs on XCD j % 8; give the
+        // RT blocks of one XCD the RT row tiles of one weight slice
+        const int nrest = gridDim.x / RT, full = (nrest / 8) * 8;       // weight slices in whole groups of 8
+        if ((int)blockIdx.x < full * RT) {
+            const int grp = blockIdx.x / (8 * RT), j = blockIdx.x % (8 * RT);
+            mt = j / 8;
+            rest = grp * 8 + (j % 8);
+        } else {                                        // the last, partial group: plain order over what is left
+            const int left = nrest - full, jj = blockIdx.x - full * RT;
+            mt = jj / left;
+            rest = full + jj % left;
+        }
+    } else {
+        mt = blockIdx.x % RT; rest = blockIdx.x / RT;
+    }
     const int s = rest % S, nt = rest / S;
     const int nb = (nt * 4 + wave) * NPW;
     const int nst_total = p.K >> 6;
@@ -118,7 +139,7 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
     }
     const size_t a_stage = (size_t)4 * p.RB * 64;
 
-    u32x4 w[2][NPW * 4], xr[XL], xf[2][MB];
+    u32x4 w[WR][NPW * 4], xr[XL], xf[2][MB];
     f32x16 acc[MB * NPW];
 #pragma unroll
     for (int m = 0; m < MB * NPW; ++m)
@@ -143,20 +164,21 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
         for (int j = 0; j < XL; ++j) buf[tid + j * NT] = xr[j];
     };
 
-    // prologue: A stages 0 and 1 into LDS, stage 2 in registers; W stages 0 and 1 in registers
+    // prologue: A stages 0 and 1 into LDS, stage 2 in registers; W stages 0 .. WR-1 in registers
     u32x4 *cur = lds, *nxt = lds + UNITS, *wr3 = lds + 2 * UNITS;
     load_x(0);
     load_w(w[0], 0);
     store_x(cur);
     load_x(1);
     store_x(nxt);
-    load_x(2);                                // issue order A(j+2), W(j+1) as in the steady state: the waitcnt states
-    load_w(w[1], 1);                          // merged at the loop header then agree and stay exact
+    if constexpr (WR == 3) load_w(w[1], 1);
+    load_x(2);                                // issue order A(j+2), W(j+WR-1) as in the steady state: the waitcnt states
+    load_w(w[WR - 1], WR - 1);                // merged at the loop header then agree and stay exact
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < MB; ++m) xf[0][m] = cur[m * 64 + lane];
 
-    // one phase = one 64-deep K stage j: 4 k-steps x 16 MFMAs.  PAR = j & 1 selects the W register slot.
+    // one phase = one 64-deep K stage j: 4 k-steps x 16 MFMAs.  PAR = j % WR selects the W register slot.
     auto phase = [&](auto PAR, int j) {
         constexpr int P = decltype(PAR)::value;
         // k-step 0 (xf[0]) | read k-step 1 -> xf[1]
@@ -194,17 +216,27 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
             acc[m * 2 + 1] = mfma32(xf[1][m], w[P][7], acc[m * 2 + 1]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        load_w(w[P], j + 2);                  // this slot's MFMAs have all issued
+        load_w(w[P], j + WR);                 // this slot's MFMAs have all issued
         __syncthreads();
         u32x4* t = cur; cur = nxt; nxt = wr3; wr3 = t;
     };
 
     int j = 0;
-    for (; j + 1 < nst; j += 2) {
-        phase(std::integral_constant<int, 0>{}, j);
-        phase(std::integral_constant<int, 1>{}, j + 1);
+    if constexpr (WR == 2) {
+        for (; j + 1 < nst; j += 2) {
+            phase(std::integral_constant<int, 0>{}, j);
+            phase(std::integral_constant<int, 1>{}, j + 1);
+        }
+        if (j < nst) phase(std::integral_constant<int, 0>{}, j);
+    } else {
+        for (; j + 2 < nst; j += 3) {
+            phase(std::integral_constant<int, 0>{}, j);
+            phase(std::integral_constant<int, 1>{}, j + 1);
+            phase(std::integral_constant<int, 2>{}, j + 2);
+        }
+        if (j < nst) phase(std::integral_constant<int, 0>{}, j);
+        if (j + 1 < nst) phase(std::integral_constant<int, 1>{}, j + 1);
     }
-    if (j < nst) phase(std::integral_constant<int, 0>{}, j);
 
     // ---- epilogue (same forms as gemm_kernel)
     const int col = nb * 32 + (lane & 31);
@@ -240,21 +272,42 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
         }
 }
 
-static int launch_gemm_wide(const GemmP& p, int epi, hipStream_t st) {
+// measurement switches of the 256-row kernel (process-wide; bd_set_gemm_option): W register ring depth and XCD placement
+static int g_wide_ring = 2, g_wide_xcd = -1;            // xcd: -1 = by shape (on when the weights outweigh the rows), 0 / 1 forced
+int bdk_set_gemm_option(const char* name, int v) {
+    const std::string n(name);
+    if (n == "wide.ring" && (v == 2 || v == 3)) { g_wide_ring = v; return 0; }
+    if (n == "wide.xcd" && v >= -1 && v <= 1) { g_wide_xcd = v; return 0; }
+    return -1;
+}
+
+template <int WR, bool XCD>
+static int launch_gemm_wide_v(const GemmP& p, int epi, hipStream_t st) {
     const int ntiles = p.N / 256;
     dim3 grid(ntiles * p.S * (p.RB / 8));
     const size_t lds = (size_t)3 * 8 * 256 * 16;
     static const bool lds_ok = [] {                            // 96 KiB of dynamic LDS needs the opt-in
         const int n = 3 * 8 * 256 * 16;
-        return hipFuncSetAttribute((const void*)gemm_wide_kernel<BD_EPI_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, n) == hipSuccess &&
-               hipFuncSetAttribute((const void*)gemm_wide_kernel<BD_EPI_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, n) == hipSuccess &&
-               hipFuncSetAttribute((const void*)gemm_wide_kernel<BD_EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, n) == hipSuccess;
+        return hipFuncSetAttribute((const void*)gemm_wide_kernel<BD_EPI_PARTIAL, WR, XCD>, hipFuncAttributeMaxDynamicSharedMemorySize, n) == hipSuccess &&
+               hipFuncSetAttribute((const void*)gemm_wide_kernel<BD_EPI_BF16, WR, XCD>, hipFuncAttributeMaxDynamicSharedMemorySize, n) == hipSuccess &&
+               hipFuncSetAttribute((const void*)gemm_wide_kernel<BD_EPI_SWIGLU, WR, XCD>, hipFuncAttributeMaxDynamicSharedMemorySize, n) == hipSuccess;
     }();
     if (!lds_ok) return -8;
-    if (epi == BD_EPI_PARTIAL) BD_LAUNCH((gemm_wide_kernel<BD_EPI_PARTIAL>), grid, dim3(256), lds, st, p);
-    else if (epi == BD_EPI_BF16) BD_LAUNCH((gemm_wide_kernel<BD_EPI_BF16>), grid, dim3(256), lds, st, p);
-    else BD_LAUNCH((gemm_wide_kernel<BD_EPI_SWIGLU>), grid, dim3(256), lds, st, p);
+    if (epi == BD_EPI_PARTIAL) BD_LAUNCH((gemm_wide_kernel<BD_EPI_PARTIAL, WR, XCD>), grid, dim3(256), lds, st, p);
+    else if (epi == BD_EPI_BF16) BD_LAUNCH((gemm_wide_kernel<BD_EPI_BF16, WR, XCD>), grid, dim3(256), lds, st, p);
+    else BD_LAUNCH((gemm_wide_kernel<BD_EPI_SWIGLU, WR, XCD>), grid, dim3(256), lds, st, p);
     return bd_launch_status();
+}
+
+static int launch_gemm_wide(const GemmP& p, int epi, hipStream_t st) {
+    // several row tiles per weight slice: keep them on one XCD when the slice is what dominates the traffic (N columns of
+    // weights against RB * 32 rows of activations per K); a large batch (ImageNet: 12 288 rows) is the other way round.
+    // Measured at 512 rows (profiles/r02_gemm_sweep3.log): adaLN 311 vs 352 us, gate/up 196 vs 207, wo / w2 (5 slices) 34.5 / 40.9
+    // vs 36.0 / 43.5 -- but the 2-slice qkv / w1 shapes LOSE (73 vs 68.5 us: with an even slice count every XCD then works on
+    // one K half only, and the two readers of a slice contend for the same L2 channels in lockstep), so: odd slice counts only.
+    const bool xcd = (p.RB > 8) && (g_wide_xcd < 0 ? (p.N > p.RB * 32 && (p.S & 1)) : g_wide_xcd == 1);
+    if (g_wide_ring == 3) return xcd ? launch_gemm_wide_v<3, true>(p, epi, st) : launch_gemm_wide_v<3, false>(p, epi, st);
+    return xcd ? launch_gemm_wide_v<2, true>(p, epi, st) : launch_gemm_wide_v<2, false>(p, epi, st);
 }
 
 // `nw_ring` = waves per workgroup (2, 4, 8, 10) + 16 * ring + 256 * (kw - 1) + 2048 * pipe: ring in {0 (=2), 3, 4} = stages of
@@ -272,10 +325,11 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
     if (ring == 0) ring = 2;
     if (ring < 2 || ring > 4 || kw > 2 || nw % kw) return -7;
     const int np = nw / kw;
-    if (K % (64 * kw) || N % (32 * np) || S < 1) return -2;
+    // a ragged last tile (N/32 not a multiple of the panels per workgroup) is supported by the single-K-part kernels
+    if (K % (64 * kw) || N % 32 || (N % (32 * np) && kw != 1) || S < 1) return -2;
     const int nst_total = K / (64 * kw), q = (nst_total + S - 1) / S;
     if ((S - 1) * q >= nst_total) return -3;                       // an empty split
-    if (epi != BD_EPI_PARTIAL && S != 1 && (out_partial == nullptr || cnt == nullptr || (nw == 10 && kw == 1))) return -4;   // needs slab scratch + counters
+    if (epi != BD_EPI_PARTIAL && S != 1 && (out_partial == nullptr || cnt == nullptr || (nw >= 9 && kw == 1))) return -4;   // needs slab scratch + counters
     size_t PS, SS;
     bdk_w_strides(N / 32, K, &PS, &SS);
     GemmP p{(const u32x4*)A, (const u32x4*)W, out_partial, (bf16_t*)out_act, (const bf16_t*)bias, cnt, nullptr, RB, N, K, S, RB * 32, PS, SS};
@@ -283,11 +337,11 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
     // else 128 / 64 / 32
     const int MB = (RB % 8 == 0 && nw >= 4 && kw == 1) ? 8 : ((RB % 4 == 0) ? 4 : RB);
     if (MB != 8 && MB != 4 && MB != 2 && MB != 1) return -5;
-    if (MB == 8 || nw == 2 || nw == 10 || kw == 2) ring = 2;       // register budget
+    if (MB == 8 || nw == 2 || nw >= 9 || kw == 2) ring = 2;        // register budget
     // 256-row passes over 256-column tiles: 4 waves x 2 panels (MFMA-friendly) instead of 8 waves x 1 panel;
     // same grid.  BD_GEMM_WIDE=0 keeps the 8-wave form (A/B switch for measurements).
     static const bool wide = [] { const char* e = getenv("BD_GEMM_WIDE"); return !(e && e[0] == '0'); }();
-    if (wide && MB == 8 && nw == 8 && epi != BD_EPI_F32 && !(S > 1 && epi != BD_EPI_PARTIAL)) return launch_gemm_wide(p, epi, st);
+    if (wide && MB == 8 && nw == 8 && N % 256 == 0 && epi != BD_EPI_F32 && !(S > 1 && epi != BD_EPI_PARTIAL)) return launch_gemm_wide(p, epi, st);
 #define BD_CASE(NPV, KWV, MBV, RV) if (np == NPV && kw == KWV && MB == MBV && ring == RV) return launch_gemm<NPV, KWV, MBV, RV>(p, epi, st);
     if (light && np == 4 && kw == 1 && MB == 4) return launch_gemm<4, 1, 4, 2, 2>(p, epi, st);
 #define BD_CASE_PIPE(NPV, KWV, MBV) if (pipe && np == NPV && kw == KWV && MB == MBV) return launch_gemm<NPV, KWV, MBV, 2, 1>(p, epi, st);
@@ -295,7 +349,7 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
 #undef BD_CASE_PIPE
     if (MB <= 2 && ring == 3) ring = 4;
     if (MB == 1) ring = 2;
-    BD_CASE(4, 1, 8, 2) BD_CASE(8, 1, 8, 2) BD_CASE(10, 1, 4, 2)
+    BD_CASE(4, 1, 8, 2) BD_CASE(8, 1, 8, 2) BD_CASE(10, 1, 4, 2) BD_CASE(9, 1, 4, 2) BD_CASE(5, 1, 4, 2)
     BD_CASE(2, 1, 4, 2) BD_CASE(4, 1, 4, 2) BD_CASE(8, 1, 4, 2) BD_CASE(4, 1, 4, 3) BD_CASE(8, 1, 4, 3) BD_CASE(4, 1, 4, 4) BD_CASE(8, 1, 4, 4)
     BD_CASE(2, 1, 2, 2) BD_CASE(4, 1, 2, 2) BD_CASE(8, 1, 2, 2) BD_CASE(4, 1, 2, 4) BD_CASE(8, 1, 2, 4)
     BD_CASE(2, 1, 1, 2) BD_CASE(4, 1, 1, 2) BD_CASE(8, 1, 1, 2)

@@ -72,12 +72,17 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
     const int S = p.S;
     const int s = blockIdx.x % S, nt = blockIdx.x / S, mt = blockIdx.y;
     const int nb = nt * NP + pw;                           // panel of this wave
+    // ragged last tile (N/32 not a multiple of NP): the waves past the last panel stream the last panel again (L2 hits, no
+    // branches in the loop) and store nothing.  Lets a GEMM pick the NP that puts ceil(panels / NP) just under 256 workgroups.
+    const int npan = p.N >> 5;
+    const bool pvalid = nb < npan;
+    const int nbl = pvalid ? nb : npan - 1;
     const int nst_total = p.K / (64 * KW);
     const int q = (nst_total + S - 1) / S;
     const int st0 = s * q;
     const int nst = min(q, nst_total - st0);
 
-    const u32x4* Wp = p.W + (size_t)nb * p.PS + (size_t)(st0 * KW + kg) * p.SS + lane;
+    const u32x4* Wp = p.W + (size_t)nbl * p.PS + (size_t)(st0 * KW + kg) * p.SS + lane;
     const size_t w_stage = p.SS * KW;
     // A: unit u of a stage = chunk (ksl = (u>>6)/MB in [0, 4*KW), mb = (u>>6)%MB), lane u&63
     size_t a_off[XL];
@@ -254,9 +259,9 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
                     }
         }
     }
-    const bool owner = (kg == 0);                                          // the wave that holds the tile's sums
+    const bool owner = (kg == 0) && pvalid;                                // the wave that holds the tile's sums
     if constexpr (WT == 1) {                                               // dequantisation scale of this lane's output column
-        const float sc = p.wscale[nb * 32 + (lane & 31)];
+        const float sc = p.wscale[nbl * 32 + (lane & 31)];
 #pragma unroll
         for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
     }
 
     // ---- epilogue.  D layout of the 32x32 MFMA: lane -> column (lane&31), reg r -> row (r&3)+8(r>>2)+4(lane>>5)
-    const int col = nb * 32 + (lane & 31);
+    const int col = nbl * 32 + (lane & 31);
     const float bias_col = ((EPI == BD_EPI_BF16 || EPI == BD_EPI_SWIGLU) && p.bias) ? bf2f(p.bias[col]) : 0.f;
     auto finalize = [&](int m) {
         const f32x16& a = acc[m];
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = f2bf(a[r] + bias_col);
         } else {  // BD_EPI_SWIGLU: lanes (l&16)==0 hold gate feature f, lanes (l&16)!=0 the matching up feature
-            const int f = nb * 16 + (lane & 15);
+            const int f = nbl * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = bfr(a[r] + bias_col);                     // Linear output rounded to bf16
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
         // its column in one dwordx4.  16 stores / loads of 16 B per lane and row block instead of 64 scalar ones: a 16 B `sc1`
         // store costs what a plain one does, a dword `sc1` store about six times as much per byte (MI355X_MICROARCH, stores).
         const __amdgpu_buffer_rsrc_t sl = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((size_t)S * p.Mpad * p.N * 4), 0x00020000);
-        const int ntl = p.N / (32 * NP);
+        const int ntl = (npan + NP - 1) / NP;
         const size_t region0 = ((size_t)(mt * ntl + nt) * NP + pw) * S;          // + slice
         auto slab_off = [&](int s_, int m, int r4) -> unsigned {
             return (unsigned)((((region0 + s_) * MB + m) * 4 + r4) * 1024 + lane * 16);
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
 
 template <int NP, int KW, int MB, int EPI, int R, bool RED, int MODE = 0, int WT = 0>
 static int launch_one(const GemmP& p, hipStream_t st) {
-    const int ntiles = p.N / (32 * NP);
+    const int ntiles = (p.N / 32 + NP - 1) / NP;          // the last tile may be ragged
     dim3 grid(ntiles * p.S, p.RB / MB);
     // two A-stage buffers; with KW > 1 the same LDS is re-used for the accumulators of K parts 1..KW-1
     constexpr size_t lds_a = (size_t)2 * MB * 256 * KW * 16, lds_r = (size_t)(KW - 1) * NP * MB * 4096;
@@ -405,7 +410,7 @@ static int launch_gemm_r(const GemmP& p, int epi, hipStream_t st) {
 // A: fragment-major bf16, RB row-blocks (RB must be 1, 2 or a multiple of 4).  W: packed.  N % (32*NP) == 0, K % (64*KW) == 0.
 template <int NP, int KW, int MB, int R, int MODE = 0, int WT = 0>
 static int launch_gemm(const GemmP& p, int epi, hipStream_t st) {
-    if constexpr (NP * KW == 10 && KW == 1) return launch_gemm_r<NP, KW, MB, R, false, 0, WT>(p, epi, st);   // single-slice tiles only
+    if constexpr (NP * KW >= 9 && KW == 1) return launch_gemm_r<NP, KW, MB, R, false, 0, WT>(p, epi, st);   // single-slice tiles only
     else return (p.S > 1 && epi != BD_EPI_PARTIAL) ? launch_gemm_r<NP, KW, MB, R, true, MODE, WT>(p, epi, st)
                                                    : launch_gemm_r<NP, KW, MB, R, false, MODE, WT>(p, epi, st);
 }

@@ -25,6 +25,7 @@ int bdk_gemm8(const void* A, int RB, const void* W8, const float* wscale, int N,
 int bdk_pack_w8(void* dst, const void* src_fp8, const void* src2_fp8, int panels, int K, int nb0, int panels_total, int mode, hipStream_t st);
 int bdk_pack_w(void* dst, const void* src, const void* src2, int panels, int K, int nb0, int panels_total, int mode, hipStream_t st);
 void bdk_set_w_layout(int v);
+int bdk_set_gemm_option(const char* name, int v);   // process-wide measurement switches (bd_gemm.hip)
 int bdk_get_w_layout();
 void bdk_w_strides(int panels_total, int K, size_t* PS, size_t* SS);
 int bdk_probe_read(const void* src, size_t bytes, int blocks, void* sink, hipStream_t st);

@@ -300,11 +300,23 @@ __global__ __launch_bounds__(640) void head_final_kernel(HeadFinalArgs a) {
     const bool two = a.sc.cfg_mult == 2;                         // block-uniform
     const bf16_t* ada = (const bf16_t*)a.ada;
     const int m0 = bp, m1 = a.BP + bp;
-    // both rows' loads are issued together, their LayerNorm statistics reduced together
+    // both rows' loads are issued together, their LayerNorm statistics reduced together; everything the kernel reads that does
+    // not depend on the statistics (scale / shift of the final modulation, the first channels of the output Linear) is in
+    // flight before the first block reduction -- the kernel is one latency chain, not a bandwidth problem
     float x0[8], x1[8], h0[8], h1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { x0[j] = x1[j] = h0[j] = h1[j] = 0.f; }
+    constexpr int PRE = 8;                                     // output channels whose weights are loaded ahead
+    u32x4 sc0r = {0, 0, 0, 0}, sf0r = sc0r, sc1r = sc0r, sf1r = sc0r, wpre[PRE];
     if (active) {
+        sc0r = ld_raw8(ada + (size_t)m0 * a.ada_ld + a.scale_off + d0);
+        sf0r = ld_raw8(ada + (size_t)m0 * a.ada_ld + a.shift_off + d0);
+        if (two) {
+            sc1r = ld_raw8(ada + (size_t)m1 * a.ada_ld + a.scale_off + d0);
+            sf1r = ld_raw8(ada + (size_t)m1 * a.ada_ld + a.shift_off + d0);
+        }
+#pragma unroll
+        for (int c = 0; c < PRE; ++c) wpre[c] = ld_raw8((const bf16_t*)a.lin_w + (size_t)min(c, a.C - 1) * a.D + d0);
         load_x_pending(x0, (const bf16_t*)a.X, a.pend, ada, a.ada_ld, a.gate_off, m0, a.D, d0);
         if (two) load_x_pending(x1, (const bf16_t*)a.X, a.pend, ada, a.ada_ld, a.gate_off, m1, a.D, d0);
     }
@@ -321,25 +333,54 @@ __global__ __launch_bounds__(640) void head_final_kernel(HeadFinalArgs a) {
     block_sum2(v0, v1, red);
     const float rstd0 = rsqrtf(v0 / (float)a.D + a.eps_ln), rstd1 = rsqrtf(v1 / (float)a.D + a.eps_ln);
     if (active) {
-        modulate8(x0, mean0, rstd0, nullptr, nullptr, ada + (size_t)m0 * a.ada_ld, a.scale_off, a.shift_off, d0, h0);
-        if (two) modulate8(x1, mean1, rstd1, nullptr, nullptr, ada + (size_t)m1 * a.ada_ld, a.scale_off, a.shift_off, d0, h1);
+        float sc[8], sf[8];
+        unpack8(sc0r, sc); unpack8(sf0r, sf);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { h0[j] = bfr(h0[j]); h1[j] = bfr(h1[j]); }     // Linear input cast
-    }
-    // D -> C Linear: per channel one 16 B weight load serves both rows; wave shuffle-sums, lane 0 parks the wave totals
-#pragma unroll 8
-    for (int c = 0; c < a.C; ++c) {
-        float p0 = 0.f, p1 = 0.f;
-        if (active) {
-            float w[8];
-            ld_bf16x8((const bf16_t*)a.lin_w + (size_t)c * a.D + d0, w);
+        for (int j = 0; j < 8; ++j)                                // LN (no affine) * bf16(1 + scale) + shift, then the Linear's input cast
+            h0[j] = bfr(fadd(fmul((x0[j] - mean0) * rstd0, bfr(1.0f + sc[j])), sf[j]));
+        if (two) {
+            unpack8(sc1r, sc); unpack8(sf1r, sf);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { p0 += h0[j] * w[j]; p1 += h1[j] * w[j]; }
+            for (int j = 0; j < 8; ++j) h1[j] = bfr(fadd(fmul((x1[j] - mean1) * rstd1, bfr(1.0f + sc[j])), sf[j]));
         }
-        p0 = wave_sum(p0);
-        p1 = wave_sum(p1);
-        if (lane == 0) { wsum[wave][c] = p0; wsum[wave][32 + c] = p1; }
     }
+    // D -> C Linear: per channel one 16 B weight load serves both rows.  Every thread keeps its 2 x 32 partial dot products;
+    // the 64 lanes of a wave then reduce all 64 of them TOGETHER by recursive halving (lane l ends up with the wave total of
+    // value l: 63 cross-lane exchanges instead of 64 x 6), and each lane parks its total.
+    float pv[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) pv[i] = 0.f;
+    if (active) {
+#pragma unroll
+        for (int c0 = 0; c0 < 32; c0 += PRE) {
+            if (c0 < a.C) {                                        // block-uniform
+                u32x4 wr[PRE];
+#pragma unroll
+                for (int c = 0; c < PRE; ++c)
+                    wr[c] = (c0 == 0) ? wpre[c] : ld_raw8((const bf16_t*)a.lin_w + (size_t)min(c0 + c, a.C - 1) * a.D + d0);
+#pragma unroll
+                for (int c = 0; c < PRE; ++c) {
+                    float w[8];
+                    unpack8(wr[c], w);
+                    float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { p0 += h0[j] * w[j]; p1 += h1[j] * w[j]; }
+                    pv[c0 + c] = p0; pv[32 + c0 + c] = p1;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int half = 32; half >= 1; half >>= 1) {
+        const bool up = (lane & half) != 0;
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+            const float mine = up ? pv[i + half] : pv[i];
+            const float other = up ? pv[i] : pv[i + half];
+            pv[i] = mine + __shfl_xor(other, half);
+        }
+    }
+    wsum[wave][lane] = pv[0];                                      // lane = row * 32 + channel (channels >= C: unused)
     __syncthreads();
     if (threadIdx.x < 64) {
         float tot = 0.f;

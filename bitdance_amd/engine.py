@@ -134,6 +134,7 @@ class HeadWeights:
     nada: int
     head_dim: int = 128                             # 128: T2I heads (flow_head_parallel_x.py:227); 64: imagenet (diff_head_parallel.py:207)
     final_sigmoid: bool = True                      # 2*sigmoid(out)-1 (flow_head_parallel_x.py:342); imagenet head: identity
+    mlp: bool = False                               # MlpEncoder of the 1x ImageNet models (imagenet_gen/src/diff_head.py:165-253)
     ptrs: dict = field(default_factory=dict)        # name -> tensor (kept alive)
     tp_size: int = 1
     wdtype: int = 0                                 # 1: fp8-e4m3 streamed weights
@@ -159,9 +160,14 @@ class HeadWeights:
         if "net.res_blocks.0.w1.weight" not in sd:
             raise BitDanceHipError("native head requires the SwiGLU variant (use_swiglu=True)")
         H = g("net.res_blocks.0.w2.weight").shape[1]             # this rank's SwiGLU features
-        if head_dim not in (64, 128) or D % head_dim:
+        # MLP head: ResBlock = norm -> modulate -> w1 (SwiGLU) -> w2 -> gated residual, adaLN blocks of 3 chunks, no attention
+        mlp = "net.res_blocks.0.attn.wqkv.weight" not in sd and "net.res_blocks.0.norm.weight" in sd
+        if mlp and tp_size > 1:
+            raise BitDanceHipError("the MLP head has no tensor-parallel form")
+        if not mlp and (head_dim not in (64, 128) or D % head_dim):
             raise BitDanceHipError(f"native head: head_dim {head_dim} unsupported for D={D}")
-        hw = HeadWeights(D=D, C=C, Dz=Dz, H=H * tp_size, nblocks=nb, nada=na, head_dim=head_dim, final_sigmoid=final_sigmoid)
+        hw = HeadWeights(D=D, C=C, Dz=Dz, H=H * tp_size, nblocks=nb, nada=na, head_dim=head_dim, final_sigmoid=final_sigmoid,
+                         mlp=mlp)
         hw.tp_size = tp_size
         hw.wdtype = int(fp8)
         p = hw.ptrs
@@ -175,13 +181,14 @@ class HeadWeights:
         p["head.ada_b"] = torch.cat([_bf16(b, device) for b in ada_b]).contiguous()
         for i in range(nb):
             s, d = f"net.res_blocks.{i}.", f"head.blk{i}."
-            for n in ("1", "2"):
-                p[d + f"ln{n}_w"] = g(s + f"norm{n}.weight").detach().to(device, torch.float32).contiguous()
-                p[d + f"ln{n}_b"] = g(s + f"norm{n}.bias").detach().to(device, torch.float32).contiguous()
-            _put_linear(p, d + "wqkv", [g(s + "attn.wqkv.weight")], device, fp8)
-            p[d + "bqkv"] = _bf16(g(s + "attn.wqkv.bias"), device)
-            _put_linear(p, d + "wo", [g(s + "attn.wo.weight")], device, fp8)
-            p[d + "bo"] = _bf16(g(s + "attn.wo.bias"), device)
+            for n, src in ((("2", "norm"),) if mlp else (("1", "norm1"), ("2", "norm2"))):
+                p[d + f"ln{n}_w"] = g(s + src + ".weight").detach().to(device, torch.float32).contiguous()
+                p[d + f"ln{n}_b"] = g(s + src + ".bias").detach().to(device, torch.float32).contiguous()
+            if not mlp:
+                _put_linear(p, d + "wqkv", [g(s + "attn.wqkv.weight")], device, fp8)
+                p[d + "bqkv"] = _bf16(g(s + "attn.wqkv.bias"), device)
+                _put_linear(p, d + "wo", [g(s + "attn.wo.weight")], device, fp8)
+                p[d + "bo"] = _bf16(g(s + "attn.wo.bias"), device)
             w1, b1 = g(s + "w1.weight"), g(s + "w1.bias")
             _put_swiglu(p, d + "w1", w1[:H], w1[H:], device, fp8)
             p[d + "b1"] = pack_swiglu_bias(b1[:H], b1[H:], device)
@@ -198,7 +205,7 @@ class HeadWeights:
     def ints(self) -> dict:
         return {"head.D": self.D, "head.C": self.C, "head.Dz": self.Dz, "head.H": self.H,
                 "head.nblocks": self.nblocks, "head.nada": self.nada, "head.dh": self.head_dim,
-                "head.sigmoid": int(self.final_sigmoid)}
+                "head.sigmoid": int(self.final_sigmoid), "head.variant": int(self.mlp)}
 
     def time_table(self, ts: torch.Tensor) -> torch.Tensor:
         """time_embed(t_i) for every eval of the schedule, bf16 [N+1, D]  (flow_head_parallel_x.py:12-27,140-143).
@@ -337,8 +344,8 @@ class Engine:
                 raise BitDanceHipError("weights were packed for a different tensor-parallel size than the engine's communicator")
         self.device = torch.device(device)
         self.head, self.proj, self.llm = head, proj, llm
-        if parallel_num not in (16, 64):
-            raise BitDanceHipError("parallel_num must be 64 (64x models) or 16 (16x models)")
+        if parallel_num not in (1, 4, 16, 64):
+            raise BitDanceHipError("parallel_num must be 64 / 16 (T2I 64x / 16x, ImageNet 16x), 4 or 1 (ImageNet 4x / 1x)")
         self.B, self.branches, self.P = num_images, branches, parallel_num
         self.BP = self.B * self.P
         self.M = self.branches * self.BP

@@ -1,4 +1,9 @@
-"""Class-conditional ImageNet BitDance (parallel "16x" variant) on the native diffusion head.
+"""Class-conditional ImageNet BitDance on the native engine: the parallel variants (16x, 4x) and the 1x models.
+
+``parallel_num`` = 16 / 4: ``imagenet_gen/src/model_parallel.py`` (BitDance-B-16x / -4x).  ``parallel_num`` = 1:
+``imagenet_gen/src/model.py`` (BitDance-B/L/H-1x) -- the same loop with one token per AR step: no
+query tokens (model.py:372-375), purely causal attention (layers.py:126-129), the RoPE table in raster order (:181-190) and the
+MLP diffusion head (diff_head.py:228-253; engine.HeadWeights detects it from the checkpoint keys, ``head.variant`` = 1).
 
 Mirrors the inference surface of ``imagenet_gen/src/model_parallel.py``:
 ``BitDance(...).sample(cond, sample_steps, cfg_scale, cfg_schedule)`` (:371-419) with ``head_sample``'s linear CFG ramp
@@ -111,8 +116,8 @@ class BitDance:
                  parallel_num: int = 16, time_shift: float = 1.0, device="cuda", vae=None, **_unused):
         if not torch.cuda.is_available():
             raise RuntimeError("bitdance_amd.imagenet.BitDance needs a GPU (HIP head); there is no CPU fallback")
-        if parallel_num != 16:
-            raise NotImplementedError("native imagenet path: parallel_num must be 16 (the 16x checkpoints)")
+        if parallel_num not in (1, 4, 16):
+            raise NotImplementedError("native imagenet path: parallel_num must be 16, 4 (parallel checkpoints) or 1 (1x checkpoints)")
         self.time_shift = float(time_shift)
         self.device = torch.device(device)
         self.dim, self.n_layer, self.n_head = dim, n_layer, n_head
@@ -251,7 +256,7 @@ class BitDance:
                 with torch.autocast("cuda", dtype=torch.bfloat16):
                     T0 = n_cls + P - 1
                     c = F.embedding(ids, w["cls_embedding.weight"]).view(bsz, n_cls, -1)
-                    x = torch.cat([c, w["query_token"].repeat(bsz, 1, 1)], dim=1)
+                    x = torch.cat([c, w["query_token"].repeat(bsz, 1, 1)], dim=1) if P > 1 else c   # 1x: model.py:372-375
                     x = self._forward_model(x, self.attn_mask[:, :, :T0, :T0], 0, T0, caches)[:, -P:, :]
                 if eng_t is not None:
                     self._load_cache(eng_t, caches, T0)

@@ -26,6 +26,10 @@ int bd_pack_weight(void* dst_packed, const void* src_bf16, int rows, int K, int 
 /* packed order in HBM: 0 (default) = panel-major; 1 = stage-major, the whole grid reads one contiguous window per
  * 64-deep K stage (an experiment: measured identical on MI355X).  Process-wide; set before packing, weights packed under one setting must be used under it. */
 int bd_set_weight_layout(int stage_major);
+/* process-wide A/B switches of the GEMM kernels, for measurement (tools/, bench.py --gemm-opt); every setting computes the same
+ * values.  "wide.ring" 2|3 = weight stages a wave of the 256-row kernel keeps in flight; "wide.xcd" -1|0|1 = row tiles of one
+ * weight slice on one XCD (by shape / off / on). */
+int bd_set_gemm_option(const char* name, int value);
 int bd_pack_weight_swiglu(void* dst_packed, const void* gate_bf16, const void* up_bf16, int F, int K, void* stream);
 int bd_rows_to_frag(void* dst_frag, const void* src, int src_is_fp32, int M, int K, int row_blocks, void* stream);
 

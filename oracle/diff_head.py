@@ -124,6 +124,39 @@ def net_forward(w: dict, x: torch.Tensor, t: torch.Tensor, c: torch.Tensor, pol:
     return 2 * torch.sigmoid(out) - 1
 
 
+def is_mlp_head(w: dict) -> bool:
+    return "net.res_blocks.0.norm.weight" in w and "net.res_blocks.0.attn.wqkv.weight" not in w
+
+
+def mlp_net_forward(w: dict, x: torch.Tensor, t: torch.Tensor, c: torch.Tensor, pol: Policy) -> torch.Tensor:
+    """The 1x ImageNet models' head: /root/reference/imagenet_gen/src/diff_head.py MlpEncoder.forward :228-253 with
+    ResBlock.forward :133-137 and FinalLayer.forward :147-151 (no output squash).  x [N, C] fp32, t [N], c [N, Dz] fp32
+    (any leading shape: every op is row-wise)."""
+    n_blocks = count(w, "net.res_blocks.")
+    n_ada = count(w, "net.ada_ln_blocks.")
+    switch = max(1, n_blocks // n_ada)
+    x = pol.linear(x, w["net.input_proj.weight"], w["net.input_proj.bias"], quant=False)
+    te = time_embed(w, t, pol)
+    if c.dim() == 3:
+        te = te.unsqueeze(1)
+    ce = pol.linear(c, w["net.cond_embed.weight"], w["net.cond_embed.bias"])
+    y = F.silu(te + ce)
+    scale, shift, gate = pol.linear(y, w["net.ada_ln_blocks.0.weight"], w["net.ada_ln_blocks.0.bias"]).chunk(3, dim=-1)
+    for i in range(n_blocks):
+        if i > 0 and i % switch == 0:
+            j = i // switch
+            scale, shift, gate = pol.linear(y, w[f"net.ada_ln_blocks.{j}.weight"], w[f"net.ada_ln_blocks.{j}.bias"]).chunk(3, dim=-1)
+        pre = f"net.res_blocks.{i}."
+        h = pol.layer_norm(x, w[pre + "norm.weight"], w[pre + "norm.bias"], 1e-6) * (1 + scale) + shift
+        h1, h2 = pol.linear(h, w[pre + "w1.weight"], w[pre + "w1.bias"]).chunk(2, dim=-1)
+        h = pol.linear(F.silu(h1) * h2, w[pre + "w2.weight"], w[pre + "w2.bias"])
+        x = x + h * gate
+    scale, shift = pol.linear(y, w["net.final_layer.ada_ln_modulation.weight"],
+                              w["net.final_layer.ada_ln_modulation.bias"]).chunk(2, dim=-1)
+    h = pol.layer_norm(x, None, None, 1e-6) * (1.0 + scale) + shift
+    return pol.linear(h, w["net.final_layer.linear.weight"], w["net.final_layer.linear.bias"], quant=False)
+
+
 def sample(w: dict, z: torch.Tensor, cfg: float, num_sampling_steps: int, noise, pol: Policy,
            time_shift: float = 1.0, trace: list | None = None) -> torch.Tensor:
     """DiffHead.sample :107-120 -> euler_maruyama.  z [cfg_mult*B, P, Dz] fp32."""

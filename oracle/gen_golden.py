@@ -343,12 +343,58 @@ def gen_imagenet():
                  calls=rn.calls, cfg=np.float32(kw["cfg_scale"]), n_steps=2)
 
 
+def gen_imagenet_variants():
+    """The other released ImageNet variants at tiny dims: 1x (imagenet_gen/src/model.py: one token per AR step, causal
+    transformer, MLP head, 16 AR steps) and 4x (src/model_parallel.py with parallel_num 4, 4 AR steps); 2 sampling steps,
+    linear CFG ramp."""
+    os.environ["TORCHDYNAMO_DISABLE"] = "1"
+    sys.path.insert(0, os.path.join(rh.REF_ROOT, "imagenet_gen"))
+    from src.model import BitDance as BitDance1x
+    from src.model_parallel import BitDance as BitDancePar
+    for name, c in (("1x", tm.TINY_IN_1X), ("4x", tm.TINY_IN_4X)):
+        shapes = tm.imagenet_shapes(c)
+        for tag in ("fp32", "amp"):
+            torch.manual_seed(0)
+            kw = dict(dim=c["dim"], n_layer=c["n_layer"], n_head=c["n_head"], diff_layers=c["diff_layers"], diff_dim=c["diff_dim"],
+                      diff_adanln_layers=c["diff_adanln_layers"], latent_dim=c["latent_dim"], down_size=c["down_size"],
+                      patch_size=c["patch_size"], resolution=c["resolution"], diff_batch_mul=1, cls_token_num=c["cls_token_num"],
+                      num_classes=c["num_classes"], time_shift=c["time_shift"])
+            m = (BitDance1x(**kw) if name == "1x" else BitDancePar(parallel_num=4, parallel_mode="patch", **kw)).eval()
+            sd = {k: tuple(v.shape) for k, v in m.state_dict().items() if not k.startswith("vae.")}
+            assert sd == {k: tuple(v) for k, v in shapes.items()}, set(sd) ^ set(shapes)
+            m.load_state_dict(tm.seeded_state(shapes, seed=31), strict=False)
+            m.vae.decode = lambda x: x
+            conds, preds = [], []
+            orig = m.head.sample
+
+            def rec(z, cfg, num_sampling_steps):
+                conds.append(z.detach().float().clone())
+                o = orig(z, cfg=cfg, num_sampling_steps=num_sampling_steps)
+                preds.append(o.detach().clone())
+                return o
+
+            m.head.sample = rec
+            ids = torch.tensor([3, 7])
+            ctx = rh.CudaAutocastOnCpu() if tag == "amp" else torch.no_grad()
+            with torch.no_grad(), ctx, rh.ReplayNoise(seed=19) as rn:
+                lat = m.sample(ids, sample_steps=2, cfg_scale=3.0, cfg_schedule="linear")
+            P = c["parallel_num"]
+            C = c["latent_dim"]
+            pr = torch.cat([p.reshape(p.shape[0], P, C) for p in preds], dim=1)          # [bsz, h*w, C]
+            n0 = [t.reshape(4, P, C) for t in rn.record if t.shape[0] == 4]
+            n1 = [t.reshape(2, P, C) for t in rn.record if t.shape[0] == 2]
+            save(f"imagenet{name}_{tag}", ids=ids, latent=lat, preds=pr, noise0=torch.stack(n0), noise1=torch.stack(n1),
+                 calls=rn.calls, cfg=np.float32(3.0), n_steps=2, rope=m.freqs_cis)
+
+
 def main():
     rh.install()
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "imagenet":
         return gen_imagenet()
+    if len(sys.argv) > 1 and sys.argv[1] == "imagenet_variants":
+        return gen_imagenet_variants()
     if len(sys.argv) > 1 and sys.argv[1] == "pipeline":
         return gen_pipeline()
     if len(sys.argv) > 1 and sys.argv[1] == "mllm":
@@ -363,6 +409,7 @@ def main():
     gen_pipeline()
     gen_misc()
     gen_imagenet()
+    gen_imagenet_variants()
     gen_mllm_equiv()
     gen_ae_c1()
 

@@ -1,4 +1,4 @@
-"""Oracle: class-conditional ImageNet BitDance (parallel / "16x" variant) -- test infrastructure only.
+"""Oracle: class-conditional ImageNet BitDance (parallel 16x / 4x variants and the 1x variant) -- test infrastructure only.
 
 Restates /root/reference/imagenet_gen/src:
   model_parallel.py   MLPConnector.forward :73-75     get_block_causal_mask :90-101
@@ -11,6 +11,12 @@ Restates /root/reference/imagenet_gen/src:
   diff_head_parallel.py  = the T2I head with head_dim 64, always the explicit-softmax attention, no final sigmoid
                       (:192-200, :296-310) -> oracle.diff_head with head_dim=64, final_sigmoid=False
   sampling_parallel.py   = sampling_x.py (same arithmetic) -> oracle.sampler
+
+The 1x models (imagenet_gen/src/model.py, layers.py, diff_head.py, sampling.py) are the same
+loop with parallel_num = 1: no query tokens (model.py:372-375), a purely causal mask (layers.py:126-129 == the block mask
+with 1-token blocks), the RoPE table without re-ordering and ``[:-1]`` (model.py:181-190), plain-raster un-patchify
+(model.py:246-255 with patch_size 1) and the MLP head (diff_head.py:228-253 -> oracle.diff_head.mlp_net_forward);
+sampling.py == sampling_parallel.py up to the rank of the row tensors.
 
 Weights: flat dict keyed like the reference's ``state_dict()`` minus ``vae.*``.
 Dtype flow under the CUDA bf16 autocast policy (probed on the GPU box, tools/probe_autocast.py): ``rms_norm`` is in
@@ -153,8 +159,8 @@ def sample(w: dict, cfg: dict, class_ids: torch.Tensor, sample_steps: int, cfg_s
     ``noise``: iterator of the reference's randn / randn_like draws in call order.  ``force_tokens`` [bsz, hw, C]
     (teacher forcing): when given, each step's binarised prediction is replaced by these before it is fed back.
     Returns (latent [n, C, h, w] in {-1, 0, +1}, tokens [bsz, hw, C], preds [bsz, hw, C] pre-sign)."""
-    noise = iter(noise)
     P, D = cfg["parallel_num"], cfg["dim"]
+    noise = iter(noise) if P > 1 else (n.reshape(-1, n.shape[-1]) for n in noise)     # 1x: the head samples rows [N, C]
     hw = cfg["resolution"] // (cfg["down_size"] * cfg["patch_size"])
     n_cls = cfg["cls_token_num"]
     total = hw * hw + n_cls
@@ -177,7 +183,7 @@ def sample(w: dict, cfg: dict, class_ids: torch.Tensor, sample_steps: int, cfg_s
     for i in range(seq_len):
         if i == 0:
             T0 = n_cls + P - 1
-            x = torch.cat([c, w["query_token"].repeat(bsz, 1, 1)], dim=1)
+            x = torch.cat([c, w["query_token"].repeat(bsz, 1, 1)], dim=1) if P > 1 else c    # model.py:372-375: class tokens only
             x = forward_model(w, cfg, x, mask_all[:, :, :T0, :T0], fc_all[0:T0], caches, 0, T0, pol)
         else:
             x = proj_in(w, last, pol)
@@ -187,10 +193,17 @@ def sample(w: dict, cfg: dict, class_ids: torch.Tensor, sample_steps: int, cfg_s
         ci = cfg_at(cfg_scale, cfg_schedule, i, seq_len)
         if trace is not None:
             trace.setdefault("z", []).append(z.float().clone())
-        fwd = lambda xx, tt, cc: diff_head.net_forward(hwt, xx, tt, cc, pol, final_sigmoid=False, head_dim=64)
+        if P == 1:
+            z = z.reshape(-1, z.shape[-1])                                # model.py:332: the MLP head sees rows
+        if diff_head.is_mlp_head(hwt):                  # 1x models: MLP head over rows (model.py:331-332: x.view(-1, D))
+            fwd = lambda xx, tt, cc: diff_head.mlp_net_forward(hwt, xx, tt, cc, pol)
+        else:
+            fwd = lambda xx, tt, cc: diff_head.net_forward(hwt, xx, tt, cc, pol, final_sigmoid=False, head_dim=64)
         from . import sampler
         pred = sampler.euler_maruyama(hwt["net.input_proj.weight"].shape[1], fwd, z, ci, sample_steps, noise,
                                       time_shift=cfg.get("time_shift", 1.0))
+        if P == 1:
+            pred = pred.view(-1, 1, pred.shape[-1])                       # model.py:346
         preds.append(pred.clone())
         tok = torch.sign(pred)                                            # LFQ :367-368
         toks.append(tok)

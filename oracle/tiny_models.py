@@ -24,6 +24,11 @@ TINY_IN = dict(dim=256, n_layer=2, n_head=4, diff_layers=4, diff_dim=256, diff_a
                down_size=16, patch_size=1, resolution=128, cls_token_num=8, num_classes=10, parallel_num=16,
                time_shift=1.0)
 
+# the other released ImageNet variants (imagenet_gen/README.md:10-15): 1x = src/model.py (one token per AR step, causal
+# transformer, MLP diffusion head src/diff_head.py), 4x = src/model_parallel.py with parallel_num 4
+TINY_IN_1X = dict(TINY_IN, resolution=64, parallel_num=1)
+TINY_IN_4X = dict(TINY_IN, resolution=64, parallel_num=4)
+
 # BASELINE config 1: the released ae_d16c32 tokenizer at full size (bitdance_14b_64x.yaml:9-16), 256x256 round trip on CPU
 AE_D16C32 = dict(ddconfig=dict(double_z=False, z_channels=32, in_channels=3, out_ch=3, ch=256, ch_mult=[1, 1, 2, 2, 4],
                                num_res_blocks=4), gan_decoder=False)
@@ -80,6 +85,34 @@ def head_shapes(cfg: dict) -> dict:
     return s
 
 
+def mlp_head_shapes(cfg: dict) -> dict:
+    """state_dict() of imagenet_gen/src/diff_head.py DiffHead (MlpEncoder :165-225): ResBlock = LayerNorm + SwiGLU MLP of
+    width 1.5 x channels (:126-137), adaLN blocks of 3 chunks (:199), final layer as in the transformer head."""
+    D, C, Z = cfg["ch_latent"], cfg["ch_target"], cfg["ch_cond"]
+    H = int(D * 1.5)
+    s = {}
+
+    def lin(name, n, k):
+        s[name + ".weight"] = (n, k)
+        s[name + ".bias"] = (n,)
+
+    lin("net.time_embed.mlp.0", D, 256)
+    lin("net.time_embed.mlp.2", D, D)
+    lin("net.cond_embed", D, Z)
+    lin("net.input_proj", D, C)
+    for i in range(cfg["depth_latent"]):
+        p = f"net.res_blocks.{i}."
+        s[p + "norm.weight"] = (D,)
+        s[p + "norm.bias"] = (D,)
+        lin(p + "w1", 2 * H, D)
+        lin(p + "w2", D, H)
+    for j in range(cfg["depth_adanln"]):
+        lin(f"net.ada_ln_blocks.{j}", 3 * D, D)
+    lin("net.final_layer.ada_ln_modulation", 2 * D, D)
+    lin("net.final_layer.linear", C, D)
+    return s
+
+
 def imagenet_shapes(cfg: dict) -> dict:
     """state_dict() of imagenet_gen BitDance minus ``vae.*`` (names/shapes asserted against the reference module)."""
     D, L = cfg["dim"], cfg["latent_dim"] * cfg["patch_size"] ** 2
@@ -87,8 +120,7 @@ def imagenet_shapes(cfg: dict) -> dict:
     ff = int(2 * 4.0 * D / 3)
     ff = ff if ff % 256 == 0 else ff + 256 - ff % 256                    # find_multiple(.., 256)
     hw = cfg["resolution"] // (cfg["down_size"] * cfg["patch_size"])
-    s = {"query_token": (1, cfg["parallel_num"] - 1, D),
-         "cls_embedding.weight": (cfg["num_classes"] + 1, D * cfg["cls_token_num"]),
+    s = {"cls_embedding.weight": (cfg["num_classes"] + 1, D * cfg["cls_token_num"]),
          "proj_in.w1.weight": (2 * hid, L), "proj_in.w1.bias": (2 * hid,),
          "proj_in.w2.weight": (D, hid), "proj_in.w2.bias": (D,),
          "emb_norm.weight": (D,), "norm.weight": (D,), "pos_for_diff.weight": (hw * hw, D)}
@@ -100,9 +132,11 @@ def imagenet_shapes(cfg: dict) -> dict:
         s[p + "feed_forward.w2.weight"] = (D, ff)
         s[p + "attention_norm.weight"] = (D,)
         s[p + "ffn_norm.weight"] = (D,)
+    if cfg["parallel_num"] > 1:                       # src/model_parallel.py; src/model.py (1x) has no query tokens
+        s["query_token"] = (1, cfg["parallel_num"] - 1, D)
     hcfg = dict(ch_target=L, ch_cond=D, ch_latent=cfg["diff_dim"], depth_latent=cfg["diff_layers"],
                 depth_adanln=cfg["diff_adanln_layers"])
-    for k, v in head_shapes(hcfg).items():
+    for k, v in (mlp_head_shapes(hcfg) if cfg["parallel_num"] == 1 else head_shapes(hcfg)).items():
         s["head." + k] = v
     return s
 

@@ -52,12 +52,14 @@ def device_seeded_state(shapes: dict, seed: int, device, gain: float = 1.0) -> d
 
 
 def head_case(device="cuda", *, D=5120, Dz=None, C=32, P=64, B=1, branches=2, depth=2, nada=2, head_dim=128,
-              sigmoid=True, n_steps=3, eval_index=1, seed=101, tune: dict | None = None, weights: str = "bf16") -> dict:
+              sigmoid=True, n_steps=3, eval_index=1, seed=101, tune: dict | None = None, weights: str = "bf16",
+              mlp: bool = False) -> dict:
     """One head evaluation at width D: device x_hat vs oracle x_hat.  eval_index > 0 exercises a non-zero timestep
-    embedding; the latent is a fixed random tensor written straight into the engine's state."""
+    embedding; the latent is a fixed random tensor written straight into the engine's state.  ``mlp``: the MLP head of the
+    1x ImageNet models (imagenet_gen/src/diff_head.py:228-253) instead of the transformer head."""
     from bitdance_amd import engine as E
     cfgd = dict(ch_target=C, ch_cond=Dz or D, ch_latent=D, depth_latent=depth, depth_adanln=nada)
-    sd_dev = device_seeded_state(tm.head_shapes(cfgd), seed, device)
+    sd_dev = device_seeded_state((tm.mlp_head_shapes if mlp else tm.head_shapes)(cfgd), seed, device)
     hw = E.HeadWeights.from_state_dict(sd_dev, device, head_dim=head_dim, final_sigmoid=sigmoid, weights=weights)
     sd = {k: v.cpu() for k, v in sd_dev.items()}
     del sd_dev
@@ -81,8 +83,11 @@ def head_case(device="cuda", *, D=5120, Dz=None, C=32, P=64, B=1, branches=2, de
     comb = torch.cat([x] * branches)
     t0 = time.perf_counter()
     with torch.no_grad():
-        ref = diff_head.net_forward(sd, comb, torch.full((branches * B,), t_i), z, Policy("fp8w" if weights == "fp8" else "autocast"),
-                                    final_sigmoid=sigmoid, head_dim=head_dim).float()
+        if mlp:
+            ref = diff_head.mlp_net_forward(sd, comb, torch.full((branches * B,), t_i), z, Policy("autocast")).float()
+        else:
+            ref = diff_head.net_forward(sd, comb, torch.full((branches * B,), t_i), z, Policy("fp8w" if weights == "fp8" else "autocast"),
+                                        final_sigmoid=sigmoid, head_dim=head_dim).float()
     t_cpu = time.perf_counter() - t0
     err = (xhat - ref).abs()
     extra = {}
@@ -92,7 +97,7 @@ def head_case(device="cuda", *, D=5120, Dz=None, C=32, P=64, B=1, branches=2, de
                                           final_sigmoid=sigmoid, head_dim=head_dim).float()
         e16 = (xhat - ref16).abs()
         extra = {"vs_bf16_max": e16.max().item(), "vs_bf16_mean": e16.mean().item()}
-    cfgs = {n: eng.gemm_config("head." + n) for n in ("ada", "qkv", "wo", "w1", "w2")}
+    cfgs = {n: eng.gemm_config("head." + n) for n in (("ada", "w1", "w2") if mlp else ("ada", "qkv", "wo", "w1", "w2"))}
     macs_per_row = (D * C + D * cfgd["ch_cond"] + (nada * 6 + 2) * D * D + depth * (3 * D * D + D * D + 3 * D * D + 1.5 * D * D) + D * C)
     return {"max_err": err.max().item(), "mean_err": err.mean().item(), "ref_abs_mean": ref.abs().mean().item(),
             "finite": bool(torch.isfinite(xhat).all()), "t_cpu_s": t_cpu, "rows": M, "macs_per_row": macs_per_row,

@@ -47,7 +47,8 @@ def frag(eng_mod, x):
 @pytest.mark.parametrize("M,N,K,S,nw", [
     (128, 256, 256, 1, 4), (128, 256, 256, 4, 2), (128, 512, 384, 3, 8), (64, 256, 256, 2, 4),
     (32, 128, 192, 1, 2), (256, 256, 256, 2, 4), (256, 512, 384, 2, 8), (256, 5120, 5120, 6, 8), (512, 512, 384, 2, 8), (512, 1024, 5120, 1, 8), (128, 5120, 5120, 4, 4), (128, 15360, 5120, 2, 4),
-    (128, 5120, 17408, 6, 4), (128, 7168, 5120, 3, 2)])
+    (128, 5120, 17408, 6, 4), (128, 7168, 5120, 3, 2),
+    (128, 352, 256, 1, 5), (128, 640, 384, 2, 9), (128, 608, 256, 1, 9)])      # ragged last tiles (5- and 9-wave workgroups)
 def test_gemm_partial(eng_mod, M, N, K, S, nw):
     """F.linear under bf16 autocast == sum of the split-K slabs (fp32 accumulation of bf16 products)."""
     from bitdance_amd._lib import check, lib
@@ -67,7 +68,7 @@ def test_gemm_partial(eng_mod, M, N, K, S, nw):
 
 
 @pytest.mark.parametrize("M,F_,K,nw", [(128, 384, 256, 2), (128, 512, 256, 4), (64, 256, 256, 2), (128, 7680, 5120, 2),
-                                       (256, 512, 256, 8), (512, 7680, 5120, 8)])
+                                       (256, 512, 256, 8), (512, 7680, 5120, 8), (128, 352, 256, 5), (128, 17408, 5120, 5)])
 def test_gemm_swiglu(eng_mod, M, F_, K, nw):
     """Linear -> chunk -> silu(h1)*h2 with the reference's bf16 rounding points (flow_head:250-251)."""
     from bitdance_amd._lib import check, lib
@@ -87,6 +88,36 @@ def test_gemm_swiglu(eng_mod, M, F_, K, nw):
     a = act.view(F_ // 16, rb, 2, 32, 8).permute(1, 3, 0, 2, 4).reshape(rb * 32, F_)[:M]
     d = (a.float() - ref.float()).abs()
     assert (d > 0).float().mean() <= 0.02 and d.max() <= 0.07, ((d > 0).float().mean(), d.max())   # <= 1 bf16 ulp flips
+
+
+@pytest.mark.parametrize("ring,xcd", [(2, 1), (3, 0), (3, 1)])
+@pytest.mark.parametrize("M,N,K,S", [(512, 1024, 5120, 1), (512, 2304, 384, 1), (512, 2304, 384, 2), (768, 2560, 448, 1)])
+def test_gemm_wide_options(eng_mod, M, N, K, S, ring, xcd):
+    """The 256-row kernel's measurement switches (weight ring depth, row tiles of a weight slice on one XCD) change the
+    schedule and the block -> tile map, never the values: bit-identical to the default setting, and right."""
+    from bitdance_amd._lib import check, lib
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)
+    xf, rb = frag(eng_mod, x)
+    wp = eng_mod.pack_linear([w], DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    try:
+        for r_, x_ in ((2, 0), (ring, xcd)):
+            check(lib().bd_set_gemm_option(b"wide.ring", r_))
+            check(lib().bd_set_gemm_option(b"wide.xcd", x_))
+            out = torch.full((S, rb * 32, N), float("nan"), device=DEV)
+            check(lib().bd_gemm_partial(xf.data_ptr(), rb, wp.data_ptr(), N, K, S, 8, out.data_ptr(), st))
+            torch.cuda.synchronize()
+            outs.append(out)
+    finally:
+        check(lib().bd_set_gemm_option(b"wide.ring", 2))
+        check(lib().bd_set_gemm_option(b"wide.xcd", -1))
+    assert torch.equal(outs[0], outs[1])
+    ref = x.to(torch.bfloat16).double() @ w.double().t()
+    err = (outs[1].sum(0)[:M].double() - ref).abs().max().item()
+    assert err <= 2e-5 * K ** 0.5 + 1e-5, err
 
 
 # ----------------------------------------------------------------------------------------------- head
@@ -533,6 +564,86 @@ def test_imagenet_sample_teacher_forced_vs_reference(golden_dir):
     torch.manual_seed(7)
     b = m.sample(g["ids"], N, cfg_scale=float(g["cfg"]))
     assert torch.equal(a, b) and a.shape == (2, c["latent_dim"], 8, 8) and set(a.unique().tolist()) <= {-1.0, 0.0, 1.0}
+
+
+@pytest.mark.parametrize("name", ["1x", "4x"])
+def test_imagenet_variants_teacher_forced_vs_reference(golden_dir, name):
+    """The other released ImageNet variants on the native engine: BitDance-*-1x (imagenet_gen/src/model.py:
+    one token per AR step, causal transformer, MLP head diff_head.py:228-253 -> head.variant 1, P = 1 decode steps) and the 4x
+    parallel variant (model_parallel.py, parallel_num 4: 4-token head attention and decode blocks).  Reference noise and tokens
+    fed back; per-AR-step pre-sign latents against the reference's own (goldens imagenet1x_amp / imagenet4x_amp), bound = the
+    oracle-vs-reference bf16 noise x 1.5 scaled by the CFG amplification; HIP transformer vs the same steps as torch ops."""
+    from bitdance_amd.imagenet import BitDance
+    g = load(golden_dir, f"imagenet{name}_amp")
+    c = dict(tm.TINY_IN_1X if name == "1x" else tm.TINY_IN_4X)
+    m = BitDance(tm.seeded_state(tm.imagenet_shapes(c), seed=31), device=DEV, **c)
+    assert m.head_w.mlp == (name == "1x")
+    N, P = int(g["n_steps"]), c["parallel_num"]
+    steps = (c["resolution"] // 16) ** 2 // P
+    noise = [g["noise0"]] + [g["noise1"][k * (N + 1):(k + 1) * (N + 1)] for k in range(steps - 1)]
+    ref_tok = torch.sign(g["preds"])
+    lat, tokens, preds = m.sample(g["ids"], N, cfg_scale=float(g["cfg"]), noise=noise, force_tokens=ref_tok,
+                                  return_tokens=True)
+    preds, lat = preds.cpu(), lat.cpu()
+    assert torch.equal(lat, g["latent"])
+    for i in range(steps):
+        sl = slice(i * P, (i + 1) * P)
+        cfg_i = 1.0 + (float(g["cfg"]) - 1.0) * i / steps
+        ref = g["preds"][:, sl]
+        d = (preds[:, sl] - ref).abs()
+        assert d.mean().item() <= 0.075 * max(1.0, 2 * cfg_i - 1) * ref.abs().mean().item() + 3e-3, (i, d.mean())
+    firm = g["preds"].abs() > 0.5
+    assert (torch.sign(preds)[firm] == ref_tok[firm]).float().mean().item() >= 0.96
+    m.native_transformer = False
+    _, _, preds_t = m.sample(g["ids"], N, cfg_scale=float(g["cfg"]), noise=noise, force_tokens=ref_tok, return_tokens=True)
+    m.native_transformer = True
+    dt = (preds - preds_t.cpu()).abs()
+    assert dt.mean().item() <= 0.09 * g["preds"].abs().mean().item(), dt.mean()
+    torch.manual_seed(7)
+    a = m.sample(g["ids"], N, cfg_scale=float(g["cfg"]))
+    torch.manual_seed(7)
+    b = m.sample(g["ids"], N, cfg_scale=float(g["cfg"]))
+    assert torch.equal(a, b) and a.shape == (2, c["latent_dim"], 4, 4) and set(a.unique().tolist()) <= {-1.0, 0.0, 1.0}
+
+
+def test_imagenet_mlp_head_eval_vs_oracle(eng_mod):
+    """One evaluation of the MLP head (imagenet_gen/src/diff_head.py:228-253: input_proj, adaLN blocks of 3 chunks, ResBlocks
+    = LayerNorm-modulate -> SwiGLU -> gated residual, final layer, no squash) on the HIP engine, rows = sequences (P = 1),
+    against the oracle's autocast policy."""
+    c = tm.TINY_IN_1X
+    sd = tm.seeded_state(tm.imagenet_shapes(c), seed=31)
+    hsd = {k[len("head."):]: v for k, v in sd.items() if k.startswith("head.")}
+    hw = eng_mod.HeadWeights.from_state_dict(hsd, DEV, head_dim=64, final_sigmoid=False)
+    assert hw.mlp
+    B, C, D = 24, c["latent_dim"], c["dim"]
+    eng = eng_mod.Engine(hw, None, None, num_images=B, branches=2, device=DEV, max_tokens=1, parallel_num=1)
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(2 * B, 1, D, generator=g)
+    noise = torch.randn(1, 4, B, 1, C, generator=g)
+    eng.set_schedule(3, 2.0, 1)
+    eng.load_noise(noise.to(DEV))
+    eng.reset([0] * 16)
+    eng.set_int("rt.dump_xhat", 1)
+    eng.set_cond(z.to(DEV))
+    x0 = noise[0, 0]
+    eng.view("head.xt", torch.float32, (B, C)).copy_(x0.reshape(B, C))
+    eng.head_cond()
+    eng.head_eval(0)
+    torch.cuda.synchronize()
+    xhat = eng.view("head.xhat", torch.float32, (eng.Mpad, C))[: 2 * B].cpu()
+    ref = diff_head.mlp_net_forward(hsd, torch.cat([x0, x0]).view(2 * B, C), torch.zeros(2 * B), z.view(2 * B, D),
+                                    Policy("autocast")).float()
+    d = (xhat - ref).abs()
+    assert d.max() <= 0.08 * ref.abs().max() + 0.02 and d.mean() <= 0.01 * ref.abs().mean() + 2e-3, (d.max(), d.mean())
+    # the whole sampler on the MLP head: CFG-mixed sample vs the oracle's, same injected noise
+    eng.head_sample()
+    torch.cuda.synchronize()
+    got = eng.pred().cpu().view(B, C)
+    from oracle import sampler
+    fwd = lambda xx, tt, cc: diff_head.mlp_net_forward(hsd, xx, tt, cc, Policy("autocast"))
+    want = sampler.euler_maruyama(C, fwd, z.view(2 * B, D), 2.0, 3, list(noise[0].reshape(4, B, C)))[:B]
+    ds = (got - want).abs()
+    assert ds.mean().item() <= 0.05 * want.abs().mean().item() + 5e-3, (ds.mean(), want.abs().mean())
 
 
 def test_imagenet_transformer_decode_step_vs_oracle():

@@ -198,7 +198,7 @@ def _cfg(l, c, name):
 
 def test_context_planning_is_host_only_and_rejects_unknown_keys():
     """bd_ctx_* up to bd_ctx_finalize is host code (no GPU): unknown keys are errors, never silent defaults; the launch plan at
-    BitDance-14B-64x dimensions is the one the headline benchmark runs (10-wave adaLN tiles, 2-slice qkv / w1, 6-slice 8-wave
+    BitDance-14B-64x dimensions is the one the headline benchmark runs (9-wave ragged adaLN tiles, 2-slice qkv / w1, 6-slice 8-wave
     N = 5120 shapes) and every workspace has a positive size."""
     l, c = _ctx(DIMS_14B)
     assert l.bd_ctx_set_int(c, b"head.Dd", 1) != 0 and b"unknown key" in l.bd_last_error()
@@ -207,7 +207,7 @@ def test_context_planning_is_host_only_and_rejects_unknown_keys():
     assert l.bd_ctx_set_float(c, b"llm.epsilon", 1e-6) != 0 and l.bd_ctx_set_float(c, b"llm.eps", 1e-6) == 0
     assert l.bd_ctx_set_int(c, b"tune.head.wo.S", 6) == 0 and l.bd_ctx_set_int(c, b"tune.head.wq.S", 6) != 0
     assert l.bd_ctx_finalize(c) == 0, l.bd_last_error()
-    assert _cfg(l, c, "head.ada") == (1, 10, 1)
+    assert _cfg(l, c, "head.ada") == (1, 9, 1)            # 2240 panels over 249 workgroups of 9 waves, ragged last tile
     assert _cfg(l, c, "head.qkv") == (2, 4, 1) and _cfg(l, c, "head.w1") == (2, 4, 1)
     assert _cfg(l, c, "head.wo") == (6, 8, 2) and _cfg(l, c, "head.w2") == (6, 8, 2) and _cfg(l, c, "llm.o") == (6, 8, 2)
     n = l.bd_ctx_ws_count(c)
@@ -240,3 +240,37 @@ def test_context_planning_tensor_parallel(tp):
     assert l3.bd_ctx_set_tp(c3, 0, 3) == 0 and l3.bd_ctx_finalize(c3) != 0 and b"divide" in l3.bd_last_error()
     assert l3.bd_ctx_set_tp(c3, 3, 3) != 0
     l3.bd_ctx_destroy(c3)
+
+
+def test_context_planning_imagenet_1x_and_4x_variants():
+    """Host-only planning of the other ImageNet variants: the MLP head (head.variant = 1) at BitDance-B-1x
+    dimensions with one token per step -- 2 adaLN blocks of THREE chunks + the final layer's two = 8 x 768 adaLN columns -- and
+    the 4-token parallel variant; a transformer head with P = 1, the Qwen3 path below 16 tokens per step and an unknown variant
+    are rejected."""
+    head_b = {"head.D": 768, "head.C": 32, "head.Dz": 768, "head.H": 1152, "head.nblocks": 6, "head.nada": 2, "head.dh": 64,
+              "head.sigmoid": 0}
+    l, c = _ctx({"B": 384, "branches": 2, "P": 1, "head.variant": 1, **head_b})
+    assert l.bd_ctx_finalize(c) == 0, l.bd_last_error()
+    ws = {l.bd_ctx_ws_name(c, i).decode(): l.bd_ctx_ws_bytes(c, i) for i in range(l.bd_ctx_ws_count(c))}
+    assert ws["head.ada_bf"] == 768 * (2 * 3 + 2) * 768 * 2                 # [768 rows][8 x 768] bf16
+    l.bd_ctx_destroy(c)
+    l, c = _ctx({"B": 384, "branches": 2, "P": 4, **head_b, "head.H": 2048})
+    assert l.bd_ctx_finalize(c) == 0, l.bd_last_error()
+    ws = {l.bd_ctx_ws_name(c, i).decode(): l.bd_ctx_ws_bytes(c, i) for i in range(l.bd_ctx_ws_count(c))}
+    assert ws["head.ada_bf"] == 3072 * (2 * 6 + 2) * 768 * 2
+    l.bd_ctx_destroy(c)
+    l, c = _ctx({"B": 2, "branches": 2, "P": 1, **head_b})
+    assert l.bd_ctx_finalize(c) != 0 and b"head.variant" in l.bd_last_error()
+    l.bd_ctx_destroy(c)
+    l, c = _ctx({"B": 2, "branches": 2, "P": 1, "head.variant": 2, **head_b})
+    assert l.bd_ctx_finalize(c) != 0
+    l.bd_ctx_destroy(c)
+    l, c = _ctx({**DIMS_14B, "P": 4})
+    assert l.bd_ctx_finalize(c) != 0 and b"Qwen3" in l.bd_last_error()
+    l.bd_ctx_destroy(c)
+    tr = {"llm.D": 768, "llm.L": 24, "llm.nh": 12, "llm.nkv": 12, "llm.F": 2048, "llm.head_dim": 64, "llm.variant": 1,
+          "llm.Lmax": 320, "llm.splits": 8, "proj.D": 768, "proj.C": 32, "proj.hid": 1152, "proj.variant": 1}
+    for P in (1, 4, 16):
+        l, c = _ctx({"B": 768, "branches": 1, "P": P, **tr})
+        assert l.bd_ctx_finalize(c) == 0, (P, l.bd_last_error())
+        l.bd_ctx_destroy(c)

@@ -239,6 +239,55 @@ def test_imagenet_other_cfg_branches_fp32(golden_dir, name, schedule):
     assert torch.equal(lat, g["latent"])
 
 
+# ------------------------------------------------------------- the other released ImageNet variants
+_IN_VARIANTS = {"1x": tm.TINY_IN_1X, "4x": tm.TINY_IN_4X}
+
+
+def _imagenet_variant_run(name, g, pol, force=None):
+    from oracle import imagenet
+    c = dict(_IN_VARIANTS[name])
+    w = tm.seeded_state(tm.imagenet_shapes(c), seed=31)
+    noise = list(g["noise0"]) + list(g["noise1"])
+    return imagenet.sample(w, c, g["ids"], int(g["n_steps"]), float(g["cfg"]), noise, pol, force_tokens=force)
+
+
+@pytest.mark.parametrize("name", ["1x", "4x"])
+def test_imagenet_variants_fp32(golden_dir, name):
+    """BitDance-*-1x (imagenet_gen/src/model.py:352-391: one token per step, causal transformer, MLP head diff_head.py:228-253)
+    and the 4x parallel variant (model_parallel.py with parallel_num 4) end to end in fp32: RoPE table exact, RNG draws =
+    AR steps x (1 + N), every token identical to the reference's, pre-sign latents to 1e-4."""
+    from oracle import imagenet
+    g = load(golden_dir, f"imagenet{name}_fp32")
+    c = _IN_VARIANTS[name]
+    assert torch.equal(imagenet.rope_table(c), g["rope"])
+    hw = c["resolution"] // 16
+    assert int(g["calls"]) == (hw * hw // c["parallel_num"]) * (int(g["n_steps"]) + 1)
+    lat, tokens, preds = _imagenet_variant_run(name, g, Policy("fp32"))
+    torch.testing.assert_close(preds, g["preds"], atol=2e-4, rtol=1e-3)
+    assert torch.equal(lat, g["latent"])
+    assert torch.equal(tokens[:2], torch.sign(g["preds"])[:2])
+
+
+@pytest.mark.parametrize("name", ["1x", "4x"])
+def test_imagenet_variants_amp_teacher_forced(golden_dir, name):
+    """The same under the emulated CUDA bf16 autocast with the reference's tokens fed back: per-step latents at bf16-noise
+    level (amplified by the CFG mix), firm signs agree."""
+    g = load(golden_dir, f"imagenet{name}_amp")
+    c = _IN_VARIANTS[name]
+    ref_tok = torch.sign(g["preds"])
+    _, tokens, preds = _imagenet_variant_run(name, g, Policy("autocast"), force=ref_tok)
+    P = c["parallel_num"]
+    steps = preds.shape[1] // P
+    for i in range(steps):
+        sl = slice(i * P, (i + 1) * P)
+        cfg_i = 1.0 + (float(g["cfg"]) - 1.0) * i / steps
+        ref = g["preds"][:, sl]
+        d = (preds[:, sl] - ref).abs()
+        assert d.mean().item() <= 0.05 * max(1.0, 2 * cfg_i - 1) * ref.abs().mean().item() + 2e-3, (i, d.mean())
+    firm = g["preds"].abs() > 0.5
+    assert (torch.sign(preds)[firm] == ref_tok[firm]).float().mean().item() >= 0.97
+
+
 @pytest.mark.parametrize("name,n_img", [("genb2", 2), ("gennocfg", 1)])
 def test_gen_tokens_batch2_and_nocfg_fp32(golden_dir, name, n_img):
     """gen_image with num_images = 2 (rows [cond x2 | uncond x2], per-image noise) and with guidance_scale <= 1 (single
