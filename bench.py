@@ -47,7 +47,14 @@ WORKLOADS = {
     "14b-16x-512": ("14b-16x", 512, 512, "images/sec @512px BitDance-14B-16x"),
     "tiny": ("tiny", 256, 256, "images/sec (tiny smoke config)"),
     "imagenet-b16x": (None, 256, 256, "images/sec @256px ImageNet BitDance-B-16x"),
+    # the other released ImageNet checkpoints (imagenet_gen/README.md:10-15): 4x parallel variant; 1x = causal transformer + MLP head
+    "imagenet-b4x": (None, 256, 256, "images/sec @256px ImageNet BitDance-B-4x"),
+    "imagenet-b1x": (None, 256, 256, "images/sec @256px ImageNet BitDance-B-1x"),
+    "imagenet-l1x": (None, 256, 256, "images/sec @256px ImageNet BitDance-L-1x"),
+    "imagenet-h1x": (None, 256, 256, "images/sec @256px ImageNet BitDance-H-1x"),
 }
+# README defaults of the reference's sampler per checkpoint: (classes per call, CFG scale)   imagenet_gen/README.md:27-80
+IMAGENET_DEFAULTS = {"b16x": (384, 6.1), "b4x": (384, 3.9), "b1x": (384, 3.2), "l1x": (352, 4.0), "h1x": (224, 4.55)}
 
 
 def parse():
@@ -229,7 +236,7 @@ def main():
         torch.cuda.synchronize()
 
     size, H0, W0, metric = WORKLOADS[args.workload]
-    if args.workload == "imagenet-b16x":
+    if args.workload.startswith("imagenet-"):
         return bench_imagenet(args, dist, world, rank, dev, metric, barrier, max_over_ranks, rank_seed)
 
     # ---------------------------------------------------------------- T2I workloads
@@ -358,10 +365,13 @@ def bench_imagenet(args, dist, world, rank, dev, metric, barrier, max_over_ranks
     """BASELINE config 2: one ``BitDance.sample`` call over ``--num-images`` (default 384) classes, 100 sampling steps,
     linear CFG 6.1, VAE decode in chunks; N > 1 = replicas over disjoint class batches (what sample_ddp_parallel.py does)."""
     from bitdance_amd import synthetic as syn
-    n_cls = args.num_images or 384
+    variant = args.workload.split("-", 1)[1]
+    n_cls = args.num_images or IMAGENET_DEFAULTS[variant][0]
     n_sampling = args.sampling_steps or 100
-    guidance = args.guidance if args.guidance is not None else 6.1
-    m = syn.build_imagenet(dev, with_vae=not args.no_decode)
+    guidance = args.guidance if args.guidance is not None else IMAGENET_DEFAULTS[variant][1]
+    mcfg = syn.IMAGENET_MODELS[variant]
+    P = mcfg["parallel_num"]
+    m = syn.build_imagenet(dev, cfg=mcfg, with_vae=not args.no_decode)
     ids = (torch.arange(n_cls) + rank * n_cls) % 1000
 
     def one_pass(i):
@@ -380,18 +390,18 @@ def bench_imagenet(args, dist, world, rank, dev, metric, barrier, max_over_ranks
     assert torch.isfinite(out_img.float()).all()
     if rank == 0:
         images = world * n_cls * args.steps
-        ar_steps = (256 // 16) ** 2 // 16
+        ar_steps = (256 // 16) ** 2 // P
         out = {"metric": metric, "value": round(images / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random weights at true shapes, class ids arange % 1000)",
-               "config": {"workload": f"imagenet_gen BitDance-B-16x 256x256, batch {n_cls} classes per call, {n_sampling} sampling steps, "
+               "config": {"workload": f"imagenet_gen BitDance-{variant[0].upper()}-{variant[1:]} 256x256, batch {n_cls} classes per call, {n_sampling} sampling steps, "
                                       f"linear CFG {guidance}, VAE decode {'off' if args.no_decode else 'on (chunks of 48)'}",
-                          "ar_steps": ar_steps, "rows_per_pass": 2 * n_cls * 16,
+                          "ar_steps": ar_steps, "rows_per_pass": 2 * n_cls * P,
                           "parallelism": f"replicas x{world}" if world > 1 else "single GPU", "hipgraph": False}}
         if not args.no_roofline:
             eng = m._eng[(n_cls, 2)]
             out["roofline"] = gemm_roofline(eng, eng.head_sample, eng.M)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and variant == "b16x":
             out["cpu_baseline"] = cpu_baseline_imagenet(n_sampling + 1, ar_steps)
         print(json.dumps(out), flush=True)
     if dist is not None:

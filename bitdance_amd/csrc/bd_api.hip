@@ -110,8 +110,11 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
     if (!two_images && c->Mpad % 128 == 0 && !c->wfp8 && N % 32 == 0 && c->geti("tune.ragged", 1) != 0) {
         const int npmin = (N / 32 + 255) / 256;
         if (npmin == 9) { g.nw = npmin; ragged = true; }
+        // 5 panels x 2 K-parts = 10 waves per workgroup over ceil(panels / 5) workgroups (gate/up: 218 CUs instead of 136) also
+        // measured slower (95.8 vs 82.2 us isolated, 100 vs 93.5 us in situ): tune.ragged52 = 1 selects it
+        if (npmin == 5 && K % 128 == 0 && c->geti("tune.ragged52", 0) != 0) { g.nw = 10; g.kw = 2; ragged = true; }
     }
-    int ntiles = (N / 32 + g.nw - 1) / g.nw;
+    int ntiles = (N / 32 + g.nw / g.kw - 1) / (g.nw / g.kw);
     // row tiles of the grid (256-row passes): a large batch (ImageNet: 12288 rows = 48 row tiles) already fills the chip
     // with N tiles x row tiles -- splitting K there only multiplies fp32 slab traffic
     const int row_tiles = two_images ? c->Mpad / 256 : 1;
@@ -147,7 +150,7 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
     g.kw = (int)c->geti("tune." + name + ".kw", g.kw);
     g.ring = (int)c->geti("tune." + name + ".ring", g.ring);
     if (g.kw < 1 || g.kw > 2 || g.nw % g.kw || K % (64 * g.kw)) g.kw = 1;
-    ragged = ragged || (g.kw == 1 && (g.nw == 5 || g.nw == 9) && !c->wfp8 && c->Mpad % 128 == 0 && !two_images);
+    ragged = ragged || (((g.kw == 1 && (g.nw == 5 || g.nw == 9)) || (g.kw == 2 && g.nw == 10)) && !c->wfp8 && c->Mpad % 128 == 0 && !two_images);
     if (N % (32 * (g.nw / g.kw)) && !ragged) { g.kw = 1; g.nw = (N % 128 == 0) ? 4 : 2; }
     const int nst = K / (64 * g.kw);
     if (g.S > nst) g.S = nst;
@@ -158,7 +161,7 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
 static const char* const kIntKeys[] = {
     "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid", "head.y_evals", "head.variant",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
-    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async", "tune.ragged"};
+    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async", "tune.ragged", "tune.ragged52"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
                                          "llm.qkv", "llm.o", "llm.gu", "llm.down"};
 static bool known_int_key(const std::string& k) {

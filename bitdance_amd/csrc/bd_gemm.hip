@@ -325,8 +325,8 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
     if (ring == 0) ring = 2;
     if (ring < 2 || ring > 4 || kw > 2 || nw % kw) return -7;
     const int np = nw / kw;
-    // a ragged last tile (N/32 not a multiple of the panels per workgroup) is supported by the single-K-part kernels
-    if (K % (64 * kw) || N % 32 || (N % (32 * np) && kw != 1) || S < 1) return -2;
+    // a ragged last tile (N/32 not a multiple of the panels per workgroup): the waves past the last panel repeat it and store nothing
+    if (K % (64 * kw) || N % 32 || S < 1) return -2;
     const int nst_total = K / (64 * kw), q = (nst_total + S - 1) / S;
     if ((S - 1) * q >= nst_total) return -3;                       // an empty split
     if (epi != BD_EPI_PARTIAL && S != 1 && (out_partial == nullptr || cnt == nullptr || (nw >= 9 && kw == 1))) return -4;   // needs slab scratch + counters

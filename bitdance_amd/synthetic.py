@@ -23,6 +23,15 @@ HEAD_14B_16X = dict(HEAD_14B_64X, parallel_num=16)          # BitDance-14B-16x: 
 IMAGENET_B_16X = dict(dim=768, n_layer=24, n_head=12, diff_layers=6, diff_dim=768, diff_adanln_layers=2, latent_dim=32,
                       down_size=16, patch_size=1, resolution=256, cls_token_num=64, num_classes=1000, parallel_num=16,
                       time_shift=1.0)
+# every released ImageNet checkpoint (imagenet_gen/README.md:10-15; model.py:394-430 / model_parallel.py:437-473)
+IMAGENET_MODELS = {
+    "b16x": IMAGENET_B_16X,
+    "b4x": dict(IMAGENET_B_16X, parallel_num=4),
+    "b1x": dict(IMAGENET_B_16X, parallel_num=1),
+    "l1x": dict(IMAGENET_B_16X, parallel_num=1, dim=1024, n_layer=32, n_head=16, diff_layers=8, diff_dim=1024),
+    "h1x": dict(IMAGENET_B_16X, parallel_num=1, dim=1280, n_layer=40, n_head=20, diff_layers=12, diff_dim=1280,
+                diff_adanln_layers=3),
+}
 AE_D16C32 = dict(ddconfig=dict(double_z=False, z_channels=32, in_channels=3, out_ch=3, ch=256, ch_mult=[1, 1, 2, 2, 4],
                                num_res_blocks=4), gan_decoder=False)      # bitdance_14b_64x.yaml:9-16
 
@@ -60,7 +69,8 @@ def random_llm_state(cfg: dict, device, seed: int = 0, std: float = 0.02) -> dic
     return sd
 
 
-def random_head_state(cfg: dict, device, seed: int = 1, std: float = 0.02) -> dict:
+def random_head_state(cfg: dict, device, seed: int = 1, std: float = 0.02, mlp: bool = False) -> dict:
+    """``mlp``: the MLP head of the 1x ImageNet models (imagenet_gen/src/diff_head.py:165-225) instead of the transformer head."""
     g = torch.Generator(device=device).manual_seed(seed)
     D, C, Z = cfg["ch_latent"], cfg["ch_target"], cfg["ch_cond"]
     H = int(D * 1.5)
@@ -76,15 +86,16 @@ def random_head_state(cfg: dict, device, seed: int = 1, std: float = 0.02) -> di
     lin("net.input_proj", D, C)
     for i in range(cfg["depth_latent"]):
         p = f"net.res_blocks.{i}."
-        for n in ("norm1", "norm2"):
+        for n in (("norm",) if mlp else ("norm1", "norm2")):
             sd[p + n + ".weight"] = torch.ones(D, dtype=torch.float32, device=device)
             sd[p + n + ".bias"] = torch.zeros(D, dtype=torch.float32, device=device)
-        lin(p + "attn.wqkv", 3 * D, D)
-        lin(p + "attn.wo", D, D)
+        if not mlp:
+            lin(p + "attn.wqkv", 3 * D, D)
+            lin(p + "attn.wo", D, D)
         lin(p + "w1", 2 * H, D)
         lin(p + "w2", D, H)
     for j in range(cfg["depth_adanln"]):
-        lin(f"net.ada_ln_blocks.{j}", 6 * D, D)
+        lin(f"net.ada_ln_blocks.{j}", (3 if mlp else 6) * D, D)
     lin("net.final_layer.ada_ln_modulation", 2 * D, D)
     lin("net.final_layer.linear", C, D)
     return sd
@@ -124,7 +135,7 @@ def random_imagenet_state(cfg: dict, device, seed: int = 4, std: float = 0.02) -
     ff = ff if ff % 256 == 0 else ff + 256 - ff % 256
     hw = cfg["resolution"] // (cfg["down_size"] * cfg["patch_size"])
     f32 = torch.float32
-    sd = {"query_token": _normal((1, cfg["parallel_num"] - 1, D), std, g, device, f32),
+    sd = {"query_token": _normal((1, cfg["parallel_num"] - 1, D), std, g, device, f32),     # absent from the 1x models (dropped below)
           "cls_embedding.weight": _normal((cfg["num_classes"] + 1, D * cfg["cls_token_num"]), std, g, device, f32),
           "proj_in.w1.weight": _normal((2 * hid, L), 1.0 / math.sqrt(L), g, device, f32),
           "proj_in.w1.bias": _normal((2 * hid,), std, g, device, f32),
@@ -142,13 +153,17 @@ def random_imagenet_state(cfg: dict, device, seed: int = 4, std: float = 0.02) -
         sd[p + "ffn_norm.weight"] = torch.ones(D, device=device)
     hcfg = dict(ch_target=L, ch_cond=D, ch_latent=cfg["diff_dim"], depth_latent=cfg["diff_layers"],
                 depth_adanln=cfg["diff_adanln_layers"])
-    for k, v in random_head_state(hcfg, device, seed=seed + 1, std=1.0 / math.sqrt(cfg["diff_dim"])).items():
+    one_x = cfg["parallel_num"] == 1                     # imagenet_gen/src/model.py: no query tokens, MLP head
+    if one_x:
+        del sd["query_token"]
+    for k, v in random_head_state(hcfg, device, seed=seed + 1, std=1.0 / math.sqrt(cfg["diff_dim"]), mlp=one_x).items():
         sd["head." + k] = v.float()
     return sd
 
 
 def build_imagenet(device: str = "cuda", cfg: dict | None = None, with_vae: bool = True):
-    """BitDance-B-16x (class-conditional ImageNet, 256 px) on random weights, optionally with the ae_d16c32 decoder."""
+    """A class-conditional ImageNet model (default BitDance-B-16x, 256 px; ``cfg`` = an IMAGENET_MODELS entry) on random
+    weights, optionally with the ae_d16c32 decoder."""
     from .autoencoder import VQModel
     from .imagenet import BitDance
     cfg = dict(cfg or IMAGENET_B_16X)

@@ -48,7 +48,8 @@ def frag(eng_mod, x):
     (128, 256, 256, 1, 4), (128, 256, 256, 4, 2), (128, 512, 384, 3, 8), (64, 256, 256, 2, 4),
     (32, 128, 192, 1, 2), (256, 256, 256, 2, 4), (256, 512, 384, 2, 8), (256, 5120, 5120, 6, 8), (512, 512, 384, 2, 8), (512, 1024, 5120, 1, 8), (128, 5120, 5120, 4, 4), (128, 15360, 5120, 2, 4),
     (128, 5120, 17408, 6, 4), (128, 7168, 5120, 3, 2),
-    (128, 352, 256, 1, 5), (128, 640, 384, 2, 9), (128, 608, 256, 1, 9)])      # ragged last tiles (5- and 9-wave workgroups)
+    (128, 352, 256, 1, 5), (128, 640, 384, 2, 9), (128, 608, 256, 1, 9), (128, 608, 256, 1, 10 + 256),
+    (128, 736, 384, 3, 10 + 256)])      # ragged last tiles (5- and 9-wave workgroups, 5 panels x 2 K-parts)
 def test_gemm_partial(eng_mod, M, N, K, S, nw):
     """F.linear under bf16 autocast == sum of the split-K slabs (fp32 accumulation of bf16 products)."""
     from bitdance_amd._lib import check, lib
@@ -68,7 +69,8 @@ def test_gemm_partial(eng_mod, M, N, K, S, nw):
 
 
 @pytest.mark.parametrize("M,F_,K,nw", [(128, 384, 256, 2), (128, 512, 256, 4), (64, 256, 256, 2), (128, 7680, 5120, 2),
-                                       (256, 512, 256, 8), (512, 7680, 5120, 8), (128, 352, 256, 5), (128, 17408, 5120, 5)])
+                                       (256, 512, 256, 8), (512, 7680, 5120, 8), (128, 352, 256, 5), (128, 17408, 5120, 5),
+                                       (128, 352, 256, 10 + 256), (128, 17408, 5120, 10 + 256)])
 def test_gemm_swiglu(eng_mod, M, F_, K, nw):
     """Linear -> chunk -> silu(h1)*h2 with the reference's bf16 rounding points (flow_head:250-251)."""
     from bitdance_amd._lib import check, lib

@@ -48,8 +48,8 @@ def sweep128():
     st = torch.cuda.current_stream().cuda_stream
     for name, N, K, form, cands in (
             ("head.ada", 71680, 5120, "b", [10, 9, 8]),
-            ("llm.gu", 34816, 5120, "s", [8, 5, 4]),
-            ("llm.gu(slabs)", 34816, 5120, "p", [8, 5])):
+            ("llm.gu", 34816, 5120, "s", [8, 5, 10 + 256, 8 + 256]),
+            ("llm.gu(slabs)", 34816, 5120, "p", [8, 10 + 256])):
         wps = weights(N, K)
         xf = torch.zeros(M * K, dtype=BF16, device=DEV)
         outb = torch.empty(M * N, dtype=BF16, device=DEV)
@@ -62,8 +62,9 @@ def sweep128():
                 if form == "s":
                     return lib().bd_gemm_swiglu(xf.data_ptr(), RB, w, None, N, K, nw, outb.data_ptr(), st)
                 return lib().bd_gemm_partial(xf.data_ptr(), RB, w, N, K, 1, nw, outp.data_ptr(), st)
-            blocks = (N // 32 + nw - 1) // nw
-            report(f"{name} waves={nw} blocks={blocks}", N, K, M, timed(launch))
+            waves, kw = nw & 15, ((nw >> 8) & 3) + 1
+            blocks = (N // 32 + waves // kw - 1) // (waves // kw)
+            report(f"{name} waves={waves} kparts={kw} blocks={blocks}", N, K, M, timed(launch))
         del wps
 
 
@@ -88,6 +89,14 @@ def sweep512():
                 report(f"{name} wide S={S} ring={ring} xcd={xcd}", N, K, M, timed(launch))
         check(lib().bd_set_gemm_option(b"wide.ring", 2))
         check(lib().bd_set_gemm_option(b"wide.xcd", -1))
+        if N == 15360:
+            # 256 rows x 128 columns per workgroup (4 waves x 1 panel): N / 128 tiles x 2 row tiles = 240 workgroups with NO K split,
+            # so the bf16 result is written straight from the accumulators (no fp32 slabs for the consumer)
+            for nw4 in (4, 8):                                     # 8: the 256-column kernel at S = 1 (120 workgroups) for comparison
+                def launch(i):
+                    return lib().bd_gemm_bf16(xf.data_ptr(), RB, wps[i % len(wps)].data_ptr(), None, N, K, 1, nw4, None, None,
+                                              outb.data_ptr(), st)
+                report(f"{name} {nw4} waves S=1 bf16 direct", N, K, M, timed(launch))
         if N == 5120:
             # 128-column tiles (4 waves x 256 rows), fewer slices, reduced inside the launch: no slabs for the consumer
             for S2 in (2, 3):

@@ -21,7 +21,7 @@ REPS = 4
 M = 128
 CAL_BYTES = 256 << 20
 # name, N, K, split-K, waves, kparts: the in-situ configuration of bench.py's default workload (roofline.per_gemm)
-SHAPES = [("head.ada", 71680, 5120, 1, 10, 1), ("head.qkv", 15360, 5120, 2, 4, 1), ("head.wo", 5120, 5120, 6, 8, 2),
+SHAPES = [("head.ada", 71680, 5120, 1, 9, 1), ("head.qkv", 15360, 5120, 2, 4, 1), ("head.wo", 5120, 5120, 6, 8, 2),
           ("head.w1", 15360, 5120, 2, 4, 1), ("head.w2", 5120, 7680, 6, 8, 2), ("head.cond", 5120, 5120, 6, 8, 2),
           ("proj.fc2", 5120, 5120, 6, 8, 2), ("llm.qkv", 7168, 5120, 4, 8, 2), ("llm.o", 5120, 5120, 6, 8, 2),
           ("llm.gu", 34816, 5120, 1, 8, 1), ("llm.down", 5120, 17408, 9, 8, 1)]
