@@ -710,6 +710,53 @@ def test_imagenet_bitdance_b_dims_run():
         assert d <= (0.0 if i == 0 else 0.08) * ref + 1e-6, (i, d, ref)
 
 
+@pytest.mark.parametrize("variant", ["b1x", "h1x", "b4x"])
+def test_imagenet_released_variants_real_dims_run(variant):
+    """The other released checkpoints at their REAL dimensions (imagenet_gen/src/model.py:394-430: B-1x width 768 / 24 layers,
+    H-1x width 1280 / 40 layers / 12-block MLP head with 3 adaLN projections; model_parallel.py B-4x), random weights, 2 sampling
+    steps, 4 classes with CFG: shape / divisibility coverage of every kernel on those widths at P = 1 and P = 4; HIP transformer
+    == torch transformer within bf16 noise on the first decode steps; deterministic."""
+    from bitdance_amd import synthetic as syn
+    from bitdance_amd.imagenet import BitDance
+    c = dict(syn.IMAGENET_MODELS[variant])
+    m = BitDance(syn.random_imagenet_state(c, DEV), device=DEV, **c)
+    P = c["parallel_num"]
+    assert m.head_w.mlp == (P == 1)
+    ids = torch.tensor([1, 207, 980, 33])
+    torch.manual_seed(11)
+    lat, tok, pred = m.sample(ids, 2, cfg_scale=4.0, return_tokens=True)
+    torch.manual_seed(11)
+    lat2, tok2, pred2 = m.sample(ids, 2, cfg_scale=4.0, return_tokens=True)
+    assert lat.shape == (4, 32, 16, 16) and torch.isfinite(pred).all() and torch.equal(pred, pred2)
+    assert set(lat.unique().tolist()) <= {-1.0, 0.0, 1.0}
+    if variant == "h1x":                                       # 40 layers as torch ops: covered at B width
+        return
+    # decode steps of the HIP transformer against the same steps as torch ops (the reference's arithmetic), compared where
+    # they differ -- norm(x), before the head's sampler amplifies bf16 noise (measured: rel. error 0.010-0.017 at every variant,
+    # tools/diag_imagenet_decode.py)
+    import torch.nn.functional as F
+    n_cls, bsz, hd = m.cls_token_num, 8, m.dim // m.n_head
+    cls_ids = torch.arange(bsz, device=DEV)
+    caches = [(torch.zeros(bsz, m.n_head, m.total_tokens, hd, device=DEV), torch.zeros(bsz, m.n_head, m.total_tokens, hd, device=DEV))
+              for _ in range(m.n_layer)]
+    T0 = n_cls + P - 1
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        x = F.embedding(cls_ids, m.w_["cls_embedding.weight"]).view(bsz, n_cls, -1)
+        if P > 1:
+            x = torch.cat([x, m.w_["query_token"].repeat(bsz, 1, 1)], dim=1)
+        m._forward_model(x, m.attn_mask[:, :, :T0, :T0], 0, T0, caches)
+    eng = m._tr_engine(bsz)
+    m._load_cache(eng, caches, T0)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for i in range(1, 4):
+        tk = torch.sign(torch.randn(bsz, P, c["latent_dim"], device=DEV, generator=g))
+        s0 = P * (i - 1) + n_cls + P - 1
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ref = m._forward_model(m._proj_in(tk), m.attn_mask[:, :, s0:s0 + P, :s0 + P], s0, s0 + P, caches).float()
+        d = (m._decode_step(eng, tk).float() - ref).abs()
+        assert d.mean().item() <= 0.03 * ref.abs().mean().item() and d.max().item() <= 0.25, (variant, i, d.mean(), d.max())
+
+
 @pytest.mark.parametrize("name,schedule", [("const", "constant"), ("nocfg", "linear")])
 def test_imagenet_other_cfg_branches_vs_reference(golden_dir, name, schedule):
     """Constant CFG (mixed from the first step, two-branch head context throughout) and cfg_scale <= 1 (single branch)
