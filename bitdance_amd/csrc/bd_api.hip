@@ -120,6 +120,17 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
     const int row_tiles = two_images ? c->Mpad / 256 : 1;
     int S = (int)std::lround((g.nw >= 8 ? 180.0 : 240.0) / ((double)ntiles * row_tiles));
     if (S < 1) S = 1;
+    if (two_images && row_tiles >= 8) {
+        // every K slice parks an fp32 slab of rows x N that the consumer re-reads: with enough row tiles to spread the work, do
+        // not split beyond the point where the slabs outweigh the operands themselves.  The 14B shapes are unaffected (few row
+        // tiles, W 157 MB vs 31 MB per slab at 512 rows).  ImageNet B-4x (3072 rows = 12 row tiles, W 1.8-3.5 MB vs 9-28 MB per
+        // slab): one slice, the GEMM rounds / applies SwiGLU in its epilogue instead of handing 2-5 slabs to ln_mod / swiglu_rows:
+        // 34.9 -> 38.1 img/s although every GEMM launch got slower.  B-1x (768 rows = 3 row tiles) keeps its splits: at one slice
+        // only 9-27 workgroups exist and the GEMMs double in time (20.9 -> 18.3 img/s measured with the cap applied there too).
+        const double operands = 2.0 * N * K + 2.0 * c->Mpad * K, slab = 4.0 * c->Mpad * N;
+        const int cap = (int)std::floor(operands / slab);
+        if (S > std::max(1, cap) && c->geti("tune.slab_cap", 1) != 0) S = std::max(1, cap);
+    }
     if (ntiles >= 260 && !swiglu && row_tiles == 1) S = 3;   // > 1 wave of workgroups: split for tail balance
     if (swiglu && ntiles >= 130) S = 1;
     const bool kw2_shape = !two_images && K % 128 == 0 && N % 64 == 0 && g.nw != 10;
@@ -161,7 +172,7 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
 static const char* const kIntKeys[] = {
     "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid", "head.y_evals", "head.variant",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
-    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async", "tune.ragged", "tune.ragged52"};
+    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async", "tune.ragged", "tune.ragged52", "tune.slab_cap"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
                                          "llm.qkv", "llm.o", "llm.gu", "llm.down"};
 static bool known_int_key(const std::string& k) {

@@ -8,8 +8,14 @@ loop serves both surfaces; this class carries the attribute names code written a
 (``tokenizer``, ``llm_model.model``, ``vision_head``, ``embed_vision_mlp``, ``vision_encoder``, ``parallel_num``, ``ps``,
 ``hidden_size``, ``config.head.vision_pred``) and forwards ``gen_image`` / ``decode_image`` with the reference's signatures.
 
-Out of scope here (training): ``forward`` / losses, ``forward_inference_block_causal``
-(interleaved text + image), ``gen_image_full_causal`` (parallel_num == 1 models) -- they raise ``NotImplementedError``.
+``forward_inference_block_causal`` (mllm.py:695-897) is served for the plans the reference itself
+can run: any user text / user image items followed by ONE model-generated image (text-to-image, image editing, multi-image
+conditioning).  Its text-generation branch does not run in the reference (the first decode step indexes ``past_key_values``
+while it is still None, :796-800; later steps would feed 2-D embeddings), so a plan that asks the model for text raises
+``NotImplementedError`` here too.  ``encode_image`` (:899-930) = the tokenizer's conv encoder (MIOpen) -> binary tokens in patch
+order -> the native projector -> + 2-D position embedding.
+
+Out of scope (training): ``forward`` / losses; ``gen_image_full_causal`` (parallel_num == 1 T2I models) -- ``NotImplementedError``.
 """
 from __future__ import annotations
 
@@ -74,5 +80,97 @@ class MLLModel:
     def forward(self, *a, **k):
         raise NotImplementedError("training forward / losses are out of scope (SURVEY.md section 8: inference hot path only)")
 
-    def forward_inference_block_causal(self, *a, **k):
-        raise NotImplementedError("interleaved text + image inference (mllm.py:695-897) is a 'next' row (SURVEY.md section 8f rank 3)")
+    # ------------------------------------------------------------------ interleaved text + image context
+    @torch.no_grad()
+    def vt_forward(self, image_list, max_bs: int = 32, ps: int = 1) -> torch.Tensor:
+        """VQModel.vt_forward (vision_encoder/autoencoder.py:402-424): images grouped by size, encoded in batches of ``max_bs``,
+        each latent [C, h, w] re-ordered 'c (h p1) (w p2) -> (h w p1 p2) c'; concatenated in list order."""
+        groups: dict = {}
+        for i, img in enumerate(image_list):
+            groups.setdefault(tuple(img.shape[-2:]), []).append((i, img))
+        out = [None] * len(image_list)
+        for items in groups.values():
+            for s0 in range(0, len(items), max_bs):
+                chunk = items[s0:s0 + max_bs]
+                quant = self.vision_encoder.encode(torch.cat([x[1] for x in chunk], dim=0).to(self.device))
+                for b, (idx, _) in enumerate(chunk):
+                    C, H, W = quant[b].shape
+                    out[idx] = quant[b].view(C, H // ps, ps, W // ps, ps).permute(1, 3, 2, 4, 0).reshape(H * W, C)
+        return torch.cat(out, dim=0)
+
+    @torch.no_grad()
+    def encode_image(self, image_list, packed_label_indexes_vision=None):
+        """mllm.py:899-930 (inference branch): -> (packed embeddings [sum h_i*w_i, D], packed binary latents [sum h_i*w_i, C])."""
+        lat = self.vt_forward(image_list, max_bs=32, ps=self.ps)
+        emb = self.embed_vision_mlp(lat)                                           # native projector, bf16 values
+        pos = torch.cat([self.get_2d_embed(img.shape[-2] // self.vae_patch_size, img.shape[-1] // self.vae_patch_size, ps=self.ps)
+                         for img in image_list], dim=0)
+        emb = (emb.float() + pos.to(emb.device)).to(emb.dtype)                     # `+=` on the bf16 tensor: one rounding
+        return emb, lat.clone()
+
+    @staticmethod
+    def remove_first_user_block(x: str) -> str:
+        """modeling/utils.py:206-216."""
+        a, b = "<|im_start|>user\n", "<|im_end|>\n"
+        i = x.find(a)
+        if i == -1:
+            return x
+        j = x.find(b, i + len(a))
+        return x if j == -1 else x[:i] + x[j + len(b):]
+
+    def _tok_id(self, name: str) -> int:
+        t = self.tokenizer
+        return getattr(t, name + "_id") if hasattr(t, name + "_id") else t.convert_tokens_to_ids(
+            {"start_of_image": "<|vision_start|>", "end_of_image": "<|vision_end|>"}.get(name, f"<|{name}|>"))
+
+    @torch.no_grad()
+    def forward_inference_block_causal(self, sequence_plan, text_list, image_list, do_sample: bool = True,
+                                       max_length_text: int = 128, max_length_vision: int = 64, temperature: float = 1.0,
+                                       sample_steps: int = 50, image_size=[256, 256], cfg_scale=7.5, *args, noise=None,
+                                       return_tokens: bool = False, force_tokens=None, trace=None, **kwargs):
+        """mllm.py:695-897 for plans that end in ONE model-generated image (see the module docstring).  The context is
+        assembled exactly as the reference does (:719-745,865-895): user text -> token embeddings (unconditional branch: the
+        text without its first user block); every image item -> [start_of_image, res_h, res_w] with the res tokens of the
+        GENERATION size; a user image -> ``encode_image`` + end_of_image; then the query tokens and the native AR loop.
+        Returns {"generated_text": [], "generated_image": [image]} (``return_tokens``: the binary tokens instead)."""
+        plan = list(sequence_plan)
+        model_items = [i for i, it in enumerate(plan) if it["from"] == "model"]
+        if model_items != [len(plan) - 1] or plan[-1]["type"] != "image":
+            raise NotImplementedError("native forward_inference_block_causal: user text / image items followed by one model-generated "
+                                      "image (the reference's text-generation branch does not run: mllm.py:796-800)")
+        texts, images = list(text_list), list(image_list)
+        use_cfg = cfg_scale > 1.0
+        P, vp = self.parallel_num, self.vae_patch_size
+        if max_length_vision != (image_size[0] // vp) * (image_size[1] // vp):
+            # the reference stops after max_length_vision tokens and then un-rasters them as a square image (:806,861)
+            raise ValueError(f"max_length_vision={max_length_vision} must equal the token count of image_size {image_size}: "
+                             f"{(image_size[0] // vp) * (image_size[1] // vp)}")
+        embed = self._p.llm_w.sd["model.embed_tokens.weight"]
+        E = lambda ids: torch.nn.functional.embedding(torch.tensor(list(ids), device=self.device, dtype=torch.long), embed)
+        start = E([self._tok_id("start_of_image"), self._tok_id(f"res_{image_size[0] // vp}"), self._tok_id(f"res_{image_size[1] // vp}")])
+        c, u = [], []
+        for item in plan:
+            if item["type"] == "image":
+                c.append(start)
+                u.append(start)
+            if item["from"] == "model":
+                q = E([self._tok_id(f"query_{i}") for i in range(1, P)])
+                c.append(q)
+                u.append(q)
+            elif item["type"] == "text":
+                t = texts.pop(0)
+                c.append(E(self.tokenizer.encode(t)))
+                if use_cfg:
+                    u.append(E(self.tokenizer.encode(self.remove_first_user_block(t))))
+            else:
+                e = self.encode_image([images.pop(0).to(self.device)])[0]
+                end = E([self._tok_id("end_of_image")])
+                c += [e, end]
+                if use_cfg:
+                    u += [e, end]
+        out = self._p.gen_image_from_context(torch.cat([x.to(torch.bfloat16) for x in c]),
+                                             torch.cat([x.to(torch.bfloat16) for x in u]) if use_cfg else None,
+                                             guidance_scale=cfg_scale, num_sampling_steps=sample_steps, num_images=1,
+                                             image_size=image_size, noise=noise, return_tokens=return_tokens,
+                                             force_tokens=force_tokens, trace=trace)
+        return {"generated_text": [], "generated_image": [out]}

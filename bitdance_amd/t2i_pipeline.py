@@ -210,10 +210,38 @@ class BitDanceT2IPipeline:
             raise ValueError(f"max_length={max_length} must equal (H/{self.vae_patch_size})*(W/{self.vae_patch_size})={h * w} "
                              f"and be a multiple of parallel_num={P}")
         cond_ids, uncond_ids = self._prompt_ids(cond_prompt, uncond_prompt, image_size, cfg_on)
-        kv_need = max(len(cond_ids), len(uncond_ids or [])) + num_steps * P + P
+        embed = self.llm_w.sd["model.embed_tokens.weight"]
+        ctx = [F.embedding(torch.tensor(ids, device=self.device, dtype=torch.long), embed) for ids in [cond_ids, uncond_ids][:branches]]
+        return self.gen_image_from_context(ctx[0], ctx[1] if cfg_on else None, guidance_scale=guidance_scale,
+                                           num_sampling_steps=num_sampling_steps, num_images=num_images, image_size=image_size,
+                                           noise=noise, return_tokens=return_tokens)
+
+    @torch.no_grad()
+    def gen_image_from_context(self, cond_ctx: torch.Tensor, uncond_ctx: torch.Tensor | None, *, guidance_scale: float = 1.0,
+                               num_sampling_steps: int = 50, num_images: int = 1, image_size=[256, 256],
+                               noise: torch.Tensor | None = None, return_tokens: bool = False,
+                               force_tokens: torch.Tensor | None = None, trace: dict | None = None):
+        """The AR loop over an arbitrary context: ``cond_ctx`` / ``uncond_ctx`` [T, D] are the input EMBEDDINGS of everything
+        before the first patch, query tokens included -- token embeddings of a prompt (``gen_image``, t2i_pipeline.py:175-198) or
+        an interleaved text + image context (``MLLModel.forward_inference_block_causal``, mllm.py:719-745).  Prefill = causal
+        over ctx[:-P], all-visible over the last P (:199-236); then the 64-step loop (:241-270).
+        ``force_tokens`` [num_images, h*w, C] / ``trace`` (tests): teacher forcing -- the fed-back tokens are replaced by these
+        (eager launches) and the pre-sign latents of every step are appended to ``trace["pred"]``."""
+        P = self.parallel_num
+        cfg_on = guidance_scale > 1.0
+        branches = 2 if cfg_on else 1
+        if cfg_on and uncond_ctx is None:
+            raise ValueError("guidance_scale > 1 needs an unconditional context")
+        h, w = image_size[0] // self.vae_patch_size, image_size[1] // self.vae_patch_size
+        if (h * w) % P:
+            raise ValueError(f"(H/{self.vae_patch_size})*(W/{self.vae_patch_size})={h * w} must be a multiple of parallel_num={P}")
+        num_steps = (h * w) // P
+        ctxs = [c.to(self.device, torch.bfloat16) for c in [cond_ctx, uncond_ctx][:branches]]
+        if any(c.dim() != 2 or c.shape[0] < P or c.shape[1] != self.hidden_size for c in ctxs):
+            raise ValueError("a context is [T >= parallel_num, hidden_size] input embeddings")
+        kv_need = max(c.shape[0] for c in ctxs) + num_steps * P + P
         eng = self._engine(num_images, branches, h * w, kv_need)
         dev = self.device
-        embed = self.llm_w.sd["model.embed_tokens.weight"]
         st = self._stream
         st.wait_stream(torch.cuda.current_stream())
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -231,14 +259,12 @@ class BitDanceT2IPipeline:
             kv = []
             if self.native_prefill:
                 embs = []
-                for ids in [cond_ids, uncond_ids][:branches]:
-                    x = F.embedding(torch.tensor(ids, device=dev, dtype=torch.long), embed)
+                for x in ctxs:
                     embs += [x] * num_images
                 hid_last, kv = prefill_native(eng, embs)
                 hid = [hid_last.to(torch.bfloat16)]
             else:
-                for br, ids in enumerate([cond_ids, uncond_ids][:branches]):
-                    x = F.embedding(torch.tensor(ids, device=dev, dtype=torch.long), embed)
+                for br, x in enumerate(ctxs):
                     x = x.unsqueeze(0).repeat(num_images, 1, 1)
                     T0 = x.shape[1] - P
                     prefill_block(eng, self.llm_w, x[:, :T0], br * num_images, 0, causal=True)
@@ -256,7 +282,16 @@ class BitDanceT2IPipeline:
                 st.synchronize()
                 self.tp.barrier()
             for step in range(num_steps):
-                if self.use_graph:
+                if force_tokens is not None or trace is not None:
+                    eng.head_sample()
+                    if trace is not None:
+                        trace.setdefault("pred", []).append(eng.pred().clone())
+                    if force_tokens is not None:
+                        eng.tok_cur().copy_(force_tokens[:, step * P:(step + 1) * P].to(dev))
+                    if step + 1 < num_steps:
+                        eng.projector()
+                        eng.llm_step()
+                elif self.use_graph:
                     eng.launch(0)
                     if step + 1 < num_steps:
                         eng.launch(1)

@@ -245,6 +245,71 @@ def gen_mllm_equiv():
     save("mllm_equiv", tokens=captured["tokens"], calls=rn.calls)
 
 
+def gen_interleaved():
+    """MLLModel.forward_inference_block_causal (modeling/mllm.py:695-897) for an image-EDITING plan: a user text, a user image
+    (encode_image :899-930 = VQModel.vt_forward -> MLPconnector -> + 2-D pos embed) and a model-generated image, CFG on (the
+    unconditional context drops the first user block of the text, utils.py:206-216, and keeps the image).  Same tiny components
+    as gen_fp32 / gen_amp; 256x256 output (4 AR steps x 4 sampling steps), 128x128 input image."""
+    from types import SimpleNamespace
+    import modeling.mllm as mm
+
+    class Tiny(mm.MLLModel):
+        device = "cpu"
+
+    for tag, dtype in (("fp32", torch.float32), ("amp", torch.bfloat16)):
+        base = build_pipeline(dtype)
+        tok = tm.FakeTokenizer()
+        tk = SimpleNamespace(encode=tok.encode, start_of_image_id=tm.VISION_START, end_of_image_id=tm.VISION_END,
+                             im_start_id=tm.IM_START, im_end_id=tm.IM_END)
+        for n in range(1, 129):
+            setattr(tk, f"res_{n}_id", tm.RES_BASE + n)
+        for i in range(1, 64):
+            setattr(tk, f"query_{i}_id", tm.QUERY_BASE + i)
+        m = object.__new__(Tiny)
+        torch.nn.Module.__init__(m)
+        m.tokenizer = tk
+        m.config = SimpleNamespace(vit_patch_size=16, encoder={"max_bs": 32})
+        m.head_config = {}
+        m.llm_model = base.llm_model
+        m.hidden_size = base.hidden_size
+        m.parallel_num, m.ps = 64, 8
+        m.vision_head_type = "diffusion_parallel_x"
+        m.vision_diffusion_head = base.vision_head
+        m.embed_vision_mlp = base.embed_vision_mlp
+        m.vision_encoder = base.ae
+        m.register_buffer("pos_embed_1d", m._get_1d_sincos_pos_embed(m.hidden_size // 2, 256), persistent=False)
+        m.eval()
+        captured, preds, ctx_len = {}, [], []
+        m.decode_image = lambda lat, image_size=None, ps=1: captured.setdefault("tokens", lat.clone())
+        orig_sample = base.vision_head.sample
+
+        def rec_sample(*a, **k):
+            o = orig_sample(*a, **k)
+            preds.append(o.detach().clone())
+            return o
+
+        base.vision_head.sample = rec_sample
+        orig_fwd = base.llm_model.model.forward
+
+        def rec_fwd(*a, **k):
+            ctx_len.append(int(k["inputs_embeds"].shape[1]))
+            return orig_fwd(*a, **k)
+
+        base.llm_model.model.forward = rec_fwd
+        g = torch.Generator().manual_seed(77)
+        img = torch.rand(1, 3, 128, 128, generator=g) * 2 - 1
+        text = "<|im_start|>user\nmake the fox red<|im_end|>\n<|im_start|>assistant\n"
+        plan = [{"type": "text", "from": "user"}, {"type": "image", "from": "user"}, {"type": "image", "from": "model"}]
+        ctx = rh.CudaAutocastOnCpu() if tag == "amp" else torch.no_grad()
+        with torch.no_grad(), ctx, rh.ReplayNoise(seed=21) as rn:
+            emb_img, lat_img = m.encode_image([img])
+            m.forward_inference_block_causal(plan, [text], [img], max_length_vision=256, sample_steps=4, image_size=[256, 256],
+                                             cfg_scale=4.0)
+        save(f"interleaved_{tag}", tokens=captured["tokens"], preds=torch.stack(preds), noise=torch.stack(rn.record), calls=rn.calls,
+             cfg=np.float32(4.0), n_steps=4, image=img, image_latents=lat_img, image_embeds=emb_img.float(),
+             prefill_lens=np.array(ctx_len[:4]))
+
+
 def gen_ae_c1():
     """BASELINE config 1: ae_d16c32 encode -> binary quantise -> decode of one 256x256 image on CPU (fp32), the
     reference VQModel at full size with seeded weights.  Stored small: the packed sign pattern of the 32x16x16 latent,
@@ -395,6 +460,8 @@ def main():
         return gen_imagenet()
     if len(sys.argv) > 1 and sys.argv[1] == "imagenet_variants":
         return gen_imagenet_variants()
+    if len(sys.argv) > 1 and sys.argv[1] == "interleaved":
+        return gen_interleaved()
     if len(sys.argv) > 1 and sys.argv[1] == "pipeline":
         return gen_pipeline()
     if len(sys.argv) > 1 and sys.argv[1] == "mllm":
@@ -411,6 +478,7 @@ def main():
     gen_imagenet()
     gen_imagenet_variants()
     gen_mllm_equiv()
+    gen_interleaved()
     gen_ae_c1()
 
 

@@ -3,7 +3,9 @@
 Restates /root/reference/modeling/t2i_pipeline.py:
   _get_1d_sincos_pos_embed :85-96     get_2d_embed :98-107
   gen_image                :157-272   decode_image (un-raster only) :274-283
-and /root/reference/modeling/utils.py MLPconnector :9-20.
+and /root/reference/modeling/utils.py MLPconnector :9-20, and the image-generating part of
+/root/reference/modeling/mllm.py ``forward_inference_block_causal`` :695-897 (interleaved text + image context,
+``encode_image`` :899-930, ``remove_first_user_block`` utils.py:206-216) on top of the same loop.
 
 Tokenisation is outside the arithmetic path: the loop takes token-id lists where the
 reference calls ``tokenizer.encode`` / ``convert_tokens_to_ids`` (:175-194).
@@ -64,16 +66,29 @@ def gen_tokens(llm_w: dict, llm_cfg: dict, head_w: dict, proj_w: dict, embed: to
     force_tokens: teacher forcing for tolerance tests -- [num_images, h*w, C] tokens fed back to the
                  LLM instead of the loop's own sign(pred) (the returned tokens are still the loop's own)
     """
+    tail = F.embedding(torch.tensor(list(start_ids) + list(query_ids)), embed)
+    ctx = [torch.cat([F.embedding(torch.tensor(list(ids)), embed), tail], dim=0) if ids is not None else None
+           for ids in (cond_ids, uncond_ids if guidance_scale > 1.0 else None)]
+    return gen_tokens_from_context(llm_w, llm_cfg, head_w, proj_w, ctx[0], ctx[1], h=h, w=w, parallel_num=parallel_num,
+                                   guidance_scale=guidance_scale, num_sampling_steps=num_sampling_steps, num_images=num_images,
+                                   noise=noise, pol=pol, max_patch=max_patch, trace=trace, force_tokens=force_tokens)
+
+
+def gen_tokens_from_context(llm_w: dict, llm_cfg: dict, head_w: dict, proj_w: dict, cond_ctx: torch.Tensor,
+                            uncond_ctx: torch.Tensor | None, *, h: int, w: int, parallel_num: int, guidance_scale: float,
+                            num_sampling_steps: int, num_images: int, noise, pol: Policy, max_patch: int = 256,
+                            trace: dict | None = None, force_tokens: torch.Tensor | None = None) -> torch.Tensor:
+    """The AR loop over an arbitrary context: ``cond_ctx`` / ``uncond_ctx`` [T, D] are the input EMBEDDINGS of everything
+    before the first patch, query tokens included (t2i_pipeline.py:195-236 with text ids; mllm.py:745-805 with an interleaved
+    text + image context).  Prefill = causal over ctx[:-P], all-visible over the last P; then :241-270 == mllm.py:806-864."""
     P = parallel_num
     ps = int(P ** 0.5)
-    D = embed.shape[1]
+    D = cond_ctx.shape[1]
     cfg_on = guidance_scale > 1.0
     noise = iter(noise)
     pos = pos_embed_2d(sincos_1d(D // 2, max_patch), h, w, ps).unsqueeze(0)          # fp32
-    tail = F.embedding(torch.tensor(list(start_ids) + list(query_ids)), embed)
 
-    def prefill(ids):
-        x = torch.cat([F.embedding(torch.tensor(list(ids)), embed), tail], dim=0)
+    def prefill(x):
         x = x.unsqueeze(0).repeat(num_images, 1, 1)
         _, cache = qwen3.model_forward(llm_w, llm_cfg, x[:, :-P], None, None, pol)
         past = cache[0][0].shape[2]
@@ -81,9 +96,9 @@ def gen_tokens(llm_w: dict, llm_cfg: dict, head_w: dict, proj_w: dict, embed: to
         hid, cache = qwen3.model_forward(llm_w, llm_cfg, x[:, -P:], cache, ones, pol)
         return hid[:, -P:], cache
 
-    hid_c, cache_c = prefill(cond_ids)
+    hid_c, cache_c = prefill(cond_ctx)
     if cfg_on:
-        hid_u, cache_u = prefill(uncond_ids)
+        hid_u, cache_u = prefill(uncond_ctx)
     out = []
     for step in range((h * w) // P):
         sl = slice(step * P, (step + 1) * P)
@@ -105,3 +120,66 @@ def gen_tokens(llm_w: dict, llm_cfg: dict, head_w: dict, proj_w: dict, embed: to
             hid_u, cache_u = qwen3.model_forward(llm_w, llm_cfg, x[num_images:], cache_u, ones[num_images:], pol)
             hid_u = hid_u[:, -P:]
     return torch.cat(out, dim=1)
+
+
+# ------------------------------------------------------------------------------------------------ interleaved context
+def remove_first_user_block(x: str) -> str:
+    """modeling/utils.py:206-216: the unconditional branch's text = the text without its first user turn."""
+    a, b = "<|im_start|>user\n", "<|im_end|>\n"
+    i = x.find(a)
+    if i == -1:
+        return x
+    j = x.find(b, i + len(a))
+    return x if j == -1 else x[:i] + x[j + len(b):]
+
+
+def image_latents_to_tokens(quant: torch.Tensor, ps: int) -> torch.Tensor:
+    """VQModel.vt_forward's re-ordering (vision_encoder/autoencoder.py:418-422): [C, h, w] -> '(h w p1 p2) c'."""
+    C, H, W = quant.shape
+    return quant.view(C, H // ps, ps, W // ps, ps).permute(1, 3, 2, 4, 0).reshape(H * W, C)
+
+
+def encode_image(proj_w: dict, latents: torch.Tensor, hw: tuple[int, int], D: int, ps: int, pol: Policy,
+                 max_patch: int = 256) -> torch.Tensor:
+    """MLLModel.encode_image (mllm.py:899-930) after the tokenizer: ``latents`` [h*w, C] binary tokens in patch order ->
+    embed_vision_mlp -> += get_2d_embed(h, w, ps) (an in-place add: the sum keeps the projector's dtype)."""
+    e = projector(proj_w, latents, pol)
+    pe = pos_embed_2d(sincos_1d(D // 2, max_patch), hw[0], hw[1], ps)
+    return (e.float() + pe).to(e.dtype)                   # `x += pos` on a bf16 x: fp32 sum, one rounding back to bf16
+
+
+def interleaved_context(embed: torch.Tensor, plan: list, texts: list, image_embeds: list, encode, *, start_of_image: int,
+                        end_of_image: int, res_ids: tuple[int, int], query_ids, cfg_on: bool):
+    """The context a model-generated IMAGE item sees in ``forward_inference_block_causal`` (mllm.py:719-745,865-895): per plan
+    item, user text -> token embeddings (uncond: the text minus its first user block); every image item -> the
+    [start_of_image, res_h, res_w] embeddings (res ids from the GENERATION size, :730-733); a user image -> its encode_image
+    embeddings + end_of_image; the generated image -> the query tokens.  Returns (cond [T, D], uncond [T', D] or None) up to
+    and including the first model-generated image's query tokens."""
+    E = lambda ids: F.embedding(torch.tensor(list(ids), dtype=torch.long), embed)
+    texts, image_embeds = list(texts), list(image_embeds)
+    c, u = [], []
+    for item in plan:
+        if item["type"] == "image":
+            s = E([start_of_image, *res_ids])
+            c.append(s)
+            u.append(s)
+        if item["from"] == "model":
+            if item["type"] != "image":
+                raise NotImplementedError("text generation")
+            q = E(query_ids)
+            c.append(q)
+            u.append(q)
+            break
+        if item["type"] == "text":
+            t = texts.pop(0)
+            c.append(E(encode(t)))
+            if cfg_on:
+                u.append(E(encode(remove_first_user_block(t))))
+        else:
+            e = image_embeds.pop(0)
+            end = E([end_of_image])
+            c += [e, end]
+            if cfg_on:
+                u += [e, end]
+    cat = lambda xs: torch.cat([x.to(xs[-1].dtype) if x.dtype != xs[-1].dtype else x for x in xs], dim=0)
+    return cat(c), (cat(u) if cfg_on else None)

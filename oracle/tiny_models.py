@@ -34,6 +34,7 @@ AE_D16C32 = dict(ddconfig=dict(double_z=False, z_channels=32, in_channels=3, out
                                num_res_blocks=4), gan_decoder=False)
 
 VISION_START, RES_BASE, QUERY_BASE = 300, 301, 430
+VISION_END, IM_START, IM_END = 495, 496, 497          # <|vision_end|>, <|im_start|>, <|im_end|> (data/data_utils.py:95-109)
 
 
 def llm_shapes(cfg: dict) -> dict:
@@ -173,6 +174,8 @@ class FakeTokenizer:
     def convert_tokens_to_ids(self, tok: str) -> int:
         if tok == "<|vision_start|>":
             return VISION_START
+        if tok in ("<|vision_end|>", "<|im_start|>", "<|im_end|>"):
+            return {"<|vision_end|>": VISION_END, "<|im_start|>": IM_START, "<|im_end|>": IM_END}[tok]
         if tok.startswith("<|res_"):
             return RES_BASE + int(tok[6:-2])
         if tok.startswith("<|query_"):

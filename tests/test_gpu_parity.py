@@ -311,6 +311,53 @@ def test_gen_image_teacher_forced_vs_reference(golden_dir):
         assert err[s_].mean() <= bound, (s_, err[s_].mean())
 
 
+@pytest.mark.parametrize("native_prefill", [True, False])
+def test_interleaved_edit_plan_vs_reference(golden_dir, native_prefill):
+    """MLLModel.forward_inference_block_causal (modeling/mllm.py:695-897) for an image-editing plan [user text, user image,
+    model image] on the native engine against the reference's golden (interleaved_amp): encode_image (:899-930: conv encoder ->
+    binary tokens in patch order -> native projector -> + 2-D pos embed) reproduces the reference's latents exactly and its
+    embeddings to bf16 noise; the generated image's pre-sign latents, teacher-forced with the reference's tokens, stay within the
+    text-to-image loop's bound; the plan validation mirrors what the reference can run; graph replay == eager."""
+    from bitdance_amd.mllm import MLLModel
+    g = load(golden_dir, "interleaved_amp")
+    m = MLLModel(tiny_pipeline(native_prefill=native_prefill))
+    img = g["image"]
+    with torch.autocast("cuda", dtype=torch.bfloat16):                       # the golden ran under (emulated) autocast: bf16 convs
+        emb, lat = m.encode_image([img.to(DEV)])
+    # sign of the conv encoder's output in patch order: exact on one device (tests/test_host_cpu.py, CPU vs the reference); MIOpen
+    # vs the CPU convolution flips the bits whose pre-sign value is ~0
+    same = lat.cpu() == g["image_latents"]
+    assert set(lat.unique().tolist()) <= {-1.0, 1.0} and same.float().mean().item() >= 0.97, same.float().mean()
+    rows = same.all(-1)                                                      # tokens with identical bits: same projector input
+    assert rows.float().mean().item() >= 0.3
+    assert (emb.float().cpu() - g["image_embeds"])[rows].abs().max().item() <= 0.06
+    text = "<|im_start|>user\nmake the fox red<|im_end|>\n<|im_start|>assistant\n"
+    plan = [{"type": "text", "from": "user"}, {"type": "image", "from": "user"}, {"type": "image", "from": "model"}]
+    n = int(g["n_steps"])
+    kw = dict(max_length_vision=256, sample_steps=n, image_size=[256, 256], cfg_scale=float(g["cfg"]),
+              noise=g["noise"].view(4, n + 1, 1, 64, 32), return_tokens=True)
+    tr = {}
+    out = m.forward_inference_block_causal(plan, [text], [img], force_tokens=g["tokens"], trace=tr, **kw)
+    assert out["generated_text"] == [] and out["generated_image"][0].shape == (1, 256, 32)
+    pred, ref = torch.stack(tr["pred"]).cpu(), g["preds"][:, :1]
+    err = (pred - ref).abs()
+    assert err.mean() <= 0.25, err.mean()                                      # the bound of the T2I / 16x loops (CFG amplifies x7)
+    firm = ref.abs() > 0.5
+    assert (torch.sign(pred)[firm] == torch.sign(ref)[firm]).float().mean() >= 0.95
+    if native_prefill:
+        m._p.use_graph = False
+        t_eager = m.forward_inference_block_causal(plan, [text], [img], **kw)["generated_image"][0].cpu()
+        m._p.use_graph = True
+        t_graph = m.forward_inference_block_causal(plan, [text], [img], **kw)["generated_image"][0].cpu()
+        assert torch.equal(t_eager, t_graph) and set(t_graph.unique().tolist()) <= {-1.0, 0.0, 1.0}
+        image = m.forward_inference_block_causal(plan, [text], [img], **dict(kw, return_tokens=False))["generated_image"][0]
+        assert image.shape == (1, 3, 256, 256) and torch.isfinite(image).all()
+        with pytest.raises(NotImplementedError):                               # the reference's text branch does not run either
+            m.forward_inference_block_causal([{"type": "text", "from": "user"}, {"type": "text", "from": "model"}], [text], [])
+        with pytest.raises(ValueError):
+            m.forward_inference_block_causal(plan, [text], [img], **dict(kw, max_length_vision=64))
+
+
 def test_gen_image_graph_equals_eager_and_decodes(golden_dir):
     """hipGraph replay == eager launches bit for bit; output image has the reference's shape/range."""
     g = load(golden_dir, "gen_amp")

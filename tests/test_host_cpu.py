@@ -274,3 +274,28 @@ def test_context_planning_imagenet_1x_and_4x_variants():
         l, c = _ctx({"B": 768, "branches": 1, "P": P, **tr})
         assert l.bd_ctx_finalize(c) == 0, (P, l.bd_last_error())
         l.bd_ctx_destroy(c)
+
+
+def test_mllm_vt_forward_and_plan_helpers(golden_dir):
+    """Host pieces of MLLModel.forward_inference_block_causal / encode_image (modeling/mllm.py:695-930) without a GPU: the
+    tokenizer pass of encode_image (VQModel.vt_forward: encode -> binary -> 'c (h p1) (w p2) -> (h w p1 p2) c', images grouped by
+    size, list order kept) reproduces the reference's latents of the interleaved golden exactly; remove_first_user_block
+    (utils.py:206-216) as the reference."""
+    from bitdance_amd.autoencoder import VQModel
+    from bitdance_amd.mllm import MLLModel
+    from oracle import tiny_models as tm
+    g = load(golden_dir, "interleaved_fp32")
+    ae = VQModel(**tm.TINY_AE).eval()
+    ae.load_state_dict(tm.seeded_state({k: tuple(v.shape) for k, v in ae.state_dict().items()}, seed=44, gain=1.4))
+    m = object.__new__(MLLModel)
+    m.device, m.vision_encoder, m.ps, m.vae_patch_size = "cpu", ae, 8, 16
+    lat = m.vt_forward([g["image"]], ps=8)
+    assert torch.equal(lat, g["image_latents"])
+    small = torch.flip(g["image"], dims=[-1])[..., :128, :128]
+    other = torch.nn.functional.interpolate(g["image"], size=(256, 128))
+    both = m.vt_forward([g["image"], other, small], ps=8)                     # two sizes, grouped; output in list order
+    assert both.shape == (64 + 128 + 64, 32) and torch.equal(both[:64], lat) and torch.equal(both[192:], m.vt_forward([small], ps=8))
+    r = MLLModel.remove_first_user_block
+    assert r("<|im_start|>user\nhi<|im_end|>\n<|im_start|>assistant\n") == "<|im_start|>assistant\n"
+    assert r("<|im_start|>user\nhi") == "<|im_start|>user\nhi" and r("plain") == "plain"
+    assert r("A<|im_start|>user\nx<|im_end|>\nB<|im_start|>user\ny<|im_end|>\n") == "AB<|im_start|>user\ny<|im_end|>\n"

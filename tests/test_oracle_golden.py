@@ -300,6 +300,77 @@ def test_gen_tokens_batch2_and_nocfg_fp32(golden_dir, name, n_img):
     torch.testing.assert_close(torch.stack(tr["pred"]), g["preds"][:, :n_img], atol=2e-4, rtol=1e-3)
 
 
+# ------------------------------------------------------------- interleaved text + image context
+_EDIT_TEXT = "<|im_start|>user\nmake the fox red<|im_end|>\n<|im_start|>assistant\n"
+_EDIT_PLAN = [{"type": "text", "from": "user"}, {"type": "image", "from": "user"}, {"type": "image", "from": "model"}]
+
+
+def _interleaved_ctx(g, pol, dtype):
+    from oracle import pipeline as op
+    proj = tm.seeded_state(tm.proj_shapes(32, 256), seed=33)
+    llm = {k: v.to(dtype) for k, v in tm.seeded_state(tm.llm_shapes(tm.TINY_LLM), seed=22).items()}
+    emb_img = op.encode_image(proj, g["image_latents"], (8, 8), 256, 8, pol)
+    tok = tm.FakeTokenizer()
+    c, u = op.interleaved_context(llm["model.embed_tokens.weight"], _EDIT_PLAN, [_EDIT_TEXT], [emb_img], tok.encode,
+                                  start_of_image=tm.VISION_START, end_of_image=tm.VISION_END,
+                                  res_ids=(tm.RES_BASE + 16, tm.RES_BASE + 16), query_ids=[tm.QUERY_BASE + i for i in range(1, 64)],
+                                  cfg_on=True)
+    return llm, proj, emb_img, c, u
+
+
+def test_interleaved_context_and_encode_image(golden_dir):
+    """mllm.py:899-930 (encode_image after the tokenizer) and the context assembly of forward_inference_block_causal
+    (:719-745,865-895) for an editing plan [user text, user image, generated image]: the image embeddings equal the reference's,
+    and the four prefill calls the reference made (cond causal / cond last block / uncond causal / uncond last block) have exactly
+    the lengths of the assembled contexts -- the unconditional one is the text without its first user block."""
+    from oracle import pipeline as op
+    g = load(golden_dir, "interleaved_fp32")
+    llm, proj, emb_img, c, u = _interleaved_ctx(g, Policy("fp32"), torch.float32)
+    torch.testing.assert_close(emb_img, g["image_embeds"], atol=1e-5, rtol=1e-5)
+    assert [c.shape[0] - 64, 64, u.shape[0] - 64, 64] == g["prefill_lens"].tolist()
+    assert op.remove_first_user_block(_EDIT_TEXT) == "<|im_start|>assistant\n" and op.remove_first_user_block("abc") == "abc"
+    q = torch.arange(2 * 16 * 8, dtype=torch.float32).view(2, 16, 8)
+    t = op.image_latents_to_tokens(q, 8)                                  # 'c (h p1) (w p2) -> (h w p1 p2) c'
+    assert t.shape == (128, 2) and t[0].tolist() == [0.0, 128.0] and t[1].tolist() == [1.0, 129.0] and t[8].tolist() == [8.0, 136.0] \
+        and t[64].tolist() == [64.0, 192.0]
+    ga = load(golden_dir, "interleaved_amp")
+    _, _, emb_a, _, _ = _interleaved_ctx(ga, Policy("autocast"), torch.bfloat16)
+    assert emb_a.dtype == torch.bfloat16 and (emb_a.float() - ga["image_embeds"]).abs().max().item() <= 0.04
+
+
+def test_interleaved_image_generation_fp32(golden_dir):
+    """The image-generating part of MLLModel.forward_inference_block_causal (mllm.py:745-864) on that context in fp32: every
+    token of the generated image equals the reference's, RNG draws = AR steps x (1 + N)."""
+    from oracle import pipeline as op
+    g = load(golden_dir, "interleaved_fp32")
+    llm, proj, _, c, u = _interleaved_ctx(g, Policy("fp32"), torch.float32)
+    head = tm.seeded_state(tm.head_shapes(tm.TINY_HEAD), seed=11)
+    assert int(g["calls"]) == 4 * (int(g["n_steps"]) + 1)
+    tr = {}
+    out = op.gen_tokens_from_context(llm, tm.TINY_LLM, head, proj, c, u, h=16, w=16, parallel_num=64, guidance_scale=float(g["cfg"]),
+                                     num_sampling_steps=int(g["n_steps"]), num_images=1, noise=list(g["noise"]), pol=Policy("fp32"),
+                                     trace=tr)
+    assert torch.equal(out, g["tokens"])
+    torch.testing.assert_close(torch.stack(tr["pred"]), g["preds"][:, :1], atol=2e-4, rtol=1e-3)
+
+
+def test_interleaved_image_generation_amp_teacher_forced(golden_dir):
+    """The same under the emulated bf16 autocast with the reference's tokens fed back: per-step latents within the bound of the
+    text-to-image loop (CFG-amplified bf16 noise)."""
+    from oracle import pipeline as op
+    g = load(golden_dir, "interleaved_amp")
+    llm, proj, _, c, u = _interleaved_ctx(g, Policy("autocast"), torch.bfloat16)
+    head = tm.seeded_state(tm.head_shapes(tm.TINY_HEAD), seed=11)
+    tr = {}
+    op.gen_tokens_from_context(llm, tm.TINY_LLM, head, proj, c, u, h=16, w=16, parallel_num=64, guidance_scale=float(g["cfg"]),
+                               num_sampling_steps=int(g["n_steps"]), num_images=1, noise=list(g["noise"]), pol=Policy("autocast"),
+                               trace=tr, force_tokens=g["tokens"])
+    pred, ref = torch.stack(tr["pred"]), g["preds"][:, :1]
+    assert (pred - ref).abs().mean() <= 0.25, (pred - ref).abs().mean()     # the bound of the 16x / T2I loops (CFG amplifies x7)
+    firm = ref.abs() > 0.5
+    assert (torch.sign(pred)[firm] == torch.sign(ref)[firm]).float().mean() >= 0.95
+
+
 def test_mllm_gen_image_is_the_same_loop(golden_dir):
     """modeling/mllm.py:386-501 (MLLModel.gen_image_block_causal) on the same components, prompt and injected noise
     produced exactly the tokens of t2i_pipeline.gen_image (golden gen_fp32) with the same number of RNG draws, so one
