@@ -5,7 +5,7 @@ the ``cpu_baseline`` leg of bench.py (which times the oracle side as the bounded
 to the throughput line).  Nothing under bitdance_amd/ imports this.
 
 The tiny-model goldens pin the *algorithm*; what they cannot show is that the kernel instantiations picked at
-BitDance-14B dimensions -- the 10-wave adaLN tile, 640-thread row kernels, 40-head attention, GQA group 5 with 56 q/k/v
+BitDance-14B dimensions -- the 9-wave ragged adaLN tile, 640-thread row kernels, 40-head attention, GQA group 5 with 56 q/k/v
 slots -- compute the same thing.  Each case here builds a model slice at true width with seeded random weights
 (values bf16-representable, so the CPU oracle and the device see identical parameters), runs
 
