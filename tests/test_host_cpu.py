@@ -299,3 +299,31 @@ def test_mllm_vt_forward_and_plan_helpers(golden_dir):
     assert r("<|im_start|>user\nhi<|im_end|>\n<|im_start|>assistant\n") == "<|im_start|>assistant\n"
     assert r("<|im_start|>user\nhi") == "<|im_start|>user\nhi" and r("plain") == "plain"
     assert r("A<|im_start|>user\nx<|im_end|>\nB<|im_start|>user\ny<|im_end|>\n") == "AB<|im_start|>user\ny<|im_end|>\n"
+
+
+def test_launch_plan_rules_measured_in_round_2():
+    """Host-only pins of the launch rules the round-2 sweeps decided (profiles/r02_gemm_sweep3.log, r02_bench_imagenet_*):
+    ragged 9-wave tiles for the adaLN projection only (gate/up keeps 8 waves: the 5-wave and 5x2 forms measured slower and stay
+    options), the slab cap from 8 row tiles up (ImageNet B-4x: one slice everywhere) but not at 3 row tiles (B-1x keeps 6 / 18)."""
+    l, c = _ctx(DIMS_14B)
+    assert l.bd_ctx_finalize(c) == 0, l.bd_last_error()
+    assert _cfg(l, c, "head.ada") == (1, 9, 1) and _cfg(l, c, "llm.gu") == (1, 8, 1) and _cfg(l, c, "llm.down")[0] == 9
+    l.bd_ctx_destroy(c)
+    l, c = _ctx({**DIMS_14B, "tune.ragged": 0})
+    assert l.bd_ctx_finalize(c) == 0 and _cfg(l, c, "head.ada") == (1, 10, 1)
+    l.bd_ctx_destroy(c)
+    l, c = _ctx({**DIMS_14B, "tune.ragged52": 1})
+    assert l.bd_ctx_finalize(c) == 0 and _cfg(l, c, "llm.gu") == (1, 10, 2)
+    l.bd_ctx_destroy(c)
+    head_b = {"head.D": 768, "head.C": 32, "head.Dz": 768, "head.nblocks": 6, "head.nada": 2, "head.dh": 64, "head.sigmoid": 0}
+    l, c = _ctx({"B": 384, "branches": 2, "P": 4, "head.H": 2048, **head_b})           # B-4x: 3072 rows = 12 row tiles
+    assert l.bd_ctx_finalize(c) == 0, l.bd_last_error()
+    assert all(_cfg(l, c, "head." + n)[0] == 1 for n in ("qkv", "wo", "w1", "w2", "ada"))
+    l.bd_ctx_destroy(c)
+    l, c = _ctx({"B": 384, "branches": 2, "P": 4, "head.H": 2048, "tune.slab_cap": 0, **head_b})
+    assert l.bd_ctx_finalize(c) == 0 and _cfg(l, c, "head.w2")[0] > 1
+    l.bd_ctx_destroy(c)
+    l, c = _ctx({"B": 384, "branches": 2, "P": 1, "head.variant": 1, "head.H": 1152, **head_b})   # B-1x: 768 rows = 3 row tiles
+    assert l.bd_ctx_finalize(c) == 0, l.bd_last_error()
+    assert _cfg(l, c, "head.w1")[0] == 6 and _cfg(l, c, "head.w2")[0] == 18
+    l.bd_ctx_destroy(c)
