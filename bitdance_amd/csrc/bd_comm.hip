@@ -222,7 +222,15 @@ bd_comm* bd_comm_create(int rank, int size, long long max_elems) {
     c->rank = rank; c->size = size;
     c->max_elems = (max_elems + 7) / 8 * 8 + 8 * BD_TP_MAX;     // slices are ceil(units / size): up to one 8-element unit of slack per rank
     const size_t dbytes = (size_t)c->max_elems * 6, fbytes = (size_t)(2 * BD_TP_MAX * BD_TP_GMAX + 1 + BD_TP_GMAX) * sizeof(int);
-    if (hipMalloc((void**)&c->data, dbytes) != hipSuccess) { delete c; bdk_set_error("bd_comm_create: hipMalloc failed"); return nullptr; }
+    // staging / result buffer: written by the PEERS over xGMI and read here inside the same kernel.  Ordinary (coarse-grained)
+    // device memory is cached in this GPU's L2 as device-coherent only -- a line kept from the previous exchange could be
+    // served instead of what a peer has pushed since (the one-GPU tests cannot show this: all "ranks" share one L2).  Uncached
+    // (fine-grained) memory is the coherence contract RCCL's own exchange buffers rely on; the same allocation kind as the flag
+    // block below, whose IPC export is covered by the two-process test.  Plain hipMalloc only if the runtime refuses the flag.
+    if (hipExtMallocWithFlags((void**)&c->data, dbytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipMalloc((void**)&c->data, dbytes) != hipSuccess) { delete c; bdk_set_error("bd_comm_create: hipMalloc failed"); return nullptr; }
+    }
     // flags: uncached (fine-grained) so a peer's write is seen by the polling loads; plain device memory + system-scope
     // atomics if this runtime refuses the flag
     if (hipExtMallocWithFlags((void**)&c->flags, fbytes, hipDeviceMallocUncached) != hipSuccess) {
