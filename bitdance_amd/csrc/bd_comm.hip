@@ -227,10 +227,14 @@ bd_comm* bd_comm_create(int rank, int size, long long max_elems) {
     // served instead of what a peer has pushed since (the one-GPU tests cannot show this: all "ranks" share one L2).  Uncached
     // (fine-grained) memory is the coherence contract RCCL's own exchange buffers rely on; the same allocation kind as the flag
     // block below, whose IPC export is covered by the two-process test.  Plain hipMalloc only if the runtime refuses the flag.
-    if (hipExtMallocWithFlags((void**)&c->data, dbytes, hipDeviceMallocUncached) != hipSuccess) {
+    bool uncached = hipExtMallocWithFlags((void**)&c->data, dbytes, hipDeviceMallocUncached) == hipSuccess;
+    if (uncached) {                                              // it has to be exportable: probe now, while falling back is still possible
+        hipIpcMemHandle_t probe;
+        if (hipIpcGetMemHandle(&probe, c->data) != hipSuccess) { (void)hipGetLastError(); hipFree(c->data); c->data = nullptr; uncached = false; }
+    } else {
         (void)hipGetLastError();
-        if (hipMalloc((void**)&c->data, dbytes) != hipSuccess) { delete c; bdk_set_error("bd_comm_create: hipMalloc failed"); return nullptr; }
     }
+    if (!uncached && hipMalloc((void**)&c->data, dbytes) != hipSuccess) { delete c; bdk_set_error("bd_comm_create: hipMalloc failed"); return nullptr; }
     // flags: uncached (fine-grained) so a peer's write is seen by the polling loads; plain device memory + system-scope
     // atomics if this runtime refuses the flag
     if (hipExtMallocWithFlags((void**)&c->flags, fbytes, hipDeviceMallocUncached) != hipSuccess) {
