@@ -12,7 +12,8 @@ loop serves both surfaces; this class carries the attribute names code written a
 can run: any user text / user image items followed by ONE model-generated image (text-to-image, image editing, multi-image
 conditioning).  Its text-generation branch does not run in the reference (the first decode step indexes ``past_key_values``
 while it is still None, :796-800; later steps would feed 2-D embeddings), so a plan that asks the model for text raises
-``NotImplementedError`` here too.  ``encode_image`` (:899-930) = the tokenizer's conv encoder (MIOpen) -> binary tokens in patch
+``NotImplementedError`` here too; the token sampler that branch would call (``sample_codebook`` / ``top_k_top_p_filtering``,
+modeling/utils.py:64-124) is provided and pinned against the reference's outputs all the same.  ``encode_image`` (:899-930) = the tokenizer's conv encoder (MIOpen) -> binary tokens in patch
 order -> the native projector -> + 2-D position embedding.
 
 Out of scope (training): ``forward`` / losses; ``gen_image_full_causal`` (parallel_num == 1 T2I models) -- ``NotImplementedError``.
@@ -117,6 +118,38 @@ class MLLModel:
             return x
         j = x.find(b, i + len(a))
         return x if j == -1 else x[:i] + x[j + len(b):]
+
+    @staticmethod
+    def top_k_top_p_filtering(logits: torch.Tensor, top_k: int = 0, top_p: float = 1.0, filter_value: float = -float("inf"),
+                              min_tokens_to_keep: int = 1) -> torch.Tensor:
+        """modeling/utils.py:64-91, vectorised over rows: keep the logits >= the k-th largest, then the shortest descending
+        prefix whose softmax mass exceeds ``top_p`` (crossing token included); everything else becomes ``filter_value``."""
+        V = logits.size(-1)
+        if top_k > 0:
+            kth = torch.topk(logits, min(max(top_k, min_tokens_to_keep), V), dim=-1).values[..., -1:]
+            logits = logits.masked_fill(logits < kth, filter_value)
+        if top_p < 1.0:
+            vals, order = torch.sort(logits, descending=True, dim=-1)
+            cum = torch.cumsum(torch.softmax(vals, dim=-1), dim=-1)
+            gone = torch.zeros_like(vals, dtype=torch.bool)
+            gone[..., 1:] = cum[..., :-1] > top_p                        # the reference's shift-right of (cum > top_p)
+            if min_tokens_to_keep > 1:
+                gone[..., : min_tokens_to_keep + 1] = False               # cleared before the shift there: one more survives
+            logits = logits.masked_fill(torch.zeros_like(gone).scatter(-1, order, gone), filter_value)
+        return logits
+
+    @staticmethod
+    def sample_codebook(pred_logits, cur_item_type, codebook, do_sample: bool = True, temperature: float = 1.0, top_k: int = 0,
+                        top_p: float = 1.0):
+        """modeling/utils.py:94-124: temperature, top-k / top-p, softmax, multinomial (or argmax) -> (tokens, codebook(tokens)).
+        Host-side plumbing (one row per sequence over the vocabulary); the reference reaches it only from the text / standard-head
+        branches of its interleaved loops."""
+        logits = pred_logits / max(temperature, 1e-5)
+        if top_k > 0 or top_p < 1.0:
+            logits = MLLModel.top_k_top_p_filtering(logits, top_k=top_k, top_p=top_p)
+        probs = torch.softmax(logits, dim=-1)
+        tokens = torch.multinomial(probs, num_samples=1).squeeze(-1) if do_sample else torch.argmax(probs, dim=-1)
+        return tokens, codebook(tokens)
 
     def _tok_id(self, name: str) -> int:
         t = self.tokenizer

@@ -310,6 +310,29 @@ def gen_interleaved():
              prefill_lens=np.array(ctx_len[:4]))
 
 
+def gen_text_sampling():
+    """modeling/utils.py:64-124 (top_k_top_p_filtering, sample_codebook): the token sampler of the reference's text / standard
+    vision-head branches.  Deterministic pieces recorded exactly; the multinomial draw under a fixed CPU seed."""
+    from modeling.utils import sample_codebook, top_k_top_p_filtering
+    g = torch.Generator().manual_seed(9)
+    logits = torch.randn(4, 97, generator=g) * 3.0
+    logits[1, 5] = logits[1, 6]                                   # a tie at the top-k threshold
+    logits[2] = logits[2].sort(descending=True)[0]
+    book = torch.nn.Embedding(97, 8)
+    with torch.no_grad():
+        book.weight.copy_(torch.randn(97, 8, generator=g))
+    out = {}
+    for name, kw in (("k5", dict(top_k=5)), ("p90", dict(top_p=0.9)), ("k20p50", dict(top_k=20, top_p=0.5)),
+                     ("p10keep3", dict(top_p=0.1, min_tokens_to_keep=3)), ("k500", dict(top_k=500))):
+        out["filt_" + name] = top_k_top_p_filtering(logits.clone(), **kw)
+    with torch.no_grad():
+        tok_g, emb_g = sample_codebook(logits.clone(), "text", book, do_sample=False, temperature=0.7, top_k=10, top_p=0.8)
+        torch.manual_seed(5)
+        tok_s, emb_s = sample_codebook(logits.clone(), "text", book, do_sample=True, temperature=1.3, top_k=12, top_p=0.95)
+    save("text_sampling", logits=logits, book=book.weight.detach(), greedy_tokens=tok_g, greedy_embeds=emb_g, sampled_tokens=tok_s,
+         sampled_embeds=emb_s, **out)
+
+
 def gen_ae_c1():
     """BASELINE config 1: ae_d16c32 encode -> binary quantise -> decode of one 256x256 image on CPU (fp32), the
     reference VQModel at full size with seeded weights.  Stored small: the packed sign pattern of the 32x16x16 latent,
@@ -460,6 +483,8 @@ def main():
         return gen_imagenet()
     if len(sys.argv) > 1 and sys.argv[1] == "imagenet_variants":
         return gen_imagenet_variants()
+    if len(sys.argv) > 1 and sys.argv[1] == "text_sampling":
+        return gen_text_sampling()
     if len(sys.argv) > 1 and sys.argv[1] == "interleaved":
         return gen_interleaved()
     if len(sys.argv) > 1 and sys.argv[1] == "pipeline":
@@ -479,6 +504,7 @@ def main():
     gen_imagenet_variants()
     gen_mllm_equiv()
     gen_interleaved()
+    gen_text_sampling()
     gen_ae_c1()
 
 

@@ -183,3 +183,43 @@ def interleaved_context(embed: torch.Tensor, plan: list, texts: list, image_embe
                 u += [e, end]
     cat = lambda xs: torch.cat([x.to(xs[-1].dtype) if x.dtype != xs[-1].dtype else x for x in xs], dim=0)
     return cat(c), (cat(u) if cfg_on else None)
+
+
+# ------------------------------------------------------------------------------------------------ token sampler
+def filter_logits(logits: torch.Tensor, top_k: int = 0, top_p: float = 1.0, min_tokens_to_keep: int = 1) -> torch.Tensor:
+    """modeling/utils.py:64-91 (top_k_top_p_filtering) as set arithmetic, row by row with numpy-style loops (small cases):
+    top-k keeps every logit >= the k-th largest (ties survive); top-p then keeps, in descending order, the shortest prefix
+    whose softmax mass exceeds top_p (the crossing token included, at least ``min_tokens_to_keep``).  Removed entries = -inf."""
+    out = logits.clone().to(F32)
+    V = out.shape[-1]
+    for r in range(out.shape[0]):
+        row = out[r]
+        if top_k > 0:
+            k = min(max(top_k, min_tokens_to_keep), V)
+            kth = torch.sort(row, descending=True)[0][k - 1]
+            row[row < kth] = float("-inf")
+        if top_p < 1.0:
+            vals, idx = torch.sort(row, descending=True)
+            cum = torch.cumsum(torch.softmax(vals, dim=-1), dim=-1)
+            drop = [False] * V
+            for j in range(1, V):                                  # token j goes when the mass BEFORE it already exceeds top_p
+                drop[j] = bool(cum[j - 1] > top_p)
+            if min_tokens_to_keep > 1:
+                for j in range(min(min_tokens_to_keep, V)):
+                    drop[j] = False
+                # the reference clears positions [0, min_keep) BEFORE shifting by one: position min_keep is then also kept
+                if min_tokens_to_keep < V:
+                    drop[min_tokens_to_keep] = False
+            for j in range(V):
+                if drop[j]:
+                    row[idx[j]] = float("-inf")
+    return out
+
+
+def sample_codebook_greedy(pred_logits: torch.Tensor, codebook: torch.Tensor, temperature: float, top_k: int, top_p: float):
+    """modeling/utils.py:94-124 with do_sample=False: argmax of softmax(filtered logits / max(T, 1e-5)) and its embedding."""
+    lg = pred_logits / max(temperature, 1e-5)
+    if top_k > 0 or top_p < 1.0:
+        lg = filter_logits(lg, top_k, top_p)
+    tok = torch.argmax(torch.softmax(lg, dim=-1), dim=-1)
+    return tok, codebook[tok]

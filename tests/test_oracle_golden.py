@@ -371,6 +371,30 @@ def test_interleaved_image_generation_amp_teacher_forced(golden_dir):
     assert (torch.sign(pred)[firm] == torch.sign(ref)[firm]).float().mean() >= 0.95
 
 
+def test_text_sampler_helpers(golden_dir):
+    """modeling/utils.py:64-124 (top_k_top_p_filtering / sample_codebook): the oracle's row-by-row restatement and the product's
+    vectorised one (bitdance_amd.mllm, plain torch: runs on CPU here) against the reference's outputs -- filtered logits exact
+    for top-k (incl. a tie at the threshold and k > vocabulary), top-p, both, min_tokens_to_keep; greedy tokens and embeddings;
+    the multinomial draw under the same CPU seed."""
+    from bitdance_amd.mllm import MLLModel
+    from oracle import pipeline as op
+    g = load(golden_dir, "text_sampling")
+    cases = {"k5": dict(top_k=5), "p90": dict(top_p=0.9), "k20p50": dict(top_k=20, top_p=0.5),
+             "p10keep3": dict(top_p=0.1, min_tokens_to_keep=3), "k500": dict(top_k=500)}
+    for name, kw in cases.items():
+        want = g["filt_" + name]
+        assert torch.equal(op.filter_logits(g["logits"], **kw), want), name
+        assert torch.equal(MLLModel.top_k_top_p_filtering(g["logits"].clone(), **kw), want), name
+    tok, emb = op.sample_codebook_greedy(g["logits"], g["book"], 0.7, 10, 0.8)
+    assert torch.equal(tok, g["greedy_tokens"]) and torch.equal(emb, g["greedy_embeds"])
+    book = lambda t: g["book"][t]
+    tok, emb = MLLModel.sample_codebook(g["logits"].clone(), "text", book, do_sample=False, temperature=0.7, top_k=10, top_p=0.8)
+    assert torch.equal(tok, g["greedy_tokens"]) and torch.equal(emb, g["greedy_embeds"])
+    torch.manual_seed(5)
+    tok, emb = MLLModel.sample_codebook(g["logits"].clone(), "text", book, do_sample=True, temperature=1.3, top_k=12, top_p=0.95)
+    assert torch.equal(tok, g["sampled_tokens"]) and torch.equal(emb, g["sampled_embeds"])
+
+
 def test_mllm_gen_image_is_the_same_loop(golden_dir):
     """modeling/mllm.py:386-501 (MLLModel.gen_image_block_causal) on the same components, prompt and injected noise
     produced exactly the tokens of t2i_pipeline.gen_image (golden gen_fp32) with the same number of RNG draws, so one
