@@ -106,6 +106,7 @@ def get_args(argv=None):
     p.add_argument("--seed", type=int, default=99)
     p.add_argument("--sample-steps", type=int, default=100)
     p.add_argument("--no-ema", action="store_true")
+    p.add_argument("--mixed-precision", type=str, default="bf16", choices=["none", "bf16"])
     p.add_argument("--to-npz", action="store_true")
     p.add_argument("--chunk-size", type=int, default=0)
     return p.parse_args(argv)
@@ -139,6 +140,8 @@ def main(argv=None) -> int:
     args = get_args(argv)
     if not torch.cuda.is_available():
         raise RuntimeError("the native sampler needs a GPU (HIP engine); there is no CPU fallback")
+    if args.mixed_precision != "bf16":
+        raise NotImplementedError("the native engine implements the bf16 autocast flow (--mixed-precision bf16)")
     dist.init_process_group("nccl")
     rank, world = dist.get_rank(), dist.get_world_size()
     device = rank % torch.cuda.device_count()
@@ -157,8 +160,11 @@ def main(argv=None) -> int:
     from PIL import Image
     t0 = time.time()
     for it, (start, labels, keep) in enumerate(rank_plan(args.num_fid_samples, args.num_classes, args.per_proc_batch_size, world, rank)):
-        imgs = model.sample(torch.from_numpy(labels).long().to(device), sample_steps=args.sample_steps,
-                            cfg_scale=args.cfg_scale, chunk_size=args.chunk_size)
+        # the reference samples under autocast(precision) (:157-163): here that governs the torch parts only (first step, VAE
+        # decode); the native engine always computes in the bf16 flow, so --mixed-precision none is refused
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            imgs = model.sample(torch.from_numpy(labels).long().to(device), sample_steps=args.sample_steps,
+                                cfg_scale=args.cfg_scale, chunk_size=args.chunk_size)
         for b, im in enumerate(to_uint8(imgs)[:keep]):
             Image.fromarray(im).save(f"{out_dir}/{start + b:06d}.png")
         if rank == 0 and it % 10 == 0:
