@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the BitDance generation hot path on N MI355X (BASELINE.json metric: images/sec @1024px BitDance-14B-64x).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 from a plain interpreter: bench.py starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 A "step" is one whole pass of the hot path: one ``gen_image`` call (prefill, 64 AR steps x [51 diffusion-head
@@ -65,6 +65,10 @@ def parse():
     ap.add_argument("--workload", default=None, choices=list(WORKLOADS))
     ap.add_argument("--size", default=None, choices=["14b-64x", "tiny"], help="(old spelling of --workload)")
     ap.add_argument("--parallel", default="tp", choices=["tp", "replicas"], help="N > 1: tensor parallel (one job) or replicas")
+    ap.add_argument("--tp-comm", default=None, choices=["ipc", "rccl"],
+                    help="tensor parallel: the per-Linear exchange as the hand-written xGMI push kernel (ipc, default) or ncclAllReduce (rccl) -- "
+                         "one lease can A/B them; default: BD_TP_COMM or ipc (falls back to rccl by itself when IPC / uncached memory / the "
+                         "self-test fails)")
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--num-images", type=int, default=None, help="images per gen_image call (imagenet: classes per sample call, default 384)")
@@ -180,6 +184,29 @@ def cpu_baseline_imagenet(n_eval: int, ar_steps: int) -> dict:
 
 
 # ---------------------------------------------------------------------------------------------------------
+def spawn_ranks(args) -> int:
+    """``python bench.py --gpus N`` from a plain interpreter: start the N ranks ourselves (one process per GPU, the launch shape
+    of the reference's multi-GPU scripts, scripts/eval/eval_bitdance_14b_64x.sh:4-16, and of the driver's own
+    ``python -m torch.distributed.run --nproc-per-node N`` line) and hand the job to them; rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and os.environ.get("BD_BENCH_BACKEND", "nccl") == "nccl":
+        print(f"[bench] --gpus {args.gpus} but only {n_dev} device(s) visible (RCCL needs one device per rank; "
+              f"BD_BENCH_BACKEND=gloo runs several ranks on one GPU as a functional check)", file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what hipIpcGetMemHandle needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    print(f"[bench] launching {args.gpus} ranks: {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def setup_dist():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -204,11 +231,15 @@ def setup_dist():
     return dist, world, rank, f"cuda:{local}"
 
 
-def tokens_agree(dist, tokens: torch.Tensor, dev) -> bool:
-    """Tensor parallel: the replicated state must be bit-identical on every rank -- compare two checksums of the tokens."""
+def token_checksum(tokens: torch.Tensor) -> torch.Tensor:
+    """Two position-weighted sums of the (+-1) tokens in float64: exact, so equal tokens <=> equal checksums in practice."""
     t = tokens.double()
     w = torch.arange(1, t.numel() + 1, device=t.device, dtype=torch.float64)
-    mine = torch.stack([t.sum(), (t.flatten() * w).sum()])
+    return torch.stack([t.sum(), (t.flatten() * w).sum()])
+
+
+def checksums_agree(dist, mine: torch.Tensor) -> bool:
+    """Tensor parallel: the replicated state must be bit-identical on every rank -- compare the checksums of every image."""
     if dist.get_backend() == "gloo":
         mine = mine.cpu()
     allv = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
@@ -216,8 +247,14 @@ def tokens_agree(dist, tokens: torch.Tensor, dev) -> bool:
     return all(torch.equal(v, allv[0]) for v in allv)
 
 
+def tokens_agree(dist, tokens: torch.Tensor, dev) -> bool:
+    return checksums_agree(dist, token_checksum(tokens))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # plain `python bench.py --gpus N`: become the launcher
+        sys.exit(spawn_ranks(args))
     dist, world, rank, dev = setup_dist()
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
@@ -252,7 +289,7 @@ def main():
     if tp_mode:
         from bitdance_amd.tp import TPComm
         rows_max = 2 * num_images * 64
-        comm = TPComm.from_process_group(max(rows_max, 128) * 5120, device=dev)
+        comm = TPComm.from_process_group(max(rows_max, 128) * 5120, device=dev, backend=args.tp_comm)
     pipe = syn.build_pipeline(size, dev, with_ae=True, tp=comm, weights=args.weights)
     if args.weights == "fp8":
         metric += " (fp8-e4m3 weights)"
@@ -304,15 +341,17 @@ def main():
         else:
             one_pass(i)
     barrier()
+    sums = []
     t0 = time.perf_counter()
     for i in range(args.steps):
         img = one_pass(args.warmup + i)
+        if tp_mode:                                            # every image's tokens, not only the first warm-up's (a few tiny
+            sums.append(token_checksum(next(iter(pipe._engines.values())).tok_all))   # device ops; compared after the clock stops)
     barrier()
     dt = time.perf_counter() - t0
     assert torch.isfinite(img).all()
     if tp_mode:
-        eng = next(iter(pipe._engines.values()))
-        assert tokens_agree(dist, eng.tok_all, dev), "tensor-parallel ranks diverged in the timed region"
+        assert checksums_agree(dist, torch.stack(sums)), "tensor-parallel ranks diverged in the timed region"
     dt = max_over_ranks(dt, dist, "cpu" if (dist is not None and dist.get_backend() == "gloo") else dev)
 
     if rank == 0:
@@ -337,7 +376,12 @@ def main():
             wbytes = sum(t.numel() * t.element_size() for w_ in (pipe.head_w, pipe.llm_w, pipe.proj_w) for t in w_.ptrs.values())
             nblk, L = pipe.head_w.nblocks, pipe.llm_w.cfg["num_hidden_layers"]
             n_x = ar_steps * (n_sampling + 1) * 2 * nblk + (ar_steps - 1) * 2 * L
-            out["tp"] = {"size": n, "exchange_backend": comm.backend, "weight_bytes_per_rank": int(wbytes),
+            info = comm.info()
+            out["tp"] = {"size": n, "world_size_seen": dist.get_world_size(), "process_group_backend": dist.get_backend(),
+                         "exchange_backend": comm.backend, "exchange_buffer_uncached": info["data_uncached"],
+                         "flag_block_uncached": info["flags_uncached"], "fallback_reason": getattr(comm, "fallback_reason", None),
+                         "images_checked_bit_identical": args.steps + (1 if args.warmup else 0),
+                         "weight_bytes_per_rank": int(wbytes),
                          "exchanges_per_image": n_x, "exchange_payload_bytes_per_rank": int(eng.M * 5120 * 6 * (n - 1) / n),
                          "ranks_bit_identical": True}
         if not args.no_roofline:

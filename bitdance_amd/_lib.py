@@ -78,6 +78,7 @@ _PROTOS = {
     "bd_comm_reset": (C.c_int, [C.c_void_p]),
     "bd_comm_error": (C.c_int, [C.c_void_p]),
     "bd_comm_exchanges": (C.c_longlong, [C.c_void_p]),
+    "bd_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
     "bd_comm_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                   C.POINTER(C.c_int), C.c_void_p]),
     "bd_comm_copy_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]),

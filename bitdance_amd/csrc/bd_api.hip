@@ -1,6 +1,7 @@
 // C ABI + native orchestration of the BitDance AR step (see include/bitdance_hip.h).
 // Everything here is host code: it sequences the kernels of bd_gemm/bd_rows/bd_attn on the caller's stream and
 // captures the two phases of an AR step into hipGraphs.  No allocation, no sync inside the step.
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -60,6 +61,10 @@ struct bd_ctx {
     bool wfp8 = false;                    // "wdtype" = 1: every streamed weight is fp8-e4m3 + "<key>_s" scales (bd_gemm8.hip)
     int tp = 1, tpr = 0;
     int hDl = 0, hHl = 0, lnhl = 0, lnkvl = 0, lFl = 0;
+    // "tune.ada_group": evaluations whose adaLN projections run as ONE GEMM (head_ada_group); 1 = one GEMM per evaluation
+    int adaG = 1;
+    // "tune.pf_blocks" / "tune.pf_kb": run-ahead weight prefetch by spare workgroups of the row kernels (PfDesc, bd_kernels.h)
+    int pf_blocks = 0, pf_bytes = 0;
 
     const GemmCfg& cfg(const char* name) const {
         auto it = g.find(name);
@@ -172,7 +177,8 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
 static const char* const kIntKeys[] = {
     "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid", "head.y_evals", "head.variant",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
-    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async", "tune.ragged", "tune.ragged52", "tune.slab_cap"};
+    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async", "tune.ragged", "tune.ragged52", "tune.slab_cap",
+    "tune.ada_group", "tune.pf_blocks", "tune.pf_kb"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
                                          "llm.qkv", "llm.o", "llm.gu", "llm.down"};
 static bool known_int_key(const std::string& k) {
@@ -390,12 +396,26 @@ int bd_ctx_finalize(bd_ctx* c) {
             c->g["head.w1"] = choose_cfg(c, "head.w1", 2 * c->hHl, c->hD, true);
             c->g["head.w2"] = choose_cfg(c, "head.w2", c->hD, c->hHl, false, tp > 1);
             const int sbr = std::max(c->cfg("head.wo").S, c->cfg("head.w2").S);
+            // The adaLN projection of evaluation i depends on (t_i, cond) only, not on the latent: the projections of G
+            // consecutive evaluations are ONE GEMM over G * Mpad rows (the 256-row kernel: weights streamed once per G
+            // evaluations instead of once per evaluation -- 21 % of the head's weight bytes; every row's K sum runs in the same
+            // order through the same MFMA, so the result is bit-identical to G separate launches).  Default: 512 rows.
+            {
+                long long g = c->geti("tune.ada_group", -1);
+                if (g < 0) g = (!c->wfp8 && Mp <= 128 && c->hNada % 256 == 0 && c->geti("tune.ada_async", 0) == 0) ? 512 / Mp : 1;
+                if (g < 1 || g > 16 || (g > 1 && ((c->RB * g) % 8 != 0 || c->hNada % 256 != 0 || c->wfp8 || c->geti("tune.ada_async", 0) != 0)))
+                    return fail("tune.ada_group: 1..16 evaluations, rows a multiple of 256, adaLN width a multiple of 256, bf16 weights, no ada_async");
+                c->adaG = (int)g;
+            }
+            c->pf_blocks = (int)c->geti("tune.pf_blocks", 128);
+            c->pf_bytes = (int)c->geti("tune.pf_kb", 16) * 1024;
+            if (c->pf_blocks < 0 || c->pf_blocks % 8 || c->pf_bytes < 0 || c->pf_bytes % 1024) return fail("tune.pf_blocks: a multiple of 8; tune.pf_kb: KiB per weight stream");
             add("head.cond_frag", Mp * c->hDz * 2);
             add("head.cond_part", (long long)c->cfg("head.cond").S * Mp * c->hD * 4);
             add("head.xt", (long long)c->BP * c->hC * 4);
             add("head.y_frag", Mp * c->hD * 2);
             add("head.X", Mp * c->hD * 2);
-            add("head.ada_bf", Mp * c->hNada * 2 * (c->geti("tune.ada_async", 0) ? 2 : 1));
+            add("head.ada_bf", Mp * c->hNada * 2 * (c->geti("tune.ada_async", 0) ? 2 : c->adaG));
             add("head.cemb", Mp * c->hD * 2);
             add("head.h_frag", Mp * c->hD * 2);
             add("head.qkv_part", (long long)c->cfg("head.qkv").S * Mp * 3 * c->hDl * 4);
@@ -568,8 +588,9 @@ static int head_cond(bd_ctx* c, hipStream_t st) {   // cond_embed(c) is constant
     // head.y_all [head.y_evals][Mpad][D] when it fits; otherwise every evaluation computes its own y)
     c->y_ready = false;
     const int n_evals = (int)c->sched.size();
-    if (n_evals > 0 && c->optr("head.y_all") && c->geti("head.y_evals", 0) >= n_evals) {
-        HeadYAllArgs ya{c->ptr("head.cemb"), c->ptr("head.temb"), c->wptr("head.y_all"), c->M, c->hD, c->RB, c->Mpad, n_evals};
+    const int G = c->adaG;
+    if (n_evals > 0 && c->optr("head.y_all") && c->geti("head.y_evals", 0) >= (n_evals + G - 1) / G * G) {
+        HeadYAllArgs ya{c->ptr("head.cemb"), c->ptr("head.temb"), c->wptr("head.y_all"), c->M, c->hD, c->RB, c->Mpad, n_evals, G};
         BD_TRY(bdk_head_y_all(ya, st));
         c->y_ready = true;
     }
@@ -580,7 +601,7 @@ static int head_cond(bd_ctx* c, hipStream_t st) {   // cond_embed(c) is constant
 static int head_ada(bd_ctx* c, int i, int buf, bool light, hipStream_t st) {
     const int D = c->hD, RB = c->RB;
     const void* y = c->ptr("head.y_frag");
-    if (c->y_ready) {                                          // every y_i of this AR step was produced with cond_embed (head_cond)
+    if (c->y_ready && c->adaG == 1) {                          // every y_i of this AR step was produced with cond_embed (head_cond)
         y = (const bf16_t*)c->ptr("head.y_all") + (size_t)i * c->Mpad * D;
     } else {
         HeadPrologueArgs pa;
@@ -597,6 +618,37 @@ static int head_ada(bd_ctx* c, int i, int buf, bool light, hipStream_t st) {
     BD_TRY(gemm(c, "head.ada", y, RB, wref(c, "head.ada_w"), c->hNada, D, 1, ga.code() + (light ? 8192 : 0), BD_EPI_BF16,
                 nullptr, out, c->ptr("head.ada_b"), st));
     return 0;
+}
+
+// The adaLN projections of evaluations g * G .. g * G + G - 1 as one GEMM over G * Mpad rows (head.y_all holds the operand in
+// that layout, head_cond); evaluation i then reads rows (i % G) * Mpad .. of head.ada_bf.
+static int head_ada_group(bd_ctx* c, int g, hipStream_t st) {
+    const int G = c->adaG, D = c->hD;
+    const bf16_t* y = (const bf16_t*)c->ptr("head.y_all") + (size_t)g * G * c->Mpad * D;
+    char name[32];
+    std::snprintf(name, sizeof(name), "head.ada[x%d]", G);      // profiling: G evaluations' worth of rows per weight pass
+    BD_TRY(gemm(c, name, y, c->RB * G, wref(c, "head.ada_w"), c->hNada, D, 1, /*8 waves, ring 2: the 256-row kernel*/ 8 + 16 * 2,
+                BD_EPI_BF16, nullptr, c->wptr("head.ada_bf"), c->ptr("head.ada_b"), st));
+    return 0;
+}
+
+// Prefetch descriptor for the GEMM `g` (N x K, packed weights W) that FOLLOWS a row kernel: bd_kernels.h PfDesc
+static PfDesc make_pf(const bd_ctx* c, const GemmCfg& g, WRef W, int N, int K) {
+    PfDesc d;
+    if (c->pf_blocks <= 0 || c->pf_bytes <= 0 || c->Mpad % 256 == 0 || bdk_get_w_layout() != 0) return d;   // 128-row passes, panel-major weights
+    const int esz = W.s ? 1 : 2, kw = g.kw, np = g.nw / g.kw;
+    const int nst_total = K / (64 * kw), q = (nst_total + g.S - 1) / g.S;
+    const int last = nst_total - (g.S - 1) * q;                     // stages of the last (shortest) slice
+    const long long stage = (long long)2048 * esz * kw;             // bytes of one (64 * kw)-deep stage of one panel
+    d.W = W.w;
+    d.panel_bytes = (long long)K * 32 * esz;
+    d.slice_bytes = q * stage;
+    d.npan = N / 32; d.NP = np; d.S = g.S;
+    d.nwg = ((d.npan + np - 1) / np) * g.S;
+    d.bytes = (int)std::min<long long>(c->pf_bytes, last * stage);
+    d.nblk = c->pf_blocks;
+    if (d.bytes < 16) d.W = nullptr;
+    return d;
 }
 
 // `ada_buf` < 0: compute y and the adaLN projection here, in line (the plain path); >= 0: they were produced ahead of time
@@ -640,10 +692,12 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0
         LnModArgs l2 = l1;
         if (!mlp) {
             l1.ln_w = (const float*)c->ptr(pre + "ln1_w"); l1.ln_b = (const float*)c->ptr(pre + "ln1_b");
+            l1.pf = make_pf(c, gq, wref(c, pre + "wqkv"), 3 * Dl, D);
             BD_TRY(bdk_ln_mod(l1, st));
             HeadAttnArgs at;
             BD_TRY(linear(c, "head.qkv", c->ptr("head.h_frag"), RB, wref(c, pre + "wqkv"), 3 * Dl, D, gq, "head.qkv_part", "head.qkv_bf",
                           c->ptr(pre + "bqkv"), Mp, &at.qkv, st));
+            at.pf = make_pf(c, go, wref(c, pre + "wo"), D, Dl);
             at.o_frag = c->wptr("head.attn_frag"); at.nseq = M / c->Pn; at.dh = (int)c->geti("head.dh", 128); at.nhead = Dl / at.dh; at.D = Dl; at.RB = RB; at.P = c->Pn;
             BD_TRY(bdk_head_attn(at, st));
             BD_TRY(linear_rowsplit(c, "head.wo", c->ptr("head.attn_frag"), RB, wref(c, pre + "wo"), D, Dl, go, "head.br_part", "head.br_bf",
@@ -653,6 +707,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0
         // MLP head (diff_head.py:133-137): the block IS the second half -- h = norm(x) * (1 + scale) + shift with the block's
         // (scale, shift) = chunks 0, 1 and the previous block's gated w2 output still pending, exactly l1's offsets above
         l2.ln_w = (const float*)c->ptr(pre + "ln2_w"); l2.ln_b = (const float*)c->ptr(pre + "ln2_b");
+        l2.pf = make_pf(c, g1, wref(c, pre + "w1"), 2 * Hl, D);
         BD_TRY(bdk_ln_mod(l2, st));
         // Linear -> chunk(2) -> silu(h1)*h2.  Fused epilogue (on the last-arriving K-slice when split) writes the next
         // operand: 46.9 + 22.9 us (w1 + w2) against 40.8 + 9.5 + 26.0 us for slabs + swiglu_rows on the same MI355X
@@ -717,7 +772,15 @@ static int head_sample(bd_ctx* c, hipStream_t st) {
     BD_TRY(bdk_init_latent(ia, st));
     BD_TRY(head_cond(c, st));
     if (!c->ada_async || c->prof_on) {
-        for (int i = 0; i <= n_steps; ++i) BD_TRY(head_eval(c, i, st, -1, /*x0_ready=*/i > 0, /*chain_next=*/true));
+        const int G = c->adaG;
+        for (int i = 0; i <= n_steps; ++i) {
+            if (G > 1 && c->y_ready) {
+                if (i % G == 0) BD_TRY(head_ada_group(c, i / G, st));
+                BD_TRY(head_eval(c, i, st, i % G, /*x0_ready=*/i > 0, /*chain_next=*/true));
+            } else {
+                BD_TRY(head_eval(c, i, st, -1, /*x0_ready=*/i > 0, /*chain_next=*/true));
+            }
+        }
         return 0;
     }
     // fork: the side stream produces y / adaLN(i) into half i & 1 as soon as evaluation i-2 has released it; the chain of

@@ -51,6 +51,10 @@ BD_DEV void p_to_afrags(const float* p, int lane, u32x4& a_lo, u32x4& a_hi) {
 __global__ __launch_bounds__(256) void head_attn_kernel(HeadAttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * KSTR];
     __shared__ __attribute__((aligned(16))) bf16_t Vs[128 * VSTR];
+    if ((int)blockIdx.x >= a.nseq * a.nhead) {               // spare workgroups: pull wo's first weight stages into L2 (PfDesc)
+        bd_prefetch_run(a.pf, blockIdx.x - a.nseq * a.nhead, 256);
+        return;
+    }
     const int seq = blockIdx.x / a.nhead, h = blockIdx.x % a.nhead;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = a.D;
@@ -342,7 +346,10 @@ __global__ __launch_bounds__(256) void head_attn16_mfma_kernel(HeadAttnArgs a) {
 
 int bdk_head_attn(const HeadAttnArgs& a, hipStream_t st) {
     if (a.dh != 128 && !(a.dh == 64 && a.P <= 16)) return -2;
-    if (a.P == 64) BD_LAUNCH(head_attn_kernel, dim3(a.nseq * a.nhead), dim3(256), 0, st, a);
+    if (a.P == 64) {
+        const int nb = a.nseq * a.nhead, extra = (a.pf.W && nb % 8 == 0) ? a.pf.nblk : 0;
+        BD_LAUNCH(head_attn_kernel, dim3(nb + extra), dim3(256), 0, st, a);
+    }
     else if (a.P == 16 && a.qkv.S == 0 && a.qkv.N % 8 == 0) {       // finished bf16 qkv: matrix-pipe scores, 4 heads per workgroup
         const int blocks = (a.nseq * a.nhead + 3) / 4;
         if (a.dh == 64) BD_LAUNCH(head_attn16_mfma_kernel<64>, dim3(blocks), dim3(256), 0, st, a);
@@ -535,7 +542,8 @@ int bdk_in_attn(const InAttnArgs& a, hipStream_t st) {
     {   // matrix-pipe form: whole 16-token blocks, score rows that fit the per-wave LDS budget
         const int LS = ((a.Lmax + 64 + 63) & ~63) + 8;             // row stride in bf16: multiple of 8 (16 B reads), off the bank period
         const size_t lds_m = (size_t)4 * (16 * LS + 64 * 64) * sizeof(bf16_t);
-        static const bool ok = hipFuncSetAttribute((const void*)in_attn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        static unsigned long long optin_m = 0;
+        const bool ok = bd_lds_optin((const void*)in_attn_mfma_kernel, 160 * 1024, &optin_m);
         if (a.P == 16 && ok && lds_m <= 160 * 1024) {
             BD_LAUNCH(in_attn_mfma_kernel, dim3((a.nseq * a.nh + 3) / 4), dim3(256), lds_m, st, a, LS);
             return bd_launch_status();
@@ -544,11 +552,8 @@ int bdk_in_attn(const InAttnArgs& a, hipStream_t st) {
     const int Lcap = a.Lmax + 64;
     const size_t lds = (size_t)(16 * 64 + 64 * 65 + 16 * (Lcap + 1)) * sizeof(float);
     if (lds > 160 * 1024) return -3;
-    static bool once = false;
-    if (!once) {
-        if (hipFuncSetAttribute((const void*)in_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -8;
-        once = true;
-    }
+    static unsigned long long optin = 0;
+    if (!bd_lds_optin((const void*)in_attn_kernel, 160 * 1024, &optin)) return -8;
     BD_LAUNCH(in_attn_kernel, dim3(a.nseq * a.nh), dim3(256), lds, st, a);
     return bd_launch_status();
 }

@@ -41,6 +41,8 @@ struct bd_comm {
     char* data = nullptr;                    // local: staging fp32 [max_elems] | result bf16 [max_elems]
     int* flags = nullptr;                    // local: A [tp][GMAX] | B [tp][GMAX] | err | epoch [GMAX]
     bool own = false;
+    bool data_uncached = false, flags_uncached = false;   // allocation kinds actually obtained (bd_comm_info): the cross-GPU
+                                                          // coherence argument of the hand-written exchange needs both
     char* peer_data[BD_TP_MAX] = {};
     int* peer_flags[BD_TP_MAX] = {};
     bool ipc_open[BD_TP_MAX] = {};
@@ -76,24 +78,36 @@ BD_DEV void tp_signal(const ArArgs& a, int base, int b, int e) {
         __hip_atomic_store(a.peer_flags[t] + base + a.rank * BD_TP_GMAX + b, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
-BD_DEV void tp_wait(const ArArgs& a, int base, int b, int e, int err_index) {
+// returns false (block-uniform) when the exchange is dead: a wait of THIS rank ran out of its budget now or earlier, or a
+// peer reported that one of its waits did (the error word travels: a rank that times out ORs its bit into every peer's error
+// word as well, so all ranks stop pushing and all of them raise at the next host check instead of one raising while the
+// others return a silently corrupted image)
+BD_DEV bool tp_wait(const ArArgs& a, int base, int b, int e, int err_index) {
+    __shared__ int alive_sh;
     const int t = threadIdx.x;
+    if (t == 0) alive_sh = 1;
+    __syncthreads();
     if (t < a.size && t != a.rank) {
         const int* f = a.flags + base + t * BD_TP_GMAX + b;
         const long long t0 = wall_clock64();
-        // once any wait of this rank has timed out the exchange is dead: later waits return at once (the host raises after
-        // the next sync) instead of spending the budget 44 000 times
-        const bool dead = __hip_atomic_load(a.flags + err_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+        bool dead = __hip_atomic_load(a.flags + err_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
         while (!dead && (int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
             __builtin_amdgcn_s_sleep(8);
             if (wall_clock64() - t0 > a.timeout_ticks) {
                 __hip_atomic_fetch_or(a.flags + err_index, 1 << t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                for (int p = 0; p < a.size; ++p)             // tell everyone: bit 8 + rank = "rank r gave up"
+                    if (p != a.rank)
+                        __hip_atomic_fetch_or(a.peer_flags[p] + err_index, 1 << (8 + a.rank), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                dead = true;
                 break;
             }
+            dead = __hip_atomic_load(a.flags + err_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
         }
+        if (dead) alive_sh = 0;
         __threadfence_system();
     }
     __syncthreads();
+    return alive_sh != 0;
 }
 
 // 16 B system-scope (sc0 sc1) accesses through buffer instructions: the compiler tracks their vmcnt like any other load, and
@@ -125,7 +139,9 @@ __global__ __launch_bounds__(256) void tp_allreduce_kernel(ArArgs a) {
         }
     }
     tp_signal(a, FA, b, e);
-    tp_wait(a, FA, b, e, ERR);
+    // a dead exchange pushes nothing further: the staged copies may be stale, and a result written now would be consumed by
+    // peers whose own waits still succeed (the host check after the next sync raises on every rank)
+    if (!tp_wait(a, FA, b, e, ERR)) { if (tid == 0) a.flags[EP + b] = e; return; }
     // ---- phase 2: reduce my slice in rank order, bias, one rounding to bf16, push the rows to every rank
     const __amdgpu_buffer_rsrc_t stage = sys_rsrc(a.peer_data[a.rank], a.data_bytes);
     for (int u = c0 + tid; u < c1; u += 256) {
@@ -168,7 +184,7 @@ __global__ __launch_bounds__(256) void tp_allreduce_kernel(ArArgs a) {
             __builtin_amdgcn_raw_buffer_store_b128(o, sys_rsrc(a.peer_data[q], a.data_bytes), ooff, 0, BD_SYS_AUX);
     }
     tp_signal(a, FB, b, e);
-    tp_wait(a, FB, b, e, ERR);
+    (void)tp_wait(a, FB, b, e, ERR);
     if (tid == 0) a.flags[EP + b] = e;
 }
 
@@ -221,6 +237,8 @@ bd_comm* bd_comm_create(int rank, int size, long long max_elems) {
     bd_comm* c = new bd_comm();
     c->rank = rank; c->size = size;
     c->max_elems = (max_elems + 7) / 8 * 8 + 8 * BD_TP_MAX;     // slices are ceil(units / size): up to one 8-element unit of slack per rank
+    // the kernel addresses an allocation through ONE buffer resource: 32-bit size and offsets
+    if (c->max_elems * 6 >= (1LL << 31)) { delete c; bdk_set_error("bd_comm_create: capacity too large (rows * N * 6 must stay below 2^31 bytes)"); return nullptr; }
     const size_t dbytes = (size_t)c->max_elems * 6, fbytes = (size_t)(2 * BD_TP_MAX * BD_TP_GMAX + 1 + BD_TP_GMAX) * sizeof(int);
     // staging / result buffer: written by the PEERS over xGMI and read here inside the same kernel.  Ordinary (coarse-grained)
     // device memory is cached in this GPU's L2 as device-coherent only -- a line kept from the previous exchange could be
@@ -235,9 +253,13 @@ bd_comm* bd_comm_create(int rank, int size, long long max_elems) {
         (void)hipGetLastError();
     }
     if (!uncached && hipMalloc((void**)&c->data, dbytes) != hipSuccess) { delete c; bdk_set_error("bd_comm_create: hipMalloc failed"); return nullptr; }
+    c->data_uncached = uncached;                                 // reported by bd_comm_info: the host routes cross-device exchanges
+                                                                 // through RCCL when this is false (tp.py)
     // flags: uncached (fine-grained) so a peer's write is seen by the polling loads; plain device memory + system-scope
     // atomics if this runtime refuses the flag
+    c->flags_uncached = true;
     if (hipExtMallocWithFlags((void**)&c->flags, fbytes, hipDeviceMallocUncached) != hipSuccess) {
+        c->flags_uncached = false;
         (void)hipGetLastError();
         if (hipMalloc((void**)&c->flags, fbytes) != hipSuccess) { hipFree(c->data); delete c; bdk_set_error("bd_comm_create: flag allocation failed"); return nullptr; }
     }
@@ -304,8 +326,16 @@ int bd_comm_reset(bd_comm* c) {
     return 0;
 }
 long long bd_comm_exchanges(bd_comm* c) { return c->n_exchanges; }
+/* out[0] = exchange buffer is uncached (fine-grained) device memory, out[1] = flag block is, out[2] = mode (0 hand-written
+ * exchange, 1 ncclAllReduce), out[3] = capacity in elements */
+int bd_comm_info(bd_comm* c, long long* out4) {
+    if (!c || !out4) return cfail("bd_comm_info: null");
+    out4[0] = c->data_uncached; out4[1] = c->flags_uncached; out4[2] = c->mode; out4[3] = c->max_elems;
+    return 0;
+}
 
-/* host-side check after a stream sync: bit p set = the wait for peer p ran out of its time budget */
+/* host-side check after a stream sync: bit p set = this rank's wait for peer p ran out of its time budget; bit 8 + r set =
+ * rank r reported that one of ITS waits did (every rank then raises together) */
 int bd_comm_error(bd_comm* c) {
     int e = 0;
     if (hipMemcpy(&e, c->flags + 2 * BD_TP_MAX * BD_TP_GMAX, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;

@@ -61,6 +61,30 @@ BD_DEV float block_sum(float v, float* red) {
     return t;
 }
 
+// Body of a prefetch workgroup (PfDesc, bd_kernels.h): j = its index among the `nblk` extra workgroups of the launch, `first` =
+// blockIdx of extra workgroup 0 (a multiple of 8, so that j % 8 is this workgroup's XCD).  Plain (cache-allocating) 16 B loads
+// whose results are never used: inline asm so that the compiler neither drops them nor waits for them one by one.
+template <class PF>
+BD_DEV void bd_prefetch_run(const PF& d, int j, int nthreads) {
+    const int per = d.nblk >> 3;                                   // prefetch workgroups per XCD
+    const int upp = d.bytes >> 4;                                  // 16 B units per stream
+    const int units = d.NP * upp;
+    const char* const W = reinterpret_cast<const char*>(d.W);
+    for (int b = (j & 7) + 8 * (j >> 3); b < d.nwg; b += 8 * per) {
+        const int s = b % d.S, nt = b / d.S;
+        for (int u = threadIdx.x; u < units; u += nthreads) {
+            const int pn = u / upp, o = u - pn * upp;
+            const int panel = nt * d.NP + pn;
+            if (panel < d.npan) {
+                const char* src = W + (size_t)panel * d.panel_bytes + (size_t)s * d.slice_bytes + (size_t)o * 16;
+                u32x4 sink;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sink) : "v"(src) : "memory");
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // Device-resident state of the autoregressive loop, read by every step-dependent kernel so that
 // one captured hipGraph can be replayed for every AR step.
 struct BdStepState {

@@ -286,12 +286,11 @@ static int launch_gemm_wide_v(const GemmP& p, int epi, hipStream_t st) {
     const int ntiles = p.N / 256;
     dim3 grid(ntiles * p.S * (p.RB / 8));
     const size_t lds = (size_t)3 * 8 * 256 * 16;
-    static const bool lds_ok = [] {                            // 96 KiB of dynamic LDS needs the opt-in
-        const int n = 3 * 8 * 256 * 16;
-        return hipFuncSetAttribute((const void*)gemm_wide_kernel<BD_EPI_PARTIAL, WR, XCD>, hipFuncAttributeMaxDynamicSharedMemorySize, n) == hipSuccess &&
-               hipFuncSetAttribute((const void*)gemm_wide_kernel<BD_EPI_BF16, WR, XCD>, hipFuncAttributeMaxDynamicSharedMemorySize, n) == hipSuccess &&
-               hipFuncSetAttribute((const void*)gemm_wide_kernel<BD_EPI_SWIGLU, WR, XCD>, hipFuncAttributeMaxDynamicSharedMemorySize, n) == hipSuccess;
-    }();
+    static unsigned long long optin[3] = {0, 0, 0};
+    const int n = 3 * 8 * 256 * 16;                                // 96 KiB of dynamic LDS needs the opt-in, per device
+    const bool lds_ok = bd_lds_optin((const void*)gemm_wide_kernel<BD_EPI_PARTIAL, WR, XCD>, n, &optin[0]) &&
+                        bd_lds_optin((const void*)gemm_wide_kernel<BD_EPI_BF16, WR, XCD>, n, &optin[1]) &&
+                        bd_lds_optin((const void*)gemm_wide_kernel<BD_EPI_SWIGLU, WR, XCD>, n, &optin[2]);
     if (!lds_ok) return -8;
     if (epi == BD_EPI_PARTIAL) BD_LAUNCH((gemm_wide_kernel<BD_EPI_PARTIAL, WR, XCD>), grid, dim3(256), lds, st, p);
     else if (epi == BD_EPI_BF16) BD_LAUNCH((gemm_wide_kernel<BD_EPI_BF16, WR, XCD>), grid, dim3(256), lds, st, p);

@@ -387,13 +387,19 @@ template <int NP, int KW, int MB, int EPI, int R, bool RED, int MODE = 0, int WT
 static int launch_one(const GemmP& p, hipStream_t st) {
     const int ntiles = (p.N / 32 + NP - 1) / NP;          // the last tile may be ragged
     dim3 grid(ntiles * p.S, p.RB / MB);
+    if constexpr (RED) {
+        // the in-launch reduction indexes its slab regions by (row tile, N tile, panel wave): with a ragged last tile that runs
+        // past the S * Mpad * N * 4 scratch (out-of-range buffer accesses are dropped silently -> wrong sums), and the tickets
+        // live in a fixed block of 16384 counters
+        if ((p.N / 32) % NP != 0) return -9;
+        if ((long long)(p.RB / MB) * ntiles > 16384) return -9;
+    }
     // two A-stage buffers; with KW > 1 the same LDS is re-used for the accumulators of K parts 1..KW-1
     constexpr size_t lds_a = (size_t)2 * MB * 256 * KW * 16, lds_r = (size_t)(KW - 1) * NP * MB * 4096;
     constexpr size_t lds = lds_a > lds_r ? lds_a : lds_r;
     if constexpr (lds > 64 * 1024) {                               // beyond 64 KiB of dynamic LDS needs the opt-in
-        static const bool ok = hipFuncSetAttribute((const void*)gemm_kernel<NP, KW, MB, EPI, R, RED, MODE, WT>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-        if (!ok) return -8;
+        static unsigned long long optin = 0;                      // per device (bd_kernels.h)
+        if (!bd_lds_optin((const void*)gemm_kernel<NP, KW, MB, EPI, R, RED, MODE, WT>, (int)lds, &optin)) return -8;
     }
     BD_LAUNCH((gemm_kernel<NP, KW, MB, EPI, R, RED, MODE, WT>), grid, dim3(NP * KW * 64), lds, st, p);
     return bd_launch_status();

@@ -8,12 +8,41 @@
 #define BD_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 static inline int bd_launch_status() { return hipGetLastError() == hipSuccess ? 0 : -1; }
 
+// Opt a kernel in to more than 64 KiB of dynamic LDS.  The attribute is PER DEVICE: a process that drives a second GPU later
+// (replicas in one process, tests that move between devices) must set it there too, so the "done" state is a bit per device id
+// in `*done_mask` (one static word per call site / kernel instantiation), not a process-wide once-flag.
+static inline bool bd_lds_optin(const void* fn, int bytes, unsigned long long* done_mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    const unsigned long long bit = 1ull << dev;
+    if (__atomic_load_n(done_mask, __ATOMIC_RELAXED) & bit) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+    __atomic_fetch_or(done_mask, bit, __ATOMIC_RELAXED);
+    return true;
+}
+
 #define BD_EPI_PARTIAL 0
 #define BD_EPI_SWIGLU 1
 #define BD_EPI_BF16 2       // out bf16 row-major [Mpad][N] = bf16(acc + bias); split-K > 1: reduced inside the launch
 #define BD_EPI_F32 3        // out fp32 row-major [Mpad][N] = the finished K sum, no bias / rounding (a tensor-parallel rank's partial)
 
 struct BdStepState;
+
+// Run-ahead weight prefetch.  The step is a dependent chain GEMM -> row kernel -> GEMM ...: while a row kernel runs (80-128
+// workgroups, a few MB of traffic, ~5-8 us) HBM idles, and the GEMM behind it then pays its pipeline ramp from a cold start.
+// A row kernel therefore carries `nblk` EXTRA workgroups that do nothing but pull the first `bytes` of every weight stream of
+// the NEXT GEMM -- stream = (GEMM workgroup, 32-column panel): one contiguous run of the packed weights -- into the L2 of the
+// XCD that GEMM workgroup will run on (workgroup b of a launch lands on XCD b % 8: a placement that is observed, not promised,
+// and used for speed only; a miss costs nothing but the saving).  Weights are data independent, so this needs no
+// synchronisation at all.  W == nullptr: nothing to prefetch.
+struct PfDesc {
+    const void* W = nullptr;    // packed weights of the next GEMM
+    long long panel_bytes = 0;  // bytes between consecutive 32-column panels
+    long long slice_bytes = 0;  // bytes between the starts of consecutive K slices inside a panel
+    int npan = 0, NP = 1, S = 1, nwg = 0;   // panels, panels per GEMM workgroup, K slices, GEMM workgroups (tiles * S)
+    int bytes = 0;              // per stream
+    int nblk = 0;               // extra workgroups (multiple of 8)
+};
 
 // ---- bd_gemm.hip
 // wscale != nullptr: W holds fp8-e4m3 weights (bdk_pack_w8) with per-packed-row fp32 scales
@@ -63,6 +92,7 @@ struct LnModArgs {          // x (+= pending branch * gate) ; h = LN(x)*(1+scale
     void* h_frag;           // out: fragment-major bf16
     int M, D, RB;
     float eps;
+    PfDesc pf;              // run-ahead prefetch of the next GEMM's weights by extra workgroups (W == nullptr: none)
 };
 int bdk_ln_mod(const LnModArgs& a, hipStream_t st);
 
@@ -101,8 +131,10 @@ int bdk_head_final(const HeadFinalArgs& a, hipStream_t st);
 struct HeadYAllArgs {       // y_i = silu(time_embed(t_i) + cond_embed(c)) for EVERY evaluation of the schedule at once: depends on
     const void* cemb;       // (t_i, cond) only (flow_head:328-330), so it is computed once per AR step, not once per evaluation
     const void* temb;       // [n_evals][D] bf16
-    void* y_all;            // out: [n_evals] fragment-major bf16 [Mpad][D]
+    void* y_all;            // out: [ceil(n_evals / G)] fragment-major bf16 matrices of G * Mpad rows: evaluation i = rows
+                            //      (i % G) * Mpad .. of matrix i / G -- the A operand of ONE adaLN GEMM over G evaluations
     int M, D, RB, Mpad, n_evals;
+    int G = 1;              // evaluations per adaLN GEMM (1: one [Mpad][D] matrix per evaluation)
 };
 int bdk_head_y_all(const HeadYAllArgs& a, hipStream_t st);
 
@@ -236,6 +268,7 @@ struct HeadAttnArgs {       // DiT attention over one patch (seq = P = 64 or 16)
     void* o_frag;           // out fragment-major bf16 [Mpad][D]
     int nseq, nhead, D, RB, P;
     int dh;                 // head dim: 128, or 64 with P = 16 (imagenet head)
+    PfDesc pf;              // run-ahead prefetch of wo's weights (P = 64 kernel only)
 };
 int bdk_head_attn(const HeadAttnArgs& a, hipStream_t st);
 

@@ -210,6 +210,7 @@ BD_DEV void modulate8(const float* x, float mean, float rstd, const float* lw, c
 
 __global__ void ln_mod_kernel(LnModArgs a) {
     __shared__ float red[32];
+    if ((int)blockIdx.x >= a.M) { bd_prefetch_run(a.pf, blockIdx.x - a.M, blockDim.x); return; }   // spare workgroups: PfDesc
     const int m = blockIdx.x, d0 = threadIdx.x * 8;
     const bool active = d0 < a.D;
     const bf16_t* ada = (const bf16_t*)a.ada + (size_t)m * a.ada_ld;
@@ -252,7 +253,8 @@ __global__ void ln_mod_kernel(LnModArgs a) {
 int bdk_ln_mod(const LnModArgs& a, hipStream_t st) {
     const int t = row_threads(a.D);
     if (t < 0 || a.D % 8) return -2;
-    BD_LAUNCH(ln_mod_kernel, dim3(a.M), dim3(t), 0, st, a);
+    const int extra = (a.pf.W && a.M % 8 == 0) ? a.pf.nblk : 0;
+    BD_LAUNCH(ln_mod_kernel, dim3(a.M + extra), dim3(t), 0, st, a);
     return bd_launch_status();
 }
 
@@ -280,7 +282,8 @@ __global__ void head_y_all_kernel(HeadYAllArgs a) {
     ld_bf16x8((const bf16_t*)a.temb + (size_t)i * a.D + d0, te);
 #pragma unroll
     for (int j = 0; j < 8; ++j) y[j] = silu_f(bfr(te[j] + ce[j]));               // bf16 + bf16 -> bf16 ; silu -> bf16 (rounded by pack8)
-    *reinterpret_cast<u32x4*>((bf16_t*)a.y_all + (size_t)i * a.Mpad * a.D + afrag_off(m, d0, a.RB)) = pack8(y);
+    *reinterpret_cast<u32x4*>((bf16_t*)a.y_all + (size_t)(i / a.G) * a.G * a.Mpad * a.D +
+                              afrag_off(m + (i % a.G) * a.Mpad, d0, a.RB * a.G)) = pack8(y);
 }
 int bdk_head_y_all(const HeadYAllArgs& a, hipStream_t st) {
     const int t = row_threads(a.D);

@@ -246,8 +246,9 @@ class ProjWeights:
 
 @dataclass
 class LlmWeights:
-    """HF Qwen3 checkpoint (``model.layers.*``) packed for the native decode step; the original bf16
-    tensors are kept for the (once-per-image) prefill, which runs on hipBLASLt/SDPA."""
+    """HF Qwen3 checkpoint (``model.layers.*``) packed for the native step kernels, which run both the decode step and the
+    once-per-image prefill (llm.prefill_native).  With ``keep_for_prefill=True`` the original-layout bf16 tensors are kept
+    as well, only for the torch cross-check path (llm.prefill_block, ``native_prefill=False``)."""
     cfg: dict
     ptrs: dict = field(default_factory=dict)
     sd: dict = field(default_factory=dict)          # original-layout bf16 tensors on device (prefill)
@@ -440,11 +441,14 @@ class Engine:
         self.noise = torch.zeros(ar_steps, n_steps + 1, self.BP, self.head.C, dtype=torch.float32, device=self.device)
         self.set_ptr("head.noise", self.noise)
         # y_i = silu(time_embed(t_i) + cond_embed(c)) of every evaluation, produced once per AR step next to cond_embed
-        y_bytes = (n_steps + 1) * self.Mpad * self.head.D * 2
+        # (capacity rounded up to whole groups of <= 16 evaluations: the adaLN projections of a group run as one GEMM whose
+        # operand is the group's rows, bd_api.hip head_ada_group; zero-filled so the rows past the schedule are finite)
+        cap = (n_steps + 1 + 15) // 16 * 16
+        y_bytes = cap * self.Mpad * self.head.D * 2
         if y_bytes <= (512 << 20):
-            self.y_all = torch.empty(y_bytes // 2, dtype=BF16, device=self.device)
+            self.y_all = torch.zeros(y_bytes // 2, dtype=BF16, device=self.device)
             self.set_ptr("head.y_all", self.y_all)
-            self.set_int("head.y_evals", n_steps + 1)
+            self.set_int("head.y_evals", cap)
         else:
             self.set_int("head.y_evals", 0)
         self.n_steps = n_steps

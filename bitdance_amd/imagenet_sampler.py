@@ -122,13 +122,23 @@ def load_model(args, device):
         sd = ck["model"]
     else:
         raise Exception("please check model weight")
+    ddconfig = None
     vae = None
-    if args.trained_vae:
+    vae_keys = {k[len("vae."):]: v for k, v in sd.items() if k.startswith("vae.")}
+    if not args.trained_vae and not vae_keys:
+        # without a tokenizer BitDance.sample returns LATENTS [n, C, h, w]; the png / npz writer below would fail (or write
+        # garbage) only after a whole batch has been sampled.  The reference builds its VAE unconditionally
+        # (model_parallel.py:137-150) and loads vae.* strictly with the checkpoint.
+        raise ValueError("no tokenizer weights: pass --trained-vae, or use a checkpoint that carries vae.* tensors")
+    if args.trained_vae or vae_keys:
         ddconfig = dict(double_z=False, z_channels=args.latent_dim, in_channels=3, out_ch=3, ch=256, ch_mult=[1, 1, 2, 2, 4],
                         num_res_blocks=4)                        # model_parallel.py:137-146
         vae = VQModel(ddconfig=ddconfig, gan_decoder=False)
-        state = torch.load(args.trained_vae, map_location="cpu")
-        vae.load_state_dict(state["state_dict"], strict=False)
+        if vae_keys:                                             # the checkpoint's own tokenizer first (the reference loads it strictly)
+            vae.load_state_dict(vae_keys, strict=False)
+        if args.trained_vae:                                     # then the override, as the reference does (:146-150)
+            state = torch.load(args.trained_vae, map_location="cpu")
+            vae.load_state_dict(state["state_dict"], strict=False)
         vae = vae.to(device).eval()
     return BitDance(sd, latent_dim=args.latent_dim, resolution=args.image_size, down_size=args.down_size,
                     patch_size=args.patch_size, cls_token_num=args.cls_token_num, num_classes=args.num_classes,

@@ -94,8 +94,9 @@ class NativeKVCache:
 
 
 class NativeQwen3Model:
-    """Qwen3Model.forward as the reference calls it: bf16 prefill calls run on hipBLASLt/SDPA (llm.prefill_block),
-    fp32 P-token decode calls on the native step."""
+    """Qwen3Model.forward as the reference calls it: fp32 P-token decode calls run the native step; bf16 prefill calls run
+    the same step kernels in their prefill mode (llm.native_block) when the pipeline has ``native_prefill`` set, else the
+    torch cross-check path (llm.prefill_block)."""
 
     def __init__(self, pipe, max_kv: int = 4608):
         self._p = pipe

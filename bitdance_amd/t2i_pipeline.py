@@ -257,6 +257,11 @@ class BitDanceT2IPipeline:
             ev[0].record(st)
             hid = []
             kv = []
+            if self.tp is not None:
+                # the first in-kernel exchanges run inside the prefill: ranks whose engine build / checkpoint load took
+                # different times must meet on the host first, or the early rank spends its wait budget on the late one
+                st.synchronize()
+                self.tp.barrier()
             if self.native_prefill:
                 embs = []
                 for x in ctxs:
@@ -270,6 +275,9 @@ class BitDanceT2IPipeline:
                     prefill_block(eng, self.llm_w, x[:, :T0], br * num_images, 0, causal=True)
                     hid.append(prefill_block(eng, self.llm_w, x[:, T0:], br * num_images, T0, causal=False))
                     kv += [x.shape[1]] * num_images
+            if self.tp is not None:
+                st.synchronize()
+                self.tp.check()                            # a failed prefill exchange raises here, on every rank, not after the loop
             cond0 = torch.cat(hid, dim=0)[:, -P:] + pos[None, :P]          # bf16 + fp32 -> fp32 (t2i:244-245)
             eng.set_cond(cond0.reshape(eng.M, -1))
             eng.reset(kv)

@@ -130,6 +130,9 @@ class TPComm:
         self = cls(rank, size, max_elems, device)
         self.group = group
         backend = backend or os.environ.get("BD_TP_COMM", "ipc")
+        if backend not in ("ipc", "rccl"):
+            raise BitDanceHipError(f"exchange backend must be 'ipc' or 'rccl', not {backend!r}")
+        self.fallback_reason = None
         if size > 1:
             # map the peers' buffers; if ANY rank cannot (IPC export / open refused on this node), every rank falls back to RCCL
             ok, why = True, ""
@@ -146,14 +149,58 @@ class TPComm:
             flags = [None] * size
             dist.all_gather_object(flags, (ok, why), group=group)
             if not all(f[0] for f in flags):
-                if rank == 0:
-                    print(f"[bitdance_amd.tp] IPC mapping failed ({[f[1] for f in flags if not f[0]][:1]}): exchanges go through RCCL", flush=True)
+                self.fallback_reason = f"IPC mapping failed ({[f[1] for f in flags if not f[0]][:1]})"
                 backend = "rccl"
+            # the hand-written exchange reads memory the peers write over xGMI inside one kernel: that is only coherent on
+            # uncached (fine-grained) allocations.  If ANY rank got plain device memory and the ranks sit on different devices,
+            # the exchange goes through RCCL (ranks sharing one device -- the single-GPU functional run -- share one L2).
+            infos = [None] * size
+            dist.all_gather_object(infos, (self.info(), _device_uuid(self.device)), group=group)
+            cross_device = len({i[1] for i in infos}) > 1
+            if backend == "ipc" and cross_device and not all(i[0]["data_uncached"] and i[0]["flags_uncached"] for i in infos):
+                self.fallback_reason = "exchange buffers are not uncached (fine-grained) on every rank"
+                backend = "rccl"
+            # one-time cross-rank self-test of the hand-written exchange (known pattern, every rank checks every element):
+            # a node on which the IPC mapping 'works' but remote writes are not seen must not find out 44 000 exchanges later
+            if backend == "ipc":
+                ok = self._self_test()
+                oks = [None] * size
+                dist.all_gather_object(oks, ok, group=group)
+                if not all(oks):
+                    self.fallback_reason = f"exchange self-test failed on ranks {[r for r, o in enumerate(oks) if not o]}"
+                    dist.barrier(group=group)
+                    check(self.l.bd_comm_reset(self.h), "bd_comm_reset")
+                    backend = "rccl"
+            if self.fallback_reason and rank == 0:
+                print(f"[bitdance_amd.tp] {self.fallback_reason}: exchanges go through RCCL (ncclAllReduce)", flush=True)
             if backend == "rccl":
                 self._init_rccl(dist, group)
             dist.barrier(group=group)
         self.backend = backend if size > 1 else "none"
         return self
+
+    def info(self) -> dict:
+        """Allocation kinds / mode of this rank's exchange state (bd_comm_info)."""
+        out = (C.c_longlong * 4)()
+        check(self.l.bd_comm_info(self.h, out), "bd_comm_info")
+        return {"data_uncached": bool(out[0]), "flags_uncached": bool(out[1]), "mode": int(out[2]), "capacity": int(out[3])}
+
+    def _self_test(self, rows: int = 32, N: int = 256) -> bool:
+        """One exchange of a known pattern: part_r[i] = (r + 1) * v[i] with v exactly representable, so the reduced bf16
+        result must equal v * size (size + 1) / 2 bit for bit on every rank.  False on a timeout or any wrong element."""
+        with torch.cuda.device(self.device):
+            v = ((torch.arange(rows * N, device=self.device) % 61) - 30).float().view(rows, N) / 4.0
+            part = (v * (self.rank + 1)).contiguous()
+            try:
+                self.set_timeout(5.0)
+                got = self.allreduce(part)
+                torch.cuda.current_stream().synchronize()
+                ok = self.l.bd_comm_error(self.h) == 0 and torch.equal(got.float(), v * (self.size * (self.size + 1) / 2))
+            except BitDanceHipError:
+                ok = False
+            finally:
+                self.set_timeout(20.0)
+        return bool(ok)
 
     def use_rccl(self) -> None:
         """Switch the per-Linear exchange to ncclAllReduce (every rank must call it; engines / graphs built before are stale)."""
@@ -224,11 +271,14 @@ class TPComm:
 
     # -- status -------------------------------------------------------------------------------------------------
     def check(self) -> None:
-        """After a stream sync: raise if any in-kernel wait ran out of its budget."""
+        """After a stream sync: raise if any in-kernel wait of this rank ran out of its budget, or a peer reported that one of
+        its waits did (the error word travels with the exchange, so every rank raises at the same check)."""
         e = self.l.bd_comm_error(self.h)
         if e != 0:
             peers = [p for p in range(self.size) if e & (1 << p)] if e > 0 else "?"
-            raise BitDanceHipError(f"tensor-parallel exchange timed out on rank {self.rank} waiting for peers {peers}")
+            gave_up = [p for p in range(self.size) if e > 0 and e & (1 << (8 + p))]
+            raise BitDanceHipError(f"tensor-parallel exchange failed on rank {self.rank}: timed out waiting for peers {peers}"
+                                   + (f"; ranks {gave_up} reported a timeout" if gave_up else ""))
 
     def exchanges(self) -> int:
         return int(self.l.bd_comm_exchanges(self.h))
@@ -253,6 +303,14 @@ class TPComm:
         t = torch.empty(rows, N, dtype=torch.bfloat16, device=part.device)
         check(self.l.bd_comm_copy_out(self.h, t.data_ptr(), t.numel() * 2, 1, st), "bd_comm_copy_out")
         return t
+
+
+def _device_uuid(device) -> str:
+    """Identifies the physical GPU behind a torch device (ranks that share one GPU share its L2)."""
+    try:
+        return str(torch.cuda.get_device_properties(device).uuid)
+    except Exception:                                         # older torch: fall back to (host pid-independent) index + name
+        return f"{torch.cuda.get_device_name(device)}#{torch.device(device).index}"
 
 
 def _dist_ready() -> bool:

@@ -116,7 +116,11 @@ void* bd_comm_local_flags(bd_comm* c);
 int bd_comm_set_rccl(bd_comm* c, void* nccl_comm, void* nccl_allreduce_fn);
 int bd_comm_set_timeout(bd_comm* c, double seconds);                 /* budget of every in-kernel wait (default 20 s) */
 int bd_comm_reset(bd_comm* c);                                       /* all ranks, between host barriers: clear flags / epochs / error */
-int bd_comm_error(bd_comm* c);                                       /* after a sync: bit p set = waiting for peer p timed out */
+int bd_comm_error(bd_comm* c);                                       /* after a sync: bit p = this rank's wait for peer p timed out;
+                                                                        bit 8+r = rank r reported a timed-out wait (all ranks raise together) */
+int bd_comm_info(bd_comm* c, long long* out4);                       /* {exchange buffer uncached, flag block uncached, mode (0 hand-written,
+                                                                        1 ncclAllReduce), capacity in elements}: the host must not run the
+                                                                        hand-written exchange ACROSS devices on cached (coarse-grained) memory */
 long long bd_comm_exchanges(bd_comm* c);                             /* exchange launches issued so far (reporting) */
 int bd_comm_allreduce(bd_comm* c, const float* part, const void* bias_bf16, int rows, int N, void** out_ptr, int* out_is_fp32,
                       void* stream);

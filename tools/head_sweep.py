@@ -1,0 +1,91 @@
+"""A/B sweep of the structural options of the head sampling chain at true 14B dimensions (one AR step = N + 1 evaluations of the
+6-block head, M = 128 rows), all in ONE process on ONE box (box-to-box spread is +-5 %):
+
+  tune.ada_group  evaluations whose adaLN projections run as one GEMM (bd_api.hip head_ada_group)
+  tune.pf_blocks / tune.pf_kb   run-ahead weight prefetch by spare workgroups of the row kernels (bd_kernels.h PfDesc)
+
+Every configuration is timed as a hipGraph replay and its sampled latent is compared bit for bit with the first one's.
+python tools/head_sweep.py [reps] [n_steps] ["k=v,k=v;k=v,..." extra configs]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bitdance_amd import engine as E                       # noqa: E402
+from oracle import tiny_models as tm                        # noqa: E402  (shape table + seeded random weights only)
+from oracle.true_dims import device_seeded_state            # noqa: E402
+
+DEFAULT = [
+    dict(ada_group=1, pf_blocks=0),
+    dict(ada_group=2, pf_blocks=0),
+    dict(ada_group=4, pf_blocks=0),
+    dict(ada_group=8, pf_blocks=0),
+    dict(ada_group=1, pf_blocks=128, pf_kb=8),
+    dict(ada_group=1, pf_blocks=128, pf_kb=16),
+    dict(ada_group=1, pf_blocks=128, pf_kb=24),
+    dict(ada_group=1, pf_blocks=128, pf_kb=32),
+    dict(ada_group=1, pf_blocks=64, pf_kb=16),
+    dict(ada_group=1, pf_blocks=64, pf_kb=32),
+    dict(ada_group=4, pf_blocks=128, pf_kb=16),
+    dict(ada_group=4, pf_blocks=128, pf_kb=24),
+    dict(ada_group=1, pf_blocks=0),
+]
+
+
+def main():
+    with torch.cuda.stream(torch.cuda.Stream()):
+        run()
+
+
+def run():
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    cfgs = list(DEFAULT)
+    if len(sys.argv) > 3:
+        cfgs = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in c.split(",") if kv) for c in sys.argv[3].split(";")]
+    dev = "cuda"
+    B = 1
+    cfgd = dict(ch_target=32, ch_cond=5120, ch_latent=5120, depth_latent=6, depth_adanln=2)
+    sd = device_seeded_state(tm.head_shapes(cfgd), 101, dev)
+    hw = E.HeadWeights.from_state_dict(sd, dev)
+    del sd
+    g = torch.Generator(device=dev).manual_seed(7)
+    cond = torch.randn(2 * B, 64, 5120, device=dev, generator=g)
+    noise = torch.randn(1, n + 1, B, 64, 32, device=dev, generator=g)
+    ref = None
+    for tune in cfgs:
+        eng = E.Engine(hw, None, None, num_images=B, branches=2, device=dev, max_tokens=64, parallel_num=64, tune=tune)
+        eng.set_schedule(n, 7.5, 1)
+        eng.load_noise(noise)
+        eng.reset([0] * (2 * B))
+        eng.set_cond(cond)
+        eng.head_sample()
+        torch.cuda.synchronize()
+        pred = eng.pred().clone()
+        if ref is None:
+            ref = pred
+        same = bool(torch.equal(pred, ref))
+        eng.capture(0)
+        eng.reset([0] * (2 * B))
+        eng.launch(0)
+        torch.cuda.synchronize()
+        same = same and bool(torch.equal(eng.pred(), ref))
+        ts = []
+        for _ in range(reps):
+            eng.reset([0] * (2 * B))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.launch(0)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        dt = min(ts)
+        print(f"{str(tune):60s} graph {dt * 1e3:8.2f} ms/AR step  {dt / (n + 1) * 1e6:8.1f} us/eval  (median {sorted(ts)[len(ts) // 2] * 1e3:.2f})  "
+              f"bit-identical to first: {same}", flush=True)
+        del eng
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
