@@ -390,7 +390,14 @@ int bd_ctx_finalize(bd_ctx* c) {
             c->hDl = c->hD / tp; c->hHl = c->hH / tp;      // this rank's attention columns / SwiGLU features
             c->g["head.cond"] = choose_cfg(c, "head.cond", c->hD, c->hDz, false);
             c->g["head.ada"] = choose_cfg(c, "head.ada", c->hNada, c->hD, false);
-            c->g["head.ada"].S = 1;                            // bf16(+bias) epilogue: 13 consumers read 2 B, not S x 4 B
+            {
+                GemmCfg& ga = c->g["head.ada"];
+                ga.S = 1;                                      // bf16(+bias) epilogue: 13 consumers read 2 B, not S x 4 B
+                // one wave per panel walks K front to back: the SAME summation order as the 256-row kernel that computes the
+                // projections of a whole group of evaluations (head_ada_group), so the grouped and the per-evaluation forms
+                // are bit-identical at every size (K-parts inside a workgroup would add two half sums instead)
+                if (ga.kw > 1) { ga.nw /= ga.kw; ga.kw = 1; }
+            }
             c->g["head.qkv"] = choose_cfg(c, "head.qkv", 3 * c->hDl, c->hD, false);
             c->g["head.wo"] = choose_cfg(c, "head.wo", c->hD, c->hDl, false, tp > 1);
             c->g["head.w1"] = choose_cfg(c, "head.w1", 2 * c->hHl, c->hD, true);
@@ -407,7 +414,7 @@ int bd_ctx_finalize(bd_ctx* c) {
                     return fail("tune.ada_group: 1..16 evaluations, rows a multiple of 256, adaLN width a multiple of 256, bf16 weights, no ada_async");
                 c->adaG = (int)g;
             }
-            c->pf_blocks = (int)c->geti("tune.pf_blocks", 128);
+            c->pf_blocks = (int)c->geti("tune.pf_blocks", 0);       // measured NEGATIVE on MI355X (profiles/r03_head_sweep1.log): off
             c->pf_bytes = (int)c->geti("tune.pf_kb", 16) * 1024;
             if (c->pf_blocks < 0 || c->pf_blocks % 8 || c->pf_bytes < 0 || c->pf_bytes % 1024) return fail("tune.pf_blocks: a multiple of 8; tune.pf_kb: KiB per weight stream");
             add("head.cond_frag", Mp * c->hDz * 2);

@@ -61,25 +61,28 @@ BD_DEV float block_sum(float v, float* red) {
     return t;
 }
 
-// Body of a prefetch workgroup (PfDesc, bd_kernels.h): j = its index among the `nblk` extra workgroups of the launch, `first` =
-// blockIdx of extra workgroup 0 (a multiple of 8, so that j % 8 is this workgroup's XCD).  Plain (cache-allocating) 16 B loads
-// whose results are never used: inline asm so that the compiler neither drops them nor waits for them one by one.
+// Body of a prefetch workgroup (PfDesc, bd_kernels.h): j = its index among the `nblk` extra workgroups of the launch (extra
+// workgroup 0 has a blockIdx that is a multiple of 8, so that j % 8 is this workgroup's XCD).  The loads are LDS-DMA
+// (global_load_lds_dwordx4: 1 KiB per wave instruction, default cache policy so the lines allocate in L2): they have NO
+// register destination -- a register load whose result is never read would leave the compiler free to reuse the destination
+// registers while the data is still in flight -- and every wave drops its kilobyte onto the same scratch in LDS.
 template <class PF>
 BD_DEV void bd_prefetch_run(const PF& d, int j, int nthreads) {
+    __shared__ __attribute__((aligned(16))) unsigned pf_sink[256];
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
     const int per = d.nblk >> 3;                                   // prefetch workgroups per XCD
     const int upp = d.bytes >> 4;                                  // 16 B units per stream
     const int units = d.NP * upp;
     const char* const W = reinterpret_cast<const char*>(d.W);
     for (int b = (j & 7) + 8 * (j >> 3); b < d.nwg; b += 8 * per) {
         const int s = b % d.S, nt = b / d.S;
+        // whole waves only (LDS-DMA writes lane-linear from an M0 base): units is a multiple of 64 (bytes % 1024 == 0)
         for (int u = threadIdx.x; u < units; u += nthreads) {
             const int pn = u / upp, o = u - pn * upp;
-            const int panel = nt * d.NP + pn;
-            if (panel < d.npan) {
-                const char* src = W + (size_t)panel * d.panel_bytes + (size_t)s * d.slice_bytes + (size_t)o * 16;
-                u32x4 sink;
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sink) : "v"(src) : "memory");
-            }
+            const int panel = min(nt * d.NP + pn, d.npan - 1);     // ragged last tile: re-touch the last panel
+            const char* src = W + (size_t)panel * d.panel_bytes + (size_t)s * d.slice_bytes + (size_t)o * 16;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)pf_sink, 16, 0, 0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
