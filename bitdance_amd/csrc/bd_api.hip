@@ -406,12 +406,14 @@ int bd_ctx_finalize(bd_ctx* c) {
             // The adaLN projection of evaluation i depends on (t_i, cond) only, not on the latent: the projections of G
             // consecutive evaluations are ONE GEMM over G * Mpad rows (the 256-row kernel: weights streamed once per G
             // evaluations instead of once per evaluation -- 21 % of the head's weight bytes; every row's K sum runs in the same
-            // order through the same MFMA, so the result is bit-identical to G separate launches).  Default: 512 rows.
+            // order through the same MFMA, so the result is bit-identical to G separate launches).  Default: 512 rows per GEMM
+            // (4 evaluations at 128 rows); larger groups measured no further gain in situ (profiles/r03_head_sweep2.log: 974 us
+            // per evaluation at G = 4, 8 and 16 against 1006 at G = 1).  The last group of a schedule is short.
             {
                 long long g = c->geti("tune.ada_group", -1);
                 if (g < 0) g = (!c->wfp8 && Mp <= 128 && c->hNada % 256 == 0 && c->geti("tune.ada_async", 0) == 0) ? 512 / Mp : 1;
-                if (g < 1 || g > 16 || (g > 1 && ((c->RB * g) % 8 != 0 || c->hNada % 256 != 0 || c->wfp8 || c->geti("tune.ada_async", 0) != 0)))
-                    return fail("tune.ada_group: 1..16 evaluations, rows a multiple of 256, adaLN width a multiple of 256, bf16 weights, no ada_async");
+                if (g < 1 || g > 64 || (g > 1 && ((c->RB * g) % 8 != 0 || c->hNada % 256 != 0 || c->wfp8 || c->geti("tune.ada_async", 0) != 0)))
+                    return fail("tune.ada_group: 1..64 evaluations, rows a multiple of 256, adaLN width a multiple of 256, bf16 weights, no ada_async");
                 c->adaG = (int)g;
             }
             c->pf_blocks = (int)c->geti("tune.pf_blocks", 0);       // measured NEGATIVE on MI355X (profiles/r03_head_sweep1.log): off
@@ -631,10 +633,12 @@ static int head_ada(bd_ctx* c, int i, int buf, bool light, hipStream_t st) {
 // that layout, head_cond); evaluation i then reads rows (i % G) * Mpad .. of head.ada_bf.
 static int head_ada_group(bd_ctx* c, int g, hipStream_t st) {
     const int G = c->adaG, D = c->hD;
+    const int left = (int)c->sched.size() - g * G, Gg = left < G ? left : G;      // the last group may be short
+    const int rbg = Gg == G ? c->RB * G : ((c->RB * Gg + 7) & ~7);                // (head_y_all_kernel lays it out with this row-block count)
     const bf16_t* y = (const bf16_t*)c->ptr("head.y_all") + (size_t)g * G * c->Mpad * D;
     char name[32];
-    std::snprintf(name, sizeof(name), "head.ada[x%d]", G);      // profiling: G evaluations' worth of rows per weight pass
-    BD_TRY(gemm(c, name, y, c->RB * G, wref(c, "head.ada_w"), c->hNada, D, 1, /*8 waves, ring 2: the 256-row kernel*/ 8 + 16 * 2,
+    std::snprintf(name, sizeof(name), "head.ada[x%d]", Gg);     // profiling: Gg evaluations' worth of rows per weight pass
+    BD_TRY(gemm(c, name, y, rbg, wref(c, "head.ada_w"), c->hNada, D, 1, /*8 waves, ring 2: the 256-row / tiled kernels*/ 8 + 16 * 2,
                 BD_EPI_BF16, nullptr, c->wptr("head.ada_bf"), c->ptr("head.ada_b"), st));
     return 0;
 }

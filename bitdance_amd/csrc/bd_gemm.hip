@@ -274,8 +274,12 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
 
 // measurement switches of the 256-row kernel (process-wide; bd_set_gemm_option): W register ring depth and XCD placement
 static int g_wide_ring = 2, g_wide_xcd = -1;            // xcd: -1 = by shape (on when the weights outweigh the rows), 0 / 1 forced
+void bdk_gemm_tile_debug(int v);
+static int g_tile = 1;                                   // >= 512 rows: the LDS-tiled MFMA-bound kernel (bd_gemm_tile.hip); 0 = 256-row kernel
 int bdk_set_gemm_option(const char* name, int v) {
     const std::string n(name);
+    if (n == "tile" && (v == 0 || v == 1)) { g_tile = v; return 0; }
+    if (n == "tile.debug" && v >= 0 && v <= 3) { bdk_gemm_tile_debug(v); return 0; }
     if (n == "wide.ring" && (v == 2 || v == 3)) { g_wide_ring = v; return 0; }
     if (n == "wide.xcd" && v >= -1 && v <= 1) { g_wide_xcd = v; return 0; }
     return -1;
@@ -340,7 +344,13 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
     // 256-row passes over 256-column tiles: 4 waves x 2 panels (MFMA-friendly) instead of 8 waves x 1 panel;
     // same grid.  BD_GEMM_WIDE=0 keeps the 8-wave form (A/B switch for measurements).
     static const bool wide = [] { const char* e = getenv("BD_GEMM_WIDE"); return !(e && e[0] == '0'); }();
-    if (wide && MB == 8 && nw == 8 && N % 256 == 0 && epi != BD_EPI_F32 && !(S > 1 && epi != BD_EPI_PARTIAL)) return launch_gemm_wide(p, epi, st);
+    if (wide && MB == 8 && nw == 8 && N % 256 == 0 && epi != BD_EPI_F32 && !(S > 1 && epi != BD_EPI_PARTIAL)) {
+        // >= 512 rows: the matrix pipe is the roofline -> both operands through LDS, 256 x 256 tiles (bd_gemm_tile.hip)
+        // (measured, profiles/r03_gemm_tile_v4.log: ahead of the 256-row kernel from 1024 rows on wide N -- adaLN x8 693 vs 786 us,
+        // ImageNet w1 89 vs 114 us -- behind it at 512 rows and on narrow N, where it has too few tiles per CU)
+        if (g_tile && RB >= 32 && N >= 4096 && g_w_layout == 0) return bdk_gemm_tile(p, epi, st);
+        return launch_gemm_wide(p, epi, st);
+    }
 #define BD_CASE(NPV, KWV, MBV, RV) if (np == NPV && kw == KWV && MB == MBV && ring == RV) return launch_gemm<NPV, KWV, MBV, RV>(p, epi, st);
     if (light && np == 4 && kw == 1 && MB == 4) return launch_gemm<4, 1, 4, 2, 2>(p, epi, st);
 #define BD_CASE_PIPE(NPV, KWV, MBV) if (pipe && np == NPV && kw == KWV && MB == MBV) return launch_gemm<NPV, KWV, MBV, 2, 1>(p, epi, st);

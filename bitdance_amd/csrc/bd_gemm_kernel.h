@@ -36,6 +36,9 @@ struct GemmP {
     size_t PS, SS;       // packed-W strides in 16 B units: panel stride, 64-deep-K-stage stride
 };
 
+// MFMA-bound form for >= 512 rows: both operands through LDS, 256 x 256 workgroup tiles (bd_gemm_tile.hip)
+int bdk_gemm_tile(const GemmP& p, int epi, hipStream_t st);
+
 // R = depth of the per-wave W register ring = number of K stages a wave keeps in flight.  The A stage is
 // prefetched equally far ahead (R-1 register slots, then one ds_write into the double-buffered LDS tile): vmcnt retires
 // in order, so an A load issued late would force every older W load to complete with it.

@@ -1,0 +1,262 @@
+// MFMA-bound GEMM for MANY rows (>= 512): out[M, N] = A[M, K] (bf16) x W[N, K]^T (bf16), fp32 accumulate.
+//
+// Who launches it: the adaLN projections of a whole group of evaluations (bd_api.hip head_ada_group: G x 128 rows per pass
+// over the 734 MB adaLN matrix, flow_head_parallel_x.py:331), the eval batch (num_images = 4: 512 rows, eval/eval_dpg.py:44)
+// and the ImageNet batch (384 classes with CFG: 12 288 rows, imagenet_gen/sample_ddp_parallel.py:199-214).  At these row
+// counts the matrix pipe, not HBM, is the roofline (arithmetic intensity = rows FLOP per weight byte >> the ~310 FLOP/B
+// ridge), so unlike the weight-streaming kernels of bd_gemm.hip BOTH operands are staged through LDS and shared by the whole
+// workgroup:
+//
+//   * workgroup tile 256 rows x 256 columns, 8 waves as 2 (rows) x 4 (columns), wave tile 128 x 64 = 8 accumulators of
+//     32x32 (128 AGPR/VGPRs); per k-step of 16 a wave reads 4 A + 2 W fragments (6 ds_read_b128, lane-linear, conflict free:
+//     both operands are ALREADY stored in MFMA-operand order in HBM -- bd_common.h afrag_off, bd_gemm.hip pack_w_kernel -- so
+//     a 1 KiB chunk is one fragment for all 64 lanes) for 8 v_mfma_f32_32x32x16_bf16: 128 FLOP per LDS byte;
+//   * global -> LDS by LDS-DMA (global_load_lds_dwordx4: one instruction moves one 1 KiB fragment chunk, no VGPR round trip,
+//     no ds_write issue slots), 4 chunks per wave per 32-deep K stage, into a ring of four 32 KiB stages; the DMA of stage
+//     j + 3 is issued right behind the barrier that opens stage j, so three stages (~1.3 us of MFMA time) of L2 / HBM latency
+//     are covered.  The DMAs are inline asm with hand-counted s_waitcnt vmcnt: hipcc counts an LDS-DMA builtin as a store to
+//     all of LDS and drains the queue before the next ds_read (no pipelining at all);
+//   * the two waves of every SIMD run half a stage apart (ping-pong): while one issues its 16 MFMAs of a stage from registers
+//     the other reads its next fragments from LDS and issues / awaits its DMAs, one s_barrier per half-step (main-loop comment);
+//   * workgroup -> tile map: block b runs on XCD b % 8 (observed placement, used for speed only).  The 32 blocks an XCD runs
+//     side by side form an 8 x 4 rectangle of tiles that walks K in step, so an A stage is fetched into that L2 once per 4
+//     column tiles and a W stage once per 8 row tiles: HBM / Infinity-Cache traffic (1/4 + 1/8) of the operand bytes per tile.
+//
+// Each accumulator sees its K steps in ascending order through the same MFMA as in the 128-row kernel (bd_gemm_kernel.h), so
+// for S = 1 the results are bit-identical to that kernel's (tests/test_gpu_parity.py::test_gemm_tile_*).
+#include "bd_gemm_kernel.h"
+
+namespace {
+
+constexpr int TS_STAGE_UNITS = 32 * 64;        // 16 B units per 32-deep stage: 16 A chunks + 16 W chunks of 64 units (1 KiB)
+constexpr int TS_SLOTS = 4;
+
+// one 1 KiB fragment chunk, global -> LDS; `lds_byte` wave-uniform.  M0 is saved / restored: it is compiler-reserved.
+BD_DEV void dma_chunk(const u32x4* gsrc, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte) : "memory");
+}
+
+}  // namespace
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_tile_kernel(GemmP p, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const u32x4* const lds = reinterpret_cast<const u32x4*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;                    // 128-row half, 64-column quarter of the tile
+
+    // ---- tile of this workgroup (header comment: 8 x 4 rectangles per XCD)
+    const int RT = p.RB >> 3, NTS = (p.N >> 8) * p.S;           // row tiles, (column tile, K slice) pairs
+    const int nRm = (RT + 7) >> 3, nRn = (NTS + 3) >> 2;
+    const int b = blockIdx.x, x = b & 7, i = b >> 3;
+    const int R = (i >> 5) * 8 + x, within = i & 31;
+    if (R >= nRm * nRn) return;
+    const int mt = (R % nRm) * 8 + (within & 7), cs = (R / nRm) * 4 + (within >> 3);
+    if (mt >= RT || cs >= NTS) return;
+    const int s = cs % p.S, nt = cs / p.S;
+    const int nst_total = p.K >> 5;                             // 32-deep stages
+    const int q = (nst_total + p.S - 1) / p.S;
+    const int st0 = s * q;
+    const int nst = min(q, nst_total - st0);
+
+    // ---- this wave's 4 DMA chunks per stage: waves 0-3 fetch A (chunk c = 4 wave + i: k-step c >> 3, row block c & 7),
+    //      waves 4-7 fetch W (c' = 4 (wave - 4) + i: panel c' >> 1, k-step c' & 1).  LDS stage = [16 A chunks | 16 W chunks].
+    const u32x4* src[4];
+    unsigned dst[4];
+    size_t stride;                                              // 16 B units per stage
+    if (wave < 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = wave * 4 + j, ks = c >> 3, rb = c & 7;
+            src[j] = p.A + ((size_t)(st0 * 2 + ks) * p.RB + mt * 8 + rb) * 64 + lane;
+            dst[j] = (unsigned)c * 1024u;
+        }
+        stride = (size_t)2 * p.RB * 64;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = (wave - 4) * 4 + j, pn = c >> 1, ks = c & 1;
+            src[j] = p.W + (size_t)(nt * 8 + pn) * p.PS + (size_t)(st0 * 2 + ks) * 64 + lane;
+            dst[j] = (unsigned)(16 + c) * 1024u;
+        }
+        stride = 128;
+    }
+    auto issue = [&](int st) {                                  // stage st (relative) -> slot st % 4
+        const unsigned slot = (unsigned)(st & (TS_SLOTS - 1)) * (TS_STAGE_UNITS * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_chunk(src[j] + (size_t)st * stride, slot + dst[j]);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    // ---- main loop: PING-PONG between the two waves of each SIMD.  Waves w and w + 4 share a SIMD (waves are dealt to the SIMDs
+    // cyclically), so the workgroup is two groups, X = waves 0-3 and Y = waves 4-7, half a stage apart: in every half-step one
+    // group issues nothing but its 16 MFMAs of a stage (fragments already in registers) while the other reads its 12 fragments
+    // of the next stage from LDS, issues its 4 DMA chunks three stages ahead and waits for them -- the matrix pipe of every SIMD
+    // always has one wave feeding it, and LDS / DMA latency sits under the partner's MFMA segment (MI355X_MICROARCH "two waves per
+    // SIMD").  One s_barrier per half-step; X fetches A chunks, Y fetches W chunks.
+    //   half-step 2j    :  X  LOAD(j)   |  Y  MFMA(j - 1)
+    //   half-step 2j + 1:  X  MFMA(j)   |  Y  LOAD(j)
+    // LOAD(j) = read this wave's fragments of stage j, then wait until the own DMAs of stage j + 1 have landed (X: A(j + 1), needed
+    // from half-step 2j + 2; Y: W(j + 1), likewise) with one younger stage still in flight; MFMA(j) also issues the own DMAs of
+    // stage j + 3.
+    u32x4 af[2][4], wf[2][2];
+    const bool isX = wave < 4;
+    auto load_seg = [&](int j) {
+        const u32x4* a = lds + (size_t)(j & (TS_SLOTS - 1)) * TS_STAGE_UNITS + lane;
+        const u32x4* w = a + 16 * 64;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) af[ks][m] = a[(ks * 8 + (wr * 4 + m)) * 64];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) wf[ks][n] = w[((wc * 2 + n) * 2 + ks) * 64];
+        }
+        // own DMAs of stage j + 1 landed (issued during MFMA(j - 2)); those of stage j + 2 (MFMA(j - 1)) may stay in flight
+        if ((dbg & 2) || j + 2 >= nst) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    };
+    // 16 MFMAs of stage j from registers, with this wave's 4 DMA chunks of stage j + 3 issued BETWEEN them (one per 4 MFMAs): a
+    // DMA issued beside ds_reads in the load segment costs the wave 100-185 cycles and made that segment longer than the MFMA
+    // segment it is supposed to hide under; between MFMAs the wave is waiting on the matrix pipe anyway.  The slot is that of
+    // stage j - 1, whose last readers (the partner's LOAD(j - 1)) finished before the barrier that opened this half-step.
+    auto mfma_seg = [&](int j) {
+        const bool dma = (j + 3 < nst) && !(dbg & 2);
+        const unsigned slot = (unsigned)((j + 3) & (TS_SLOTS - 1)) * (TS_STAGE_UNITS * 16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = mfma32(af[ks][m], wf[ks][n], acc[m][n]);
+                if ((m & 1) == 1) {
+                    const int c = ks * 2 + (m >> 1);
+                    if (dma) dma_chunk(src[c] + (size_t)(j + 3) * stride, slot + dst[c]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: three stages in flight; stage 0 must have landed for everybody before the first LOAD
+    issue(0);
+    if (1 < nst) issue(1);
+    if (2 < nst) issue(2);
+    {
+        const int younger = min(nst - 1, 2);
+        if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // two loops, one per group: the same number of barriers on both sides (2 per stage)
+    if (isX) {
+        for (int j = 0; j < nst; ++j) {
+            __syncthreads();                                    // opens half-step 2j
+            load_seg(j);
+            __syncthreads();                                    // opens half-step 2j + 1
+            if (!(dbg & 1)) mfma_seg(j);
+        }
+        __syncthreads();                                        // Y has read its last fragments: LDS is free for the epilogue
+    } else {
+        __syncthreads();
+        __syncthreads();
+        load_seg(0);
+        for (int j = 1; j < nst; ++j) {
+            __syncthreads();                                    // opens half-step 2j
+            if (!(dbg & 1)) mfma_seg(j - 1);
+            __syncthreads();                                    // opens half-step 2j + 1
+            load_seg(j);
+        }
+        __syncthreads();
+        if (!(dbg & 1)) mfma_seg(nst - 1);                      // Y's last stage
+    }
+
+    // ---- epilogue.  D layout of the 32x32 MFMA: lane -> column lane & 31, reg r -> row (r&3)+8(r>>2)+4(lane>>5).
+    if constexpr (EPI == BD_EPI_BF16) {
+        // bf16(+bias) row-major: straight from the accumulators every store instruction would write 2 bytes per lane (23 us of a
+        // 140 us tile).  Each wave instead lays its 128 x 64 sub-tile down in its own 16 KiB of LDS (free since the barrier
+        // above) and writes it out as 16 B per lane, 8 rows x 128 contiguous bytes per instruction.
+        bf16_t* const mine = reinterpret_cast<bf16_t*>(smem) + (size_t)wave * (128 * 64);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int lc = n * 32 + (lane & 31);
+            const float bias_col = p.bias ? bf2f(p.bias[(nt * 8 + wc * 2 + n) * 32 + (lane & 31)]) : 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    mine[(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + lc] = f2bf(acc[m][n][r] + bias_col);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): the wave's own LDS writes (no other wave reads them)
+        const u32x4* const rd = reinterpret_cast<const u32x4*>(mine);
+        bf16_t* const o = p.act + (size_t)((mt * 8 + wr * 4) * 32) * p.N + (size_t)(nt * 8 + wc * 2) * 32;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 8 + (lane >> 3), seg = lane & 7;
+            *reinterpret_cast<u32x4*>(o + (size_t)row * p.N + seg * 8) = rd[row * 8 + seg];
+        }
+        return;
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int panel = nt * 8 + wc * 2 + n;
+        const int col = panel * 32 + (lane & 31);
+        const float bias_col = (EPI != BD_EPI_PARTIAL && p.bias) ? bf2f(p.bias[col]) : 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x16& a = acc[m][n];
+            const int row0 = (mt * 8 + wr * 4 + m) * 32;
+            if (EPI == BD_EPI_PARTIAL) {
+                float* o = p.out + ((size_t)s * p.Mpad + row0) * p.N + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = a[r];
+            } else {                                             // BD_EPI_SWIGLU: lanes (l & 16) == 0 hold gate f, the others the matching up
+                const int f = panel * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = bfr(a[r] + bias_col);
+                    const float other = __shfl_xor(v, 16);
+                    if ((lane & 16) == 0) {
+                        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        p.act[afrag_off(row, f, p.RB)] = f2bf(silu_bf(v) * other);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// RB % 8 == 0 (256-row tiles), N % 256 == 0, K % 32 == 0, panel-major weights; S > 1 only with fp32 slabs (BD_EPI_PARTIAL)
+static int g_tile_dbg = 0;                                       // measurement only: 1 = no MFMA work, 2 = no DMA after the prologue
+void bdk_gemm_tile_debug(int v) { g_tile_dbg = v; }
+int bdk_gemm_tile(const GemmP& p, int epi, hipStream_t st) {
+    if (p.RB % 8 || p.N % 256 || p.K % 32 || p.S < 1 || (p.S > 1 && epi != BD_EPI_PARTIAL) || epi == BD_EPI_F32) return -2;
+    const int nst_total = p.K / 32, q = (nst_total + p.S - 1) / p.S;
+    if ((p.S - 1) * q >= nst_total) return -3;
+    const int RT = p.RB / 8, NTS = (p.N / 256) * p.S;
+    const int nR = ((RT + 7) / 8) * ((NTS + 3) / 4);
+    const int blocks = ((nR + 7) / 8) * 8 * 32;
+    constexpr int lds = TS_SLOTS * TS_STAGE_UNITS * 16;            // 128 KiB: one workgroup per CU
+    static unsigned long long optin[3] = {0, 0, 0};
+    if (epi == BD_EPI_PARTIAL) {
+        if (!bd_lds_optin((const void*)gemm_tile_kernel<BD_EPI_PARTIAL>, lds, &optin[0])) return -8;
+        BD_LAUNCH(gemm_tile_kernel<BD_EPI_PARTIAL>, dim3(blocks), dim3(512), lds, st, p, g_tile_dbg);
+    } else if (epi == BD_EPI_BF16) {
+        if (!bd_lds_optin((const void*)gemm_tile_kernel<BD_EPI_BF16>, lds, &optin[1])) return -8;
+        BD_LAUNCH(gemm_tile_kernel<BD_EPI_BF16>, dim3(blocks), dim3(512), lds, st, p, g_tile_dbg);
+    } else {
+        if (!bd_lds_optin((const void*)gemm_tile_kernel<BD_EPI_SWIGLU>, lds, &optin[2])) return -8;
+        BD_LAUNCH(gemm_tile_kernel<BD_EPI_SWIGLU>, dim3(blocks), dim3(512), lds, st, p, g_tile_dbg);
+    }
+    return bd_launch_status();
+}

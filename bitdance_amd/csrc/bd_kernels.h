@@ -131,8 +131,9 @@ int bdk_head_final(const HeadFinalArgs& a, hipStream_t st);
 struct HeadYAllArgs {       // y_i = silu(time_embed(t_i) + cond_embed(c)) for EVERY evaluation of the schedule at once: depends on
     const void* cemb;       // (t_i, cond) only (flow_head:328-330), so it is computed once per AR step, not once per evaluation
     const void* temb;       // [n_evals][D] bf16
-    void* y_all;            // out: [ceil(n_evals / G)] fragment-major bf16 matrices of G * Mpad rows: evaluation i = rows
-                            //      (i % G) * Mpad .. of matrix i / G -- the A operand of ONE adaLN GEMM over G evaluations
+    void* y_all;            // out: [ceil(n_evals / G)] fragment-major bf16 matrices, one every G * Mpad * D elements: evaluation i = rows
+                            //      (i % G) * Mpad .. of matrix i / G -- the A operand of ONE adaLN GEMM over G evaluations.  The last
+                            //      matrix holds the n_evals % G left-over evaluations only, its row-block count rounded up to 8
     int M, D, RB, Mpad, n_evals;
     int G = 1;              // evaluations per adaLN GEMM (1: one [Mpad][D] matrix per evaluation)
 };

@@ -282,8 +282,9 @@ __global__ void head_y_all_kernel(HeadYAllArgs a) {
     ld_bf16x8((const bf16_t*)a.temb + (size_t)i * a.D + d0, te);
 #pragma unroll
     for (int j = 0; j < 8; ++j) y[j] = silu_f(bfr(te[j] + ce[j]));               // bf16 + bf16 -> bf16 ; silu -> bf16 (rounded by pack8)
-    *reinterpret_cast<u32x4*>((bf16_t*)a.y_all + (size_t)(i / a.G) * a.G * a.Mpad * a.D +
-                              afrag_off(m + (i % a.G) * a.Mpad, d0, a.RB * a.G)) = pack8(y);
+    const int g = i / a.G, left = a.n_evals - g * a.G;              // evaluations in this group's matrix
+    const int rbg = (left >= a.G || a.G == 1) ? a.RB * a.G : ((a.RB * left + 7) & ~7);
+    *reinterpret_cast<u32x4*>((bf16_t*)a.y_all + (size_t)g * a.G * a.Mpad * a.D + afrag_off(m + (i % a.G) * a.Mpad, d0, rbg)) = pack8(y);
 }
 int bdk_head_y_all(const HeadYAllArgs& a, hipStream_t st) {
     const int t = row_threads(a.D);

@@ -441,9 +441,9 @@ class Engine:
         self.noise = torch.zeros(ar_steps, n_steps + 1, self.BP, self.head.C, dtype=torch.float32, device=self.device)
         self.set_ptr("head.noise", self.noise)
         # y_i = silu(time_embed(t_i) + cond_embed(c)) of every evaluation, produced once per AR step next to cond_embed
-        # (capacity rounded up to whole groups of <= 16 evaluations: the adaLN projections of a group run as one GEMM whose
+        # (capacity rounded up to whole groups of <= 64 evaluations: the adaLN projections of a group run as one GEMM whose
         # operand is the group's rows, bd_api.hip head_ada_group; zero-filled so the rows past the schedule are finite)
-        cap = (n_steps + 1 + 15) // 16 * 16
+        cap = (n_steps + 1 + 63) // 64 * 64
         y_bytes = cap * self.Mpad * self.head.D * 2
         if y_bytes <= (512 << 20):
             self.y_all = torch.zeros(y_bytes // 2, dtype=BF16, device=self.device)

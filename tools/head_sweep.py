@@ -18,19 +18,13 @@ from oracle import tiny_models as tm                        # noqa: E402  (shape
 from oracle.true_dims import device_seeded_state            # noqa: E402
 
 DEFAULT = [
-    dict(ada_group=1, pf_blocks=0),
-    dict(ada_group=2, pf_blocks=0),
-    dict(ada_group=4, pf_blocks=0),
-    dict(ada_group=8, pf_blocks=0),
-    dict(ada_group=1, pf_blocks=128, pf_kb=8),
-    dict(ada_group=1, pf_blocks=128, pf_kb=16),
-    dict(ada_group=1, pf_blocks=128, pf_kb=24),
-    dict(ada_group=1, pf_blocks=128, pf_kb=32),
-    dict(ada_group=1, pf_blocks=64, pf_kb=16),
-    dict(ada_group=1, pf_blocks=64, pf_kb=32),
-    dict(ada_group=4, pf_blocks=128, pf_kb=16),
-    dict(ada_group=4, pf_blocks=128, pf_kb=24),
-    dict(ada_group=1, pf_blocks=0),
+    dict(ada_group=1),
+    dict(ada_group=4),
+    dict(ada_group=8),
+    dict(ada_group=16),
+    dict(ada_group=26),
+    dict(ada_group=52),
+    dict(ada_group=1),
 ]
 
 
