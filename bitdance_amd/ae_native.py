@@ -1,0 +1,168 @@
+"""Native conv decoder of the binary tokenizer: ``Decoder.forward`` (/root/reference/modeling/vision_encoder/autoencoder.py:129-196,
+ResBlock :13-57, Upsampler / depth_to_space :198-250, AdaptiveGroupNorm :251-277) on the hand-written gfx950 kernels of
+csrc/bd_conv.hip -- 3x3 / 1x1 convolutions as implicit GEMMs on the matrix pipe, GroupNorm statistics + fused
+normalise / AdaGN / swish passes, depth-to-space in the upsampling convolution's epilogue -- instead of MIOpen.
+
+This module is plumbing: it takes the weights out of the (checkpoint-compatible) torch ``Decoder`` module, packs them once, owns
+the activation buffers (torch tensors) and sequences the launches with the dtype flow the reference has under bf16 autocast:
+convolution outputs bf16, GroupNorm / swish / AdaGN in fp32, the residual stream fp32 after an AdaptiveGroupNorm until a
+channel-changing block (bf16 conv + bf16 shortcut) or an upsampler makes it bf16 again.  No CPU path.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import BitDanceHipError, check, lib
+
+BF16 = torch.bfloat16
+
+
+def _st() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _Conv:
+    """One nn.Conv2d (3x3 pad 1, or 1x1) packed for bd_conv: [Cout -> 256-multiple][taps * Cin], K ordered (ky, kx, ci)."""
+
+    def __init__(self, conv: torch.nn.Conv2d, device):
+        w = conv.weight.detach().to(device=device, dtype=torch.float32)
+        self.cout, self.cin, kh, kw = w.shape
+        self.taps = kh * kw
+        if (kh, kw) not in ((3, 3), (1, 1)) or self.cin % 32:
+            raise BitDanceHipError(f"native decoder: unsupported convolution {tuple(w.shape)}")
+        npad = (self.cout + 255) // 256 * 256
+        m = torch.zeros(npad, self.taps * self.cin, dtype=BF16, device=device)
+        m[: self.cout] = w.permute(0, 2, 3, 1).reshape(self.cout, -1).to(BF16)
+        self.w = torch.empty(npad * self.taps * self.cin, dtype=BF16, device=device)
+        check(lib().bd_pack_weight(self.w.data_ptr(), m.data_ptr(), npad, self.taps * self.cin, 0, npad, _st()), "bd_pack_weight")
+        self.bias = None if conv.bias is None else conv.bias.detach().to(device=device, dtype=BF16).contiguous()
+        torch.cuda.current_stream().synchronize()
+
+
+class _Norm:
+    def __init__(self, gn: torch.nn.GroupNorm, device):
+        if gn.num_groups != 32:
+            raise BitDanceHipError("native decoder: GroupNorm(32) only")
+        self.eps = float(gn.eps)
+        self.gamma = None if gn.weight is None else gn.weight.detach().to(device, torch.float32).contiguous()
+        self.beta = None if gn.bias is None else gn.bias.detach().to(device, torch.float32).contiguous()
+
+
+class NativeDecoder:
+    """``decode(z)`` == ``Decoder.forward(z)`` under ``torch.autocast('cuda', bfloat16)`` (values within bf16 accumulation noise of
+    the MIOpen path; tests/test_gpu_ae.py).  ``dec``: a loaded ``autoencoder.Decoder``."""
+
+    def __init__(self, dec, device):
+        self.device = torch.device(device)
+        self.dec = dec
+        self.nlev, self.nres = dec.nlev, dec.nres
+        C = lambda m: _Conv(m, self.device)
+        self.conv_in = C(dec.conv_in)
+        self.mid = [self._block(b) for b in dec.mid_block]
+        self.levels = []
+        for lv in range(self.nlev):
+            level = dec.up[lv]
+            self.levels.append({"blocks": [self._block(b) for b in level.block],
+                                "up": C(level.upsample.conv1) if lv > 0 else None,
+                                "ada": dec.adaptive[lv]})
+        self.norm_out = _Norm(dec.norm_out, self.device)
+        self.conv_out = C(dec.conv_out)
+        self._buf: dict = {}
+
+    def _block(self, b):
+        d = {"n1": _Norm(b.norm1, self.device), "n2": _Norm(b.norm2, self.device), "c1": _Conv(b.conv1, self.device),
+             "c2": _Conv(b.conv2, self.device), "sc": None}
+        if b.cin != b.cout:
+            d["sc"] = _Conv(b.nin_shortcut, self.device)
+        return d
+
+    # -- buffers: one per (role, shape, dtype), reused across calls; padded buffers keep their zero border ---------------------
+    def _get(self, role: str, shape, dtype, zero: bool = False) -> torch.Tensor:
+        key = (role, tuple(shape), dtype)
+        t = self._buf.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=self.device)
+            self._buf[key] = t
+        return t
+
+    def _padded(self, role, n, H, W, C):
+        return self._get(role, (n, H + 2, W + 2, C), BF16, zero=True)
+
+    # -- operators ---------------------------------------------------------------------------------------------------
+    def _conv(self, cv: _Conv, x, out, n, H, W, *, mode=0, res=None):
+        l = lib()
+        check(l.bd_conv(x.data_ptr(), cv.w.data_ptr(), None if cv.bias is None else cv.bias.data_ptr(),
+                        None if res is None else res.data_ptr(), int(res is not None and res.dtype == torch.float32),
+                        out.data_ptr(), mode, int(out.dtype == torch.float32), n, H, W, cv.cin, cv.cout, cv.taps, _st()), "bd_conv")
+        return out
+
+    def _stats(self, x, n, H, W, C, eps):
+        chunks = (H * W + 255) // 256
+        part = self._get("gn.partial", (n, chunks, 32, 2), torch.float32)
+        st = self._get("gn.stats", (n, 32, 2), torch.float32)
+        check(lib().bd_gn_stats(x.data_ptr(), int(x.dtype == torch.float32), part.data_ptr(), st.data_ptr(), n, H * W, C, eps, _st()), "bd_gn_stats")
+        return st
+
+    def _apply(self, x, st, out, mode, swish, n, H, W, C, gamma=None, beta=None, scale=None, bias=None):
+        p = lambda t: None if t is None else t.data_ptr()
+        check(lib().bd_gn_apply(x.data_ptr(), int(x.dtype == torch.float32), p(st), p(gamma), p(beta), p(scale), p(bias), out.data_ptr(), mode,
+                                int(swish), n, H, W, C, _st()), "bd_gn_apply")
+        return out
+
+    def _norm_swish_pad(self, nm: _Norm, x, role, n, H, W, C):
+        st = self._stats(x, n, H, W, C, nm.eps)
+        return self._apply(x, st, self._padded(role, n, H, W, C), 0, True, n, H, W, C, gamma=nm.gamma, beta=nm.beta)
+
+    def _resblock(self, blk, x, n, H, W, tag):
+        cin, cout = blk["c1"].cin, blk["c1"].cout
+        p1 = self._norm_swish_pad(blk["n1"], x, "p.a", n, H, W, cin)
+        t = self._conv(blk["c1"], p1, self._get("t", (n, H, W, cout), BF16), n, H, W)
+        p2 = self._norm_swish_pad(blk["n2"], t, "p.b", n, H, W, cout)
+        if blk["sc"] is not None:                              # bf16 conv + bf16 shortcut(x) -> bf16 stream
+            xb = x if x.dtype == BF16 else self._apply(x, None, self._get("xb", (n, H, W, cin), BF16), 2, False, n, H, W, cin)
+            sc = self._conv(blk["sc"], xb, self._get("sc", (n, H, W, cout), BF16), n, H, W)
+            out = self._get("s." + tag, (n, H, W, cout), BF16)
+            return self._conv(blk["c2"], p2, out, n, H, W, res=sc)
+        out = self._get("s." + tag, (n, H, W, cout), x.dtype)    # bf16 + bf16 -> bf16 ; bf16 + fp32 -> fp32
+        return self._conv(blk["c2"], p2, out, n, H, W, res=x)
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor) -> torch.Tensor:
+        """z [B, C, h, w] (the +-1 token map) -> [B, 3, H, W] bf16 (what ``Decoder.forward`` returns under bf16 autocast)."""
+        if not z.is_cuda:
+            raise BitDanceHipError("native decoder: CUDA/HIP tensors only (no CPU path)")
+        n, Cz, H, W = z.shape
+        tw = 32 if W % 32 == 0 else 16
+        if W % tw or H % (256 // tw):
+            raise BitDanceHipError(f"native decoder: latent grid {H}x{W} does not tile into 256-pixel blocks")
+        zf = z.to(torch.float32).contiguous()
+        p0 = self._padded("p.in", n, H, W, Cz)
+        check(lib().bd_tokens_to_padded(zf.data_ptr(), p0.data_ptr(), n, Cz, H, W, _st()), "bd_tokens_to_padded")
+        c = self.conv_in.cout
+        x = self._conv(self.conv_in, p0, self._get("s.in", (n, H, W, c), BF16), n, H, W)
+        for i, blk in enumerate(self.mid):
+            x = self._resblock(blk, x, n, H, W, f"mid{i & 1}")
+        for lv in reversed(range(self.nlev)):
+            L = self.levels[lv]
+            c = x.shape[-1]
+            # AdaptiveGroupNorm: scale / bias from the token statistics (tiny: torch), then scale * gn(x) + bias in fp32
+            ada = L["ada"]
+            with torch.autocast("cuda", dtype=BF16):
+                flat = zf.flatten(2)
+                scale = ada.gamma((flat.var(dim=-1) + ada.eps).sqrt())
+                bias = ada.beta(flat.mean(dim=-1))
+            st = self._stats(x, n, H, W, c, float(ada.eps))
+            x = self._apply(x, st, self._get(f"s.ada", (n, H, W, c), torch.float32), 1, False, n, H, W, c,
+                            scale=scale.float().contiguous(), bias=bias.float().contiguous())
+            for i, blk in enumerate(L["blocks"]):
+                x = self._resblock(blk, x, n, H, W, f"l{i & 1}")
+            if lv > 0:
+                c = x.shape[-1]
+                px = self._apply(x, None, self._padded("p.up", n, H, W, c), 0, False, n, H, W, c)
+                x = self._conv(L["up"], px, self._get("s.up", (n, 2 * H, 2 * W, c), BF16), n, H, W, mode=1)
+                H, W = 2 * H, 2 * W
+        c = x.shape[-1]
+        pn = self._norm_swish_pad(self.norm_out, x, "p.a", n, H, W, c)
+        img = torch.empty(n, self.conv_out.cout, H, W, dtype=torch.float32, device=self.device)
+        self._conv(self.conv_out, pn, img, n, H, W, mode=2)
+        return img.to(BF16)

@@ -392,7 +392,7 @@ int bdk_probe_read(const void* src, size_t bytes, int blocks, void* sink, hipStr
 int bdk_pack_w(void* dst, const void* src, const void* src2, int panels, int K, int nb0, int panels_total, int mode, hipStream_t st) {
     size_t PS, SS;
     bdk_w_strides(panels_total, K, &PS, &SS);
-    if (K % 64 || nb0 + panels > panels_total) return -2;
+    if (K % 16 || nb0 + panels > panels_total) return -2;          // whole k-steps; the GEMM / conv launchers check their own stage depth
     const size_t total = (size_t)panels * (K / 16) * 64;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     BD_LAUNCH(pack_w_kernel, dim3(blocks), dim3(256), 0, st, (u32x4*)dst, (const bf16_t*)src,

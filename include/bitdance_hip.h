@@ -132,6 +132,26 @@ int bd_comm_copy_out(bd_comm* c, void* dst, long long bytes, int from_result, vo
 int bd_gfq_indices(const float* z, int* idx, int ntok, int ncodebooks, int bits, void* stream);
 int bd_gfq_codes(const int* idx, float* codes, int ntok, int ncodebooks, int bits, void* stream);
 
+/* ---- conv decoder of the binary tokenizer (/root/reference/modeling/vision_encoder/autoencoder.py:129-277:
+ *      Decoder.forward = conv_in, ResBlocks (GroupNorm -> swish -> conv3x3, x2, + shortcut), AdaptiveGroupNorm, depth-to-space
+ *      upsamplers, norm_out -> swish -> conv_out).  Kernel-level entry points; the module that sequences them and carries the
+ *      checkpoint surface is bitdance_amd/ae_native.py.  Activations NHWC; a convolution input is bf16 with a one-pixel zero
+ *      border [n][H+2][W+2][C] ("padded").
+ *      bd_conv: 3x3 (taps 9, padded input) or 1x1 (taps 1, unpadded input) as an implicit GEMM on the matrix pipe; w_packed =
+ *      bd_pack_weight of the [Cout rounded up to 256][taps * Cin] matrix with K ordered (ky, kx, ci); conv output = bf16(acc + bias)
+ *      (F.conv2d under bf16 autocast), then out_mode 0: unpadded NHWC (+ residual fp32 / bf16 -> fp32 / bf16), 1: depth-to-space
+ *      (autoencoder.py:198-230, DCR) bf16 NHWC [n][2H][2W][Cout/4], 2: fp32 NCHW image, 3: padded bf16 NHWC. */
+int bd_conv(const void* in, const void* w_packed, const void* bias_bf16, const void* res, int res_f32, void* out, int out_mode, int out_f32,
+            int n, int H, int W, int Cin, int Cout, int taps, void* stream);
+/* GroupNorm(32) statistics (nn.GroupNorm(32, C, eps), autoencoder.py:9-11) of an unpadded NHWC tensor: stats [n][32][2] = (mean, rstd);
+ * `partial` = scratch [n][ceil(HW / 256)][32][2] fp32; deterministic (no atomics) */
+int bd_gn_stats(const void* x, int x_f32, float* partial, float* stats, int n, int HW, int C, float eps, void* stream);
+/* y = (x - mean) rstd [gamma, beta] [AdaptiveGroupNorm scale, bias per (image, channel): autoencoder.py:251-277] [swish], all fp32,
+ * out_mode 0: padded bf16 NHWC, 1: unpadded fp32, 2: unpadded bf16; stats == NULL: y = x (a cast / re-layout) */
+int bd_gn_apply(const void* x, int x_f32, const float* stats, const float* gamma, const float* beta, const float* scale, const float* bias,
+                void* out, int out_mode, int swish, int n, int H, int W, int C, void* stream);
+int bd_tokens_to_padded(const float* z_nchw, void* out_padded_bf16, int n, int C, int H, int W, void* stream);
+
 /* ---- measurement support (bench.py): in-situ HIP-event timing of every weight-streaming GEMM launch (eager mode) */
 int bd_prof_enable(bd_ctx* c, int on);
 int bd_prof_count(bd_ctx* c);

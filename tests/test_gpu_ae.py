@@ -1,0 +1,171 @@
+"""Native conv decoder (csrc/bd_conv.hip + bitdance_amd/ae_native.py) against torch's own operators on the same device, under the
+same bf16 autocast the pipeline decodes in: the convolution (3x3 / 1x1 implicit GEMM on the matrix pipe, every epilogue form), the
+GroupNorm statistics / apply kernels, and the whole ``Decoder.forward`` (/root/reference/modeling/vision_encoder/autoencoder.py:
+129-277) at the tiny test config and at the released ae_d16c32 dimensions.  The decoder module itself is pinned against the
+reference on CPU (tests/test_host_cpu.py::test_autoencoder_matches_reference); here the comparison is MIOpen vs the native
+kernels: same bf16 inputs, fp32 accumulation in another order -> bf16-level differences."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF16 = torch.bfloat16
+
+
+def _lib():
+    from bitdance_amd._lib import check, lib
+    return lib(), check
+
+
+def _pack_conv(w):
+    from bitdance_amd.ae_native import _Conv
+    conv = torch.nn.Conv2d(w.shape[1], w.shape[0], w.shape[2], bias=False)
+    conv.weight.data = w
+    return _Conv(conv, DEV)
+
+
+@pytest.mark.parametrize("n,H,W,cin,cout,k", [(1, 32, 32, 64, 256, 3), (2, 16, 16, 32, 96, 3), (1, 64, 32, 128, 512, 1), (1, 8, 64, 256, 40, 3)])
+def test_conv_vs_torch(n, H, W, cin, cout, k):
+    """bd_conv (out_mode 0, bf16 out, bias, bf16 and fp32 residuals) == F.conv2d on the same bf16 operands with fp32 accumulation."""
+    l, check = _lib()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(n, cin, H, W, device=DEV, generator=g).to(BF16)
+    w = (torch.randn(cout, cin, k, k, device=DEV, generator=g) / (cin * k * k) ** 0.5).to(BF16)
+    b = (torch.randn(cout, device=DEV, generator=g) * 0.1).to(BF16)
+    cv = _pack_conv(w.float())
+    st = torch.cuda.current_stream().cuda_stream
+    xh = x.permute(0, 2, 3, 1).contiguous()
+    if k == 3:
+        xin = torch.zeros(n, H + 2, W + 2, cin, dtype=BF16, device=DEV)
+        xin[:, 1:-1, 1:-1] = xh
+    else:
+        xin = xh
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=k // 2).to(BF16).float()          # fp32 accumulate, one rounding
+    for res_dtype in (None, BF16, torch.float32):
+        res = None if res_dtype is None else torch.randn(n, H, W, cout, device=DEV, generator=g).to(res_dtype)
+        out = torch.empty(n, H, W, cout, dtype=torch.float32 if res_dtype == torch.float32 else BF16, device=DEV)
+        check(l.bd_conv(xin.data_ptr(), cv.w.data_ptr(), b.data_ptr(), None if res is None else res.data_ptr(), int(res_dtype == torch.float32),
+                        out.data_ptr(), 0, int(out.dtype == torch.float32), n, H, W, cin, cout, k * k, st), "bd_conv")
+        want = ref.permute(0, 2, 3, 1)
+        if res is not None:
+            want = want + res.float()
+            if res_dtype == BF16:
+                want = want.to(BF16).float()
+        d = (out.float() - want).abs()
+        assert d.max().item() <= 0.05 and d.mean().item() <= 2e-3, (res_dtype, d.max().item(), d.mean().item())
+
+
+def test_conv_depth_to_space_padded_and_image_outputs():
+    """The other epilogues: depth-to-space (autoencoder.py:198-230, DCR: channel = (dy, dx, c)), padded bf16 output, fp32 NCHW image."""
+    from bitdance_amd.autoencoder import depth_to_space
+    l, check = _lib()
+    g = torch.Generator(device=DEV).manual_seed(6)
+    n, H, W, cin = 1, 16, 32, 64
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.randn(n, cin, H, W, device=DEV, generator=g).to(BF16)
+    xin = torch.zeros(n, H + 2, W + 2, cin, dtype=BF16, device=DEV)
+    xin[:, 1:-1, 1:-1] = x.permute(0, 2, 3, 1)
+    for cout, mode in ((256, 1), (64, 3), (3, 2)):
+        w = (torch.randn(cout, cin, 3, 3, device=DEV, generator=g) / (cin * 9) ** 0.5).to(BF16)
+        b = (torch.randn(cout, device=DEV, generator=g) * 0.1).to(BF16)
+        cv = _pack_conv(w.float())
+        ref = F.conv2d(x.float(), w.float(), b.float(), padding=1).to(BF16).float()
+        if mode == 1:
+            out = torch.zeros(n, 2 * H, 2 * W, cout // 4, dtype=BF16, device=DEV)
+            want = depth_to_space(ref, 2).permute(0, 2, 3, 1)
+        elif mode == 3:
+            out = torch.zeros(n, H + 2, W + 2, cout, dtype=BF16, device=DEV)
+            want = torch.zeros_like(out, dtype=torch.float32)
+            want[:, 1:-1, 1:-1] = ref.permute(0, 2, 3, 1)
+        else:
+            out = torch.zeros(n, cout, H, W, dtype=torch.float32, device=DEV)
+            want = ref
+        check(l.bd_conv(xin.data_ptr(), cv.w.data_ptr(), b.data_ptr(), None, 0, out.data_ptr(), mode, int(mode == 2), n, H, W, cin, cout, 9, st), "bd_conv")
+        d = (out.float() - want).abs()
+        assert d.max().item() <= 0.05 and d.mean().item() <= 2e-3, (mode, d.max().item(), d.mean().item())
+
+
+@pytest.mark.parametrize("C,H,W,f32", [(256, 32, 32, True), (64, 16, 48, False), (1024, 8, 8, True), (32, 16, 16, False)])
+def test_group_norm_stats_and_apply_vs_torch(C, H, W, f32):
+    """GroupNorm(32) in fp32 on an NHWC tensor + affine + swish, written as the next convolution's padded bf16 input; the
+    AdaptiveGroupNorm form (no affine, per-image scale / bias, fp32 out); the statistics are deterministic."""
+    l, check = _lib()
+    g = torch.Generator(device=DEV).manual_seed(7)
+    n = 2
+    st = torch.cuda.current_stream().cuda_stream
+    x = (torch.randn(n, H, W, C, device=DEV, generator=g) * 2 + 0.5).to(torch.float32 if f32 else BF16)
+    gamma = torch.randn(C, device=DEV, generator=g)
+    beta = torch.randn(C, device=DEV, generator=g)
+    chunks = (H * W + 255) // 256
+    part = torch.empty(n, chunks, 32, 2, device=DEV)
+    stats = torch.empty(n, 32, 2, device=DEV)
+    check(l.bd_gn_stats(x.data_ptr(), int(f32), part.data_ptr(), stats.data_ptr(), n, H * W, C, 1e-6, st), "bd_gn_stats")
+    s2 = torch.empty_like(stats)
+    check(l.bd_gn_stats(x.data_ptr(), int(f32), part.data_ptr(), s2.data_ptr(), n, H * W, C, 1e-6, st), "bd_gn_stats")
+    assert torch.equal(stats, s2)
+    xc = x.float().permute(0, 3, 1, 2)
+    y = F.group_norm(xc, 32, gamma, beta, 1e-6)
+    want = (y * torch.sigmoid(y)).permute(0, 2, 3, 1)
+    out = torch.zeros(n, H + 2, W + 2, C, dtype=BF16, device=DEV)
+    check(l.bd_gn_apply(x.data_ptr(), int(f32), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, None, out.data_ptr(), 0, 1, n, H, W, C, st))
+    d = (out[:, 1:-1, 1:-1].float() - want).abs()
+    assert d.max().item() <= 0.05 and d.mean().item() <= 4e-3, (d.max().item(), d.mean().item())
+    assert out[:, 0].abs().max().item() == 0 and out[:, :, 0].abs().max().item() == 0          # the zero border is untouched
+    scale, bias = torch.randn(n, C, device=DEV, generator=g), torch.randn(n, C, device=DEV, generator=g)
+    want2 = (scale[:, :, None, None] * F.group_norm(xc, 32, None, None, 1e-6) + bias[:, :, None, None]).permute(0, 2, 3, 1)
+    out2 = torch.empty(n, H, W, C, device=DEV)
+    check(l.bd_gn_apply(x.data_ptr(), int(f32), stats.data_ptr(), None, None, scale.data_ptr(), bias.data_ptr(), out2.data_ptr(), 1, 0, n, H, W, C, st))
+    assert (out2 - want2).abs().max().item() <= 2e-3 * max(1.0, want2.abs().max().item())
+
+
+def _decoders(cfg, seed):
+    from bitdance_amd.ae_native import NativeDecoder
+    from bitdance_amd.autoencoder import VQModel
+    from oracle import tiny_models as tm
+    ae = VQModel(**cfg).eval()
+    shapes = {k: tuple(v.shape) for k, v in ae.state_dict().items()}
+    ae.load_state_dict(tm.seeded_state(shapes, seed=seed, gain=1.4))
+    ae = ae.to(DEV)
+    return ae, NativeDecoder(ae.decoder, DEV)
+
+
+def test_native_decoder_tiny_vs_torch():
+    """Whole Decoder.forward at the tiny test config (channels 32 .. 128: partial 256-channel tiles, 16-pixel-wide maps)."""
+    from oracle import tiny_models as tm
+    ae, nat = _decoders(tm.TINY_AE, 44)
+    z = torch.sign(torch.randn(2, 32, 16, 16, generator=torch.Generator().manual_seed(1))).to(DEV)
+    with torch.no_grad(), torch.autocast("cuda", dtype=BF16):
+        ref = ae.decoder(z).float()
+    got = nat.decode(z).float()
+    assert got.shape == ref.shape == (2, 3, 256, 256)
+    d = (got - ref).abs()
+    scale = ref.abs().mean().item()
+    print(f"[ae tiny] max {d.max().item():.4f} mean {d.mean().item():.5f} (ref mean |x| {scale:.3f})")
+    assert d.mean().item() <= 0.02 * scale + 2e-3 and d.max().item() <= 0.25 * max(1.0, ref.abs().max().item())
+    assert torch.equal(nat.decode(z), nat.decode(z))                       # deterministic (no atomics anywhere)
+
+
+def test_native_decoder_released_dims_vs_torch():
+    """ae_d16c32 (train/configs/bitdance_14b_64x.yaml:9-16: z 32, ch 256, ch_mult [1,1,2,2,4], 4 res-blocks) on a 256 x 256 image:
+    every convolution shape of the released decoder at its real channel counts, both fp32- and bf16-stream blocks."""
+    from bitdance_amd import synthetic as syn
+    from bitdance_amd.ae_native import NativeDecoder
+    from bitdance_amd.autoencoder import VQModel
+    ae = VQModel(**syn.AE_D16C32).eval()
+    ae.load_state_dict(syn.random_ae_state(syn.AE_D16C32, DEV), strict=True, assign=True)
+    ae.to(DEV)
+    nat = NativeDecoder(ae.decoder, DEV)
+    z = torch.sign(torch.randn(1, 32, 16, 16, generator=torch.Generator().manual_seed(2))).to(DEV)
+    prev = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = True
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=BF16):
+            ref = ae.decoder(z).float()
+    finally:
+        torch.backends.cudnn.benchmark = prev
+    got = nat.decode(z).float()
+    d = (got - ref).abs()
+    scale = ref.abs().mean().item()
+    print(f"[ae d16c32 256px] max {d.max().item():.4f} mean {d.mean().item():.5f} (ref mean |x| {scale:.3f})")
+    assert torch.isfinite(got).all() and d.mean().item() <= 0.03 * scale + 2e-3
