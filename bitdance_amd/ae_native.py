@@ -132,9 +132,6 @@ class NativeDecoder:
         if not z.is_cuda:
             raise BitDanceHipError("native decoder: CUDA/HIP tensors only (no CPU path)")
         n, Cz, H, W = z.shape
-        tw = 32 if W % 32 == 0 else 16
-        if W % tw or H % (256 // tw):
-            raise BitDanceHipError(f"native decoder: latent grid {H}x{W} does not tile into 256-pixel blocks")
         zf = z.to(torch.float32).contiguous()
         p0 = self._padded("p.in", n, H, W, Cz)
         check(lib().bd_tokens_to_padded(zf.data_ptr(), p0.data_ptr(), n, Cz, H, W, _st()), "bd_tokens_to_padded")

@@ -1,5 +1,7 @@
-"""Binary tokenizer (conv autoencoder + sign quantiser), kept on MIOpen/rocBLAS through torch.nn as the north star
-asks.  Module/parameter names mirror the reference checkpoint
+"""Binary tokenizer (conv autoencoder + sign quantiser).  The torch modules below carry the checkpoint surface (and run the
+encoder, and the decoder on CPU / behind ``native_decoder = False``, on MIOpen / rocBLAS through torch.nn); on a GPU
+``VQModel.decode`` runs the DECODER on the hand-written gfx950 kernels (ae_native.py / csrc/bd_conv.hip, SURVEY.md section 8f
+row 2).  Module/parameter names mirror the reference checkpoint
 (``ae.safetensors``: ``encoder.*`` / ``decoder.*``, modeling/vision_encoder/autoencoder.py) so that
 ``load_state_dict(strict=True)`` works on the released files; the implementation itself is written against the
 checkpoint layout, not copied.
@@ -170,6 +172,10 @@ class VQModel(nn.Module):
             raise NotImplementedError("gan_decoder=True tokenizers are outside the T2I hot path")
         self.encoder = Encoder(**ddconfig)
         self.decoder = Decoder(**ddconfig)
+        # GPU decode on the native kernels (False: torch / MIOpen, the cross-check path).  Built on first use: the weights have to
+        # be loaded first.  The native path implements the bf16-autocast flow the pipelines decode under.
+        self.native_decoder = True
+        self._native = None
 
     def encode(self, x):
         h = self.encoder(x)
@@ -177,7 +183,16 @@ class VQModel(nn.Module):
         return torch.where(h > 0, one, -one)
 
     def decode(self, quant):
+        if self.native_decoder and quant.is_cuda and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+            if self._native is None or self._native.device != quant.device:
+                from .ae_native import NativeDecoder
+                self._native = NativeDecoder(self.decoder, quant.device)
+            return self._native.decode(quant)
         return self.decoder(quant)
+
+    def load_state_dict(self, *a, **k):
+        self._native = None                                   # packed copies of the old weights
+        return super().load_state_dict(*a, **k)
 
     def forward(self, x):
         q = self.encode(x)

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(512) void conv_tile_kernel(ConvP p) {
     // ---- tile: blockIdx.x -> (pixel tile, channel tile); pixel tiles fastest within groups of 8 so that the workgroups that share a
     //      weight tile are dispatched together (weights from L2), and neighbouring pixel tiles share their halo rows
     const int TW = p.TW, TH = 256 / TW;
-    const int tiles_x = p.W / TW, tiles_y = p.H / TH, tiles_img = tiles_x * tiles_y;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH, tiles_img = tiles_x * tiles_y;   // edge tiles may be partial
     const int MT = p.n * tiles_img, NT = (p.Cout + 255) >> 8;
     const int b = blockIdx.x;
     const int grp = b / (8 * NT), rem = b - grp * 8 * NT;        // groups of 8 pixel tiles x all channel tiles
@@ -80,7 +80,8 @@ __global__ __launch_bounds__(512) void conv_tile_kernel(ConvP p) {
         for (int j = 0; j < 4; ++j) {
             const int c = wave * 4 + j, ks = c >> 3, rb = c & 7;
             const int pix = rb * 32 + (lane & 31), ty = pix / TW, tx = pix - ty * TW;
-            src[j] = reinterpret_cast<const char*>(p.in + (((size_t)img * Hp + y0 + ty) * Wp + x0 + tx) * p.Cin + ks * 16 + (lane >> 5) * 8);
+            const int yy = min(y0 + ty, p.H - 1), xx = min(x0 + tx, p.W - 1);      // pixels past the edge of a partial tile: re-read the edge
+            src[j] = reinterpret_cast<const char*>(p.in + (((size_t)img * Hp + yy) * Wp + xx) * p.Cin + ks * 16 + (lane >> 5) * 8);
             dst[j] = (unsigned)c * 1024u;
         }
     } else {
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(512) void conv_tile_kernel(ConvP p) {
         const int lp = it * 8 + (lane >> 3);                    // pixel of this wave's 128
         const int pix = wr * 128 + lp, ty = pix / TW, tx = pix - ty * TW;
         const int y = y0 + ty, x = x0 + tx;
+        if (y >= p.H || x >= p.W) continue;                     // partial edge tile
         const u32x4 q = rd[lp * 8 + seg];
         float v[8];
 #pragma unroll
@@ -395,19 +397,28 @@ static int bd_last_error_set(const char* m) { bdk_set_error(m); return -1; }
 extern "C" {
 
 /* 3x3 (taps = 9, `in` padded) or 1x1 (taps = 1, `in` unpadded) convolution; w = bd_pack_weight of [Cout padded to 256][taps * Cin]
- * with K ordered (ky, kx, ci).  H * W tiles of 256 pixels: W % TW == 0 and H % (256 / TW) == 0 with TW = 32 (or 16 when W == 16). */
+ * with K ordered (ky, kx, ci).  The image is covered by 256-pixel tiles of (256 / TW) rows x TW columns, TW in {32, 16, 8} chosen for
+ * the least padding (the released sizes have latent grids of any multiple of 8: 16 .. 128); edge tiles may be partial. */
 int bd_conv(const void* in, const void* w_packed, const void* bias, const void* res, int res_f32, void* out, int out_mode, int out_f32,
             int n, int H, int W, int Cin, int Cout, int taps, void* stream) {
-    const int TW = (W % 32 == 0) ? 32 : 16;
-    if ((taps != 9 && taps != 1) || Cin % 32 || (Cout % 8 && out_mode != 2) || W % TW || H % (256 / TW) || out_mode < 0 || out_mode > 3 ||
+    int TW = 32;
+    {
+        long long best = -1;
+        for (int tw : {32, 16, 8}) {
+            const int th = 256 / tw;
+            const long long area = (long long)((W + tw - 1) / tw) * tw * ((H + th - 1) / th) * th;
+            if (best < 0 || area < best) { best = area; TW = tw; }
+        }
+    }
+    if ((taps != 9 && taps != 1) || Cin % 32 || (Cout % 8 && out_mode != 2) || H < 1 || W < 1 || out_mode < 0 || out_mode > 3 ||
         (out_mode == 1 && (Cout % 4 || (Cout / 4) % 8)))
-        return bd_last_error_set("bd_conv: taps 9 / 1, Cin % 32, Cout % 8, pixel tiles of 256 = (256 / TW) x TW with TW = 32 or 16");
+        return bd_last_error_set("bd_conv: taps 9 / 1, Cin % 32, Cout % 8 (any Cout for the image output), depth-to-space needs Cout / 4 % 8 == 0");
     ConvP p;
     p.in = (const bf16_t*)in; p.Wt = (const u32x4*)w_packed; p.bias = (const bf16_t*)bias; p.res = res; p.out = out;
     p.n = n; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.taps = taps; p.TW = TW;
     p.res_f32 = res_f32; p.out_f32 = out_f32; p.out_mode = out_mode;
     p.PS = (size_t)((taps * Cin) >> 4) * 64;
-    const int MT = n * (H / (256 / TW)) * (W / TW), NT = (Cout + 255) / 256;
+    const int MT = n * ((H + 256 / TW - 1) / (256 / TW)) * ((W + TW - 1) / TW), NT = (Cout + 255) / 256;
     const int blocks = ((MT + 7) / 8) * 8 * NT;
     constexpr int lds = CV_SLOTS * CV_STAGE_UNITS * 16;
     static unsigned long long optin = 0;

@@ -25,7 +25,8 @@ def _pack_conv(w):
     return _Conv(conv, DEV)
 
 
-@pytest.mark.parametrize("n,H,W,cin,cout,k", [(1, 32, 32, 64, 256, 3), (2, 16, 16, 32, 96, 3), (1, 64, 32, 128, 512, 1), (1, 8, 64, 256, 40, 3)])
+@pytest.mark.parametrize("n,H,W,cin,cout,k", [(1, 32, 32, 64, 256, 3), (2, 16, 16, 32, 96, 3), (1, 64, 32, 128, 512, 1), (1, 8, 64, 256, 40, 3),
+                                             (1, 40, 24, 64, 256, 3), (2, 24, 56, 32, 64, 3)])
 def test_conv_vs_torch(n, H, W, cin, cout, k):
     """bd_conv (out_mode 0, bf16 out, bias, bf16 and fp32 residuals) == F.conv2d on the same bf16 operands with fp32 accumulation."""
     l, check = _lib()
@@ -130,20 +131,29 @@ def _decoders(cfg, seed):
     return ae, NativeDecoder(ae.decoder, DEV)
 
 
-def test_native_decoder_tiny_vs_torch():
-    """Whole Decoder.forward at the tiny test config (channels 32 .. 128: partial 256-channel tiles, 16-pixel-wide maps)."""
+@pytest.mark.parametrize("gh,gw", [(16, 16), (24, 40), (8, 56)])
+def test_native_decoder_tiny_vs_torch(gh, gw):
+    """Whole Decoder.forward at the tiny test config (channels 32 .. 128: partial 256-channel tiles, narrow maps), square and the
+    aspect-ratio grids of IMAGE_SIZE_LIST (t2i_pipeline.py:27-31: any multiple of 8 per side -> partial pixel tiles)."""
     from oracle import tiny_models as tm
     ae, nat = _decoders(tm.TINY_AE, 44)
-    z = torch.sign(torch.randn(2, 32, 16, 16, generator=torch.Generator().manual_seed(1))).to(DEV)
+    z = torch.sign(torch.randn(2, 32, gh, gw, generator=torch.Generator().manual_seed(1))).to(DEV)
     with torch.no_grad(), torch.autocast("cuda", dtype=BF16):
         ref = ae.decoder(z).float()
     got = nat.decode(z).float()
-    assert got.shape == ref.shape == (2, 3, 256, 256)
+    assert got.shape == ref.shape == (2, 3, 16 * gh, 16 * gw)
     d = (got - ref).abs()
     scale = ref.abs().mean().item()
     print(f"[ae tiny] max {d.max().item():.4f} mean {d.mean().item():.5f} (ref mean |x| {scale:.3f})")
     assert d.mean().item() <= 0.02 * scale + 2e-3 and d.max().item() <= 0.25 * max(1.0, ref.abs().max().item())
     assert torch.equal(nat.decode(z), nat.decode(z))                       # deterministic (no atomics anywhere)
+    with torch.no_grad(), torch.autocast("cuda", dtype=BF16):              # the module's own decode() takes the native path on a GPU
+        via = ae.decode(z)
+    assert torch.equal(via, nat.decode(z))
+    ae.native_decoder = False
+    with torch.no_grad(), torch.autocast("cuda", dtype=BF16):
+        alt = ae.decode(z).float()                                         # torch / MIOpen again (solver choice may differ call to call)
+    assert (alt - ref).abs().mean().item() <= 5e-3 * max(1.0, scale)
 
 
 def test_native_decoder_released_dims_vs_torch():
