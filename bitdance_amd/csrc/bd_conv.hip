@@ -310,21 +310,30 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnStatsP p) {
 }
 
 struct GnFinalP { const float* partial; float* stats; int n, HW, C, chunks; float eps; };
-__global__ void gn_finalize_kernel(GnFinalP p) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;         // (image, group)
-    if (i >= p.n * 32) return;
-    const int img = i >> 5, g = i & 31;
+// one workgroup per (image, group): thread t adds chunks t, t + 256, ... in double, then a fixed-shape tree over the 256 threads
+__global__ __launch_bounds__(256) void gn_finalize_kernel(GnFinalP p) {
+    __shared__ double r1[256], r2[256];
+    const int i = blockIdx.x, img = i >> 5, g = i & 31, tid = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int c = 0; c < p.chunks; ++c) {
-        s1 += (double)p.partial[(((size_t)img * p.chunks + c) * 32 + g) * 2];
-        s2 += (double)p.partial[(((size_t)img * p.chunks + c) * 32 + g) * 2 + 1];
+    for (int c = tid; c < p.chunks; c += 256) {
+        const float* q = p.partial + (((size_t)img * p.chunks + c) * 32 + g) * 2;
+        s1 += (double)q[0];
+        s2 += (double)q[1];
     }
-    const double cnt = (double)p.HW * (p.C >> 5);
-    const double mean = s1 / cnt;
-    double var = s2 / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    p.stats[i * 2] = (float)mean;
-    p.stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    r1[tid] = s1; r2[tid] = s2;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (tid < h) { r1[tid] += r1[tid + h]; r2[tid] += r2[tid + h]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double cnt = (double)p.HW * (p.C >> 5);
+        const double mean = r1[0] / cnt;
+        double var = r2[0] / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        p.stats[i * 2] = (float)mean;
+        p.stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
 }
 
 // y = (x - mean) * rstd [* gamma[c] + beta[c]] [then scale[n][c] * y + bias[n][c]] [then y * sigmoid(y)]
@@ -337,45 +346,55 @@ struct GnApplyP {
     void* out; int out_mode; int swish;
     int n, H, W, C;
 };
+// one workgroup per image row; a thread keeps ONE channel octet (C / 8 divides 256 or is a multiple of it), so its affine
+// parameters, group statistics and AdaGN scale / bias are loaded once, and all index math is 32-bit shifts
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyP p) {
     const int C8 = p.C >> 3, cpg = p.C >> 5;
-    const size_t total = (size_t)p.n * p.H * p.W * C8;
-    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (size_t)gridDim.x * 256) {
-        const int oct = (int)(u % C8);
-        const size_t pxl = u / C8;
-        const int x = (int)(pxl % p.W), y = (int)((pxl / p.W) % p.H), img = (int)(pxl / ((size_t)p.W * p.H));
-        const size_t o = pxl * p.C + oct * 8;
-        float v[8];
-        if (p.x_f32) {
-            const f32x4 r0 = *reinterpret_cast<const f32x4*>((const float*)p.x + o), r1 = *reinterpret_cast<const f32x4*>((const float*)p.x + o + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v[j] = r0[j]; v[4 + j] = r1[j]; }
-        } else {
-            const u32x4 q = *reinterpret_cast<const u32x4*>((const bf16_t*)p.x + o);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v[2 * j] = bf2f((bf16_t)(q[j] & 0xffff)); v[2 * j + 1] = bf2f((bf16_t)(q[j] >> 16)); }
-        }
+    const int row = blockIdx.x, img = row / p.H, y = row - img * p.H;
+    const int tid = threadIdx.x;
+    for (int oct0 = tid % C8; oct0 < C8; oct0 += 256) {          // one pass unless C8 > 256
+        float ga[8], be[8], mu[8], rs[8], sc[8], bi[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = oct * 8 + j;
-            float t = v[j];
-            if (p.stats) {
-                const float* st = p.stats + ((size_t)img * 32 + c / cpg) * 2;
-                t = (t - st[0]) * st[1];
-            }
-            if (p.gamma) t = t * p.gamma[c] + p.beta[c];
-            if (p.scale) t = p.scale[(size_t)img * p.C + c] * t + p.bias[(size_t)img * p.C + c];
-            if (p.swish) t = t * (1.0f / (1.0f + expf(-t)));
-            v[j] = t;
+            const int c = oct0 * 8 + j;
+            ga[j] = p.gamma ? p.gamma[c] : 1.f;
+            be[j] = p.beta ? p.beta[c] : 0.f;
+            if (p.stats) { const float* st = p.stats + ((size_t)img * 32 + c / cpg) * 2; mu[j] = st[0]; rs[j] = st[1]; }
+            else { mu[j] = 0.f; rs[j] = 1.f; }
+            sc[j] = p.scale ? p.scale[(size_t)img * p.C + c] : 1.f;
+            bi[j] = p.bias ? p.bias[(size_t)img * p.C + c] : 0.f;
         }
-        if (p.out_mode == 0) {
-            const size_t po = (((size_t)img * (p.H + 2) + y + 1) * (p.W + 2) + x + 1) * p.C + oct * 8;
-            *reinterpret_cast<u32x4*>((bf16_t*)p.out + po) = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
-        } else if (p.out_mode == 1) {
-            *reinterpret_cast<f32x4*>((float*)p.out + o) = (f32x4){v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>((float*)p.out + o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-        } else {
-            *reinterpret_cast<u32x4*>((bf16_t*)p.out + o) = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+        // units with this octet: v = x * C8 + oct0, visited by this thread for x = x_first, x_first + 256 / C8 (or every x when C8 >= 256)
+        const int xstep = C8 >= 256 ? 1 : 256 / C8, xfirst = C8 >= 256 ? 0 : tid / C8;
+        for (int x = xfirst; x < p.W; x += xstep) {
+            const size_t o = (((size_t)img * p.H + y) * p.W + x) * p.C + oct0 * 8;
+            float v[8];
+            if (p.x_f32) {
+                const f32x4 r0 = *reinterpret_cast<const f32x4*>((const float*)p.x + o), r1 = *reinterpret_cast<const f32x4*>((const float*)p.x + o + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = r0[j]; v[4 + j] = r1[j]; }
+            } else {
+                const u32x4 q = *reinterpret_cast<const u32x4*>((const bf16_t*)p.x + o);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[2 * j] = bf2f((bf16_t)(q[j] & 0xffff)); v[2 * j + 1] = bf2f((bf16_t)(q[j] >> 16)); }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = (v[j] - mu[j]) * rs[j];
+                if (p.gamma) t = t * ga[j] + be[j];
+                if (p.scale) t = sc[j] * t + bi[j];
+                if (p.swish) t = t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * t));
+                v[j] = t;
+            }
+            if (p.out_mode == 0) {
+                const size_t po = (((size_t)img * (p.H + 2) + y + 1) * (p.W + 2) + x + 1) * p.C + oct0 * 8;
+                *reinterpret_cast<u32x4*>((bf16_t*)p.out + po) = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+            } else if (p.out_mode == 1) {
+                *reinterpret_cast<f32x4*>((float*)p.out + o) = (f32x4){v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>((float*)p.out + o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+            } else {
+                *reinterpret_cast<u32x4*>((bf16_t*)p.out + o) = (u32x4){pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+            }
         }
     }
 }
@@ -433,7 +452,7 @@ int bd_gn_stats(const void* x, int x_f32, float* partial, float* stats, int n, i
     GnStatsP p{x, x_f32, partial, n, HW, C, (HW + 255) / 256};
     BD_LAUNCH(gn_stats_kernel, dim3(p.chunks, n), dim3(256), 0, (hipStream_t)stream, p);
     GnFinalP f{partial, stats, n, HW, C, p.chunks, eps};
-    BD_LAUNCH(gn_finalize_kernel, dim3((n * 32 + 63) / 64), dim3(64), 0, (hipStream_t)stream, f);
+    BD_LAUNCH(gn_finalize_kernel, dim3(n * 32), dim3(256), 0, (hipStream_t)stream, f);
     return bd_launch_status() == 0 ? 0 : bd_last_error_set("bd_gn_stats: launch failed");
 }
 
@@ -441,9 +460,8 @@ int bd_gn_apply(const void* x, int x_f32, const float* stats, const float* gamma
                 void* out, int out_mode, int swish, int n, int H, int W, int C, void* stream) {
     if (C % 32) return bd_last_error_set("bd_gn_apply: C % 32");
     GnApplyP p{x, x_f32, stats, gamma, beta, scale, bias, out, out_mode, swish, n, H, W, C};
-    const size_t total = (size_t)n * H * W * (C / 8);
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    BD_LAUNCH(gn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    if ((C / 8) < 256 ? (256 % (C / 8)) != 0 : ((C / 8) % 256) != 0) return bd_last_error_set("bd_gn_apply: C / 8 must divide, or be a multiple of, 256");
+    BD_LAUNCH(gn_apply_kernel, dim3(n * H), dim3(256), 0, (hipStream_t)stream, p);
     return bd_launch_status() == 0 ? 0 : bd_last_error_set("bd_gn_apply: launch failed");
 }
 

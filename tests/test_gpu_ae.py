@@ -153,7 +153,8 @@ def test_native_decoder_tiny_vs_torch(gh, gw):
     ae.native_decoder = False
     with torch.no_grad(), torch.autocast("cuda", dtype=BF16):
         alt = ae.decode(z).float()                                         # torch / MIOpen again (solver choice may differ call to call)
-    assert (alt - ref).abs().mean().item() <= 5e-3 * max(1.0, scale)
+    # (MIOpen against itself, another solver pick: ~0.006 mean on this model -- the same order as native vs MIOpen, 0.009)
+    assert (alt - ref).abs().mean().item() <= 2e-2 * max(1.0, scale)
 
 
 def test_native_decoder_released_dims_vs_torch():
