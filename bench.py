@@ -52,6 +52,10 @@ WORKLOADS = {
     "imagenet-b1x": (None, 256, 256, "images/sec @256px ImageNet BitDance-B-1x"),
     "imagenet-l1x": (None, 256, 256, "images/sec @256px ImageNet BitDance-L-1x"),
     "imagenet-h1x": (None, 256, 256, "images/sec @256px ImageNet BitDance-H-1x"),
+    # the tokenizer's conv decoder alone on a random +-1 latent (config 5's ae_d32c256 decoder cannot be fed by a 14B
+    # checkpoint with a 32-channel head, so it is benchmarked standalone; ae-d16c32 = the decoder the headline pipeline ends in)
+    "ae-d32c256-decode": (None, 1024, 1024, "images/sec @1024px ae_d32c256 decoder (standalone)"),
+    "ae-d16c32-decode": (None, 1024, 1024, "images/sec @1024px ae_d16c32 decoder (standalone)"),
 }
 # README defaults of the reference's sampler per checkpoint: (classes per call, CFG scale)   imagenet_gen/README.md:27-80
 IMAGENET_DEFAULTS = {"b16x": (384, 6.1), "b4x": (384, 3.9), "b1x": (384, 3.2), "l1x": (352, 4.0), "h1x": (224, 4.55)}
@@ -297,6 +301,8 @@ def main():
     size, H0, W0, metric = WORKLOADS[args.workload]
     if args.workload.startswith("imagenet-"):
         return bench_imagenet(args, dist, world, rank, dev, metric, barrier, max_over_ranks, rank_seed)
+    if args.workload.startswith("ae-"):
+        return bench_ae_decode(args, dist, world, rank, dev, metric, barrier, max_over_ranks)
 
     # ---------------------------------------------------------------- T2I workloads
     H, W = args.height or H0, args.width or W0
@@ -470,6 +476,74 @@ def bench_imagenet(args, dist, world, rank, dev, metric, barrier, max_over_ranks
         if world == 1 and not args.no_cpu_baseline and variant == "b16x":
             out["cpu_baseline"] = cpu_baseline_imagenet(n_sampling + 1, ar_steps)
         print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_ae_decode(args, dist, world, rank, dev, metric, barrier, max_over_ranks):
+    """Standalone conv decoder (VQModel.decode, modeling/vision_encoder/autoencoder.py:129-196,514-516): a step = one decode of
+    ``--num-images`` (default 1) random +-1 latents to ``--height`` x ``--width`` (default 1024 x 1024) on the native kernels
+    (csrc/bd_conv.hip); N > 1 = replicas.  roofline = the convolution kernel (MFMA-bound): algorithmic FLOPs of every
+    convolution of the decode / the HIP-event time of the whole decode (GroupNorm passes included: a lower bound for the kernel)."""
+    from bitdance_amd import synthetic as syn
+    from bitdance_amd.autoencoder import VQModel
+    cfg = syn.AE_D32C256 if args.workload.startswith("ae-d32c256") else syn.AE_D16C32
+    patch = 2 ** (len(cfg["ddconfig"]["ch_mult"]) - 1)
+    H, W = args.height or 1024, args.width or 1024
+    n_img = args.num_images or 1
+    ae = VQModel(**cfg).eval()
+    ae.load_state_dict(syn.random_ae_state(cfg, dev), strict=True, assign=True)
+    ae.to(dev)
+    g = torch.Generator(device=dev).manual_seed(1 + rank)
+    z = torch.sign(torch.randn(n_img, cfg["ddconfig"]["z_channels"], H // patch, W // patch, device=dev, generator=g))
+
+    def one_pass():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return ae.decode(z)
+
+    for _ in range(max(1, args.warmup)):
+        out = one_pass()
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        out = one_pass()
+    e1.record()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, dist, "cpu" if (dist is not None and dist.get_backend() == "gloo") else dev)
+    assert torch.isfinite(out.float()).all() and out.shape == (n_img, 3, H, W)
+    if rank == 0:
+        # algorithmic FLOPs of the decoder's convolutions (2 * pixels * taps * Cin * Cout each), from the module itself
+        flops = 0
+        dec = ae.decoder
+        hh, ww = H // patch, W // patch
+        def conv_fl(c, h_, w_):
+            return 2.0 * h_ * w_ * c.kernel_size[0] * c.kernel_size[1] * c.in_channels * c.out_channels
+        flops += conv_fl(dec.conv_in, hh, ww)
+        for b in dec.mid_block:
+            flops += conv_fl(b.conv1, hh, ww) + conv_fl(b.conv2, hh, ww)
+        for lv in reversed(range(dec.nlev)):
+            for b in dec.up[lv].block:
+                flops += conv_fl(b.conv1, hh, ww) + conv_fl(b.conv2, hh, ww) + (conv_fl(b.nin_shortcut, hh, ww) if b.cin != b.cout else 0)
+            if lv > 0:
+                flops += conv_fl(dec.up[lv].upsample.conv1, hh, ww)
+                hh, ww = 2 * hh, 2 * ww
+        flops += conv_fl(dec.conv_out, hh, ww)
+        flops *= n_img
+        ms = e0.elapsed_time(e1) / args.steps
+        ach = flops / (ms * 1e-3) / 1e12
+        out_j = {"metric": metric, "value": round(world * n_img * args.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+                 "warmup": max(1, args.warmup), "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+                 "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random weights at the decoder's shapes, random +-1 latent)",
+                 "config": {"workload": f"{args.workload}: VQModel.decode of {n_img} x [{cfg['ddconfig']['z_channels']},{H // patch},{W // patch}] -> {H}x{W}, "
+                                        f"ch_mult {cfg['ddconfig']['ch_mult']}, native gfx950 kernels",
+                            "parallelism": f"replicas x{world}" if world > 1 else "single GPU"},
+                 "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFS, 4),
+                              "traffic": None, "kernel": "conv_tile_kernel (bd_conv.hip): convolution FLOPs of one decode / HIP-event time of the whole "
+                              "decode (GroupNorm passes included)", "flop_per_decode": int(flops), "decode_ms": round(ms, 2)}}
+        print(json.dumps(out_j), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -52,6 +52,7 @@ _PROTOS = {
     "bd_ctx_ws_bytes": (C.c_longlong, [C.c_void_p, C.c_int]),
     "bd_ctx_bind": (C.c_int, [C.c_void_p]),
     "bd_head_set_schedule": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_float]),
+    "bd_head_set_cfg": (C.c_int, [C.c_void_p, C.c_float]),
     "bd_head_sample": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bd_head_cond": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bd_head_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

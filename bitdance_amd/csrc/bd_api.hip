@@ -51,6 +51,7 @@ struct bd_ctx {
 
     // derived
     int B = 1, branches = 2, Pn = 64, BP = 64, M = 128, RB = 4, RBp = 2, Mpad = 128, BPpad = 64;
+    int prows = 64;                       // rows the projector runs over: BP, or M with "proj.rows_all" (imagenet: every CFG branch's tokens)
     int hD = 0, hC = 0, hDz = 0, hH = 0, hNB = 0, hNA = 0, hNada = 0, hT = 0;
     int hMlp = 0;                         // "head.variant" = 1: MLP head of the 1x ImageNet models (imagenet_gen/src/diff_head.py), no attention
     int lD = 0, lL = 0, lnh = 0, lnkv = 0, lF = 0, lLmax = 0, lsplits = 8, lNqkv = 0;
@@ -176,7 +177,7 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
 
 static const char* const kIntKeys[] = {
     "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid", "head.y_evals", "head.variant",
-    "proj.D", "proj.C", "proj.hid", "proj.variant", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
+    "proj.D", "proj.C", "proj.hid", "proj.variant", "proj.rows_all", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
     "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async", "tune.ragged", "tune.ragged52", "tune.slab_cap",
     "tune.ada_group", "tune.pf_blocks", "tune.pf_kb"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
@@ -192,7 +193,7 @@ static bool known_int_key(const std::string& k) {
 }
 static const char* const kPtrKeys[] = {
     "head.cond_w", "head.cond_b", "head.in_w", "head.in_b", "head.ada_w", "head.ada_b", "head.lin_w", "head.lin_b", "head.temb",
-    "head.noise", "head.tok_all", "head.y_all", "proj.w1", "proj.b1", "proj.w2", "proj.b2", "llm.final_norm", "llm.emb_norm", "llm.rope2d",
+    "head.noise", "head.tok_all", "head.y_all", "head.cfg_table", "proj.w1", "proj.b1", "proj.w2", "proj.b2", "llm.final_norm", "llm.emb_norm", "llm.rope2d",
     "llm.cos", "llm.sin", "pos",
     // workspaces (the caller allocates them after bd_ctx_finalize; a head-/projector-only context may borrow another's)
     "state", "gemm.cnt", "head.cond_frag", "head.cond_part", "head.xt", "head.y_frag", "head.X", "head.ada_bf", "head.cemb",
@@ -356,6 +357,10 @@ int bd_ctx_finalize(bd_ctx* c) {
         c->BPpad = pad_rows(c->BP);
         c->RB = c->Mpad / 32;
         c->RBp = c->BPpad / 32;
+        c->prows = c->BP;
+        if (c->geti("proj.rows_all", 0)) {                 // the projector feeds all branches * B sequences from their own token rows
+            c->prows = c->M; c->BPpad = c->Mpad; c->RBp = c->RB;
+        }
         c->has_head = c->I.count("head.D") > 0;
         c->has_llm = c->I.count("llm.D") > 0;
         c->has_proj = c->I.count("proj.D") > 0;
@@ -435,7 +440,7 @@ int bd_ctx_finalize(bd_ctx* c) {
             add("head.act_frag", Mp * c->hHl * 2);
             add("head.w1_part", (long long)c->cfg("head.w1").S * Mp * 2 * c->hHl * 4);
             add("head.pred", (long long)c->BP * c->hC * 4);
-            add("head.tok_cur", (long long)c->BP * c->hC * 4);
+            add("head.tok_cur", (long long)(c->geti("proj.rows_all", 0) ? c->M : c->BP) * c->hC * 4);
             add("head.xhat", Mp * c->hC * 4);
             if (tp > 1) add("head.tp_part", Mp * c->hD * 4);   // this rank's fp32 partial of a row-split Linear (wo / w2)
         }
@@ -518,6 +523,14 @@ int bd_head_set_schedule(bd_ctx* c, int n_steps, const float* s, float cfg) {
     }
     c->ada_async = c->has_head && c->geti("tune.ada_async", 0) != 0;
     if (c->ada_async && async_setup(c, n_steps + 1) != 0) return -1;
+    return 0;
+}
+
+/* the guidance scale alone (the ImageNet sampler's linear ramp changes it every AR step, model_parallel.py:356-365): a host-side
+ * scalar of the schedule -- eager launches pick it up at once; captured graphs hold the value they were captured with */
+int bd_head_set_cfg(bd_ctx* c, float cfg) {
+    if (!c || c->sched.empty()) return fail("bd_head_set_cfg: no schedule set");
+    for (auto& q : c->sched) q.cfg = cfg;
     return 0;
 }
 
@@ -754,6 +767,8 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0
     fa.xhat_out = c->geti("rt.dump_xhat", 0) ? (float*)c->wptr("head.xhat") : nullptr;
     fa.sc = c->sched[i];
     fa.BP = c->BP; fa.D = D; fa.C = c->hC; fa.M = M; fa.eps_ln = 1e-6f; fa.sigmoid = (int)c->geti("head.sigmoid", 1);
+    fa.cfg_table = (const float*)c->optr("head.cfg_table");
+    fa.tok_branches = (c->geti("proj.rows_all", 0) && c->has_proj) ? c->branches : 1;
     if (chain_next) { fa.X_next = c->wptr("head.X"); fa.in_w = c->ptr("head.in_w"); fa.in_b = c->ptr("head.in_b"); }
     BD_TRY(bdk_head_final(fa, st));
     return 0;
@@ -812,7 +827,7 @@ static int head_sample(bd_ctx* c, hipStream_t st) {
 static int projector_in(bd_ctx* c, hipStream_t st) {
     const int D = (int)c->geti("proj.D"), hid = (int)c->geti("proj.hid");
     InProjFc1Args f1{(const float*)c->ptr("head.tok_cur"), c->ptr("proj.w1"), c->ptr("proj.b1"), c->wptr("proj.h_frag"),
-                     c->BP, hid, (int)c->geti("proj.C"), c->RBp};
+                     c->prows, hid, (int)c->geti("proj.C"), c->RBp};
     BD_TRY(bdk_in_proj_fc1(f1, st));
     const GemmCfg& g = c->cfg("proj.fc2");
     InRmsArgs e;
@@ -820,7 +835,7 @@ static int projector_in(bd_ctx* c, hipStream_t st) {
                   c->ptr("proj.b2"), c->BPpad, &e.pend, st));
     e.R = (float*)c->wptr("llm.R"); e.init_from_pend = 1; e.renorm_to_R = 1; e.w = (const float*)c->ptr("llm.emb_norm");
     e.a_frag = nullptr; e.hidden_out = nullptr; e.cond_frag = nullptr; e.pos = nullptr;
-    e.state = (const BdStepState*)c->ptr("state"); e.M = c->BP; e.D = D; e.RB = c->RBp; e.P = c->Pn;
+    e.state = (const BdStepState*)c->ptr("state"); e.M = c->prows; e.D = D; e.RB = c->RBp; e.P = c->Pn;
     e.eps = (float)c->getf("llm.eps", 1e-6);
     BD_TRY(bdk_in_rms(e, st));
     return 0;

@@ -122,6 +122,9 @@ struct HeadFinalArgs {      // pending update, final LN-mod, Linear(D->C), 2*sig
     int BP, D, C, M;
     float eps_ln;
     int sigmoid;            // 1: x_hat = 2*sigmoid(out)-1 (flow_head_parallel_x.py:342); 0: x_hat = out (diff_head_parallel.py:310)
+    const float* cfg_table = nullptr;   // not null: the guidance scale of THIS AR step = cfg_table[state->step] (the ImageNet sampler's
+                            // linear ramp, model_parallel.py:356-365, as device data so that one captured graph serves every step)
+    int tok_branches = 1;   // final step: tok_cur gets this many copies, rows r * BP + bp (the imagenet projector feeds every CFG branch)
     void* X_next = nullptr; // not null (and not the final step): x0 = input_proj(x_t) of the NEXT evaluation, written over X's rows of this
     const void* in_w = nullptr;   // workgroup (flow_head:326) -- saves the next evaluation's prologue launch
     const void* in_b = nullptr;

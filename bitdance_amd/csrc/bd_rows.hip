@@ -410,7 +410,8 @@ __global__ __launch_bounds__(640) void head_final_kernel(HeadFinalArgs a) {
         float v = fdiv(fsub(xh[c], x), s.den);                    // (x_hat - x) / clamp_min(1-t, .05)
         if (s.cfg_mult == 2) {
             const float vu = fdiv(fsub(xh[32 + c], x), s.den);
-            v = fadd(vu, fmul(s.cfg, fsub(v, vu)));                // v_u + cfg (v_c - v_u)
+            const float cfg = a.cfg_table ? a.cfg_table[a.state->step] : s.cfg;
+            v = fadd(vu, fmul(cfg, fsub(v, vu)));                  // v_u + cfg (v_c - v_u)
         }
         float xn;
         if (!s.is_final) {
@@ -422,7 +423,8 @@ __global__ __launch_bounds__(640) void head_final_kernel(HeadFinalArgs a) {
             xn = fadd(x, fmul(v, s.dt));
             if (a.pred_out) a.pred_out[idx] = xn;
             const float sg = (xn > 0.f) ? 1.f : ((xn < 0.f) ? -1.f : xn);                    // torch.sign (0 -> 0)
-            if (a.tok_cur) a.tok_cur[idx] = sg;
+            if (a.tok_cur)
+                for (int r = 0; r < a.tok_branches; ++r) a.tok_cur[(size_t)r * a.BP * a.C + idx] = sg;
             if (a.tok_all) {
                 const int b = bp / a.P, pp = bp % a.P;
                 a.tok_all[((size_t)b * a.T + (size_t)a.state->step * a.P + pp) * a.C + c] = sg;

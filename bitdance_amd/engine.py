@@ -335,7 +335,8 @@ class Engine:
 
     def __init__(self, head: HeadWeights | None, proj: ProjWeights | None, llm: LlmWeights | None, *,
                  num_images: int, branches: int, device, max_tokens: int = 64, max_kv: int = 256,
-                 attn_splits: int = 8, tune: dict | None = None, parallel_num: int = 64, comm=None):
+                 attn_splits: int = 8, tune: dict | None = None, parallel_num: int = 64, comm=None,
+                 extra_ints: dict | None = None):
         """``comm``: a tp.TPComm -- this engine is then rank comm.rank of a tensor-parallel group and ``head`` / ``llm`` must
         have been packed with the same (tp_rank, tp_size)."""
         self.l = lib()
@@ -354,6 +355,7 @@ class Engine:
         self.Lmax = ((max_kv + 63) // 64) * 64
         self._keep: dict[str, torch.Tensor] = {}
         self._sched_key = None
+        self._cfg = None
         self._captured: set = set()
         wd = {getattr(w, "wdtype", 0) for w in (head, proj, llm) if w is not None}
         if len(wd) > 1:
@@ -370,6 +372,7 @@ class Engine:
             ints.update(llm.ints(self.Lmax, attn_splits))
         for k, v in (tune or {}).items():
             ints["tune." + k] = v
+        ints.update(extra_ints or {})
         for k, v in ints.items():
             check(self.l.bd_ctx_set_int(self.ctx, k.encode(), int(v)))
         if llm is not None:
@@ -430,9 +433,16 @@ class Engine:
     def set_schedule(self, n_steps: int, cfg: float, ar_steps: int, time_shift: float = 1.0) -> None:
         """Sampler scalars of DiffHead.sample (sampling_x.py:62-64; ``time_shift`` = the head config's, 1.0 in the
         released configs), the time-embedding table and the noise buffer."""
-        key = (n_steps, float(cfg), ar_steps, float(time_shift))
+        key = (n_steps, ar_steps, float(time_shift))
         if self._sched_key == key:
+            # same schedule, another guidance scale (the ImageNet linear ramp changes it every AR step): a host-side scalar --
+            # no table / noise / workspace is rebuilt; graphs captured with the old value are dropped
+            if float(cfg) != self._cfg:
+                check(self.l.bd_head_set_cfg(self.ctx, float(cfg)), "bd_head_set_cfg")
+                self._cfg = float(cfg)
+                self._captured.clear()
             return
+        self._cfg = float(cfg)
         sc, ts = sampler_scalars(n_steps, self.device, time_shift=float(time_shift))
         self._sc = sc
         check(self.l.bd_head_set_schedule(self.ctx, n_steps, sc.data_ptr(), float(cfg)), "bd_head_set_schedule")

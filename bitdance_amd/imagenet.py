@@ -140,6 +140,13 @@ class BitDance:
         self.proj_w = _InProj(sd, self.device)
         self.tr_w = _InTransformer(sd, n_layer, n_head, self.freqs_cis, self.device)
         self._tr: dict = {}
+        # AR steps 1 .. on ONE engine (head + proj_in + transformer, the T2I loop's structure) as replays of two captured hipGraphs
+        # per step; combined_engine = False: the per-step path over separate head / transformer engines (cross-check),
+        # use_graph = False: the combined engine with eager launches
+        self.combined_engine = True
+        self.use_graph = True
+        self._comb: dict = {}
+        self._stream = None
 
     # ------------------------------------------------------------------ transformer (torch, reference arithmetic)
     def _rope(self, x, fc):
@@ -209,6 +216,65 @@ class BitDance:
         eng.llm_step()
         return eng.hidden().view(bsz, self.P, -1)
 
+    # ------------------------------------------------------------------ the whole AR step on one engine (HIP graphs)
+    def _combined_engine(self, n: int, branches: int) -> Engine:
+        """Head + proj_in + transformer for ``n`` samples x ``branches`` CFG branches (sequences ordered [cond.., uncond..] like the
+        reference's ``torch.cat([cond, cond_null])``, model_parallel.py:377-380): phase 1 = proj_in + forward_model of the last
+        tokens -> the head's condition (norm(x) + pos_for_diff, fused), phase 0 = DiffHead.sample with the step's guidance scale
+        read from a device table."""
+        key = (n, branches)
+        if key not in self._comb:
+            eng = Engine(self.head_w, self.proj_w, self.tr_w, num_images=n, branches=branches, device=self.device,
+                         max_tokens=self.h * self.w, max_kv=self.total_tokens, parallel_num=self.P, extra_ints={"proj.rows_all": 1})
+            eng.pos[: self.h * self.w].copy_(self.w_["pos_for_diff.weight"])
+            eng.cfg_table = torch.ones(self.h * self.w // self.P + 1, dtype=torch.float32, device=self.device)
+            eng.set_ptr("head.cfg_table", eng.cfg_table)
+            self._comb[key] = eng
+        return self._comb[key]
+
+    def _graph_steps(self, eng: Engine, caches, T0: int, last: torch.Tensor, sample_steps: int, cfgs: list, noise, force_tokens,
+                     preds: list, toks: list) -> None:
+        """AR steps 1 .. seq_len - 1 on the combined engine.  ``last``: the tokens of step 0 for all sequences [bsz, P, C];
+        ``cfgs[i]``: guidance scale of AR step i.  RNG: the draws of every remaining step, in the reference's order, up front."""
+        P, seq_len, mult = self.P, len(cfgs), eng.branches
+        n = eng.B
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=self.device)
+        st = self._stream
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            self._load_cache(eng, caches, T0)
+            eng.set_schedule(sample_steps, cfgs[1], seq_len, time_shift=self.time_shift)
+            eng.cfg_table[:seq_len].copy_(torch.tensor(cfgs, dtype=torch.float32))
+            if noise is None:
+                shp = (n, P, self.head_w.C)
+                for s_ in range(1, seq_len):
+                    x = torch.randn(shp, device=self.device)
+                    eng.noise[s_, 0] = x.view(n * P, -1)
+                    for k in range(sample_steps):
+                        eng.noise[s_, k + 1] = torch.randn_like(x).view(n * P, -1)
+            else:
+                for s_ in range(1, seq_len):
+                    eng.noise[s_].copy_(noise[s_].to(self.device).view(sample_steps + 1, n * P, -1))
+            tok_cur = eng.view("head.tok_cur", torch.float32, (mult * n * P, self.head_w.C))
+            tok_cur.copy_(last.reshape(mult * n * P, -1))
+            if self.use_graph:
+                eng.capture(1)                                   # (stream capture records the launches, it does not run them)
+                eng.capture(0)
+            for i in range(1, seq_len):
+                if self.use_graph:
+                    eng.launch(1)
+                    eng.launch(0)
+                else:
+                    eng.projector(); eng.llm_step(); eng.head_sample()
+                pred = torch.cat([eng.pred().clone()] * mult, dim=0)
+                preds.append(pred)
+                tok = torch.sign(pred)
+                toks.append(tok)
+                if force_tokens is not None:
+                    tok_cur.copy_(force_tokens[:, i * P:(i + 1) * P].to(self.device, torch.float32).reshape(mult * n * P, -1))
+        torch.cuda.current_stream().wait_stream(st)
+
     # ------------------------------------------------------------------ head (HIP)
     def _head_sample(self, z: torch.Tensor, cfg: float, steps: int, noise=None) -> torch.Tensor:
         """DiffHead.sample on the native head.  z [rows, P, D] fp32; returns [rows, P, C] like the reference
@@ -231,6 +297,24 @@ class BitDance:
         eng.head_sample()
         x = eng.pred().clone()
         return torch.cat([x] * mult, dim=0)
+
+    @staticmethod
+    def _cfg_at(cfg_scale: float, cfg_schedule: str, i: int, seq_len: int) -> float:
+        """Guidance scale of AR step i (model_parallel.py:356-365)."""
+        if cfg_scale <= 1.0:
+            return 1.0
+        if cfg_schedule == "constant":
+            return cfg_scale
+        if cfg_schedule == "linear":
+            return 1.0 + (cfg_scale - 1.0) * i / seq_len
+        raise NotImplementedError(f"unknown cfg_schedule {cfg_schedule}")
+
+    def _graph_ok(self, cfg_scale: float, cfg_schedule: str, seq_len: int) -> bool:
+        """The combined-engine path needs every step after the first to have the same CFG arity (true for both schedules: the
+        linear ramp is > 1 from step 1 on) and the sequence count to fit the engine."""
+        if not self.combined_engine:
+            return False
+        return all((self._cfg_at(cfg_scale, cfg_schedule, j, seq_len) > 1.0) == (cfg_scale > 1.0) for j in range(1, seq_len))
 
     # ------------------------------------------------------------------ BitDance.sample
     @torch.no_grad()
@@ -267,20 +351,19 @@ class BitDance:
                     s0 = P * (i - 1) + n_cls + P - 1
                     x = self._forward_model(self._proj_in(last), self.attn_mask[:, :, s0:s0 + P, :s0 + P], s0, s0 + P, caches)
             z = x.float() + w["pos_for_diff.weight"][i * P:(i + 1) * P, :]
-            if cfg_scale > 1.0:
-                if cfg_schedule == "constant":
-                    ci = cfg_scale
-                elif cfg_schedule == "linear":
-                    ci = 1.0 + (cfg_scale - 1.0) * i / seq_len
-                else:
-                    raise NotImplementedError(f"unknown cfg_schedule {cfg_schedule}")
-            else:
-                ci = 1.0
+            ci = self._cfg_at(cfg_scale, cfg_schedule, i, seq_len)
             pred = self._head_sample(z.float(), ci, sample_steps, None if noise is None else noise[i].to(dev))
             preds.append(pred)
             tok = torch.sign(pred)
             toks.append(tok)
             last = tok if force_tokens is None else force_tokens[:, i * P:(i + 1) * P].to(dev, tok.dtype)
+            if i == 0 and eng_t is not None and seq_len > 1 and self._graph_ok(cfg_scale, cfg_schedule, seq_len):
+                # every later step: one engine, two graph replays per step (projector + transformer | head sampling)
+                mult = 2 if cfg_scale > 1.0 else 1
+                cfgs = [self._cfg_at(cfg_scale, cfg_schedule, j, seq_len) for j in range(seq_len)]
+                self._graph_steps(self._combined_engine(bsz // mult, mult), caches, T0, last, sample_steps, cfgs, noise, force_tokens,
+                                  preds, toks)
+                break
         tokens = torch.cat(toks, dim=-2)
         used = tokens if force_tokens is None else force_tokens.to(dev, tokens.dtype)
         p = int(P ** 0.5)

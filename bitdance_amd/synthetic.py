@@ -34,6 +34,11 @@ IMAGENET_MODELS = {
 }
 AE_D16C32 = dict(ddconfig=dict(double_z=False, z_channels=32, in_channels=3, out_ch=3, ch=256, ch_mult=[1, 1, 2, 2, 4],
                                num_res_blocks=4), gan_decoder=False)      # bitdance_14b_64x.yaml:9-16
+# ae_d32c256 (README.md:69: 2^256 codebook, 32x down-sampling): z 256, patch 32.  Its config json is not in the reference tree
+# (hosted next to the weights); the shape below continues ae_d16c32's ladder one level (ch_mult [1,1,2,2,4,4]) -- an ASSUMPTION,
+# used only by the standalone decoder benchmark (bench.py --workload ae-d32c256-decode).
+AE_D32C256 = dict(ddconfig=dict(double_z=False, z_channels=256, in_channels=3, out_ch=3, ch=256, ch_mult=[1, 1, 2, 2, 4, 4],
+                                num_res_blocks=4), gan_decoder=False)
 
 TINY_LLM = dict(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2, head_dim=128,
                 intermediate_size=512, vocab_size=512, rms_norm_eps=1e-6, rope_theta=1000000.0)

@@ -82,6 +82,8 @@ int bd_ctx_bind(bd_ctx* c);                           /* after all workspace poi
  * scalars: [n_steps+1][6] = {t, dt, den=clamp_min(1-t,.05), var, 1-t, noise_scale} per eval, computed by the
  * host exactly as the reference computes its 0-dim tensors (last row: t=1-last_step, dt=last_step). */
 int bd_head_set_schedule(bd_ctx* c, int n_steps, const float* scalars, float cfg);
+int bd_head_set_cfg(bd_ctx* c, float cfg);            /* the guidance scale alone (imagenet linear ramp, model_parallel.py:356-365):
+                                                         eager launches use it at once; captured graphs keep theirs */
 int bd_head_sample(bd_ctx* c, void* stream);          /* cond (ws head.cond_frag) + noise -> head.pred / tokens */
 int bd_head_cond(bd_ctx* c, void* stream);            /* cond_embed(c) once per AR step (value-identical hoist) */
 int bd_head_eval(bd_ctx* c, int i, void* stream);     /* one TransEncoder.forward (:325-342) + sampler step i */

@@ -874,6 +874,29 @@ def test_gen_image_batch2_and_nocfg_vs_reference(golden_dir, name, n_img):
     assert (torch.sign(pred)[firm] == torch.sign(ref)[firm]).float().mean() >= 0.97
 
 
+@pytest.mark.parametrize("variant", ["16x", "4x", "1x"])
+def test_imagenet_combined_engine_graph_equals_per_step_path(variant):
+    """BitDance.sample runs AR steps 1.. on one engine (head + proj_in + transformer) as two graph replays per step, the guidance
+    scale of the linear ramp read from a device table (model_parallel.py:352-419).  Same kernels, same launch configurations as the
+    per-step path over separate engines: identical latents, eager and replayed, for the 16x / 4x / 1x models."""
+    from bitdance_amd.imagenet import BitDance
+    c = dict({"16x": tm.TINY_IN, "4x": tm.TINY_IN_4X, "1x": tm.TINY_IN_1X}[variant])
+    m = BitDance(tm.seeded_state(tm.imagenet_shapes(c), seed=41), device=DEV, **c)
+    ids = torch.tensor([3, 7, 1])
+    outs = {}
+    for mode in ("separate", "eager", "graph"):
+        m.combined_engine = mode != "separate"
+        m.use_graph = mode == "graph"
+        torch.manual_seed(5)
+        _, tok, pred = m.sample(ids, 3, cfg_scale=3.0, return_tokens=True)
+        outs[mode] = (tok.clone(), pred.clone())
+    assert torch.equal(outs["eager"][1], outs["graph"][1]) and torch.equal(outs["eager"][0], outs["graph"][0])
+    assert torch.equal(outs["separate"][1], outs["eager"][1])
+    torch.manual_seed(5)
+    _, tok2, pred2 = m.sample(ids, 3, cfg_scale=3.0, return_tokens=True)        # second call: graphs reused
+    assert torch.equal(pred2, outs["graph"][1])
+
+
 def test_imagenet_more_than_16_sequences():
     """Batches beyond the 16 per-sequence length slots of the step state (the eval batch is 384 classes): every imagenet
     sequence has the same length, so slot 0 serves all of them.  40 sequences: HIP transformer == torch transformer within
