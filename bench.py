@@ -469,10 +469,18 @@ def bench_imagenet(args, dist, world, rank, dev, metric, barrier, max_over_ranks
                "config": {"workload": f"imagenet_gen BitDance-{variant[0].upper()}-{variant[1:]} 256x256, batch {n_cls} classes per call, {n_sampling} sampling steps, "
                                       f"linear CFG {guidance}, VAE decode {'off' if args.no_decode else 'on (chunks of 48)'}",
                           "ar_steps": ar_steps, "rows_per_pass": 2 * n_cls * P,
-                          "parallelism": f"replicas x{world}" if world > 1 else "single GPU", "hipgraph": False}}
+                          "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
+                          "hipgraph": bool(m.combined_engine and m.use_graph)}}
         if not args.no_roofline:
-            eng = m._eng[(n_cls, 2)]
-            out["roofline"] = gemm_roofline(eng, eng.head_sample, eng.M)
+            if (n_cls, 2) in m._comb:                            # the combined engine of AR steps 1..: projector + transformer + head
+                eng = m._comb[(n_cls, 2)]
+                # back to the state right after the first step: the KV cache is full after a whole sample, one more decode step
+                # would append past its end
+                eng.reset([mcfg["cls_token_num"] + P - 1] * min(2 * n_cls, 16))
+                out["roofline"] = gemm_roofline(eng, lambda: (eng.projector(), eng.llm_step(), eng.head_sample()), eng.M)
+            else:
+                eng = m._eng[(n_cls, 2)]
+                out["roofline"] = gemm_roofline(eng, eng.head_sample, eng.M)
         if world == 1 and not args.no_cpu_baseline and variant == "b16x":
             out["cpu_baseline"] = cpu_baseline_imagenet(n_sampling + 1, ar_steps)
         print(json.dumps(out), flush=True)

@@ -593,6 +593,7 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(QkvPostArgs a) {
     const int nslot = a.nh + 2 * a.nkv;
     const int seq = m / a.P, p = m % a.P;
     const int pos = a.state->kv_len[seq] + p;
+    if (pos >= a.Lmax) return;                                     // a step past the end of the static cache (caller error): no out-of-range write
     const bf16_t* QW = (const bf16_t*)a.qn_w;
     const bf16_t* KW = (const bf16_t*)a.kn_w;
     for (int slot = blockIdx.y * 4 + (threadIdx.x >> 6); slot < nslot; slot += gridDim.y * 4) {
@@ -719,6 +720,7 @@ __global__ __launch_bounds__(256) void in_qkv_post_kernel(InQkvPostArgs a) {
     const int D = a.nh * 64, nslot = 3 * a.nh;
     const int seq = m / a.P, p = m % a.P;
     const int pos = a.state->kv_len[0] + p;                        // every sequence has the same length here
+    if (pos >= a.Lmax) return;                                     // a step past the end of the static cache (caller error): no out-of-range write
     for (int slot = blockIdx.y * 4 + (threadIdx.x >> 6); slot < nslot; slot += gridDim.y * 4) {
         const int which = slot / a.nh, h = slot % a.nh;
         float x = slab_bf(a.qkv, m, which * D + h * 64 + lane);
