@@ -82,8 +82,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="imagenet: skip the conv decoder (MIOpen) in the timed pass")
-    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"],
-                    help="fp8: streamed Linear weights as e4m3 + per-channel scales (BASELINE config 5; a separate precision mode)")
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8", "fp8a"],
+                    help="fp8: streamed Linear weights as e4m3 + per-channel scales (BASELINE config 5; a separate precision mode); "
+                         "fp8a: also e4m3 activations (per-row scales) on the fp8 matrix pipe for the GEMMs fed by a row kernel")
     ap.add_argument("--attn-splits", type=int, default=None, help="KV splits of the LLM decode attention (default 8)")
     ap.add_argument("--tune", default="", help="comma list name.S=4,name.nw=2,kw2=0 overriding GEMM launch configs")
     a = ap.parse_args()
@@ -321,6 +322,8 @@ def main():
     pipe = syn.build_pipeline(size, dev, with_ae=True, tp=comm, weights=args.weights)
     if args.weights == "fp8":
         metric += " (fp8-e4m3 weights)"
+    elif args.weights == "fp8a":
+        metric += " (fp8-e4m3 weights + activations, fp8 MFMA)"
     pipe.tune = tune or None
     if args.attn_splits:
         pipe.attn_splits = args.attn_splits
@@ -391,7 +394,9 @@ def main():
             "metric": metric, "value": round(images / dt, 5), "unit": "images/s", "n_gpus": n, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "strong" if tp_mode else "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.weights == "bf16" else "bf16 activations / fp32 accumulate, fp8-e4m3 weights (per-channel scales)",
+            "dtype": {"bf16": "bf16", "fp8": "bf16 activations / fp32 accumulate, fp8-e4m3 weights (per-channel scales)",
+                      "fp8a": "fp8-e4m3 weights (per-channel scales) and activations (per-row scales) on the fp8 MFMA for adaLN / qkv / w1 / "
+                              "LLM qkv / gate-up, bf16 activations elsewhere, fp32 accumulate"}[args.weights],
             "data": "synthetic (random weights at true shapes, fixed token ids)",
             "config": {"workload": f"BitDance-{size.upper()} T2I {H}x{W}, {n_sampling} sampling steps, cfg {guidance}, "
                                    f"num_images={num_images} per {'job' if tp_mode else 'GPU'}" if size != "tiny" else "tiny",

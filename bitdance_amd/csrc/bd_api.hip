@@ -59,13 +59,13 @@ struct bd_ctx {
     bool has_head = false, has_llm = false, has_proj = false;
     // tensor parallelism: weights arrive pre-sliced (engine.py); every dim below with an `l` suffix is this rank's
     bd_comm* comm = nullptr;
-    bool wfp8 = false;                    // "wdtype" = 1: every streamed weight is fp8-e4m3 + "<key>_s" scales (bd_gemm8.hip)
+    bool wfp8 = false;                    // "wdtype" >= 1: every streamed weight is fp8-e4m3 + "<key>_s" scales (bd_gemm8.hip)
+    bool fp8a = false;                    // "wdtype" = 2: ALSO fp8 activations, on the fp8 matrix pipe, for the GEMMs a row kernel feeds
+                                          //   (head.ada / qkv / w1, llm.qkv / gu: their weights are packed for it, bd_pack_weight8k)
     int tp = 1, tpr = 0;
     int hDl = 0, hHl = 0, lnhl = 0, lnkvl = 0, lFl = 0;
     // "tune.ada_group": evaluations whose adaLN projections run as ONE GEMM (head_ada_group); 1 = one GEMM per evaluation
     int adaG = 1;
-    // "tune.pf_blocks" / "tune.pf_kb": run-ahead weight prefetch by spare workgroups of the row kernels (PfDesc, bd_kernels.h)
-    int pf_blocks = 0, pf_bytes = 0;
 
     const GemmCfg& cfg(const char* name) const {
         auto it = g.find(name);
@@ -105,7 +105,8 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
     const bool two_images = (c->Mpad % 256 == 0);      // 256-row passes (MB = 8) need the 8-wave variant for occupancy
     g.nw = (N % 256 == 0 && (N >= 8192 || K >= 16384 || two_images)) ? 8 : ((N % 128 == 0) ? 4 : 2);
     // one workgroup per CU and a single wave of workgroups: 10-wave tiles when that lands N/320 just under 256 tiles
-    if (!two_images && c->Mpad % 128 == 0 && N % 320 == 0 && N / 320 > 200 && N / 320 <= 256) g.nw = 10;
+    // (not with fp8 activations: the fp8 x fp8 loop needs ~190 registers, a 10-wave workgroup has 168 per wave)
+    if (!two_images && c->Mpad % 128 == 0 && N % 320 == 0 && N / 320 > 200 && N / 320 <= 256 && !c->fp8a) g.nw = 10;
     // ~120 tiles of 128 columns: two splits give 240 workgroups and only TWO slabs for the consumer to re-read
     if (!two_images && N % 128 == 0 && N / 128 >= 100 && N / 128 <= 128 && K <= 8192) g.nw = 4;
     // one wave of workgroups with a RAGGED last tile: N/32 panels over ceil(panels / 9) workgroups of 9 waves when that lands just
@@ -179,7 +180,7 @@ static const char* const kIntKeys[] = {
     "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid", "head.y_evals", "head.variant",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "proj.rows_all", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
     "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async", "tune.ragged", "tune.ragged52", "tune.slab_cap",
-    "tune.ada_group", "tune.pf_blocks", "tune.pf_kb"};
+    "tune.ada_group"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
                                          "llm.qkv", "llm.o", "llm.gu", "llm.down"};
 static bool known_int_key(const std::string& k) {
@@ -193,12 +194,12 @@ static bool known_int_key(const std::string& k) {
 }
 static const char* const kPtrKeys[] = {
     "head.cond_w", "head.cond_b", "head.in_w", "head.in_b", "head.ada_w", "head.ada_b", "head.lin_w", "head.lin_b", "head.temb",
-    "head.noise", "head.tok_all", "head.y_all", "head.cfg_table", "proj.w1", "proj.b1", "proj.w2", "proj.b2", "llm.final_norm", "llm.emb_norm", "llm.rope2d",
+    "head.noise", "head.tok_all", "head.y_all", "head.y_scale_all", "head.cfg_table", "proj.w1", "proj.b1", "proj.w2", "proj.b2", "llm.final_norm", "llm.emb_norm", "llm.rope2d",
     "llm.cos", "llm.sin", "pos",
     // workspaces (the caller allocates them after bd_ctx_finalize; a head-/projector-only context may borrow another's)
     "state", "gemm.cnt", "head.cond_frag", "head.cond_part", "head.xt", "head.y_frag", "head.X", "head.ada_bf", "head.cemb",
-    "head.h_frag", "head.qkv_part", "head.qkv_bf", "head.br_bf", "head.attn_frag", "head.br_part", "head.act_frag", "head.w1_part",
-    "head.pred", "head.tok_cur", "head.xhat", "head.tp_part", "proj.h_frag", "proj.part", "proj.out_bf", "llm.R", "llm.a_frag", "llm.qkv_part",
+    "head.h_frag", "head.h_scale", "head.y_scale", "head.qkv_part", "head.qkv_bf", "head.br_bf", "head.attn_frag", "head.br_part", "head.act_frag", "head.w1_part",
+    "head.pred", "head.tok_cur", "head.xhat", "head.tp_part", "proj.h_frag", "proj.part", "proj.out_bf", "llm.R", "llm.a_frag", "llm.a_scale", "llm.qkv_part",
     "llm.qkv_bf", "llm.br_bf", "llm.gu_part", "llm.q", "llm.k_cache", "llm.vt_cache", "llm.attn_opart", "llm.attn_ml",
     "llm.attn_frag", "llm.br_part", "llm.act_frag", "llm.hidden", "llm.tp_part"};
 static bool known_ptr_key(const std::string& k) {
@@ -287,6 +288,32 @@ int bd_pack_weight8_swiglu(void* dst, const void* gate_fp8, const void* up_fp8, 
     BD_TRY(bdk_pack_w8(dst, gate_fp8, up_fp8, F / 16, K, 0, F / 16, 1, (hipStream_t)stream));
     return 0;
 }
+/* fp8 weights for the fp8 x fp8 GEMMs (wdtype 2: head.ada / qkv / w1, llm.qkv / gu): e4m3 bytes in the K = 64 operand order */
+int bd_pack_weight8k(void* dst, const void* src_fp8, int rows, int K, int dst_row0, int dst_rows_total, void* stream) {
+    if (rows % 32 || dst_row0 % 32 || dst_rows_total % 32 || dst_row0 + rows > dst_rows_total)
+        return fail("bd_pack_weight8k: rows, dst_row0, dst_rows_total must be multiples of 32 and nest");
+    BD_TRY(bdk_pack_w8k(dst, src_fp8, nullptr, rows / 32, K, dst_row0 / 32, dst_rows_total / 32, 0, (hipStream_t)stream));
+    return 0;
+}
+int bd_pack_weight8k_swiglu(void* dst, const void* gate_fp8, const void* up_fp8, int F, int K, void* stream) {
+    if (F % 16) return fail("bd_pack_weight8k_swiglu: F must be a multiple of 16");
+    BD_TRY(bdk_pack_w8k(dst, gate_fp8, up_fp8, F / 16, K, 0, F / 16, 1, (hipStream_t)stream));
+    return 0;
+}
+/* standalone fp8 x fp8 GEMM (tests): a8 / ascale = fp8 activations in the A8 layout + per-row scales (bd_quant_rows8) */
+int bd_gemm_w8a8(const void* a8, const float* ascale, int RB, const void* w8k, const float* wscale, const void* bias, int N, int K, int S, int nw,
+                 int epi, float* scratch, int* counters, void* out, void* stream) {
+    if (!wscale || !ascale) return fail("bd_gemm_w8a8: scales required");
+    if (epi < 0 || epi > 3) return fail("bd_gemm_w8a8: epi 0 = fp32 slabs, 1 = SwiGLU, 2 = bf16(+bias), 3 = fp32 sum");
+    BD_TRY(bdk_gemm8a(a8, ascale, RB, w8k, wscale, N, K, S, nw, epi, epi == BD_EPI_PARTIAL ? (float*)out : scratch,
+                      epi == BD_EPI_PARTIAL ? nullptr : out, bias, counters, (hipStream_t)stream));
+    return 0;
+}
+/* rows [M][K] fp32 -> fp8-e4m3 activations in the A8 layout + per-row scales (what the row kernels emit in wdtype 2) */
+int bd_quant_rows8(void* a8, float* ascale, const float* src, int M, int K, int RB, void* stream) {
+    BD_TRY(bdk_quant_rows8(a8, ascale, src, M, K, RB, (hipStream_t)stream));
+    return 0;
+}
 int bd_gemm_w8(const void* a, int RB, const void* w8, const float* wscale, const void* bias, int N, int K, int S, int nw, int epi,
                float* scratch, int* counters, void* out, void* stream) {
     if (!wscale) return fail("bd_gemm_w8: scales required");
@@ -364,11 +391,13 @@ int bd_ctx_finalize(bd_ctx* c) {
         c->has_head = c->I.count("head.D") > 0;
         c->has_llm = c->I.count("llm.D") > 0;
         c->has_proj = c->I.count("proj.D") > 0;
-        c->wfp8 = c->geti("wdtype", 0) == 1;
-        // the step state has 16 per-sequence KV-length slots: a limit of the Qwen3 decode path only (prompts differ in
+        c->wfp8 = c->geti("wdtype", 0) >= 1;
+        c->fp8a = c->geti("wdtype", 0) == 2;
+        if (c->fp8a && c->has_llm && c->geti("llm.variant", 0) != 0) return fail("wdtype 2 (fp8 activations): the T2I paths only");
+        // the step state has BD_MAX_SEQ (64) per-sequence KV-length slots: a limit of the Qwen3 decode path only (prompts differ in
         // length); head-only contexts read just the step counter, imagenet sequences all share slot 0
-        if (c->branches * c->B > 16 && c->has_llm && c->geti("llm.variant", 0) == 0)
-            return fail("too many sequences for the Qwen3 decode path (max 16)");
+        if (c->branches * c->B > BD_MAX_SEQ && c->has_llm && c->geti("llm.variant", 0) == 0)
+            return fail("too many sequences for the Qwen3 decode path (max 64: num_images <= 32 with CFG)");
         if (c->Pn < 16 && c->has_llm && c->geti("llm.variant", 0) == 0)
             return fail("the Qwen3 decode path takes 64 or 16 tokens per step");
         c->hMlp = c->has_head ? (int)c->geti("head.variant", 0) : 0;
@@ -416,14 +445,14 @@ int bd_ctx_finalize(bd_ctx* c) {
             // per evaluation at G = 4, 8 and 16 against 1006 at G = 1).  The last group of a schedule is short.
             {
                 long long g = c->geti("tune.ada_group", -1);
-                if (g < 0) g = (!c->wfp8 && Mp <= 128 && c->hNada % 256 == 0 && c->geti("tune.ada_async", 0) == 0) ? 512 / Mp : 1;
-                if (g < 1 || g > 64 || (g > 1 && ((c->RB * g) % 8 != 0 || c->hNada % 256 != 0 || c->wfp8 || c->geti("tune.ada_async", 0) != 0)))
+                const bool can = !c->wfp8 && c->hNada % 256 == 0 && c->geti("tune.ada_async", 0) == 0;
+                // 128 rows and fewer: 512 rows per GEMM; 256 / 512 rows (num_images 2 / 4): 1024 rows per GEMM, where the LDS-tiled
+                // MFMA-bound kernel takes over (bd_gemm_tile.hip: adaLN at 1024 rows 694 vs 786 us on the 256-row kernel)
+                if (g < 0) g = !can ? 1 : (Mp <= 128 ? 512 / Mp : (Mp <= 512 && 1024 % Mp == 0 ? 1024 / Mp : 1));
+                if (g < 1 || g > 64 || (g > 1 && ((c->RB * g) % 8 != 0 || !can)))
                     return fail("tune.ada_group: 1..64 evaluations, rows a multiple of 256, adaLN width a multiple of 256, bf16 weights, no ada_async");
                 c->adaG = (int)g;
             }
-            c->pf_blocks = (int)c->geti("tune.pf_blocks", 0);       // measured NEGATIVE on MI355X (profiles/r03_head_sweep1.log): off
-            c->pf_bytes = (int)c->geti("tune.pf_kb", 16) * 1024;
-            if (c->pf_blocks < 0 || c->pf_blocks % 8 || c->pf_bytes < 0 || c->pf_bytes % 1024) return fail("tune.pf_blocks: a multiple of 8; tune.pf_kb: KiB per weight stream");
             add("head.cond_frag", Mp * c->hDz * 2);
             add("head.cond_part", (long long)c->cfg("head.cond").S * Mp * c->hD * 4);
             add("head.xt", (long long)c->BP * c->hC * 4);
@@ -432,6 +461,8 @@ int bd_ctx_finalize(bd_ctx* c) {
             add("head.ada_bf", Mp * c->hNada * 2 * (c->geti("tune.ada_async", 0) ? 2 : c->adaG));
             add("head.cemb", Mp * c->hD * 2);
             add("head.h_frag", Mp * c->hD * 2);
+            add("head.h_scale", Mp * 4);                       // fp8 activations: per-row scales of h / y (wdtype 2)
+            add("head.y_scale", Mp * 4);
             add("head.qkv_part", (long long)c->cfg("head.qkv").S * Mp * 3 * c->hDl * 4);
             add("head.qkv_bf", Mp * 3 * c->hDl * 2);
             add("head.br_bf", Mp * c->hD * 2);
@@ -476,6 +507,7 @@ int bd_ctx_finalize(bd_ctx* c) {
             const int sbr = std::max(c->cfg("llm.o").S, c->cfg("llm.down").S);
             add("llm.R", Mp * c->lD * 4);
             add("llm.a_frag", Mp * c->lD * 2);
+            add("llm.a_scale", Mp * 4);
             add("llm.qkv_part", (long long)c->cfg("llm.qkv").S * Mp * c->lNqkv * 4);
             add("llm.qkv_bf", Mp * c->lNqkv * 2);
             add("llm.br_bf", Mp * c->lD * 2);
@@ -540,10 +572,11 @@ int bd_head_set_cfg(bd_ctx* c, float cfg) {
 // every weight-streaming GEMM of the step goes through here; with profiling on (eager mode only) each launch is
 // bracketed by HIP events on the launch stream so bench.py can report in-situ per-launch durations.
 // a streamed weight: packed bf16, or packed fp8-e4m3 + per-output-channel fp32 scales ("<key>_s") when the context is fp8
-struct WRef { const void* w; const float* s; };
-static WRef wref(const bd_ctx* c, const std::string& key) {
+struct WRef { const void* w; const float* s; const float* a = nullptr; };   // a: per-row scales of an fp8 ACTIVATION operand (wdtype 2)
+static WRef wref(const bd_ctx* c, const std::string& key, const char* ascale_ws = nullptr) {
     WRef r{c->ptr(key), nullptr};
     if (c->wfp8) r.s = (const float*)c->ptr(key + "_s");
+    if (c->fp8a && ascale_ws) r.a = (const float*)c->ptr(ascale_ws);
     return r;
 }
 
@@ -556,7 +589,8 @@ static int gemm(bd_ctx* c, const char* name, const void* A, int RB, WRef W, int 
         hipEventRecord(r.e0, st);
     }
     int* cnt = (epi != BD_EPI_PARTIAL && S > 1) ? (int*)c->wptr("gemm.cnt") : nullptr;   // in-launch reduction tickets
-    const int rc = bdk_gemm(A, RB, W.w, N, K, S, nw, epi, out, act, bias, cnt, st, W.s);
+    const int rc = W.a ? bdk_gemm8a(A, W.a, RB, W.w, W.s, N, K, S, nw, epi, out, act, bias, cnt, st)
+                       : bdk_gemm(A, RB, W.w, N, K, S, nw, epi, out, act, bias, cnt, st, W.s);
     if (c->prof_on) { hipEventRecord(r.e1, st); c->prof.push_back(r); }
     return rc;
 }
@@ -613,6 +647,7 @@ static int head_cond(bd_ctx* c, hipStream_t st) {   // cond_embed(c) is constant
     const int G = c->adaG;
     if (n_evals > 0 && c->optr("head.y_all") && c->geti("head.y_evals", 0) >= (n_evals + G - 1) / G * G) {
         HeadYAllArgs ya{c->ptr("head.cemb"), c->ptr("head.temb"), c->wptr("head.y_all"), c->M, c->hD, c->RB, c->Mpad, n_evals, G};
+        if (c->fp8a) ya.a8_scale = (float*)c->wptr("head.y_scale_all");   // (G == 1 in the fp8 modes)
         BD_TRY(bdk_head_y_all(ya, st));
         c->y_ready = true;
     }
@@ -623,8 +658,10 @@ static int head_cond(bd_ctx* c, hipStream_t st) {   // cond_embed(c) is constant
 static int head_ada(bd_ctx* c, int i, int buf, bool light, hipStream_t st) {
     const int D = c->hD, RB = c->RB;
     const void* y = c->ptr("head.y_frag");
+    const float* ysc = c->fp8a ? (const float*)c->ptr("head.y_scale") : nullptr;
     if (c->y_ready && c->adaG == 1) {                          // every y_i of this AR step was produced with cond_embed (head_cond)
         y = (const bf16_t*)c->ptr("head.y_all") + (size_t)i * c->Mpad * D;
+        if (c->fp8a) ysc = (const float*)c->ptr("head.y_scale_all") + (size_t)i * c->Mpad;
     } else {
         HeadPrologueArgs pa;
         pa.cemb = c->ptr("head.cemb");
@@ -632,12 +669,15 @@ static int head_ada(bd_ctx* c, int i, int buf, bool light, hipStream_t st) {
         pa.xt = nullptr; pa.in_w = nullptr; pa.in_b = nullptr; pa.X = nullptr;
         pa.y_frag = c->wptr("head.y_frag");
         pa.M = c->M; pa.BP = c->BP; pa.D = D; pa.C = c->hC; pa.RB = RB;
+        if (c->fp8a) pa.a8_scale = (float*)c->wptr("head.y_scale");
         BD_TRY(bdk_head_prologue(pa, st));
     }
     GemmCfg ga = c->cfg("head.ada");
     if (light) { ga.nw = 4; ga.kw = 1; ga.ring = 2; }
     bf16_t* out = (bf16_t*)c->wptr("head.ada_bf") + (size_t)buf * c->Mpad * c->hNada;
-    BD_TRY(gemm(c, "head.ada", y, RB, wref(c, "head.ada_w"), c->hNada, D, 1, ga.code() + (light ? 8192 : 0), BD_EPI_BF16,
+    WRef wa = wref(c, "head.ada_w");
+    wa.a = ysc;
+    BD_TRY(gemm(c, "head.ada", y, RB, wa, c->hNada, D, 1, ga.code() + (light ? 8192 : 0), BD_EPI_BF16,
                 nullptr, out, c->ptr("head.ada_b"), st));
     return 0;
 }
@@ -654,25 +694,6 @@ static int head_ada_group(bd_ctx* c, int g, hipStream_t st) {
     BD_TRY(gemm(c, name, y, rbg, wref(c, "head.ada_w"), c->hNada, D, 1, /*8 waves, ring 2: the 256-row / tiled kernels*/ 8 + 16 * 2,
                 BD_EPI_BF16, nullptr, c->wptr("head.ada_bf"), c->ptr("head.ada_b"), st));
     return 0;
-}
-
-// Prefetch descriptor for the GEMM `g` (N x K, packed weights W) that FOLLOWS a row kernel: bd_kernels.h PfDesc
-static PfDesc make_pf(const bd_ctx* c, const GemmCfg& g, WRef W, int N, int K) {
-    PfDesc d;
-    if (c->pf_blocks <= 0 || c->pf_bytes <= 0 || c->Mpad % 256 == 0 || bdk_get_w_layout() != 0) return d;   // 128-row passes, panel-major weights
-    const int esz = W.s ? 1 : 2, kw = g.kw, np = g.nw / g.kw;
-    const int nst_total = K / (64 * kw), q = (nst_total + g.S - 1) / g.S;
-    const int last = nst_total - (g.S - 1) * q;                     // stages of the last (shortest) slice
-    const long long stage = (long long)2048 * esz * kw;             // bytes of one (64 * kw)-deep stage of one panel
-    d.W = W.w;
-    d.panel_bytes = (long long)K * 32 * esz;
-    d.slice_bytes = q * stage;
-    d.npan = N / 32; d.NP = np; d.S = g.S;
-    d.nwg = ((d.npan + np - 1) / np) * g.S;
-    d.bytes = (int)std::min<long long>(c->pf_bytes, last * stage);
-    d.nblk = c->pf_blocks;
-    if (d.bytes < 16) d.W = nullptr;
-    return d;
 }
 
 // `ada_buf` < 0: compute y and the adaLN projection here, in line (the plain path); >= 0: they were produced ahead of time
@@ -713,15 +734,14 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0
         l1.gate_off = ((b - 1 < 0 ? 0 : b - 1) / sw) * nc * D + (nc - 1) * D;
         l1.scale_off = base; l1.shift_off = base + D;
         l1.h_frag = c->wptr("head.h_frag"); l1.M = M; l1.D = D; l1.RB = RB; l1.eps = 1e-6f;
+        if (c->fp8a) l1.a8_scale = (float*)c->wptr("head.h_scale");
         LnModArgs l2 = l1;
         if (!mlp) {
             l1.ln_w = (const float*)c->ptr(pre + "ln1_w"); l1.ln_b = (const float*)c->ptr(pre + "ln1_b");
-            l1.pf = make_pf(c, gq, wref(c, pre + "wqkv"), 3 * Dl, D);
             BD_TRY(bdk_ln_mod(l1, st));
             HeadAttnArgs at;
-            BD_TRY(linear(c, "head.qkv", c->ptr("head.h_frag"), RB, wref(c, pre + "wqkv"), 3 * Dl, D, gq, "head.qkv_part", "head.qkv_bf",
+            BD_TRY(linear(c, "head.qkv", c->ptr("head.h_frag"), RB, wref(c, pre + "wqkv", "head.h_scale"), 3 * Dl, D, gq, "head.qkv_part", "head.qkv_bf",
                           c->ptr(pre + "bqkv"), Mp, &at.qkv, st));
-            at.pf = make_pf(c, go, wref(c, pre + "wo"), D, Dl);
             at.o_frag = c->wptr("head.attn_frag"); at.nseq = M / c->Pn; at.dh = (int)c->geti("head.dh", 128); at.nhead = Dl / at.dh; at.D = Dl; at.RB = RB; at.P = c->Pn;
             BD_TRY(bdk_head_attn(at, st));
             BD_TRY(linear_rowsplit(c, "head.wo", c->ptr("head.attn_frag"), RB, wref(c, pre + "wo"), D, Dl, go, "head.br_part", "head.br_bf",
@@ -731,16 +751,15 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0
         // MLP head (diff_head.py:133-137): the block IS the second half -- h = norm(x) * (1 + scale) + shift with the block's
         // (scale, shift) = chunks 0, 1 and the previous block's gated w2 output still pending, exactly l1's offsets above
         l2.ln_w = (const float*)c->ptr(pre + "ln2_w"); l2.ln_b = (const float*)c->ptr(pre + "ln2_b");
-        l2.pf = make_pf(c, g1, wref(c, pre + "w1"), 2 * Hl, D);
         BD_TRY(bdk_ln_mod(l2, st));
         // Linear -> chunk(2) -> silu(h1)*h2.  Fused epilogue (on the last-arriving K-slice when split) writes the next
         // operand: 46.9 + 22.9 us (w1 + w2) against 40.8 + 9.5 + 26.0 us for slabs + swiglu_rows on the same MI355X
         // (tune.w1_fused = 0 selects the latter).
         if (g1.S == 1 || c->geti("tune.w1_fused", (c->Mpad % 256 == 0) ? 0 : 1)) {
-            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, wref(c, pre + "w1"), 2 * Hl, D, g1.S, g1.code(), BD_EPI_SWIGLU,
+            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, wref(c, pre + "w1", "head.h_scale"), 2 * Hl, D, g1.S, g1.code(), BD_EPI_SWIGLU,
                         (float*)c->wptr("head.w1_part"), c->wptr("head.act_frag"), c->ptr(pre + "b1"), st));
         } else {
-            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, wref(c, pre + "w1"), 2 * Hl, D, g1.S, g1.code(), BD_EPI_PARTIAL,
+            BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, wref(c, pre + "w1", "head.h_scale"), 2 * Hl, D, g1.S, g1.code(), BD_EPI_PARTIAL,
                         (float*)c->wptr("head.w1_part"), nullptr, nullptr, st));
             SwigluArgs sw_;
             sw_.up = part(c, "head.w1_part", c->ptr(pre + "b1"), g1.S, 2 * Hl, Mp);
@@ -897,7 +916,7 @@ static int llm_step_in(bd_ctx* c, hipStream_t st) {
         BD_TRY(linear(c, "llm.down", c->ptr("llm.act_frag"), RB, wref(c, pre + "wdown"), D, F, gd, "llm.br_part", "llm.br_bf",
                       nullptr, Mp, &br, st));
     }
-    StepAdvanceArgs sa{state, nseq < 16 ? nseq : 16, c->Pn};
+    StepAdvanceArgs sa{state, nseq < BD_MAX_SEQ ? nseq : BD_MAX_SEQ, c->Pn};
     BD_TRY(bdk_step_advance(sa, st));
     InRmsArgs rf = r1;
     rf.pend = br; rf.w = (const float*)c->ptr("llm.final_norm"); rf.a_frag = nullptr;
@@ -930,10 +949,11 @@ static int llm_step(bd_ctx* c, hipStream_t st) {
         r1.w = c->ptr(pre + "in_norm"); r1.a_frag = c->wptr("llm.a_frag");
         r1.hidden_out = nullptr; r1.cond_frag = nullptr; r1.pos = nullptr; r1.state = state;
         r1.M = M; r1.D = D; r1.RB = RB; r1.P = c->Pn; r1.eps = eps; r1.bf16_stream = bf16s;
+        if (c->fp8a) r1.a8_scale = (float*)c->wptr("llm.a_scale");
         BD_TRY(bdk_rms(r1, st));
 
         QkvPostArgs qa;
-        BD_TRY(linear(c, "llm.qkv", c->ptr("llm.a_frag"), RB, wref(c, pre + "wqkv"), c->lNqkv, D, gq, "llm.qkv_part", "llm.qkv_bf",
+        BD_TRY(linear(c, "llm.qkv", c->ptr("llm.a_frag"), RB, wref(c, pre + "wqkv", "llm.a_scale"), c->lNqkv, D, gq, "llm.qkv_part", "llm.qkv_bf",
                       nullptr, Mp, &qa.qkv, st));
         qa.qn_w = c->ptr(pre + "q_norm"); qa.kn_w = c->ptr(pre + "k_norm");
         qa.cos = (const float*)c->ptr("llm.cos"); qa.sin = (const float*)c->ptr("llm.sin");
@@ -954,7 +974,7 @@ static int llm_step(bd_ctx* c, hipStream_t st) {
                                "llm.tp_part", nullptr, Mp, M, &r2.pend, st));
         r2.w = c->ptr(pre + "post_norm");
         BD_TRY(bdk_rms(r2, st));
-        BD_TRY(gemm(c, "llm.gu", c->ptr("llm.a_frag"), RB, wref(c, pre + "wgu"), 2 * F, D, gg.S, gg.code(), BD_EPI_SWIGLU,
+        BD_TRY(gemm(c, "llm.gu", c->ptr("llm.a_frag"), RB, wref(c, pre + "wgu", "llm.a_scale"), 2 * F, D, gg.S, gg.code(), BD_EPI_SWIGLU,
                         (float*)c->wptr("llm.gu_part"), c->wptr("llm.act_frag"), nullptr, st));
         BD_TRY(linear_rowsplit(c, "llm.down", c->ptr("llm.act_frag"), RB, wref(c, pre + "wdown"), D, F, gd, "llm.br_part", "llm.br_bf",
                                "llm.tp_part", nullptr, Mp, M, &br, st));
@@ -976,10 +996,10 @@ static int llm_step(bd_ctx* c, hipStream_t st) {
     return 0;
 }
 
-struct ResetArgs { BdStepState* state; int kv[16]; int nseq; };
+struct ResetArgs { BdStepState* state; int kv[BD_MAX_SEQ]; int nseq; };
 __global__ void step_reset_kernel(ResetArgs a) {
     if (threadIdx.x == 0) a.state->step = 0;
-    if ((int)threadIdx.x < 16) a.state->kv_len[threadIdx.x] = ((int)threadIdx.x < a.nseq) ? a.kv[threadIdx.x] : 0;
+    if ((int)threadIdx.x < BD_MAX_SEQ) a.state->kv_len[threadIdx.x] = ((int)threadIdx.x < a.nseq) ? a.kv[threadIdx.x] : 0;
 }
 
 extern "C" {
@@ -999,9 +1019,9 @@ int bd_llm_step(bd_ctx* c, void* s) { BD_GUARD(return llm_step(c, (hipStream_t)s
 
 int bd_step_reset(bd_ctx* c, const int* kv_len, int nseq, void* s) {
     BD_GUARD(
-        if (nseq > 16) return fail("bd_step_reset: nseq > 16");
+        if (nseq > BD_MAX_SEQ) return fail("bd_step_reset: nseq > 64");
         ResetArgs a; a.state = (BdStepState*)c->wptr("state"); a.nseq = nseq;
-        for (int i = 0; i < 16; ++i) a.kv[i] = i < nseq ? kv_len[i] : 0;
+        for (int i = 0; i < BD_MAX_SEQ; ++i) a.kv[i] = i < nseq ? kv_len[i] : 0;
         BD_LAUNCH(step_reset_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, a);
         return bd_launch_status() == 0 ? 0 : fail("step_reset launch failed");)
 }

@@ -51,10 +51,6 @@ BD_DEV void p_to_afrags(const float* p, int lane, u32x4& a_lo, u32x4& a_hi) {
 __global__ __launch_bounds__(256) void head_attn_kernel(HeadAttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * KSTR];
     __shared__ __attribute__((aligned(16))) bf16_t Vs[128 * VSTR];
-    if ((int)blockIdx.x >= a.nseq * a.nhead) {               // spare workgroups: pull wo's first weight stages into L2 (PfDesc)
-        bd_prefetch_run(a.pf, blockIdx.x - a.nseq * a.nhead, 256);
-        return;
-    }
     const int seq = blockIdx.x / a.nhead, h = blockIdx.x % a.nhead;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = a.D;
@@ -346,10 +342,7 @@ __global__ __launch_bounds__(256) void head_attn16_mfma_kernel(HeadAttnArgs a) {
 
 int bdk_head_attn(const HeadAttnArgs& a, hipStream_t st) {
     if (a.dh != 128 && !(a.dh == 64 && a.P <= 16)) return -2;
-    if (a.P == 64) {
-        const int nb = a.nseq * a.nhead, extra = (a.pf.W && nb % 8 == 0) ? a.pf.nblk : 0;
-        BD_LAUNCH(head_attn_kernel, dim3(nb + extra), dim3(256), 0, st, a);
-    }
+    if (a.P == 64) BD_LAUNCH(head_attn_kernel, dim3(a.nseq * a.nhead), dim3(256), 0, st, a);
     else if (a.P == 16 && a.qkv.S == 0 && a.qkv.N % 8 == 0) {       // finished bf16 qkv: matrix-pipe scores, 4 heads per workgroup
         const int blocks = (a.nseq * a.nhead + 3) / 4;
         if (a.dh == 64) BD_LAUNCH(head_attn16_mfma_kernel<64>, dim3(blocks), dim3(256), 0, st, a);

@@ -61,36 +61,49 @@ BD_DEV float block_sum(float v, float* red) {
     return t;
 }
 
-// Body of a prefetch workgroup (PfDesc, bd_kernels.h): j = its index among the `nblk` extra workgroups of the launch (extra
-// workgroup 0 has a blockIdx that is a multiple of 8, so that j % 8 is this workgroup's XCD).  The loads are LDS-DMA
-// (global_load_lds_dwordx4: 1 KiB per wave instruction, default cache policy so the lines allocate in L2): they have NO
-// register destination -- a register load whose result is never read would leave the compiler free to reuse the destination
-// registers while the data is still in flight -- and every wave drops its kilobyte onto the same scratch in LDS.
-template <class PF>
-BD_DEV void bd_prefetch_run(const PF& d, int j, int nthreads) {
-    __shared__ __attribute__((aligned(16))) unsigned pf_sink[256];
-    typedef __attribute__((address_space(1))) const void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    const int per = d.nblk >> 3;                                   // prefetch workgroups per XCD
-    const int upp = d.bytes >> 4;                                  // 16 B units per stream
-    const int units = d.NP * upp;
-    const char* const W = reinterpret_cast<const char*>(d.W);
-    for (int b = (j & 7) + 8 * (j >> 3); b < d.nwg; b += 8 * per) {
-        const int s = b % d.S, nt = b / d.S;
-        // whole waves only (LDS-DMA writes lane-linear from an M0 base): units is a multiple of 64 (bytes % 1024 == 0)
-        for (int u = threadIdx.x; u < units; u += nthreads) {
-            const int pn = u / upp, o = u - pn * upp;
-            const int panel = min(nt * d.NP + pn, d.npan - 1);     // ragged last tile: re-touch the last panel
-            const char* src = W + (size_t)panel * d.panel_bytes + (size_t)s * d.slice_bytes + (size_t)o * 16;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)pf_sink, 16, 0, 0);
-        }
+// block-wide max over <=16 waves (non-negative values); `red` is >=16 floats of LDS.  All threads get the result.
+BD_DEV float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
+// fp8-e4m3 activation operand of the fp8 matrix pipe ("A8", bd_gemm_kernel.h WT = 2): 2 KiB chunks per (64-deep stage, row block of
+// 32), each two lane-linear 1 KiB halves; lane l = row (l & 31), k = stage * 64 + (l >> 5) * 32 + byte.  BYTE offset of (row, k):
+BD_DEV size_t a8_off(int row, int k, int RB) {
+    return (((((size_t)(k >> 6) * RB + (row >> 5)) * 2 + ((k >> 4) & 1)) * 64) + ((row & 31) + (((k >> 5) & 1) << 5))) * 16 + (k & 15);
+}
+// one row's per-row quantisation: amax over the row -> scale = amax / 448 (what the GEMM multiplies back), inv = 448 / amax;
+// a thread's 8 consecutive k: q = e4m3(v * inv) (round to nearest even), 8 bytes in one store.  amax == 0: scale 0, bytes 0.
+BD_DEV void quant8_store(unsigned char* a8, int row, int k0, int RB, const float* v, float inv) {
+    int w0 = 0, w1 = 0;
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(__fmul_rn(v[0], inv), __fmul_rn(v[1], inv), w0, false);
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(__fmul_rn(v[2], inv), __fmul_rn(v[3], inv), w0, true);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(__fmul_rn(v[4], inv), __fmul_rn(v[5], inv), w1, false);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(__fmul_rn(v[6], inv), __fmul_rn(v[7], inv), w1, true);
+    *reinterpret_cast<uint2*>(a8 + a8_off(row, k0, RB)) = make_uint2((unsigned)w0, (unsigned)w1);
+}
+// the row's (scale, inv) from the block-wide amax of |v|; thread 0 publishes the scale
+BD_DEV float row_quant_scale(const float* v, bool active, float* red, float* scale_out, int row) {
+    float am = 0.f;
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) am = fmaxf(am, fabsf(v[j]));
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    am = block_max(am, red);
+    if (threadIdx.x == 0) scale_out[row] = __fdiv_rn(am, 448.0f);
+    return am > 0.f ? __fdiv_rn(448.0f, am) : 0.f;
 }
 
 // Device-resident state of the autoregressive loop, read by every step-dependent kernel so that
 // one captured hipGraph can be replayed for every AR step.
+#define BD_MAX_SEQ 64  // per-sequence KV-length slots: num_images <= 32 with CFG on the Qwen3 path (imagenet sequences share slot 0)
 struct BdStepState {
-    int step;          // AR step index (0-based)
-    int kv_len[16];    // per sequence (branch-major: cond b0.., uncond b0..): tokens already in the KV cache
+    int step;                  // AR step index (0-based)
+    int kv_len[BD_MAX_SEQ];    // per sequence (branch-major: cond b0.., uncond b0..): tokens already in the KV cache
 };

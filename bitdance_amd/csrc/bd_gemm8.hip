@@ -37,6 +37,59 @@ int bdk_pack_w8(void* dst, const void* src, const void* src2, int panels, int K,
     return bd_launch_status();
 }
 
+// ---- fp8 weights for the fp8 x fp8 matrix pipe (WT = 2, bd_gemm_kernel.h mfma32_f8): 2 KiB per (panel, 64-deep stage) as two
+// lane-linear 1 KiB halves; lane l, half h = the 16 weights W[panel*32 + (l&31)][kk*64 + (l>>5)*32 + 16 h + 0..15]
+__global__ void pack_w8k_kernel(u32x4* __restrict__ dst, const unsigned char* __restrict__ src, const unsigned char* __restrict__ src2,
+                                int panels, int K, int nb0, int mode) {
+    const int KS = K >> 6;                                   // 64-deep stages
+    const size_t total = (size_t)panels * KS * 128;
+    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(u & 63), h = (int)((u >> 6) & 1);
+        const size_t c = u >> 7;
+        const int kk = (int)(c % KS);
+        const int pn = (int)(c / KS);
+        const int i = l & 31;
+        const unsigned char* row;
+        if (mode == 0) row = src + ((size_t)pn * 32 + i) * K;
+        else row = (i < 16) ? src + ((size_t)pn * 16 + i) * K : src2 + ((size_t)pn * 16 + (i - 16)) * K;
+        dst[(((size_t)(nb0 + pn) * KS + kk) * 2 + h) * 64 + l] = *reinterpret_cast<const u32x4*>(row + kk * 64 + (l >> 5) * 32 + 16 * h);
+    }
+}
+
+int bdk_pack_w8k(void* dst, const void* src, const void* src2, int panels, int K, int nb0, int panels_total, int mode, hipStream_t st) {
+    if (K % 64 || nb0 + panels > panels_total) return -2;
+    const size_t total = (size_t)panels * (K / 64) * 128;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    BD_LAUNCH(pack_w8k_kernel, dim3(blocks), dim3(256), 0, st, (u32x4*)dst, (const unsigned char*)src, (const unsigned char*)src2,
+              panels, K, nb0, mode);
+    return bd_launch_status();
+}
+
+// fp8 weights AND fp8 activations (A: the A8 layout + `ascale` [rows] fp32): the launch forms of the 128-row kernel
+int bdk_gemm8a(const void* A8, const float* ascale, int RB, const void* W8k, const float* wscale, int N, int K, int S, int nw_ring, int epi,
+               float* out_partial, void* out_act, const void* bias, int* cnt, hipStream_t st) {
+    const int nw = nw_ring & 15;
+    const int kw = ((nw_ring >> 8) & 3) + 1;
+    if (kw > 2 || nw % kw || !ascale || !wscale) return -7;
+    const int np = nw / kw;
+    if (K % (64 * kw) || N % (32 * np) || S < 1) return -2;
+    const int nst_total = K / (64 * kw), q = (nst_total + S - 1) / S;
+    if ((S - 1) * q >= nst_total) return -3;
+    if (epi != BD_EPI_PARTIAL && S != 1 && (out_partial == nullptr || cnt == nullptr)) return -4;
+    const size_t PS = (size_t)(K >> 6) * 128, SS = 128;
+    GemmP p{(const u32x4*)A8, (const u32x4*)W8k, out_partial, (bf16_t*)out_act, (const bf16_t*)bias, cnt, wscale, RB, N, K, S, RB * 32, PS, SS};
+    p.ascale = ascale;
+    const int MB = (RB % 4 == 0) ? 4 : RB;
+    if (MB != 4 && MB != 2 && MB != 1) return -5;
+    // ring 4: a 64-deep fp8 stage is only 2 KiB per wave, and the fp8 MFMA leaves the loop latency-bound on bytes in flight (ring 2:
+    // qkv 33.0 us = 2.4 TB/s of fp8 bytes, profiles/r03_bench_fp8a_v1.json).  No 9 / 10-wave tiles: the loop needs ~190 registers.
+#define BD_CASE8A(NPV, KWV, MBV) if (np == NPV && kw == KWV && MB == MBV) return launch_gemm<NPV, KWV, MBV, 4, 0, 2>(p, epi, st);
+    BD_CASE8A(4, 1, 4) BD_CASE8A(8, 1, 4) BD_CASE8A(2, 1, 4) BD_CASE8A(4, 2, 4) BD_CASE8A(2, 2, 4)
+    BD_CASE8A(4, 1, 2) BD_CASE8A(8, 1, 2) BD_CASE8A(2, 1, 2) BD_CASE8A(4, 1, 1) BD_CASE8A(8, 1, 1) BD_CASE8A(2, 1, 1)
+#undef BD_CASE8A
+    return -6;
+}
+
 int bdk_gemm8(const void* A, int RB, const void* W8, const float* wscale, int N, int K, int S, int nw_ring, int epi,
               float* out_partial, void* out_act, const void* bias, int* cnt, hipStream_t st) {
     const int nw = nw_ring & 15;

@@ -24,6 +24,16 @@ BD_DEV u32x4 fp8x8_to_bf16x8(unsigned lo, unsigned hi) {
                    __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, true))};
 }
 
+// fp8 x fp8 on the block-scaled matrix pipe (the only low-precision MFMA at 2x the bf16 rate, MI355X_MICROARCH): 32x32x64,
+// A / B = 32 e4m3 bytes per lane (row / column lane & 31, k = (lane >> 5) * 32 + byte), all block scales = 2^0 (E8M0 127): the real
+// scales are one fp32 per activation ROW and one per weight CHANNEL, applied to the fp32 accumulator after the K loop
+typedef __attribute__((ext_vector_type(8))) int bd_i32x8;
+BD_DEV f32x16 mfma32_f8(u32x4 a0, u32x4 a1, u32x4 b0, u32x4 b1, f32x16 c) {
+    const bd_i32x8 a = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+    const bd_i32x8 b = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+
 struct GemmP {
     const u32x4* A;      // fragment-major activations, RB row-blocks
     const u32x4* W;      // packed weights
@@ -34,6 +44,7 @@ struct GemmP {
     const float* wscale; // fp8 weights: per packed output row [N] fp32 dequantisation scale (null for bf16 weights)
     int RB, N, K, S, Mpad;
     size_t PS, SS;       // packed-W strides in 16 B units: panel stride, 64-deep-K-stage stride
+    const float* ascale = nullptr;   // fp8 ACTIVATIONS (WT = 2): per row [Mpad] fp32 dequantisation scale
 };
 
 // MFMA-bound form for >= 512 rows: both operands through LDS, 256 x 256 workgroup tiles (bd_gemm_tile.hip)
@@ -56,13 +67,17 @@ int bdk_gemm_tile(const GemmP& p, int epi, hipStream_t st);
 // WT = weight storage: 0 bf16 (1 KiB chunk per (panel, k-step of 16)), 1 fp8-e4m3 with per-output-channel scales (1 KiB
 // chunk per (panel, PAIR of k-steps): a lane's 16 B = its 8 weights of k-step 2j, then of 2j+1; converted to bf16 in registers
 // right before the MFMA, the scale multiplied into the accumulator after the K loop): half the bytes per weight.
+// WT = 2: fp8 weights AND fp8 activations on the fp8 matrix pipe (mfma32_f8): a 64-deep stage is ONE MFMA per row block instead
+// of four bf16 ones at twice the rate, and half the LDS bytes for the activations.  Weights: 2 KiB per (panel, 64-deep stage) as
+// two lane-linear 1 KiB halves (bytes 0-15 / 16-31 of every lane's 32); activations: the same chunk shape per (stage, row block),
+// produced by the row kernels together with one fp32 scale per row (bd_rows.hip quant8_store).
 template <int NP, int KW, int MB, int EPI, int R, bool RED, int MODE = 0, int WT = 0>
 __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
-    constexpr int WL = (WT == 1) ? 2 : 4;                 // 16 B loads per lane and 64-deep stage
+    constexpr int WL = (WT != 0) ? 2 : 4;                 // 16 B loads per lane and 64-deep stage
     constexpr bool PIPE = (MODE == 1);                    // MODE 2 ("light"): one k-step of fragments resident at a time -- a
                                                           // ~170-register wave that fits NEXT to a 300-register one on a SIMD
     constexpr int NW = NP * KW, NT = NW * 64;
-    constexpr int UNITS = MB * 256 * KW;                  // 16 B units per (64*KW)-deep A stage
+    constexpr int UNITS = MB * (WT == 2 ? 128 : 256) * KW; // 16 B units per (64*KW)-deep A stage
     constexpr int XL = (UNITS + NT - 1) / NT;             // A loads per thread per stage
     constexpr int XR = R - 1;                             // A register-ring slots
     constexpr int U = (R == 2) ? 8 : 12;
@@ -88,14 +103,18 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
     const u32x4* Wp = p.W + (size_t)nbl * p.PS + (size_t)(st0 * KW + kg) * p.SS + lane;
     const size_t w_stage = p.SS * KW;
     // A: unit u of a stage = chunk (ksl = (u>>6)/MB in [0, 4*KW), mb = (u>>6)%MB), lane u&63
+    // (WT = 2: half-chunk c = u >> 6 of a stage = (K part c / (2 MB), row block (c >> 1) % MB, half c & 1); global order [stage][rb][half])
     size_t a_off[XL];
 #pragma unroll
     for (int j = 0; j < XL; ++j) {
         const int u = tid + j * NT;
         const int c = u >> 6;
-        a_off[j] = (((size_t)(st0 * 4 * KW + c / MB) * p.RB) + mt * MB + (c % MB)) * 64 + (u & 63);
+        if constexpr (WT == 2)
+            a_off[j] = ((((size_t)(st0 * KW + c / (2 * MB)) * p.RB) + mt * MB + ((c >> 1) % MB)) * 2 + (c & 1)) * 64 + (u & 63);
+        else
+            a_off[j] = (((size_t)(st0 * 4 * KW + c / MB) * p.RB) + mt * MB + (c % MB)) * 64 + (u & 63);
     }
-    const size_t a_stage = (size_t)4 * KW * p.RB * 64;
+    const size_t a_stage = (WT == 2) ? (size_t)KW * p.RB * 128 : (size_t)4 * KW * p.RB * 64;
 
     u32x4 w[R][WL], xr[XR][XL];
     f32x16 acc[MB];
@@ -127,6 +146,24 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
     // was bound by the ds_read -> MFMA chain, not by HBM).
     constexpr int KG = (MODE != 2 && MB <= 4 && NW <= 8) ? 4 : 1;      // k-steps whose A fragments are resident at once (VGPR budget)
     auto compute = [&](const u32x4* stage, const u32x4(&wr)[WL]) {
+        if constexpr (WT == 2) {                                          // one fp8 MFMA (K = 64) per row block
+            const u32x4* buf8 = stage + kg * MB * 128;
+            if constexpr (NW > 8) {                                      // 9 / 10 waves: 168 registers per wave -- one row block's fragments at a time
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    const u32x4 x0 = buf8[(m * 2) * 64 + lane], x1 = buf8[(m * 2 + 1) * 64 + lane];
+                    acc[m] = mfma32_f8(x0, x1, wr[0], wr[1], acc[m]);
+                }
+            } else {
+                u32x4 x0[MB], x1[MB];
+#pragma unroll
+                for (int m = 0; m < MB; ++m) { x0[m] = buf8[(m * 2) * 64 + lane]; x1[m] = buf8[(m * 2 + 1) * 64 + lane]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MB; ++m) acc[m] = mfma32_f8(x0[m], x1[m], wr[0], wr[1], acc[m]);
+            }
+            return;
+        }
         const u32x4* buf = stage + kg * MB * 256;
 #pragma unroll
         for (int k0 = 0; k0 < 4; k0 += KG) {
@@ -146,7 +183,7 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
     };
 
   if constexpr (PIPE) {
-    static_assert(R == 2 && KG == 4, "pipelined loop: two W stages in flight, whole-stage fragment sets");
+    static_assert(R == 2 && KG == 4 && WT != 2, "pipelined loop: two W stages in flight, whole-stage fragment sets (bf16 MFMA forms)");
     u32x4 xf[2][4][MB];
     auto read_stage = [&](u32x4(&x)[4][MB], const u32x4* stage) {
         const u32x4* buf = stage + kg * MB * 256;
@@ -263,12 +300,20 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
         }
     }
     const bool owner = (kg == 0) && pvalid;                                // the wave that holds the tile's sums
-    if constexpr (WT == 1) {                                               // dequantisation scale of this lane's output column
+    if constexpr (WT != 0) {                                               // dequantisation scale of this lane's output column
         const float sc = p.wscale[nbl * 32 + (lane & 31)];
 #pragma unroll
         for (int m = 0; m < MB; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] *= sc;
+    }
+    if constexpr (WT == 2) {                                               // ... and of the activation rows (reg r -> row (r&3)+8(r>>2)+4(lane>>5))
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const float* as = p.ascale + (mt * MB + m) * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] *= as[(r & 3) + 8 * (r >> 2)];
+        }
     }
 
     // ---- epilogue.  D layout of the 32x32 MFMA: lane -> column (lane&31), reg r -> row (r&3)+8(r>>2)+4(lane>>5)

@@ -28,22 +28,6 @@ static inline bool bd_lds_optin(const void* fn, int bytes, unsigned long long* d
 
 struct BdStepState;
 
-// Run-ahead weight prefetch.  The step is a dependent chain GEMM -> row kernel -> GEMM ...: while a row kernel runs (80-128
-// workgroups, a few MB of traffic, ~5-8 us) HBM idles, and the GEMM behind it then pays its pipeline ramp from a cold start.
-// A row kernel therefore carries `nblk` EXTRA workgroups that do nothing but pull the first `bytes` of every weight stream of
-// the NEXT GEMM -- stream = (GEMM workgroup, 32-column panel): one contiguous run of the packed weights -- into the L2 of the
-// XCD that GEMM workgroup will run on (workgroup b of a launch lands on XCD b % 8: a placement that is observed, not promised,
-// and used for speed only; a miss costs nothing but the saving).  Weights are data independent, so this needs no
-// synchronisation at all.  W == nullptr: nothing to prefetch.
-struct PfDesc {
-    const void* W = nullptr;    // packed weights of the next GEMM
-    long long panel_bytes = 0;  // bytes between consecutive 32-column panels
-    long long slice_bytes = 0;  // bytes between the starts of consecutive K slices inside a panel
-    int npan = 0, NP = 1, S = 1, nwg = 0;   // panels, panels per GEMM workgroup, K slices, GEMM workgroups (tiles * S)
-    int bytes = 0;              // per stream
-    int nblk = 0;               // extra workgroups (multiple of 8)
-};
-
 // ---- bd_gemm.hip
 // wscale != nullptr: W holds fp8-e4m3 weights (bdk_pack_w8) with per-packed-row fp32 scales
 int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw, int epi,
@@ -51,6 +35,10 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw, 
 // ---- bd_gemm8.hip : the same GEMM on fp8-e4m3 weights
 int bdk_gemm8(const void* A, int RB, const void* W8, const float* wscale, int N, int K, int S, int nw, int epi,
               float* out_partial, void* out_act, const void* bias, int* tile_counters, hipStream_t st);
+// fp8 weights + fp8 activations on the fp8 matrix pipe (bd_gemm_kernel.h WT = 2)
+int bdk_gemm8a(const void* A8, const float* ascale, int RB, const void* W8k, const float* wscale, int N, int K, int S, int nw, int epi,
+               float* out_partial, void* out_act, const void* bias, int* tile_counters, hipStream_t st);
+int bdk_pack_w8k(void* dst, const void* src_fp8, const void* src2_fp8, int panels, int K, int nb0, int panels_total, int mode, hipStream_t st);
 int bdk_pack_w8(void* dst, const void* src_fp8, const void* src2_fp8, int panels, int K, int nb0, int panels_total, int mode, hipStream_t st);
 int bdk_pack_w(void* dst, const void* src, const void* src2, int panels, int K, int nb0, int panels_total, int mode, hipStream_t st);
 void bdk_set_w_layout(int v);
@@ -58,6 +46,7 @@ int bdk_set_gemm_option(const char* name, int v);   // process-wide measurement 
 int bdk_get_w_layout();
 void bdk_w_strides(int panels_total, int K, size_t* PS, size_t* SS);
 int bdk_probe_read(const void* src, size_t bytes, int blocks, void* sink, hipStream_t st);
+int bdk_quant_rows8(void* a8, float* ascale, const float* src, int M, int K, int RB, hipStream_t st);   // bd_rows.hip
 int bdk_rows_to_afrag(void* dst, const float* src32, const void* src16, int M, int K, int RB, hipStream_t st);
 
 // ---- bd_rows.hip : row-wise kernels (one workgroup per activation row)
@@ -78,6 +67,7 @@ struct HeadPrologueArgs {   // y = silu(t_emb + cond_embed(c)) ; x0 = input_proj
     void* y_frag;           // out: fragment-major bf16 [Mpad][D]
     void* X;                // out: bf16 row-major [Mpad][D]
     int M, BP, D, C, RB;
+    float* a8_scale = nullptr;   // not null: y goes out as fp8-e4m3 (A8 layout) + per-row scale
 };
 int bdk_head_prologue(const HeadPrologueArgs& a, hipStream_t st);
 
@@ -89,10 +79,10 @@ struct LnModArgs {          // x (+= pending branch * gate) ; h = LN(x)*(1+scale
     int gate_off, scale_off, shift_off;   // column offsets inside the adaLN output
     const float* ln_w;      // [D] fp32 or null (no affine)
     const float* ln_b;
-    void* h_frag;           // out: fragment-major bf16
+    void* h_frag;           // out: fragment-major bf16 (or the fp8 operand when a8_scale is set)
     int M, D, RB;
     float eps;
-    PfDesc pf;              // run-ahead prefetch of the next GEMM's weights by extra workgroups (W == nullptr: none)
+    float* a8_scale = nullptr;   // not null: h goes out as fp8-e4m3 in the A8 layout + one fp32 scale per row (fp8 x fp8 GEMMs)
 };
 int bdk_ln_mod(const LnModArgs& a, hipStream_t st);
 
@@ -139,6 +129,7 @@ struct HeadYAllArgs {       // y_i = silu(time_embed(t_i) + cond_embed(c)) for E
                             //      matrix holds the n_evals % G left-over evaluations only, its row-block count rounded up to 8
     int M, D, RB, Mpad, n_evals;
     int G = 1;              // evaluations per adaLN GEMM (1: one [Mpad][D] matrix per evaluation)
+    float* a8_scale = nullptr;   // not null (G == 1 only): fp8-e4m3 operands (A8 layout) + scales [n_evals][Mpad]
 };
 int bdk_head_y_all(const HeadYAllArgs& a, hipStream_t st);
 
@@ -186,6 +177,7 @@ struct RmsArgs {            // R (+= bf16(pending)) ; a = bf16(w * R*rsqrt(mean(
     const BdStepState* state;
     int M, D, RB, P;
     float eps;
+    float* a8_scale = nullptr;   // not null: a_frag goes out as fp8-e4m3 (A8 layout) + per-row scale
     int bf16_stream = 0;    // 1: prefill -- the residual stream is bf16 (bf16 embeds, no fp32 position table added): the branch add
                             //    and both RMSNorm products round to bf16 (HF:59-64 with a bf16 input)
 };
@@ -272,7 +264,6 @@ struct HeadAttnArgs {       // DiT attention over one patch (seq = P = 64 or 16)
     void* o_frag;           // out fragment-major bf16 [Mpad][D]
     int nseq, nhead, D, RB, P;
     int dh;                 // head dim: 128, or 64 with P = 16 (imagenet head)
-    PfDesc pf;              // run-ahead prefetch of wo's weights (P = 64 kernel only)
 };
 int bdk_head_attn(const HeadAttnArgs& a, hipStream_t st);
 

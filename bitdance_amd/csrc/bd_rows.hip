@@ -123,10 +123,30 @@ int bdk_finalize_rows(const FinalizeRowsArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// standalone per-row e4m3 quantisation into the A8 layout (tests; the row kernels do this in their epilogues)
+// ------------------------------------------------------------------------------------------------
+__global__ void quant_rows8_kernel(unsigned char* a8, float* ascale, const float* src, int M, int K, int RB) {
+    __shared__ float red[32];
+    const int m = blockIdx.x;
+    float am = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) am = fmaxf(am, fabsf(src[(size_t)m * K + k]));
+    am = block_max(am, red);
+    if (threadIdx.x == 0) ascale[m] = __fdiv_rn(am, 448.0f);
+    const float inv = am > 0.f ? __fdiv_rn(448.0f, am) : 0.f;
+    for (int k0 = threadIdx.x * 8; k0 < K; k0 += blockDim.x * 8) quant8_store(a8, m, k0, RB, src + (size_t)m * K + k0, inv);
+}
+int bdk_quant_rows8(void* a8, float* ascale, const float* src, int M, int K, int RB, hipStream_t st) {
+    if (K % 64) return -2;
+    BD_LAUNCH(quant_rows8_kernel, dim3(M), dim3(256), 0, st, (unsigned char*)a8, ascale, src, M, K, RB);
+    return bd_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
 // head prologue:  y = silu(time_embed(t) + cond_embed(c)),  x0 = input_proj(x_t)     flow_head:326-330
 // ------------------------------------------------------------------------------------------------
 __global__ void head_prologue_kernel(HeadPrologueArgs a) {
     extern __shared__ float sh[];                    // C floats of the latent row (bf16-rounded)
+    __shared__ float red8[32];
     const int m = blockIdx.x;
     const int src = m % a.BP;                        // cond / uncond rows share the latent (sampling_x.py:71)
     if (a.X) {
@@ -134,17 +154,29 @@ __global__ void head_prologue_kernel(HeadPrologueArgs a) {
         __syncthreads();
     }
     const int d0 = threadIdx.x * 8;
-    if (d0 >= a.D) return;
+    const bool act_ = d0 < a.D;
     // either half may be switched off (null output): y depends on (t_i, cond) only and can run ahead of the chain on a
     // second stream; x0 depends on the latent the previous evaluation produced
     if (a.y_frag) {
         float ce[8], te[8], y[8];
-        ld_bf16x8((const bf16_t*)a.cemb + (size_t)m * a.D + d0, ce);
-        ld_bf16x8((const bf16_t*)a.temb + d0, te);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = silu_f(bfr(te[j] + ce[j]));           // bf16 + bf16 -> bf16 ; silu -> bf16 (rounded by pack8)
-        *reinterpret_cast<u32x4*>((bf16_t*)a.y_frag + afrag_off(m, d0, a.RB)) = pack8(y);
+        for (int j = 0; j < 8; ++j) y[j] = 0.f;
+        if (act_) {
+            ld_bf16x8((const bf16_t*)a.cemb + (size_t)m * a.D + d0, ce);
+            ld_bf16x8((const bf16_t*)a.temb + d0, te);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = silu_f(bfr(te[j] + ce[j]));       // bf16 + bf16 -> bf16 ; silu -> bf16 (rounded by pack8)
+        }
+        if (a.a8_scale) {                                          // fp8 x fp8 adaLN GEMM: per-row e4m3 of the bf16 silu output
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = bfr(y[j]);
+            const float inv = row_quant_scale(y, act_, red8, a.a8_scale, m);
+            if (act_) quant8_store((unsigned char*)a.y_frag, m, d0, a.RB, y, inv);
+        } else if (act_) {
+            *reinterpret_cast<u32x4*>((bf16_t*)a.y_frag + afrag_off(m, d0, a.RB)) = pack8(y);
+        }
     }
+    if (!act_) return;
     if (a.X) {
         float x0[8], b[8];
         ld_bf16x8((const bf16_t*)a.in_b + d0, b);
@@ -210,7 +242,6 @@ BD_DEV void modulate8(const float* x, float mean, float rstd, const float* lw, c
 
 __global__ void ln_mod_kernel(LnModArgs a) {
     __shared__ float red[32];
-    if ((int)blockIdx.x >= a.M) { bd_prefetch_run(a.pf, blockIdx.x - a.M, blockDim.x); return; }   // spare workgroups: PfDesc
     const int m = blockIdx.x, d0 = threadIdx.x * 8;
     const bool active = d0 < a.D;
     const bf16_t* ada = (const bf16_t*)a.ada + (size_t)m * a.ada_ld;
@@ -238,23 +269,31 @@ __global__ void ln_mod_kernel(LnModArgs a) {
     }
     float mean, rstd;
     ln_stats(x, active, a.D, a.eps, red, mean, rstd);
-    if (!active) return;
+    if (!active && !a.a8_scale) return;
     float h[8], sc[8], sf[8];
-    unpack8(scr, sc);
-    unpack8(sfr, sf);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float ln = (x[j] - mean) * rstd;
-        if (a.ln_w) ln = ln * w[j] + b[j];
-        h[j] = fadd(fmul(ln, bfr(1.0f + sc[j])), sf[j]);           // fp32 * bf16 + bf16 -> fp32, separate ops
+    for (int j = 0; j < 8; ++j) h[j] = 0.f;
+    if (active) {
+        unpack8(scr, sc);
+        unpack8(sfr, sf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float ln = (x[j] - mean) * rstd;
+            if (a.ln_w) ln = ln * w[j] + b[j];
+            h[j] = fadd(fmul(ln, bfr(1.0f + sc[j])), sf[j]);           // fp32 * bf16 + bf16 -> fp32, separate ops
+        }
+    }
+    if (a.a8_scale) {                                              // fp8 x fp8 GEMMs behind this row kernel: per-row e4m3 of the fp32 h
+        const float inv = row_quant_scale(h, active, red, a.a8_scale, m);
+        if (active) quant8_store((unsigned char*)a.h_frag, m, d0, a.RB, h, inv);
+        return;
     }
     *reinterpret_cast<u32x4*>((bf16_t*)a.h_frag + afrag_off(m, d0, a.RB)) = pack8(h);   // cast by the next Linear
 }
 int bdk_ln_mod(const LnModArgs& a, hipStream_t st) {
     const int t = row_threads(a.D);
     if (t < 0 || a.D % 8) return -2;
-    const int extra = (a.pf.W && a.M % 8 == 0) ? a.pf.nblk : 0;
-    BD_LAUNCH(ln_mod_kernel, dim3(a.M + extra), dim3(t), 0, st, a);
+    BD_LAUNCH(ln_mod_kernel, dim3(a.M), dim3(t), 0, st, a);
     return bd_launch_status();
 }
 
@@ -275,13 +314,26 @@ BD_DEV void block_sum2(float& v0, float& v1, float* red) {
 }
 
 __global__ void head_y_all_kernel(HeadYAllArgs a) {
+    __shared__ float red8[32];
     const int m = blockIdx.x, i = blockIdx.y, d0 = threadIdx.x * 8;
-    if (d0 >= a.D) return;
+    const bool act_ = d0 < a.D;
+    if (!act_ && !a.a8_scale) return;
     float ce[8], te[8], y[8];
-    ld_bf16x8((const bf16_t*)a.cemb + (size_t)m * a.D + d0, ce);
-    ld_bf16x8((const bf16_t*)a.temb + (size_t)i * a.D + d0, te);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) y[j] = silu_f(bfr(te[j] + ce[j]));               // bf16 + bf16 -> bf16 ; silu -> bf16 (rounded by pack8)
+    for (int j = 0; j < 8; ++j) y[j] = 0.f;
+    if (act_) {
+        ld_bf16x8((const bf16_t*)a.cemb + (size_t)m * a.D + d0, ce);
+        ld_bf16x8((const bf16_t*)a.temb + (size_t)i * a.D + d0, te);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = silu_f(bfr(te[j] + ce[j]));           // bf16 + bf16 -> bf16 ; silu -> bf16 (rounded by pack8)
+    }
+    if (a.a8_scale) {                                              // (G == 1) evaluation i's operand sits at the same element offset, half used
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = bfr(y[j]);
+        const float inv = row_quant_scale(y, act_, red8, a.a8_scale + (size_t)i * a.Mpad, m);
+        if (act_) quant8_store((unsigned char*)((bf16_t*)a.y_all + (size_t)i * a.Mpad * a.D), m, d0, a.RB, y, inv);
+        return;
+    }
     const int g = i / a.G, left = a.n_evals - g * a.G;              // evaluations in this group's matrix
     const int rbg = (left >= a.G || a.G == 1) ? a.RB * a.G : ((a.RB * left + 7) & ~7);
     *reinterpret_cast<u32x4*>((bf16_t*)a.y_all + (size_t)g * a.G * a.Mpad * a.D + afrag_off(m + (i % a.G) * a.Mpad, d0, rbg)) = pack8(y);
@@ -560,13 +612,22 @@ __global__ void rms_kernel(RmsArgs a) {
         for (int j = 0; j < 8; ++j) ss += r[j] * r[j];
     }
     const float rs = rsqrtf(block_sum(ss, red) / (float)a.D + a.eps);
-    if (!active) return;
+    if (!active && !a.a8_scale) return;
     float w[8], n[8];
-    unpack8(wr, w);
 #pragma unroll
-    for (int j = 0; j < 8; ++j)                                     // weight * (x * rsqrt(var+eps)).to(input dtype): fp32, or twice-rounded bf16
-        n[j] = a.bf16_stream ? bfr(fmul(w[j], bfr(fmul(r[j], rs)))) : fmul(w[j], fmul(r[j], rs));
-    if (a.a_frag) *reinterpret_cast<u32x4*>((bf16_t*)a.a_frag + afrag_off(m, d0, a.RB)) = pack8(n);   // cast by the next Linear
+    for (int j = 0; j < 8; ++j) n[j] = 0.f;
+    if (active) {
+        unpack8(wr, w);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)                                 // weight * (x * rsqrt(var+eps)).to(input dtype): fp32, or twice-rounded bf16
+            n[j] = a.bf16_stream ? bfr(fmul(w[j], bfr(fmul(r[j], rs)))) : fmul(w[j], fmul(r[j], rs));
+    }
+    if (a.a8_scale && a.a_frag) {                                  // fp8 x fp8 q/k/v and gate/up GEMMs: per-row e4m3 of the normed row
+        const float inv = row_quant_scale(n, active, red, a.a8_scale, m);
+        if (active) quant8_store((unsigned char*)a.a_frag, m, d0, a.RB, n, inv);
+    }
+    if (!active) return;
+    if (a.a_frag && !a.a8_scale) *reinterpret_cast<u32x4*>((bf16_t*)a.a_frag + afrag_off(m, d0, a.RB)) = pack8(n);   // cast by the next Linear
     if (a.hidden_out) st_f32x8(a.hidden_out + (size_t)m * a.D + d0, n);
     if (a.cond_frag) {                                             // cond = hidden + pos (t2i:244-245), cast by cond_embed
         float p[8];

@@ -63,8 +63,9 @@ def quantize_rows_fp8(w: torch.Tensor):
     return q.view(torch.uint8).contiguous(), s.contiguous()
 
 
-def pack_linear_fp8(ws: list[torch.Tensor], device):
-    """pack_linear for the fp8 weight path: (packed e4m3 bytes, fp32 scales [N]) (csrc/bd_gemm8.hip)."""
+def pack_linear_fp8(ws: list[torch.Tensor], device, k64: bool = False):
+    """pack_linear for the fp8 weight path: (packed e4m3 bytes, fp32 scales [N]) (csrc/bd_gemm8.hip).  ``k64``: the operand order
+    of the fp8 x fp8 matrix pipe (weights of the GEMMs that also take fp8 activations, ``weights="fp8a"``)."""
     K = ws[0].shape[1]
     n = sum(w.shape[0] for w in ws)
     if K % 64 or any(w.shape[0] % 32 for w in ws):
@@ -74,36 +75,39 @@ def pack_linear_fp8(ws: list[torch.Tensor], device):
     row = 0
     for w in ws:
         q, s_ = quantize_rows_fp8(w.to(device))
-        check(lib().bd_pack_weight8(out.data_ptr(), q.data_ptr(), q.shape[0], K, row, n, _stream()), "bd_pack_weight8")
+        check((lib().bd_pack_weight8k if k64 else lib().bd_pack_weight8)(out.data_ptr(), q.data_ptr(), q.shape[0], K, row, n, _stream()),
+              "bd_pack_weight8")
         scales.append(s_)
         row += q.shape[0]
     torch.cuda.current_stream().synchronize()
     return out, torch.cat(scales).contiguous()
 
 
-def pack_swiglu_fp8(gate: torch.Tensor, up: torch.Tensor, device):
+def pack_swiglu_fp8(gate: torch.Tensor, up: torch.Tensor, device, k64: bool = False):
     F_, K = gate.shape
     if K % 64 or F_ % 32:
         raise BitDanceHipError(f"pack_swiglu_fp8: unsupported shape F={F_} K={K}")
     qg, sg = quantize_rows_fp8(gate.to(device))
     qu, su = quantize_rows_fp8(up.to(device))
     out = torch.empty(2 * F_ * K, dtype=torch.uint8, device=device)
-    check(lib().bd_pack_weight8_swiglu(out.data_ptr(), qg.data_ptr(), qu.data_ptr(), F_, K, _stream()), "bd_pack_weight8_swiglu")
+    check((lib().bd_pack_weight8k_swiglu if k64 else lib().bd_pack_weight8_swiglu)(out.data_ptr(), qg.data_ptr(), qu.data_ptr(), F_, K, _stream()),
+          "bd_pack_weight8_swiglu")
     torch.cuda.current_stream().synchronize()
     scales = torch.stack([sg.view(-1, 16), su.view(-1, 16)], dim=1).reshape(-1).contiguous()      # packed row order
     return out, scales
 
 
-def _put_linear(p: dict, key: str, ws: list, device, fp8: bool) -> None:
+def _put_linear(p: dict, key: str, ws: list, device, fp8: int, act8: bool = False) -> None:
+    """``fp8``: 0 bf16, 1 fp8 weights, 2 fp8 weights + (for the GEMMs marked ``act8``: the ones a row kernel feeds) fp8 activations."""
     if fp8:
-        p[key], p[key + "_s"] = pack_linear_fp8(ws, device)
+        p[key], p[key + "_s"] = pack_linear_fp8(ws, device, k64=(fp8 == 2 and act8))
     else:
         p[key] = pack_linear(ws, device)
 
 
-def _put_swiglu(p: dict, key: str, gate, up, device, fp8: bool) -> None:
+def _put_swiglu(p: dict, key: str, gate, up, device, fp8: int, act8: bool = False) -> None:
     if fp8:
-        p[key], p[key + "_s"] = pack_swiglu_fp8(gate, up, device)
+        p[key], p[key + "_s"] = pack_swiglu_fp8(gate, up, device, k64=(fp8 == 2 and act8))
     else:
         p[key] = pack_swiglu(gate, up, device)
 
@@ -112,10 +116,13 @@ def pack_swiglu_bias(bg: torch.Tensor, bu: torch.Tensor, device) -> torch.Tensor
     return torch.stack([_bf16(bg, device).view(-1, 16), _bf16(bu, device).view(-1, 16)], dim=1).reshape(-1).contiguous()
 
 
-def _fp8_flag(weights: str) -> bool:
-    if weights not in ("bf16", "fp8"):
-        raise BitDanceHipError(f"weights must be 'bf16' or 'fp8', not {weights!r}")
-    return weights == "fp8"
+def _fp8_flag(weights: str) -> int:
+    """0 bf16; 1 "fp8": e4m3 weights, bf16 activations; 2 "fp8a": e4m3 weights everywhere + e4m3 activations (per-row scales) on the
+    fp8 matrix pipe for the GEMMs fed by a row kernel (head adaLN / qkv / w1, LLM q/k/v and gate/up)."""
+    modes = {"bf16": 0, "fp8": 1, "fp8a": 2}
+    if weights not in modes:
+        raise BitDanceHipError(f"weights must be one of {sorted(modes)}, not {weights!r}")
+    return modes[weights]
 
 
 def row_blocks(m: int) -> int:
@@ -177,7 +184,7 @@ class HeadWeights:
         p["head.in_b"] = _bf16(g("net.input_proj.bias"), device)
         ada_w = [g(f"net.ada_ln_blocks.{j}.weight") for j in range(na)] + [g("net.final_layer.ada_ln_modulation.weight")]
         ada_b = [g(f"net.ada_ln_blocks.{j}.bias") for j in range(na)] + [g("net.final_layer.ada_ln_modulation.bias")]
-        _put_linear(p, "head.ada_w", ada_w, device, fp8)
+        _put_linear(p, "head.ada_w", ada_w, device, fp8, act8=True)
         p["head.ada_b"] = torch.cat([_bf16(b, device) for b in ada_b]).contiguous()
         for i in range(nb):
             s, d = f"net.res_blocks.{i}.", f"head.blk{i}."
@@ -185,12 +192,12 @@ class HeadWeights:
                 p[d + f"ln{n}_w"] = g(s + src + ".weight").detach().to(device, torch.float32).contiguous()
                 p[d + f"ln{n}_b"] = g(s + src + ".bias").detach().to(device, torch.float32).contiguous()
             if not mlp:
-                _put_linear(p, d + "wqkv", [g(s + "attn.wqkv.weight")], device, fp8)
+                _put_linear(p, d + "wqkv", [g(s + "attn.wqkv.weight")], device, fp8, act8=True)
                 p[d + "bqkv"] = _bf16(g(s + "attn.wqkv.bias"), device)
                 _put_linear(p, d + "wo", [g(s + "attn.wo.weight")], device, fp8)
                 p[d + "bo"] = _bf16(g(s + "attn.wo.bias"), device)
             w1, b1 = g(s + "w1.weight"), g(s + "w1.bias")
-            _put_swiglu(p, d + "w1", w1[:H], w1[H:], device, fp8)
+            _put_swiglu(p, d + "w1", w1[:H], w1[H:], device, fp8, act8=True)
             p[d + "b1"] = pack_swiglu_bias(b1[:H], b1[H:], device)
             _put_linear(p, d + "w2", [g(s + "w2.weight")], device, fp8)
             p[d + "b2"] = _bf16(g(s + "w2.bias"), device)
@@ -236,7 +243,7 @@ class ProjWeights:
         pw.wdtype = int(_fp8_flag(weights))
         pw.ptrs["proj.w1"] = _bf16(sd["fc1.weight"], device)
         pw.ptrs["proj.b1"] = _bf16(sd["fc1.bias"], device)
-        _put_linear(pw.ptrs, "proj.w2", [sd["fc2.weight"]], device, bool(pw.wdtype))
+        _put_linear(pw.ptrs, "proj.w2", [sd["fc2.weight"]], device, pw.wdtype)
         pw.ptrs["proj.b2"] = _bf16(sd["fc2.bias"], device)
         return pw
 
@@ -273,9 +280,9 @@ class LlmWeights:
         for i in range(cfg["num_hidden_layers"]):
             s, d = f"model.layers.{i}.", f"llm.l{i}."
             q, k, v = (sd[s + f"self_attn.{n}_proj.weight"] for n in "qkv")
-            _put_linear(p, d + "wqkv", [q, k, v], device, fp8)
+            _put_linear(p, d + "wqkv", [q, k, v], device, fp8, act8=True)
             _put_linear(p, d + "wo", [sd[s + "self_attn.o_proj.weight"]], device, fp8)
-            _put_swiglu(p, d + "wgu", sd[s + "mlp.gate_proj.weight"], sd[s + "mlp.up_proj.weight"], device, fp8)
+            _put_swiglu(p, d + "wgu", sd[s + "mlp.gate_proj.weight"], sd[s + "mlp.up_proj.weight"], device, fp8, act8=True)
             _put_linear(p, d + "wdown", [sd[s + "mlp.down_proj.weight"]], device, fp8)
             p[d + "in_norm"] = _bf16(sd[s + "input_layernorm.weight"], device)
             p[d + "post_norm"] = _bf16(sd[s + "post_attention_layernorm.weight"], device)
@@ -458,6 +465,9 @@ class Engine:
         if y_bytes <= (512 << 20):
             self.y_all = torch.zeros(y_bytes // 2, dtype=BF16, device=self.device)
             self.set_ptr("head.y_all", self.y_all)
+            if self.wdtype == 2:                             # fp8 activations: per-row scales of every evaluation's y
+                self.y_scale_all = torch.zeros(cap * self.Mpad, dtype=torch.float32, device=self.device)
+                self.set_ptr("head.y_scale_all", self.y_scale_all)
             self.set_int("head.y_evals", cap)
         else:
             self.set_int("head.y_evals", 0)

@@ -61,6 +61,15 @@ int bd_pack_weight8(void* dst_packed, const void* src_fp8, int rows, int K, int 
 int bd_pack_weight8_swiglu(void* dst_packed, const void* gate_fp8, const void* up_fp8, int F, int K, void* stream);
 int bd_gemm_w8(const void* a_frag, int row_blocks, const void* w8_packed, const float* wscale, const void* bias_bf16, int N, int K,
                int splitk, int nwaves, int epi, float* scratch, int* counters, void* out, void* stream);
+/* fp8 x fp8 on the block-scaled fp8 matrix pipe ("wdtype" 2): the GEMMs a row kernel feeds (head adaLN / qkv / w1, LLM q/k/v and
+ * gate/up) take their activations as e4m3 with one fp32 scale per ROW (emitted by that row kernel) next to the e4m3 weights with one
+ * scale per output channel; their weights are packed in the K = 64 operand order by these entry points.  bd_quant_rows8 +
+ * bd_gemm_w8a8: the same arithmetic standalone (tests).  A separate precision mode with its own oracle policy ("fp8wa"). */
+int bd_pack_weight8k(void* dst, const void* src_fp8, int rows, int K, int dst_row0, int dst_rows_total, void* stream);
+int bd_pack_weight8k_swiglu(void* dst, const void* gate_fp8, const void* up_fp8, int F, int K, void* stream);
+int bd_quant_rows8(void* a8, float* ascale, const float* src_rows_f32, int M, int K, int RB, void* stream);
+int bd_gemm_w8a8(const void* a8, const float* ascale, int RB, const void* w8k, const float* wscale, const void* bias, int N, int K, int S, int nw,
+                 int epi, float* scratch, int* counters, void* out, void* stream);
 
 /* ---- context: named ints / floats / device pointers, then finalize.  Keys are listed in DESIGN.md; an unknown key is an
  *      error (-1, text in bd_last_error()), never a silent default. */

@@ -49,7 +49,7 @@ def attention(w: dict, pre: str, x: torch.Tensor, n_head: int, pol: Policy) -> t
     bsz, seqlen, dim = x.shape
     hd = dim // n_head
     scale = hd ** -0.5
-    qkv = pol.linear(x, w[pre + "wqkv.weight"], w[pre + "wqkv.bias"])
+    qkv = pol.linear(x, w[pre + "wqkv.weight"], w[pre + "wqkv.bias"], act8=True)
     q, k, v = qkv.chunk(3, dim=-1)
     q = q.view(bsz, seqlen, n_head, hd).transpose(1, 2)
     k = k.view(bsz, seqlen, n_head, hd).transpose(1, 2)
@@ -80,7 +80,7 @@ def trans_block(w: dict, i: int, x, mods, n_head: int, pol: Policy):
     x = x + h * g1
     h = pol.layer_norm(x, w[pre + "norm2.weight"], w[pre + "norm2.bias"], 1e-6) * (1 + s2) + b2
     if (pre + "w1.weight") in w:
-        h1, h2 = pol.linear(h, w[pre + "w1.weight"], w[pre + "w1.bias"]).chunk(2, dim=-1)
+        h1, h2 = pol.linear(h, w[pre + "w1.weight"], w[pre + "w1.bias"], act8=True).chunk(2, dim=-1)
         h = pol.linear(F.silu(h1) * h2, w[pre + "w2.weight"], w[pre + "w2.bias"])
     else:  # non-SwiGLU MLP (:246-248)
         h = pol.linear(h, w[pre + "mlp.0.weight"], w[pre + "mlp.0.bias"])
@@ -107,16 +107,16 @@ def net_forward(w: dict, x: torch.Tensor, t: torch.Tensor, c: torch.Tensor, pol:
     y = F.silu(te + ce)
     if trace is not None:
         trace["x0"], trace["y"] = x, y
-    mods = pol.linear(y, w["net.ada_ln_blocks.0.weight"], w["net.ada_ln_blocks.0.bias"]).chunk(6, dim=-1)
+    mods = pol.linear(y, w["net.ada_ln_blocks.0.weight"], w["net.ada_ln_blocks.0.bias"], act8=True).chunk(6, dim=-1)
     for i in range(n_blocks):
         if i > 0 and i % switch == 0:
             j = i // switch
-            mods = pol.linear(y, w[f"net.ada_ln_blocks.{j}.weight"], w[f"net.ada_ln_blocks.{j}.bias"]).chunk(6, dim=-1)
+            mods = pol.linear(y, w[f"net.ada_ln_blocks.{j}.weight"], w[f"net.ada_ln_blocks.{j}.bias"], act8=True).chunk(6, dim=-1)
         x = trans_block(w, i, x, mods, n_head, pol)
         if trace is not None:
             trace[f"x{i + 1}"] = x
     scale, shift = pol.linear(y, w["net.final_layer.ada_ln_modulation.weight"],
-                              w["net.final_layer.ada_ln_modulation.bias"]).chunk(2, dim=-1)
+                              w["net.final_layer.ada_ln_modulation.bias"], act8=True).chunk(2, dim=-1)
     h = pol.layer_norm(x, None, None, 1e-6) * (1.0 + scale) + shift
     out = pol.linear(h, w["net.final_layer.linear.weight"], w["net.final_layer.linear.bias"], quant=False)
     if not final_sigmoid:                     # imagenet variant, diff_head_parallel.py:310
@@ -141,18 +141,18 @@ def mlp_net_forward(w: dict, x: torch.Tensor, t: torch.Tensor, c: torch.Tensor, 
         te = te.unsqueeze(1)
     ce = pol.linear(c, w["net.cond_embed.weight"], w["net.cond_embed.bias"])
     y = F.silu(te + ce)
-    scale, shift, gate = pol.linear(y, w["net.ada_ln_blocks.0.weight"], w["net.ada_ln_blocks.0.bias"]).chunk(3, dim=-1)
+    scale, shift, gate = pol.linear(y, w["net.ada_ln_blocks.0.weight"], w["net.ada_ln_blocks.0.bias"], act8=True).chunk(3, dim=-1)
     for i in range(n_blocks):
         if i > 0 and i % switch == 0:
             j = i // switch
-            scale, shift, gate = pol.linear(y, w[f"net.ada_ln_blocks.{j}.weight"], w[f"net.ada_ln_blocks.{j}.bias"]).chunk(3, dim=-1)
+            scale, shift, gate = pol.linear(y, w[f"net.ada_ln_blocks.{j}.weight"], w[f"net.ada_ln_blocks.{j}.bias"], act8=True).chunk(3, dim=-1)
         pre = f"net.res_blocks.{i}."
         h = pol.layer_norm(x, w[pre + "norm.weight"], w[pre + "norm.bias"], 1e-6) * (1 + scale) + shift
-        h1, h2 = pol.linear(h, w[pre + "w1.weight"], w[pre + "w1.bias"]).chunk(2, dim=-1)
+        h1, h2 = pol.linear(h, w[pre + "w1.weight"], w[pre + "w1.bias"], act8=True).chunk(2, dim=-1)
         h = pol.linear(F.silu(h1) * h2, w[pre + "w2.weight"], w[pre + "w2.bias"])
         x = x + h * gate
     scale, shift = pol.linear(y, w["net.final_layer.ada_ln_modulation.weight"],
-                              w["net.final_layer.ada_ln_modulation.bias"]).chunk(2, dim=-1)
+                              w["net.final_layer.ada_ln_modulation.bias"], act8=True).chunk(2, dim=-1)
     h = pol.layer_norm(x, None, None, 1e-6) * (1.0 + scale) + shift
     return pol.linear(h, w["net.final_layer.linear.weight"], w["net.final_layer.linear.bias"], quant=False)
 

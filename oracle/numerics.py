@@ -36,21 +36,33 @@ F32 = torch.float32
 
 class Policy:
     def __init__(self, name: str = "autocast"):
-        if name not in ("fp32", "autocast", "fp8w"):
+        if name not in ("fp32", "autocast", "fp8w", "fp8wa"):
             raise ValueError(f"unknown policy {name!r}")
         self.name = name
 
     @property
     def amp(self) -> bool:
-        return self.name in ("autocast", "fp8w")
+        return self.name in ("autocast", "fp8w", "fp8wa")
 
     # -- F.linear under the policy -------------------------------------------------
-    def linear(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None = None, quant: bool = True) -> torch.Tensor:
+    def linear(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor | None = None, quant: bool = True, act8: bool = False) -> torch.Tensor:
+        """``quant``: this Linear's weights are streamed (fp8 modes quantise them per output channel).  ``act8``: its input comes
+        straight from a row kernel (LayerNorm-modulate, RMSNorm, the silu of the adaLN input): policy "fp8wa" quantises that input
+        per ROW to e4m3 as well -- scale = amax / 448, q = e4m3(x * (448 / amax)) from the value the row kernel holds (no bf16 step
+        in between) -- and the product runs on the fp8 matrix pipe (csrc/bd_gemm_kernel.h WT = 2)."""
         if not self.amp:
             return F.linear(x, w, b)
         xb = x.to(BF16).to(F32)
         wb = w.to(BF16).to(F32)
-        if self.name == "fp8w" and quant:
+        if self.name == "fp8wa" and quant and act8:
+            xs = x.to(F32)
+            am = xs.abs().amax(dim=-1, keepdim=True)
+            inv = torch.where(am > 0, 448.0 / am, torch.zeros_like(am))
+            xq = (xs * inv).to(torch.float8_e4m3fn).to(F32)
+            s = (wb.abs().amax(dim=1) / 448.0).clamp_min(1e-12)
+            q = (wb / s[:, None]).to(torch.float8_e4m3fn).to(F32)
+            acc = ((xq @ q.t()) * s) * (am / 448.0)
+        elif self.name in ("fp8w", "fp8wa") and quant:
             s = (wb.abs().amax(dim=1) / 448.0).clamp_min(1e-12)
             q = (wb / s[:, None]).to(torch.float8_e4m3fn).to(F32)
             acc = (xb @ q.t()) * s

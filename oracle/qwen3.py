@@ -95,9 +95,9 @@ def model_forward(w: dict, cfg: dict, inputs_embeds: torch.Tensor, cache: list |
         p = f"model.layers.{li}."
         resid = h
         x = rms_norm(h, w[p + "input_layernorm.weight"], eps)
-        q = pol.linear(x, w[p + "self_attn.q_proj.weight"]).view(B, T, nh, hd)
-        k = pol.linear(x, w[p + "self_attn.k_proj.weight"]).view(B, T, nkv, hd)
-        v = pol.linear(x, w[p + "self_attn.v_proj.weight"]).view(B, T, nkv, hd)
+        q = pol.linear(x, w[p + "self_attn.q_proj.weight"], act8=True).view(B, T, nh, hd)
+        k = pol.linear(x, w[p + "self_attn.k_proj.weight"], act8=True).view(B, T, nkv, hd)
+        v = pol.linear(x, w[p + "self_attn.v_proj.weight"], act8=True).view(B, T, nkv, hd)
         q = rms_norm(q, w[p + "self_attn.q_norm.weight"], eps).transpose(1, 2)
         k = rms_norm(k, w[p + "self_attn.k_norm.weight"], eps).transpose(1, 2)
         v = v.transpose(1, 2)
@@ -114,8 +114,8 @@ def model_forward(w: dict, cfg: dict, inputs_embeds: torch.Tensor, cache: list |
         h = resid + pol.linear(a, w[p + "self_attn.o_proj.weight"])
         resid = h
         x = rms_norm(h, w[p + "post_attention_layernorm.weight"], eps)
-        g = pol.linear(x, w[p + "mlp.gate_proj.weight"])
-        u = pol.linear(x, w[p + "mlp.up_proj.weight"])
+        g = pol.linear(x, w[p + "mlp.gate_proj.weight"], act8=True)
+        u = pol.linear(x, w[p + "mlp.up_proj.weight"], act8=True)
         h = resid + pol.linear(F.silu(g) * u, w[p + "mlp.down_proj.weight"])
         if trace is not None:
             trace[f"h{li}"] = h

@@ -86,12 +86,12 @@ def head_case(device="cuda", *, D=5120, Dz=None, C=32, P=64, B=1, branches=2, de
         if mlp:
             ref = diff_head.mlp_net_forward(sd, comb, torch.full((branches * B,), t_i), z, Policy("autocast")).float()
         else:
-            ref = diff_head.net_forward(sd, comb, torch.full((branches * B,), t_i), z, Policy("fp8w" if weights == "fp8" else "autocast"),
+            ref = diff_head.net_forward(sd, comb, torch.full((branches * B,), t_i), z, Policy({"fp8": "fp8w", "fp8a": "fp8wa"}.get(weights, "autocast")),
                                         final_sigmoid=sigmoid, head_dim=head_dim).float()
     t_cpu = time.perf_counter() - t0
     err = (xhat - ref).abs()
     extra = {}
-    if weights == "fp8":                                    # how far the fp8 mode is from the bf16 reference flow
+    if weights in ("fp8", "fp8a"):                          # how far the fp8 modes are from the bf16 reference flow
         with torch.no_grad():
             ref16 = diff_head.net_forward(sd, comb, torch.full((branches * B,), t_i), z, Policy("autocast"),
                                           final_sigmoid=sigmoid, head_dim=head_dim).float()
@@ -138,7 +138,7 @@ def llm_case(device="cuda", *, layers=1, P=64, past=(1000, 1017), cfg: dict | No
     eng.llm_step()
     torch.cuda.synchronize()
     got = eng.hidden().cpu().view(nseq, P, D)
-    pol = Policy("fp8w" if weights == "fp8" else "autocast")
+    pol = Policy({"fp8": "fp8w", "fp8a": "fp8wa"}.get(weights, "autocast"))
     t0 = time.perf_counter()
     refs = []
     with torch.no_grad():

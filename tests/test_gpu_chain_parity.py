@@ -105,6 +105,41 @@ def test_chained_loop_vs_oracle_autocast(golden_dir, name, P, h, w, n_img):
         assert (torch.sign(got)[firm] == torch.sign(ref)[firm]).float().mean().item() >= (0.995 if cfg else 0.97)
 
 
+def test_interleaved_context_loop_vs_oracle_autocast(golden_dir):
+    """The interleaved (image-editing) loop of MLLModel.forward_inference_block_causal (modeling/mllm.py:745-864): the context
+    [user text, start_of_image, res tokens, user-image embeddings, end_of_image, start_of_image, res tokens, query tokens] assembled by
+    the ORACLE (oracle/pipeline.py interleaved_context / encode_image on the golden's tokenizer latents) goes to both sides, so the
+    comparison isolates the loop over a long mixed context: native ragged prefill + 4 teacher-forced AR steps, HIP vs the oracle's
+    autocast flow, at the golden's guidance scale and at 1.25."""
+    g = load(golden_dir, "interleaved_amp")
+    pol = Policy("autocast")
+    proj = tm.seeded_state(tm.proj_shapes(32, 256), seed=33)
+    llm = {k: v.to(torch.bfloat16) for k, v in tm.seeded_state(tm.llm_shapes(tm.TINY_LLM), seed=22).items()}
+    emb_img = op.encode_image(proj, g["image_latents"], (8, 8), 256, 8, pol)
+    tok = tm.FakeTokenizer()
+    text = "<|im_start|>user\nmake the fox red<|im_end|>\n<|im_start|>assistant\n"
+    plan = [{"type": "text", "from": "user"}, {"type": "image", "from": "user"}, {"type": "image", "from": "model"}]
+    c, u = op.interleaved_context(llm["model.embed_tokens.weight"], plan, [text], [emb_img], tok.encode, start_of_image=tm.VISION_START,
+                                  end_of_image=tm.VISION_END, res_ids=(tm.RES_BASE + 16, tm.RES_BASE + 16),
+                                  query_ids=[tm.QUERY_BASE + i for i in range(1, 64)], cfg_on=True)
+    head = tm.seeded_state(tm.head_shapes(tm.TINY_HEAD), seed=11)
+    n = int(g["n_steps"])
+    pipe = tiny_pipeline()
+    for cfg, bound in ((float(g["cfg"]), BOUND_GOLDEN_CFG), (1.25, BOUND_LOW_CFG)):
+        tr = {}
+        op.gen_tokens_from_context(llm, tm.TINY_LLM, head, proj, c, u, h=16, w=16, parallel_num=64, guidance_scale=cfg, num_sampling_steps=n,
+                                   num_images=1, noise=list(g["noise"]), pol=pol, trace=tr, force_tokens=g["tokens"])
+        ref = torch.stack(tr["pred"])
+        th = {}
+        pipe.gen_image_from_context(c.to(DEV), u.to(DEV), guidance_scale=cfg, num_sampling_steps=n, num_images=1, image_size=[256, 256],
+                                    noise=g["noise"].view(4, n + 1, 1, 64, 32), return_tokens=True, force_tokens=g["tokens"], trace=th)
+        got = torch.stack(th["pred"]).cpu()
+        err = (got - ref).abs()
+        print(f"[chain parity] interleaved cfg {cfg}: mean |HIP - oracle| = {err.mean().item():.5f} (max {err.max().item():.4f}, per step "
+              f"{[round(err[s].mean().item(), 5) for s in range(err.shape[0])]})")
+        assert err.mean().item() <= bound, (cfg, err.mean())
+
+
 # ------------------------------------------------------------------------------------------- depth growth at true width
 def test_head_full_depth_error_growth_true_dims():
     """The FULL BitDance-14B head (6 blocks, 2 adaLN projections, D = 5120, M = 128 rows) against the oracle, next to the 2-block
