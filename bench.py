@@ -144,7 +144,7 @@ def gemm_roofline(eng, run, rows: int) -> dict:
     # wide-read correction: tools/pmc_gemm_traffic.py -> profiles/r0*_pmc_gemm_traffic.json), weighted by this step's
     # launch mix; only valid for the shapes / launch configs that pass measured, else null
     traffic, traffic_src = None, None
-    for fn in ("r02_pmc_gemm_traffic.json", "r01_pmc_gemm_traffic.json"):
+    for fn in ("r03_pmc_gemm_traffic.json", "r02_pmc_gemm_traffic.json", "r01_pmc_gemm_traffic.json"):
         pj = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(pj) or rows != 128:
             continue

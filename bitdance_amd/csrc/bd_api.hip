@@ -162,7 +162,10 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
         if (S < 1) S = 1;
     }
     g.S = S;
-    g.ring = 2;                                        // K stages in flight per wave; deeper rings measured no gain
+    // K stages in flight per wave: 2; 3 for the 4-wave tiles of the 128-row passes (qkv / w1: only 32 KiB per CU in flight at ring 2;
+    // in situ on one box, profiles/r03_bench_b1_ring*.json: qkv 39.4 vs 41.6 us, w1 42.5 vs 44.8, image 0.2597 vs 0.2552 /s; ring 4 and
+    // the 8-wave tiles: no gain)
+    g.ring = (!two_images && c->Mpad % 128 == 0 && g.nw == 4 && g.kw == 1 && !c->wfp8) ? 3 : 2;
     g.S = (int)c->geti("tune." + name + ".S", g.S);
     g.nw = (int)c->geti("tune." + name + ".nw", g.nw);
     g.kw = (int)c->geti("tune." + name + ".kw", g.kw);

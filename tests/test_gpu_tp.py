@@ -348,3 +348,26 @@ def test_rccl_exchange_plumbing_single_rank():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_bench_gpus2_from_plain_python_starts_its_own_ranks():
+    """`python bench.py --gpus 2` from a plain interpreter (how the driver runs --gpus 1) must start the two ranks itself -- the
+    reference's launch shape is one process per GPU (scripts/eval/eval_bitdance_14b_64x.sh:4-16) -- and report n_gpus 2 with the
+    exchange backend, the allocation kind of the exchange buffers and the per-image token agreement.  Two ranks share this box's
+    one GPU (BD_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BD_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "tp2"
+    tp = d["tp"]
+    assert tp["size"] == 2 and tp["world_size_seen"] == 2 and tp["exchange_backend"] == "ipc" and tp["ranks_bit_identical"] is True
+    assert tp["exchange_buffer_uncached"] in (True, False) and tp["images_checked_bit_identical"] == 2
