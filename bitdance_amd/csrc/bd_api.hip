@@ -148,10 +148,21 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
         if (s64 < 1) s64 = 1;
         if (t64 * s64 <= 256 && t64 * s64 >= 200 && s64 <= 3) { g.nw = 4; g.kw = 2; S = s64; ntiles = t64; }
     }
-    // 128-column tiles whose slices stay with the consumer (S >= 4: the N = 5120 shapes): 8 waves as 4 panels x 2 K-parts --
-    // two waves per SIMD overlap each other's LDS / MFMA latencies at the same tile, grid and slab count
-    // (profiles/r02_gemm_sweep2_pipe.log: wo 16.6 vs 17.8 us, w2 20.2 vs 23.3 us)
-    if (!two_images && g.nw == 4 && g.kw == 1 && S >= 4 && K % 128 == 0 && K <= 8192 && c->geti("tune.kparts8", 1) != 0) {
+    // The N = 5120 shapes (wo, w2, o_proj, cond, fc2: 40 tiles of 128 columns would need 6 K slices = 6 fp32 slabs of 2.6 MB that the
+    // consumer row kernel re-reads): 64-column tiles of 2 panels x 2 K-parts instead -- 80 tiles x 3 slices, HALF the slab traffic.
+    // The GEMM itself is no faster (wo 20.9 vs 20.5 us, w2 25.0 vs 22.5) but everything around it is: ln_mod reads 3 slabs instead of
+    // 6 and the next GEMM starts behind less dirty data -- in situ on one box (profiles/r03_bench_b1_s3slabs.json vs _v4.json): AR loop
+    // 3695 vs 3794 ms, image 0.2638 vs 0.2569 /s.  3 slices stay slabs (tune.reduce_max_s = 2: the in-launch reduction of 3 costs 8 us).
+    bool slab3 = false;
+    if (!two_images && !reduce3 && g.nw == 4 && g.kw == 1 && S >= 4 && K % 128 == 0 && N % 64 == 0 && K <= 8192 && !c->wfp8 &&
+        c->geti("tune.slab3", 1) != 0) {
+        const int t64 = N / 64, s64 = std::min(3, (int)std::lround(240.0 / t64));
+        // (exactly 3: the 2-slice case, llm.qkv N = 7168, would turn 4 slabs into an in-launch reduction: 27.9 vs 23.9 us measured)
+        if (s64 == 3 && t64 * s64 <= 256 && t64 * s64 >= 200) { g.nw = 4; g.kw = 2; S = s64; ntiles = t64; slab3 = true; }
+    }
+    // otherwise, 128-column tiles whose slices stay with the consumer (S >= 4): 8 waves as 4 panels x 2 K-parts -- two waves per SIMD
+    // overlap each other's LDS / MFMA latencies at the same tile, grid and slab count (profiles/r02_gemm_sweep2_pipe.log)
+    if (!slab3 && !two_images && g.nw == 4 && g.kw == 1 && S >= 4 && K % 128 == 0 && K <= 8192 && c->geti("tune.kparts8", 1) != 0) {
         g.nw = 8; g.kw = 2;
     }
     if (reduce3 && S > 3) {
@@ -182,7 +193,7 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
 static const char* const kIntKeys[] = {
     "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid", "head.y_evals", "head.variant",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "proj.rows_all", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
-    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async", "tune.ragged", "tune.ragged52", "tune.slab_cap",
+    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async", "tune.ragged", "tune.ragged52", "tune.slab_cap", "tune.slab3",
     "tune.ada_group"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
                                          "llm.qkv", "llm.o", "llm.gu", "llm.down"};
@@ -613,7 +624,7 @@ static int linear(bd_ctx* c, const char* name, const void* A, int RB, WRef W, in
                   const char* scratch_ws, const char* out_ws, const void* bias, int Mpad, Partial* res, hipStream_t st,
                   bool force_reduce = false) {
     // 256-row passes run the 4-wave x 2-panel kernel, which has no in-launch reduction: slabs for the consumer there
-    const int max_s = (int)c->geti("tune.reduce_max_s", (c->Mpad % 256 == 0) ? 0 : 3);
+    const int max_s = (int)c->geti("tune.reduce_max_s", (c->Mpad % 256 == 0) ? 0 : 2);
     if (g.S <= max_s || g.S == 1 || force_reduce) {            // a single slice needs no reduction: bias + rounding in the epilogue
         BD_TRY(gemm(c, name, A, RB, W, N, K, g.S, g.code(), BD_EPI_BF16, (float*)c->wptr(scratch_ws), c->wptr(out_ws), bias, st));
         *res = Partial{(const float*)c->ptr(out_ws), nullptr, 0, N, Mpad};

@@ -6,7 +6,7 @@
   2. python tools/pmc_gemm_traffic.py parse out.json fetch.db write.db sq.db
 
 `run` launches each (shape, split-K, waves) exactly as the engine configures it at M = 128 -- fp32 slabs where the engine
-leaves the slices to the consumer (split-K > 3), the in-launch reduction to bf16 otherwise -- REPS times in a row, preceded by
+leaves the slices to the consumer (split-K > 2), the in-launch reduction to bf16 otherwise -- REPS times in a row, preceded by
 two calibration dispatches of known size (a 256 MiB fill = pure write, a 256 MiB read-reduce = pure read).  `parse` takes the
 gemm dispatches in order, REPS per shape.  FETCH_SIZE on gfx950 tallies a wide (16 B/lane) streaming read's 128 B requests as
 64 B: the guide's x2 correction is applied and cross-checked against the calibration read; WRITE_SIZE is scaled by the
@@ -22,9 +22,9 @@ M = 128
 CAL_BYTES = 256 << 20
 # name, N, K, split-K, waves, kparts, ring: the in-situ configuration of bench.py's default workload (roofline.per_gemm).  head.ada is
 # the per-evaluation launch (the default pipeline runs it grouped over 4 evaluations on the 256-row kernel: MFMA-bound, listed apart)
-SHAPES = [("head.ada", 71680, 5120, 1, 9, 1, 2), ("head.qkv", 15360, 5120, 2, 4, 1, 3), ("head.wo", 5120, 5120, 6, 8, 2, 2),
-          ("head.w1", 15360, 5120, 2, 4, 1, 3), ("head.w2", 5120, 7680, 6, 8, 2, 2), ("head.cond", 5120, 5120, 6, 8, 2, 2),
-          ("proj.fc2", 5120, 5120, 6, 8, 2, 2), ("llm.qkv", 7168, 5120, 4, 8, 2, 2), ("llm.o", 5120, 5120, 6, 8, 2, 2),
+SHAPES = [("head.ada", 71680, 5120, 1, 9, 1, 2), ("head.qkv", 15360, 5120, 2, 4, 1, 3), ("head.wo", 5120, 5120, 3, 4, 2, 2),
+          ("head.w1", 15360, 5120, 2, 4, 1, 3), ("head.w2", 5120, 7680, 3, 4, 2, 2), ("head.cond", 5120, 5120, 3, 4, 2, 2),
+          ("proj.fc2", 5120, 5120, 3, 4, 2, 2), ("llm.qkv", 7168, 5120, 4, 8, 2, 2), ("llm.o", 5120, 5120, 3, 4, 2, 2),
           ("llm.gu", 34816, 5120, 1, 8, 1, 2), ("llm.down", 5120, 17408, 9, 8, 1, 2)]
 
 
@@ -52,7 +52,7 @@ def run():
         cnt = torch.zeros(16384, dtype=torch.int32, device="cuda")
         code = nw + 16 * ring + 256 * (kw - 1)
         for _ in range(REPS):
-            if S > 3 or name == "llm.gu":
+            if (S > 2 and name not in ("head.cond", "proj.fc2")) or name == "llm.gu":      # > 2 slices: slabs for the consumer
                 check(lib().bd_gemm_partial(xf.data_ptr(), M // 32, wp.data_ptr(), N, K, S, code, out.data_ptr(), st))
             else:
                 check(lib().bd_gemm_bf16(xf.data_ptr(), M // 32, wp.data_ptr(), None, N, K, S, code, out.data_ptr(), cnt.data_ptr(),
