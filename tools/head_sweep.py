@@ -2,7 +2,8 @@
 6-block head, M = 128 rows), all in ONE process on ONE box (box-to-box spread is +-5 %):
 
   tune.ada_group  evaluations whose adaLN projections run as one GEMM (bd_api.hip head_ada_group)
-  tune.pf_blocks / tune.pf_kb   run-ahead weight prefetch by spare workgroups of the row kernels (bd_kernels.h PfDesc)
+  tune.<gemm>.{S,nw,kw,ring}, tune.slab3, ...   launch configurations (bd_api.hip choose_cfg)
+(the run-ahead weight prefetch this tool also swept in round 3 -- profiles/r03_head_sweep1.log -- measured negative and is gone)
 
 Every configuration is timed as a hipGraph replay and its sampled latent is compared bit for bit with the first one's.
 python tools/head_sweep.py [reps] [n_steps] ["k=v,k=v;k=v,..." extra configs]"""
