@@ -102,44 +102,57 @@ def gemm_roofline(eng, run, rows: int) -> dict:
     (several images / the imagenet batch): the MFMA roofline bounds it: achieved = 2*rows*N*K / event time."""
     prof = eng.profile_gemms(run)
     # a launch named "<gemm>[xG]" is ONE pass over the weights for G evaluations' rows (the grouped adaLN projection, bd_api.hip
-    # head_ada_group): G * rows rows per pass -- above 256 rows per pass the matrix pipe, not HBM, bounds it, so it is listed with
-    # its TFLOP/s and kept out of the HBM family's byte / time sums
+    # head_ada_group): G * rows rows per pass -- the matrix pipe, not HBM, bounds that launch; it is listed with its TFLOP/s, counts
+    # G x N*K*2 algorithmic bytes in "achieved" and stays out of the "streamed" sums
     def split(name):
         if name.endswith("]") and "[x" in name:
             base, g = name[:-1].split("[x")
             return base, int(g)
         return name, 1
-    per, mfma_side = [], []
-    fam = {}
+    per, grouped = [], []
+    fam, allg = {}, {}
     for name, r in sorted(prof.items()):
         base, G = split(name)
         S, nw = eng.gemm_config(base)
         rec = {"name": name, "launches": r["count"], "avg_us": round(r["ms"] / r["count"] * 1e3, 2),
                "GBs": round(r["bytes"] / r["ms"] / 1e6, 1), "splitk": S if G == 1 else 1, "nwaves": (nw & 15) if G == 1 else 4,
-               "ring": (nw >> 4) & 15, "kparts": (((nw >> 8) & 3) + 1) if G == 1 else 1}
+               "ring": (nw >> 4) & 15 if G == 1 else 2, "kparts": (((nw >> 8) & 3) + 1) if G == 1 else 1}
+        allg[name] = dict(r, G=G)
         if G * rows > 256 and rows <= 256:
             rec["rows_per_pass"] = G * rows
+            rec["evaluations_per_launch"] = G
+            rec["algorithmic_GBs"] = round(r["bytes"] * G / r["ms"] / 1e6, 1)
             rec["TFLOPs"] = round(r["bytes"] * G * rows / r["ms"] / 1e9, 1)
             rec["frac_of_mfma_peak"] = round(rec["TFLOPs"] / MFMA_PEAK_TFS, 4)
-            rec["note"] = f"weights streamed once per {G} evaluations (256-row kernel): MFMA-bound, not part of the HBM family sums"
-            mfma_side.append(rec)
+            rec["note"] = (f"ONE pass over the weights serves {G} evaluations (256-row kernel, MFMA-bound at {G * rows} rows): GBs = bytes "
+                           f"physically streamed / time, algorithmic_GBs = {G} x N*K*2 (the reference streams them once per evaluation) / time")
+            grouped.append(rec)
         else:
             fam[name] = r
-            per.append(rec)
+        per.append(rec)
     tot_b = sum(r["bytes"] for r in fam.values())
     tot_ms = sum(r["ms"] for r in fam.values())
     n_launch = sum(r["count"] for r in fam.values())
     common = {"kernel": "gemm_kernel<NP,KW,MB,EPI,R,RED> / gemm_wide_kernel (bd_gemm.hip): every GEMM launch of one AR step, in situ",
               "launches": n_launch, "avg_launch_us": round(tot_ms / n_launch * 1e3, 2), "per_gemm": per}
-    if mfma_side:
-        common["mfma_bound_launches"] = mfma_side
     prof = fam
     if rows > 256:
         ach = tot_b * rows / tot_ms / 1e9                      # 2*rows*N*K flop = bytes * rows
         return {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s",
                 "frac": round(ach / MFMA_PEAK_TFS, 4), "traffic": None, "rows": rows,
                 "flop_per_launch": int(tot_b * rows / n_launch), **common}
-    ach = tot_b / tot_ms / 1e6
+    # Algorithmic bytes (SURVEY 8d): N*K*2 per Linear and EVALUATION -- what the reference's loop streams.  A launch that serves G
+    # evaluations in one pass over its weights (the grouped adaLN projection) therefore counts G x N*K*2: achieved = algorithmic bytes
+    # of ALL GEMM launches of the step / their summed time.  "streamed" restates it over the bytes physically moved by the launches
+    # that are HBM-bound (one evaluation per pass), the definition rounds 1-2 used when every launch was of that kind.
+    all_b = sum(r["bytes"] * r["G"] for r in allg.values())
+    all_ms = sum(r["ms"] for r in allg.values())
+    all_n = sum(r["count"] for r in allg.values())
+    ach = all_b / all_ms / 1e6
+    streamed = {"achieved": round(tot_b / tot_ms / 1e6, 1), "frac": round(tot_b / tot_ms / 1e6 / HBM_PEAK_GBS, 4), "launches": n_launch,
+                "bytes_per_launch": int(tot_b / n_launch),
+                "note": "bytes physically streamed / time over the launches with one evaluation per pass (HBM-bound); the grouped launches are in per_gemm with their TFLOP/s"}
+    common.update(launches=all_n, avg_launch_us=round(all_ms / all_n * 1e3, 2))
     # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs, gfx950 x2
     # wide-read correction: tools/pmc_gemm_traffic.py -> profiles/r0*_pmc_gemm_traffic.json), weighted by this step's
     # launch mix; only valid for the shapes / launch configs that pass measured, else null
@@ -150,15 +163,22 @@ def gemm_roofline(eng, run, rows: int) -> dict:
             continue
         pm = json.load(open(pj))["gemms"]
         cfgs = {q["name"]: q for q in per}
-        if all(n in pm and pm[n]["splitk"] == cfgs[n]["splitk"] and pm[n]["nwaves"] == cfgs[n]["nwaves"] and
-               pm[n].get("kparts", 1) == cfgs[n]["kparts"] and
-               pm[n]["N"] * pm[n]["K"] * 2 * r["count"] == int(r["bytes"]) for n, r in prof.items()):
-            traffic = int(sum((pm[n]["hbm_read_bytes"] + pm[n].get("hbm_write_bytes", 0)) * r["count"] for n, r in prof.items()) / n_launch)
+
+        def entry(n):                                           # a short last group ("[x3]") streams the same weights as "[x4]"
+            if n in pm:
+                return pm[n]
+            base, G = split(n)
+            alts = [v for k, v in pm.items() if G > 1 and k.startswith(base + "[x")]
+            return alts[0] if alts else None
+        if all(entry(n) is not None and entry(n)["splitk"] == cfgs[n]["splitk"] and entry(n)["nwaves"] == cfgs[n]["nwaves"] and
+               entry(n).get("kparts", 1) == cfgs[n]["kparts"] and
+               entry(n)["N"] * entry(n)["K"] * 2 * r["count"] == int(r["bytes"]) for n, r in allg.items()):
+            traffic = int(sum((entry(n)["hbm_read_bytes"] + entry(n).get("hbm_write_bytes", 0)) * r["count"] for n, r in allg.items()) / all_n)
             traffic_src = f"profiles/{fn} (FETCH_SIZE{' + WRITE_SIZE' if any('hbm_write_bytes' in v for v in pm.values()) else ''}, bytes per launch, launch-mix weighted)"
             break
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "bytes_per_launch": int(tot_b / n_launch), **common}
+            "bytes_per_launch": int(all_b / all_n), "streamed": streamed, **common}
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -1162,6 +1162,8 @@ def test_bench_contract_on_tiny_workload():
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
+    if rf["bound"] == "hbm":                                   # physically streamed bytes next to the algorithmic ones
+        assert rf["streamed"]["frac"] > 0 and rf["streamed"]["launches"] <= rf["launches"]
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert cb["parity"]["within_bounds"] is True

@@ -198,18 +198,20 @@ def _cfg(l, c, name):
 
 def test_context_planning_is_host_only_and_rejects_unknown_keys():
     """bd_ctx_* up to bd_ctx_finalize is host code (no GPU): unknown keys are errors, never silent defaults; the launch plan at
-    BitDance-14B-64x dimensions is the one the headline benchmark runs (9-wave ragged adaLN tiles, 2-slice qkv / w1, 6-slice 8-wave
-    N = 5120 shapes) and every workspace has a positive size."""
+    BitDance-14B-64x dimensions is the one the headline benchmark runs (9-wave ragged adaLN tiles, 2-slice qkv / w1, the N = 5120
+    shapes as 64-column tiles of 2 panels x 2 K-parts over 3 slices) and every workspace has a positive size."""
     l, c = _ctx(DIMS_14B)
     assert l.bd_ctx_set_int(c, b"head.Dd", 1) != 0 and b"unknown key" in l.bd_last_error()
     assert l.bd_ctx_set_ptr(c, b"head.blk0.wqkx", 0) != 0
     assert l.bd_ctx_set_ptr(c, b"head.blk12.wqkv", 0) == 0 and l.bd_ctx_set_ptr(c, b"llm.l39.wdown_s", 0) == 0
     assert l.bd_ctx_set_float(c, b"llm.epsilon", 1e-6) != 0 and l.bd_ctx_set_float(c, b"llm.eps", 1e-6) == 0
-    assert l.bd_ctx_set_int(c, b"tune.head.wo.S", 6) == 0 and l.bd_ctx_set_int(c, b"tune.head.wq.S", 6) != 0
+    assert l.bd_ctx_set_int(c, b"tune.head.wo.S", 2) == 0 and l.bd_ctx_set_int(c, b"tune.head.wq.S", 6) != 0
     assert l.bd_ctx_finalize(c) == 0, l.bd_last_error()
     assert _cfg(l, c, "head.ada") == (1, 9, 1)            # 2240 panels over 249 workgroups of 9 waves, ragged last tile
     assert _cfg(l, c, "head.qkv") == (2, 4, 1) and _cfg(l, c, "head.w1") == (2, 4, 1)
-    assert _cfg(l, c, "head.wo") == (6, 8, 2) and _cfg(l, c, "head.w2") == (6, 8, 2) and _cfg(l, c, "llm.o") == (6, 8, 2)
+    assert _cfg(l, c, "head.wo") == (2, 4, 2)             # the per-GEMM override above
+    assert _cfg(l, c, "head.w2") == (3, 4, 2) and _cfg(l, c, "llm.o") == (3, 4, 2) and _cfg(l, c, "head.cond") == (3, 4, 2)
+    assert _cfg(l, c, "llm.qkv") == (4, 8, 2) and _cfg(l, c, "llm.gu") == (1, 8, 1) and _cfg(l, c, "llm.down") == (9, 8, 1)
     n = l.bd_ctx_ws_count(c)
     names = [l.bd_ctx_ws_name(c, i).decode() for i in range(n)]
     assert "llm.k_cache" in names and "head.ada_bf" in names and "head.tp_part" not in names

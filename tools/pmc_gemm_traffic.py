@@ -25,7 +25,14 @@ CAL_BYTES = 256 << 20
 SHAPES = [("head.ada", 71680, 5120, 1, 9, 1, 2), ("head.qkv", 15360, 5120, 2, 4, 1, 3), ("head.wo", 5120, 5120, 3, 4, 2, 2),
           ("head.w1", 15360, 5120, 2, 4, 1, 3), ("head.w2", 5120, 7680, 3, 4, 2, 2), ("head.cond", 5120, 5120, 3, 4, 2, 2),
           ("proj.fc2", 5120, 5120, 3, 4, 2, 2), ("llm.qkv", 7168, 5120, 4, 8, 2, 2), ("llm.o", 5120, 5120, 3, 4, 2, 2),
-          ("llm.gu", 34816, 5120, 1, 8, 1, 2), ("llm.down", 5120, 17408, 9, 8, 1, 2)]
+          ("llm.gu", 34816, 5120, 1, 8, 1, 2), ("llm.down", 5120, 17408, 9, 8, 1, 2),
+          # the grouped adaLN projection as the pipeline launches it: 4 evaluations x 128 rows on the 256-row kernel
+          ("head.ada[x4]", 71680, 5120, 1, 4, 1, 2, 512)]
+
+
+def _shape(sh):
+    """(name, N, K, S, nw, kw, ring, rows): rows defaults to M."""
+    return tuple(sh) + ((M,) if len(sh) == 7 else ())
 
 
 def run():
@@ -40,7 +47,7 @@ def run():
         cal.fill_(1.0)                                                                  # calibration: 256 MiB written
         check(lib().bd_probe_read(cal.data_ptr(), CAL_BYTES, 1024, sink.data_ptr(), st))  # calibration: 256 MiB read (16 B/lane)
     torch.cuda.synchronize()
-    for name, N, K, S, nw, kw, ring in SHAPES:
+    for name, N, K, S, nw, kw, ring, M in map(_shape, SHAPES):
         w = (torch.randn(N, K, device="cuda") * 0.02).to(torch.bfloat16)
         wp = E.pack_linear([w], "cuda")
         del w
@@ -99,11 +106,11 @@ def parse(out_path, fetch_db, write_db=None, sq_db=None):
     gw = gemms(wr) if wr else None
     gs = {c: gemms(r) for c, r in sq.items() if r} if sq else {}
     res = {}
-    for i, (name, N, K, S, nw, kw, ring) in enumerate(SHAPES):
+    for i, (name, N, K, S, nw, kw, ring, rows) in enumerate(map(_shape, SHAPES)):
         sl = slice(i * REPS + 1, (i + 1) * REPS)              # drop the first launch of each shape (cold TLB / code)
         avg = lambda g: sum(r[2] for r in g[sl]) / (REPS - 1)
         alg = N * K * 2
-        e = dict(N=N, K=K, splitk=S, nwaves=nw, kparts=kw, ring=ring, fetch_size_kib_raw=round(avg(gf), 1), hbm_read_bytes=round(avg(gf) * fetch_scale),
+        e = dict(N=N, K=K, rows=rows, splitk=S, nwaves=nw, kparts=kw, ring=ring, fetch_size_kib_raw=round(avg(gf), 1), hbm_read_bytes=round(avg(gf) * fetch_scale),
                  algorithmic_bytes=alg)
         e["read_ratio"] = round(e["hbm_read_bytes"] / alg, 4)
         e["avg_ns"] = round(sum(r[3] for r in gf[sl]) / (REPS - 1))
@@ -114,7 +121,7 @@ def parse(out_path, fetch_db, write_db=None, sq_db=None):
             mf, gui = avg(gs["SQ_VALU_MFMA_BUSY_CYCLES"]), avg(gs["GRBM_GUI_ACTIVE"])
             e["mfma_busy_cycles"], e["gui_active_cycles"] = round(mf), round(gui)
             e["mfma_util"] = round(mf / (gui * 1024.0), 4)    # matrix-pipe busy cycles / (kernel cycles x 256 CUs x 4 SIMDs)
-            e["mfma_util_from_flops"] = round(2.0 * M * N * K / (e["avg_ns"] * 1e-9) / 2.5e15, 4)   # same thing from 2*M*N*K / time / 2.5 PFLOP/s
+            e["mfma_util_from_flops"] = round(2.0 * rows * N * K / (e["avg_ns"] * 1e-9) / 2.5e15, 4)   # same thing from 2*M*N*K / time / 2.5 PFLOP/s
             if "SQ_BUSY_CYCLES" in gs:
                 e["sq_busy_cycles"] = round(avg(gs["SQ_BUSY_CYCLES"]))
         res[name] = e
