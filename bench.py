@@ -367,6 +367,8 @@ def main():
         """One pass; True iff it completed on every rank AND every rank holds bit-identical tokens."""
         ok = 1
         try:
+            if os.environ.get("BD_BENCH_FAIL_TP"):             # test hook: exercise the fall-back chain on a healthy node
+                raise RuntimeError("BD_BENCH_FAIL_TP is set")
             one_pass(i)
         except Exception as e:                                 # in-kernel wait budget exceeded etc.: all ranks must agree on what happens next
             print(f"[bench] rank {rank}: tensor-parallel pass failed: {e}", file=sys.stderr, flush=True)
@@ -377,18 +379,45 @@ def main():
             return False
         return tokens_agree(dist, next(iter(pipe._engines.values())).tok_all, dev)
 
+    tp_note = None
     for i in range(args.warmup):
         if tp_mode and i == 0:
             if not tp_pass_ok(i):
-                if comm.backend == "rccl":
-                    raise RuntimeError("tensor-parallel ranks failed or diverged (RCCL exchange)")
-                if rank == 0:
-                    print("[bench] the IPC exchange failed or diverged on this node: falling back to RCCL all-reduce", file=sys.stderr, flush=True)
-                pipe._engines.clear()
-                comm.reset()
-                comm.use_rccl()
-                if not tp_pass_ok(i):
-                    raise RuntimeError("tensor-parallel ranks failed or diverged with the RCCL exchange too")
+                why = None
+                if comm.backend != "rccl":
+                    if rank == 0:
+                        print("[bench] the IPC exchange failed or diverged on this node: falling back to RCCL all-reduce", file=sys.stderr, flush=True)
+                    pipe._engines.clear()
+                    ok = 1
+                    try:
+                        comm.reset()
+                        comm.use_rccl()
+                    except Exception as e:                     # e.g. ncclCommInitRank refusing the topology
+                        print(f"[bench] rank {rank}: switching to the RCCL exchange failed: {e}", file=sys.stderr, flush=True)
+                        ok = 0
+                    flag = torch.tensor([ok], device="cpu" if dist.get_backend() == "gloo" else dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    if int(flag.item()) == 0 or not tp_pass_ok(i):
+                        why = "tensor-parallel ranks failed or diverged with the hand-written exchange AND with the RCCL exchange"
+                else:
+                    why = "tensor-parallel ranks failed or diverged (RCCL exchange)"
+                if why is not None:
+                    # last resort, so that the node still gets a measured line: every rank runs the whole model on its own GPU over
+                    # its own images (what the reference's evaluation scripts do) -- reported as replicas, weak scaling, with the reason
+                    if rank == 0:
+                        print(f"[bench] {why}: falling back to independent replicas", file=sys.stderr, flush=True)
+                    tp_note = why
+                    tp_mode = False
+                    pipe._engines.clear()
+                    del pipe
+                    comm = None
+                    torch.cuda.empty_cache()
+                    pipe = syn.build_pipeline(size, dev, with_ae=True, tp=None, weights=args.weights)
+                    pipe.tune = tune or None
+                    if args.attn_splits:
+                        pipe.attn_splits = args.attn_splits
+                    pipe.use_graph = not args.no_graph
+                    one_pass(i)
         else:
             one_pass(i)
     barrier()
@@ -422,7 +451,7 @@ def main():
                                    f"num_images={num_images} per {'job' if tp_mode else 'GPU'}" if size != "tiny" else "tiny",
                        "ar_steps": ar_steps, "rows_per_pass": eng.M,
                        "parallelism": (f"tp{n}" if tp_mode else f"replicas x{n}") if n > 1 else "single GPU",
-                       "hipgraph": pipe.use_graph},
+                       "hipgraph": pipe.use_graph, **({"tensor_parallel_fallback": tp_note} if tp_note else {})},
             "phases_ms_last_step": {k: round(v, 1) for k, v in pipe.timings().items()},
         }
         if tp_mode:

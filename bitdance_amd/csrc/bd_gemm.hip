@@ -146,13 +146,24 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
+    // one row tile per weight slice: non-temporal (the slice is read once, keep it out of L2's way).  Several row tiles: the SAME
+    // slice is read by RT workgroups a few hundred ns apart -- a non-temporal line is gone again by then (PMC, 512 rows, adaLN:
+    // 2.16 x the weight bytes fetched, profiles/r03_pmc_gemm_traffic.json), a default-policy line is still in that XCD's L2
+    const bool keep = p.w_keep != 0;
     auto load_w = [&](u32x4(&wr)[NPW * 4], int i) {
         i = min(i, last);
+        if (keep) {
 #pragma unroll
-        for (int pn = 0; pn < NPW; ++pn)
+            for (int pn = 0; pn < NPW; ++pn)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                wr[pn * 4 + j] = __builtin_nontemporal_load(Wp + (size_t)pn * p.PS + (size_t)i * w_stage + j * 64);
+                for (int j = 0; j < 4; ++j) wr[pn * 4 + j] = Wp[(size_t)pn * p.PS + (size_t)i * w_stage + j * 64];
+        } else {
+#pragma unroll
+            for (int pn = 0; pn < NPW; ++pn)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    wr[pn * 4 + j] = __builtin_nontemporal_load(Wp + (size_t)pn * p.PS + (size_t)i * w_stage + j * 64);
+        }
     };
     auto load_x = [&](int i) {
         i = min(i, last);
@@ -273,6 +284,7 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
 }
 
 // measurement switches of the 256-row kernel (process-wide; bd_set_gemm_option): W register ring depth and XCD placement
+static int g_wide_keep = -1;                              // weight loads of the 256-row kernel: -1 = default policy when > 1 row tile, 0 = always nt, 1 = never nt
 static int g_wide_ring = 2, g_wide_xcd = -1;            // xcd: -1 = by shape (on when the weights outweigh the rows), 0 / 1 forced
 void bdk_gemm_tile_debug(int v);
 static int g_tile = 1;                                   // >= 512 rows: the LDS-tiled MFMA-bound kernel (bd_gemm_tile.hip); 0 = 256-row kernel
@@ -282,6 +294,7 @@ int bdk_set_gemm_option(const char* name, int v) {
     if (n == "tile.debug" && v >= 0 && v <= 3) { bdk_gemm_tile_debug(v); return 0; }
     if (n == "wide.ring" && (v == 2 || v == 3)) { g_wide_ring = v; return 0; }
     if (n == "wide.xcd" && v >= -1 && v <= 1) { g_wide_xcd = v; return 0; }
+    if (n == "wide.keep" && v >= -1 && v <= 1) { g_wide_keep = v; return 0; }
     return -1;
 }
 
@@ -302,7 +315,9 @@ static int launch_gemm_wide_v(const GemmP& p, int epi, hipStream_t st) {
     return bd_launch_status();
 }
 
-static int launch_gemm_wide(const GemmP& p, int epi, hipStream_t st) {
+static int launch_gemm_wide(const GemmP& p0, int epi, hipStream_t st) {
+    GemmP p = p0;
+    p.w_keep = g_wide_keep < 0 ? (p.RB > 8) : g_wide_keep;
     // several row tiles per weight slice: keep them on one XCD when the slice is what dominates the traffic (N columns of
     // weights against RB * 32 rows of activations per K); a large batch (ImageNet: 12 288 rows) is the other way round.
     // Measured at 512 rows (profiles/r02_gemm_sweep3.log): adaLN 311 vs 352 us, gate/up 196 vs 207, wo / w2 (5 slices) 34.5 / 40.9

@@ -45,6 +45,7 @@ struct GemmP {
     int RB, N, K, S, Mpad;
     size_t PS, SS;       // packed-W strides in 16 B units: panel stride, 64-deep-K-stage stride
     const float* ascale = nullptr;   // fp8 ACTIVATIONS (WT = 2): per row [Mpad] fp32 dequantisation scale
+    int w_keep = 0;                  // 256-row kernel: 1 = default-policy weight loads (several row tiles read each slice: let L2 keep it)
 };
 
 // MFMA-bound form for >= 512 rows: both operands through LDS, 256 x 256 workgroup tiles (bd_gemm_tile.hip)

@@ -371,3 +371,24 @@ def test_bench_gpus2_from_plain_python_starts_its_own_ranks():
     tp = d["tp"]
     assert tp["size"] == 2 and tp["world_size_seen"] == 2 and tp["exchange_backend"] == "ipc" and tp["ranks_bit_identical"] is True
     assert tp["exchange_buffer_uncached"] in (True, False) and tp["images_checked_bit_identical"] == 2
+
+
+def test_bench_tensor_parallel_failure_ends_in_replicas_not_in_a_crash():
+    """The fall-back chain of `bench.py --gpus N` on a node where the tensor-parallel path does not work (forced here by
+    BD_BENCH_FAIL_TP): hand-written exchange -> RCCL exchange (refused on this box: two ranks on one device) -> independent replicas,
+    one whole model per rank, reported as such ("weak", "replicas x2", the reason in config) -- a measured line instead of no line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BD_BENCH_BACKEND="gloo", BD_BENCH_FAIL_TP="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "1", "--warmup", "1",
+           "--no-cpu-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "replicas x2" and "tp" not in d
+    assert "RCCL" in d["config"]["tensor_parallel_fallback"] and d["value"] > 0

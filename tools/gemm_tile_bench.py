@@ -2,7 +2,8 @@
 values (bit-identical for one K slice: same MFMA, same K order) and time, at the shapes that launch it -- the adaLN projection
 of 4 .. 52 evaluations (N = 71 680, K = 5120), the eval batch (512 rows: qkv / wo / w1 / w2 of the 14B head) and the ImageNet
 batch (12 288 rows at width 768).  Random bf16 data (timing on zeros overstates throughput: clocks).
-python tools/gemm_tile_bench.py"""
+python tools/gemm_tile_bench.py            tile kernel vs 256-row kernel
+python tools/gemm_tile_bench.py keep       256-row kernel only: non-temporal vs default-policy weight loads (bd_gemm.hip wide.keep)"""
 import os
 import sys
 
@@ -38,6 +39,9 @@ def main():
         ("head.w2 512", 5120, 7680, 16, "p", 5), ("llm.gu 512", 34816, 5120, 16, "s", 1),
         ("imagenet qkv", 2304, 768, 384, "b", 1), ("imagenet w1", 4096, 768, 384, "s", 1), ("imagenet w2", 768, 2048, 384, "b", 1),
     ]
+    keep_mode = len(sys.argv) > 1 and sys.argv[1] == "keep"
+    if keep_mode:
+        shapes = [sh for sh in shapes if sh[3] <= 64]
     for name, N, K, RB, form, S in shapes:
         M = RB * 32
         nrot = max(1, min(4, int(600e6 // (N * K * 2))))
@@ -47,7 +51,11 @@ def main():
         outs = {}
         res = {}
         for tile in (0, 1):
-            check(l.bd_set_gemm_option(b"tile", tile))
+            if keep_mode:                                   # slot 0: nt loads, slot 1: default-policy loads, both on the 256-row kernel
+                check(l.bd_set_gemm_option(b"tile", 0))
+                check(l.bd_set_gemm_option(b"wide.keep", tile))
+            else:
+                check(l.bd_set_gemm_option(b"tile", tile))
             if form == "p":
                 out = torch.zeros(S * M * N, dtype=torch.float32, device=DEV)
                 launch = lambda i: check(l.bd_gemm_partial(a.data_ptr(), RB, ws[i % nrot].data_ptr(), N, K, S, 8, out.data_ptr(), st), "gemm_partial")
@@ -66,11 +74,13 @@ def main():
             res[tile] = timed(launch, reps)
         same = torch.equal(outs[0].view(torch.int16 if form != "p" else torch.int32), outs[1].view(torch.int16 if form != "p" else torch.int32))
         fl = 2.0 * M * N * K
-        print(f"{name:16s} N={N:6d} K={K:5d} rows={M:6d} S={S}  256-row kernel {res[0]:9.1f} us {fl / res[0] / 1e6:7.0f} TFLOP/s | "
-              f"tile kernel {res[1]:9.1f} us {fl / res[1] / 1e6:7.0f} TFLOP/s ({fl / res[1] / 1e6 / 2500:.3f} of peak) | bit-identical {same}", flush=True)
+        la, lb = ("nt loads      ", "default loads") if keep_mode else ("256-row kernel", "tile kernel")
+        print(f"{name:16s} N={N:6d} K={K:5d} rows={M:6d} S={S}  {la} {res[0]:9.1f} us {fl / res[0] / 1e6:7.0f} TFLOP/s | "
+              f"{lb} {res[1]:9.1f} us {fl / res[1] / 1e6:7.0f} TFLOP/s ({fl / res[1] / 1e6 / 2500:.3f} of peak) | bit-identical {same}", flush=True)
         del ws, a, outs
         torch.cuda.empty_cache()
     check(l.bd_set_gemm_option(b"tile", 1))
+    check(l.bd_set_gemm_option(b"wide.keep", -1))
 
 
 if __name__ == "__main__":

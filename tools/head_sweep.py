@@ -50,7 +50,13 @@ def run():
     cond = torch.randn(2 * B, 64, 5120, device=dev, generator=g)
     noise = torch.randn(1, n + 1, B, 64, 32, device=dev, generator=g)
     ref = None
+    from bitdance_amd._lib import check, lib
     for tune in cfgs:
+        tune = dict(tune)
+        opts = {k: tune.pop(k) for k in list(tune) if k.startswith("wide.") or k == "tile"}      # process-wide GEMM options
+        for k, v in opts.items():
+            check(lib().bd_set_gemm_option(k.encode(), v))
+        tune_shown = dict(tune, **opts)
         eng = E.Engine(hw, None, None, num_images=B, branches=2, device=dev, max_tokens=64, parallel_num=64, tune=tune)
         eng.set_schedule(n, 7.5, 1)
         eng.load_noise(noise)
@@ -76,9 +82,11 @@ def run():
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
         dt = min(ts)
-        print(f"{str(tune):60s} graph {dt * 1e3:8.2f} ms/AR step  {dt / (n + 1) * 1e6:8.1f} us/eval  (median {sorted(ts)[len(ts) // 2] * 1e3:.2f})  "
+        print(f"{str(tune_shown):60s} graph {dt * 1e3:8.2f} ms/AR step  {dt / (n + 1) * 1e6:8.1f} us/eval  (median {sorted(ts)[len(ts) // 2] * 1e3:.2f})  "
               f"bit-identical to first: {same}", flush=True)
         del eng
+        for k in opts:
+            check(lib().bd_set_gemm_option(k.encode(), {"wide.ring": 2, "tile": 1}.get(k, -1)))
         torch.cuda.empty_cache()
 
 
