@@ -140,8 +140,17 @@ class TPComm:
             if self.l.bd_comm_ipc_handles(self.h, buf) != 0:
                 ok, why = False, self.l.bd_last_error().decode()
             handles = [None] * size
-            dist.all_gather_object(handles, (bytes(buf.raw), ok, why), group=group)
+            my_dev = torch.device(self.device).index if self.device is not None else None
+            if my_dev is None:
+                my_dev = torch.cuda.current_device()
+            dist.all_gather_object(handles, (bytes(buf.raw), ok, why, my_dev, _device_uuid(self.device)), group=group)
             ok = all(h[1] for h in handles)
+            if ok and torch.cuda.device_count() >= size:
+                # ask the runtime before touching a peer's memory: a mapping that "opens" but faults on the first remote store
+                # takes the process down, which no fall-back can catch (ranks that see only their own device cannot ask: skipped)
+                for p in range(size):
+                    if p != rank and handles[p][4] != handles[rank][4] and not torch.cuda.can_device_access_peer(my_dev, handles[p][3]):
+                        ok, why = False, f"device {my_dev} cannot access device {handles[p][3]} (no peer-to-peer path)"
             if ok:
                 for p in range(size):
                     if p != rank and self.l.bd_comm_open_peer(self.h, p, C.create_string_buffer(handles[p][0], 128)) != 0:
