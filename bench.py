@@ -122,8 +122,10 @@ def gemm_roofline(eng, run, rows: int) -> dict:
             rec["rows_per_pass"] = G * rows
             rec["evaluations_per_launch"] = G
             rec["algorithmic_GBs"] = round(r["bytes"] * G / r["ms"] / 1e6, 1)
-            rec["TFLOPs"] = round(r["bytes"] * G * rows / r["ms"] / 1e9, 1)
-            rec["frac_of_mfma_peak"] = round(rec["TFLOPs"] / MFMA_PEAK_TFS, 4)
+            bpw = 1 if eng.wdtype else 2                          # bytes per weight: 2 * rows * N * K flop = bytes * rows * 2 / bpw
+            peak = MFMA_PEAK_TFS * (2 if eng.wdtype == 2 else 1)  # fp8 x fp8 MFMA: twice the bf16 rate
+            rec["TFLOPs"] = round(r["bytes"] * (2 / bpw) * G * rows / r["ms"] / 1e9, 1)
+            rec["frac_of_mfma_peak"] = round(rec["TFLOPs"] / peak, 4)
             rec["note"] = (f"ONE pass over the weights serves {G} evaluations (256-row kernel, MFMA-bound at {G * rows} rows): GBs = bytes "
                            f"physically streamed / time, algorithmic_GBs = {G} x N*K*2 (the reference streams them once per evaluation) / time")
             grouped.append(rec)

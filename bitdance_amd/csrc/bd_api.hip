@@ -155,7 +155,7 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
     // 3695 vs 3794 ms, image 0.2638 vs 0.2569 /s.  3 slices stay slabs (tune.reduce_max_s = 2: the in-launch reduction of 3 costs 8 us).
     bool slab3 = false;
     if (!two_images && !reduce3 && g.nw == 4 && g.kw == 1 && S >= 4 && K % 128 == 0 && N % 64 == 0 && K <= 8192 && !c->wfp8 &&
-        c->geti("tune.slab3", 1) != 0) {
+        c->geti("tune.slab3", 1) != 0) {     // (fp8 weights: measured 2 % SLOWER, profiles/r03_head_sweep5_fp8a.log -- the 26-39 MB streams are all fill / drain)
         const int t64 = N / 64, s64 = std::min(3, (int)std::lround(240.0 / t64));
         // (exactly 3: the 2-slice case, llm.qkv N = 7168, would turn 4 slabs into an in-launch reduction: 27.9 vs 23.9 us measured)
         if (s64 == 3 && t64 * s64 <= 256 && t64 * s64 >= 200) { g.nw = 4; g.kw = 2; S = s64; ntiles = t64; slab3 = true; }
@@ -194,7 +194,7 @@ static const char* const kIntKeys[] = {
     "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid", "head.y_evals", "head.variant",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "proj.rows_all", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
     "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async", "tune.ragged", "tune.ragged52", "tune.slab_cap", "tune.slab3",
-    "tune.ada_group"};
+    "tune.ada_group", "tune.ada_group_nw"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
                                          "llm.qkv", "llm.o", "llm.gu", "llm.down"};
 static bool known_int_key(const std::string& k) {
@@ -459,12 +459,13 @@ int bd_ctx_finalize(bd_ctx* c) {
             // per evaluation at G = 4, 8 and 16 against 1006 at G = 1).  The last group of a schedule is short.
             {
                 long long g = c->geti("tune.ada_group", -1);
-                const bool can = !c->wfp8 && c->hNada % 256 == 0 && c->geti("tune.ada_async", 0) == 0;
+                // (fp8 weights with bf16 activations have no 256-row form; fp8 weights + activations do: bd_gemm8.hip)
+                const bool can = (!c->wfp8 || c->fp8a) && c->hNada % 256 == 0 && c->geti("tune.ada_async", 0) == 0;
                 // 128 rows and fewer: 512 rows per GEMM; 256 / 512 rows (num_images 2 / 4): 1024 rows per GEMM, where the LDS-tiled
                 // MFMA-bound kernel takes over (bd_gemm_tile.hip: adaLN at 1024 rows 694 vs 786 us on the 256-row kernel)
                 if (g < 0) g = !can ? 1 : (Mp <= 128 ? 512 / Mp : (Mp <= 512 && 1024 % Mp == 0 ? 1024 / Mp : 1));
                 if (g < 1 || g > 64 || (g > 1 && ((c->RB * g) % 8 != 0 || !can)))
-                    return fail("tune.ada_group: 1..64 evaluations, rows a multiple of 256, adaLN width a multiple of 256, bf16 weights, no ada_async");
+                    return fail("tune.ada_group: 1..64 evaluations, rows a multiple of 256, adaLN width a multiple of 256, bf16 weights or fp8 weights + activations, no ada_async");
                 c->adaG = (int)g;
             }
             add("head.cond_frag", Mp * c->hDz * 2);
@@ -661,7 +662,7 @@ static int head_cond(bd_ctx* c, hipStream_t st) {   // cond_embed(c) is constant
     const int G = c->adaG;
     if (n_evals > 0 && c->optr("head.y_all") && c->geti("head.y_evals", 0) >= (n_evals + G - 1) / G * G) {
         HeadYAllArgs ya{c->ptr("head.cemb"), c->ptr("head.temb"), c->wptr("head.y_all"), c->M, c->hD, c->RB, c->Mpad, n_evals, G};
-        if (c->fp8a) ya.a8_scale = (float*)c->wptr("head.y_scale_all");   // (G == 1 in the fp8 modes)
+        if (c->fp8a) ya.a8_scale = (float*)c->wptr("head.y_scale_all");
         BD_TRY(bdk_head_y_all(ya, st));
         c->y_ready = true;
     }
@@ -705,7 +706,9 @@ static int head_ada_group(bd_ctx* c, int g, hipStream_t st) {
     const bf16_t* y = (const bf16_t*)c->ptr("head.y_all") + (size_t)g * G * c->Mpad * D;
     char name[32];
     std::snprintf(name, sizeof(name), "head.ada[x%d]", Gg);     // profiling: Gg evaluations' worth of rows per weight pass
-    BD_TRY(gemm(c, name, y, rbg, wref(c, "head.ada_w"), c->hNada, D, 1, /*8 waves, ring 2: the 256-row / tiled kernels*/ 8 + 16 * 2,
+    WRef wa = wref(c, "head.ada_w");
+    if (c->fp8a) wa.a = (const float*)c->ptr("head.y_scale_all") + (size_t)g * G * c->Mpad;
+    BD_TRY(gemm(c, name, y, rbg, wa, c->hNada, D, 1, /*8 waves, ring 2: the 256-row / tiled kernels*/ (int)c->geti("tune.ada_group_nw", c->fp8a ? 4 : 8) + 16 * 2,
                 BD_EPI_BF16, nullptr, c->wptr("head.ada_bf"), c->ptr("head.ada_b"), st));
     return 0;
 }

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
     auto compute = [&](const u32x4* stage, const u32x4(&wr)[WL]) {
         if constexpr (WT == 2) {                                          // one fp8 MFMA (K = 64) per row block
             const u32x4* buf8 = stage + kg * MB * 128;
-            if constexpr (NW > 8) {                                      // 9 / 10 waves: 168 registers per wave -- one row block's fragments at a time
+            if constexpr (NW > 8 || MB > 4) {                            // 9 / 10 waves (168 registers per wave) or 256 rows (128 accumulator registers): one row block's fragments at a time
 #pragma unroll
                 for (int m = 0; m < MB; ++m) {
                     const u32x4 x0 = buf8[(m * 2) * 64 + lane], x1 = buf8[(m * 2 + 1) * 64 + lane];

@@ -327,16 +327,18 @@ __global__ void head_y_all_kernel(HeadYAllArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) y[j] = silu_f(bfr(te[j] + ce[j]));           // bf16 + bf16 -> bf16 ; silu -> bf16 (rounded by pack8)
     }
-    if (a.a8_scale) {                                              // (G == 1) evaluation i's operand sits at the same element offset, half used
-#pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = bfr(y[j]);
-        const float inv = row_quant_scale(y, act_, red8, a.a8_scale + (size_t)i * a.Mpad, m);
-        if (act_) quant8_store((unsigned char*)((bf16_t*)a.y_all + (size_t)i * a.Mpad * a.D), m, d0, a.RB, y, inv);
-        return;
-    }
     const int g = i / a.G, left = a.n_evals - g * a.G;              // evaluations in this group's matrix
     const int rbg = (left >= a.G || a.G == 1) ? a.RB * a.G : ((a.RB * left + 7) & ~7);
-    *reinterpret_cast<u32x4*>((bf16_t*)a.y_all + (size_t)g * a.G * a.Mpad * a.D + afrag_off(m + (i % a.G) * a.Mpad, d0, rbg)) = pack8(y);
+    bf16_t* const base = (bf16_t*)a.y_all + (size_t)g * a.G * a.Mpad * a.D;      // (fp8: the group's operand uses half of this span)
+    const int row = m + (i % a.G) * a.Mpad;
+    if (a.a8_scale) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = bfr(y[j]);
+        const float inv = row_quant_scale(y, act_, red8, a.a8_scale + (size_t)i * a.Mpad, m);   // scales [eval][Mpad]: a group's rows are contiguous
+        if (act_) quant8_store((unsigned char*)base, row, d0, rbg, y, inv);
+        return;
+    }
+    *reinterpret_cast<u32x4*>(base + afrag_off(row, d0, rbg)) = pack8(y);
 }
 int bdk_head_y_all(const HeadYAllArgs& a, hipStream_t st) {
     const int t = row_threads(a.D);

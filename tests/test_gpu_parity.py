@@ -1108,14 +1108,16 @@ def test_head_sample_chain_equals_standalone_evaluations(eng_mod, B, branches):
     assert torch.equal(s.pred(), b.pred())
 
 
-@pytest.mark.parametrize("P,B,groups", [(64, 1, (1, 2, 4)), (16, 1, (1, 16)), (16, 2, (1, 8))])
-def test_grouped_adaln_projection_bit_identical(eng_mod, P, B, groups):
+@pytest.mark.parametrize("P,B,groups,weights", [(64, 1, (1, 2, 4), "bf16"), (16, 1, (1, 16), "bf16"), (16, 2, (1, 8), "bf16"),
+                                                 (64, 1, (1, 2, 4), "fp8a"), (16, 1, (1, 16), "fp8a"), (16, 2, (1, 8), "fp8a")])
+def test_grouped_adaln_projection_bit_identical(eng_mod, P, B, groups, weights):
     """The adaLN projection depends on (t_i, cond) only, so head_sample computes it for G evaluations per GEMM launch
     (tune.ada_group; default 512 rows per launch).  Every row's K sum runs in the same order through the same MFMA as in the
-    per-evaluation launch: the sampled latents are bit-identical for every G, eager and as a replayed graph."""
+    per-evaluation launch: the sampled latents are bit-identical for every G, eager and as a replayed graph.  fp8a: the group's
+    e4m3 operand and per-row scales come from head_y_all_kernel, the 256-row form of the fp8 x fp8 kernel multiplies them."""
     cfg = dict(tm.TINY_HEAD, parallel_num=P)
     sd = tm.seeded_state(tm.head_shapes(cfg), seed=13)
-    hw = eng_mod.HeadWeights.from_state_dict(sd, DEV)
+    hw = eng_mod.HeadWeights.from_state_dict(sd, DEV, weights=weights)
     n = 6
     g = torch.Generator().manual_seed(2)
     noise = torch.randn(1, n + 1, B, P, 32, generator=g)

@@ -6,7 +6,7 @@
 (the run-ahead weight prefetch this tool also swept in round 3 -- profiles/r03_head_sweep1.log -- measured negative and is gone)
 
 Every configuration is timed as a hipGraph replay and its sampled latent is compared bit for bit with the first one's.
-python tools/head_sweep.py [reps] [n_steps] ["k=v,k=v;k=v,..." extra configs]"""
+python tools/head_sweep.py [reps] [n_steps] ["k=v,k=v;k=v,..." extra configs] [bf16|fp8|fp8a]"""
 import os
 import sys
 import time
@@ -44,7 +44,7 @@ def run():
     B = 1
     cfgd = dict(ch_target=32, ch_cond=5120, ch_latent=5120, depth_latent=6, depth_adanln=2)
     sd = device_seeded_state(tm.head_shapes(cfgd), 101, dev)
-    hw = E.HeadWeights.from_state_dict(sd, dev)
+    hw = E.HeadWeights.from_state_dict(sd, dev, weights=sys.argv[4] if len(sys.argv) > 4 else "bf16")
     del sd
     g = torch.Generator(device=dev).manual_seed(7)
     cond = torch.randn(2 * B, 64, 5120, device=dev, generator=g)
