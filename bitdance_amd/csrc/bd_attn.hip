@@ -653,6 +653,7 @@ __global__ __launch_bounds__(640) void llm_attn_kernel(LlmAttnArgs a) {
                 }
             }
         }
+        BD_MFMA_DRAIN();                                     // the loop's exit edge leads straight to the accumulator reads (bd_common.h)
     }
     // partial results: [seq][kvh][split][G*P rows][128] and (m, l) per row
     const size_t blk = ((size_t)seq * a.nkv + kvh) * a.splits + split;

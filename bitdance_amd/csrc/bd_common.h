@@ -11,6 +11,16 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define BD_DEV __device__ __forceinline__
 
+// hipcc (ROCm 7.2, gfx950) under-counts the MFMA -> accumulator-read wait states across a TAKEN BRANCH: a guarded loop tail whose last
+// executed phase ends in MFMAs jumps to a join that reads the last accumulator registers 6 instructions later (one `s_nop 0` inserted,
+// >= 11 needed for an 8-pass MFMA).  Observed: acc[MB-1][15] stale -- rows 27 / 31 of the last row block wrong -- exactly when the K
+// stages fill the whole tail (tools/ring_debug.py: gemm_kernel<2,2,4,..,R=3> at 14 stages, <4,1,4,..,R=4> at 15 / 27).  The forms the
+// engine launches never hit that stage count, but nothing guaranteed it.  The accumulator copies are emitted at the very top of the
+// join block, ahead of anything the source can place there, so the drain (32 wait states: a 16-pass MFMA needs 19) goes at the END of
+// the block that holds the last MFMAs: the final guarded phase of a K loop, the last statement of an MFMA loop body.
+#define BD_MFMA_DRAIN() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); \
+                             __builtin_amdgcn_sched_barrier(0); } while (0)
+
 BD_DEV float bf2f(bf16_t x) { return __uint_as_float(((unsigned)x) << 16); }
 
 // fp32 -> bf16 round-to-nearest-even (what torch's .to(bfloat16) does): gfx950 has it in hardware (v_cvt_pk_bf16_f32).

@@ -166,6 +166,7 @@ __global__ __launch_bounds__(512) void conv_tile_kernel(ConvP p) {
             mfma_seg(j);
         }
         __syncthreads();
+        BD_MFMA_DRAIN();                                        // (bd_common.h: drain in the block that holds the last MFMAs)
     } else {
         __syncthreads();
         __syncthreads();
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(512) void conv_tile_kernel(ConvP p) {
         }
         __syncthreads();
         mfma_seg(nst - 1);
+        BD_MFMA_DRAIN();
     }
 
     // ---- epilogue: conv output = bf16(acc + bias) (what F.conv2d returns under autocast), parked per wave in LDS as

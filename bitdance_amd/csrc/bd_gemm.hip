@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
         if (j + 1 < nst) phase(std::integral_constant<int, 1>{}, j + 1);
     }
 
+    // (every phase ends in a workgroup barrier behind its MFMAs: no accumulator read can follow them closely)
     // ---- epilogue (same forms as gemm_kernel)
     const int col = nb * 32 + (lane & 31);
     float bias_pn[NPW];
@@ -355,7 +356,7 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
     // else 128 / 64 / 32
     const int MB = (RB % 8 == 0 && nw >= 4 && kw == 1) ? 8 : ((RB % 4 == 0) ? 4 : RB);
     if (MB != 8 && MB != 4 && MB != 2 && MB != 1) return -5;
-    if (MB == 8 || nw == 2 || nw >= 9 || kw == 2) ring = 2;        // register budget
+    if (MB == 8 || nw == 2 || nw >= 9 || (kw == 2 && !(nw == 4 && MB == 4 && ring == 3))) ring = 2;        // register budget
     // 256-row passes over 256-column tiles: 4 waves x 2 panels (MFMA-friendly) instead of 8 waves x 1 panel;
     // same grid.  BD_GEMM_WIDE=0 keeps the 8-wave form (A/B switch for measurements).
     static const bool wide = [] { const char* e = getenv("BD_GEMM_WIDE"); return !(e && e[0] == '0'); }();
@@ -377,7 +378,7 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
     BD_CASE(2, 1, 4, 2) BD_CASE(4, 1, 4, 2) BD_CASE(8, 1, 4, 2) BD_CASE(4, 1, 4, 3) BD_CASE(8, 1, 4, 3) BD_CASE(4, 1, 4, 4) BD_CASE(8, 1, 4, 4)
     BD_CASE(2, 1, 2, 2) BD_CASE(4, 1, 2, 2) BD_CASE(8, 1, 2, 2) BD_CASE(4, 1, 2, 4) BD_CASE(8, 1, 2, 4)
     BD_CASE(2, 1, 1, 2) BD_CASE(4, 1, 1, 2) BD_CASE(8, 1, 1, 2)
-    BD_CASE(1, 2, 4, 2) BD_CASE(2, 2, 4, 2) BD_CASE(4, 2, 4, 2) BD_CASE(5, 2, 4, 2)
+    BD_CASE(1, 2, 4, 2) BD_CASE(2, 2, 4, 2) BD_CASE(4, 2, 4, 2) BD_CASE(5, 2, 4, 2) BD_CASE(2, 2, 4, 3)
     BD_CASE(1, 2, 2, 2) BD_CASE(2, 2, 2, 2) BD_CASE(4, 2, 2, 2)
     BD_CASE(1, 2, 1, 2) BD_CASE(2, 2, 1, 2) BD_CASE(4, 2, 1, 2)
 #undef BD_CASE

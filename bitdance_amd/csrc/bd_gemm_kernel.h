@@ -235,6 +235,7 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
                 load_w(w[ph & 1], j + 2);
             }
             if (j + 1 < nst) __syncthreads();
+            else BD_MFMA_DRAIN();                          // the last executed phase branches straight to the accumulator reads (bd_common.h)
         }
     }
   } else {
@@ -269,6 +270,8 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
                 store_x(lds + ((ph + 1) & 1) * UNITS, xr[(ph + 1) % XR]);
                 if (j + R < nst) { load_x(xr[(ph + 1) % XR], j + R); load_w(w[ph % R], j + R); }
                 __syncthreads();
+            } else {
+                BD_MFMA_DRAIN();                           // the last executed phase branches straight to the accumulator reads (bd_common.h)
             }
         }
     }

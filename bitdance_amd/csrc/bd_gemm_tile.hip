@@ -167,6 +167,7 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(GemmP p, int dbg) {
             if (!(dbg & 1)) mfma_seg(j);
         }
         __syncthreads();                                        // Y has read its last fragments: LDS is free for the epilogue
+        BD_MFMA_DRAIN();                                        // (bd_common.h: drain in the block that holds the last MFMAs)
     } else {
         __syncthreads();
         __syncthreads();
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(GemmP p, int dbg) {
         }
         __syncthreads();
         if (!(dbg & 1)) mfma_seg(nst - 1);                      // Y's last stage
+        BD_MFMA_DRAIN();
     }
 
     // ---- epilogue.  D layout of the 32x32 MFMA: lane -> column lane & 31, reg r -> row (r&3)+8(r>>2)+4(lane>>5).

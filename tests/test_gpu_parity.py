@@ -68,6 +68,31 @@ def test_gemm_partial(eng_mod, M, N, K, S, nw):
     assert err <= 2e-5 * K ** 0.5 + 1e-5, err              # fp32 accumulation-order noise only
 
 
+@pytest.mark.parametrize("nw,kw,ring", [(4, 1, 2), (4, 1, 3), (4, 1, 4), (8, 1, 2), (8, 1, 3), (8, 1, 4), (2, 1, 2), (4, 2, 2), (4, 2, 3),
+                                        (8, 2, 2), (2, 2, 2), (9, 1, 2), (10, 1, 2)])
+def test_gemm_every_stage_count(eng_mod, nw, kw, ring):
+    """Every K-stage count 1 .. 30 through every tile form / register-ring depth: the guarded tail of the K loop runs 1 .. U + R - 1
+    phases.  Regression for a compiler hazard (bd_common.h BD_MFMA_DRAIN): when the LAST tail phase executed, its final MFMA was
+    followed across a taken branch by the accumulator copies with too few wait states -- acc[3][15] (rows 27 / 31 of the last row
+    block) stale at exactly 14 stages (ring 3, K-part tiles) or 15 / 27 (ring 4); tools/ring_debug.py."""
+    from bitdance_amd._lib import check, lib
+    M, N = 128, 32 * (nw // kw) * 2
+    g = torch.Generator(device=DEV).manual_seed(100 * nw + 10 * kw + ring)
+    st = torch.cuda.current_stream().cuda_stream
+    for n in range(1, 31):
+        K = 64 * kw * n
+        x = torch.randn(M, K, device=DEV, generator=g)
+        w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)
+        xf, rb = frag(eng_mod, x)
+        wp = eng_mod.pack_linear([w], DEV)
+        out = torch.full((1, rb * 32, N), float("nan"), device=DEV)
+        check(lib().bd_gemm_partial(xf.data_ptr(), rb, wp.data_ptr(), N, K, 1, nw + 16 * ring + 256 * (kw - 1), out.data_ptr(), st))
+        torch.cuda.synchronize()
+        ref = x.to(torch.bfloat16).double() @ w.double().t()
+        err = (out[0, :M].double() - ref).abs().max().item()
+        assert err <= 2e-5 * K ** 0.5 + 1e-5, (n, err)
+
+
 @pytest.mark.parametrize("M,F_,K,nw", [(128, 384, 256, 2), (128, 512, 256, 4), (64, 256, 256, 2), (128, 7680, 5120, 2),
                                        (256, 512, 256, 8), (512, 7680, 5120, 8), (128, 352, 256, 5), (128, 17408, 5120, 5),
                                        (128, 352, 256, 10 + 256), (128, 17408, 5120, 10 + 256)])
