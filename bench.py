@@ -85,7 +85,7 @@ def parse():
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8", "fp8a"],
                     help="fp8: streamed Linear weights as e4m3 + per-channel scales (BASELINE config 5; a separate precision mode); "
                          "fp8a: also e4m3 activations (per-row scales) on the fp8 matrix pipe for the GEMMs fed by a row kernel")
-    ap.add_argument("--attn-splits", type=int, default=None, help="KV splits of the LLM decode attention (default 8)")
+    ap.add_argument("--attn-splits", type=int, default=None, help="KV splits of the LLM decode attention (default: 12 beyond 2k cached tokens, else 8)")
     ap.add_argument("--tune", default="", help="comma list name.S=4,name.nw=2,kw2=0 overriding GEMM launch configs")
     a = ap.parse_args()
     if a.workload is None:

@@ -182,7 +182,10 @@ class BitDanceT2IPipeline:
             self._engines[key] = Engine(self.head_w, self.proj_w, self.llm_w, num_images=num_images,
                                         branches=branches, device=self.device, max_tokens=tokens, max_kv=lmax,
                                         tune=getattr(self, "tune", None), parallel_num=self.parallel_num, comm=self.tp,
-                                        attn_splits=getattr(self, "attn_splits", 8))
+                                        # flash-decode splits of the KV cache: 12 once the cache passes ~2k tokens (a 1024 px image ends
+                                        # at 4.4k): 248 vs 265 us per layer at 4096 cached tokens, no difference below 1k
+                                        # (profiles/r03_llm_attn_splits.log); more splits only add partial-output traffic
+                                        attn_splits=getattr(self, "attn_splits", None) or (12 if lmax > 2048 else 8))
         return self._engines[key]
 
     def _prompt_ids(self, cond_prompt, uncond_prompt, image_size, cfg_on):

@@ -2,7 +2,8 @@
 on ONE box: a 12-layer slice of the model at true dimensions (7.9 GB of packed weights: every layer's weights come from HBM),
 caches ~1k tokens long, the step run eagerly and timed with events on the launch stream, plus the in-situ time of each GEMM.
 
-python tools/llm_sweep.py [reps] ["k=v,k=v;k=v,..." configs]      keys: llm.<gemm>.{S,nw,kw,ring}, slab3, kparts8, ..."""
+python tools/llm_sweep.py [reps] ["k=v,k=v;k=v,..." configs] [cached tokens]      keys: llm.<gemm>.{S,nw,kw,ring}, slab3, kparts8, ...,
+                                                                                    splits (flash-decode splits of the attention)"""
 import os
 import sys
 
@@ -45,13 +46,18 @@ def run():
     g = torch.Generator(device=dev).manual_seed(3)
     x = torch.randn(128, cfg["hidden_size"], device=dev, generator=g)
     ref = None
+    past = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
     for tune in cfgs:
-        eng = E.Engine(None, None, lw, num_images=1, branches=2, device=dev, max_tokens=64, max_kv=1280, tune=tune)
+        tune = dict(tune)
+        splits = tune.pop("splits", 8)
+        eng = E.Engine(None, None, lw, num_images=1, branches=2, device=dev, max_tokens=64, max_kv=past + 256, attn_splits=splits,
+                       tune=tune)
+        tune["splits"] = splits
         eng.set_int("rt.emit_cond", 0)                      # no head in this context
         st = torch.cuda.current_stream()
 
         def step():
-            eng.reset([1024, 1019])
+            eng.reset([past, past - 5])
             eng.residual()[:128].copy_(x)
             eng.llm_step()
 
@@ -63,7 +69,7 @@ def run():
         err = float((hid - ref).abs().max())
         ts = []
         for _ in range(reps):
-            eng.reset([1024, 1019])
+            eng.reset([past, past - 5])
             eng.residual()[:128].copy_(x)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
