@@ -185,7 +185,9 @@ class BitDanceT2IPipeline:
                                         # flash-decode splits of the KV cache: 12 once the cache passes ~2k tokens (a 1024 px image ends
                                         # at 4.4k): 248 vs 265 us per layer at 4096 cached tokens, no difference below 1k
                                         # (profiles/r03_llm_attn_splits.log); more splits only add partial-output traffic
-                                        attn_splits=getattr(self, "attn_splits", None) or (12 if lmax > 2048 else 8))
+                                        # (a tensor-parallel rank holds 8 / tp kv heads: scale the splits so the grid keeps its size)
+                                        attn_splits=getattr(self, "attn_splits", None)
+                                        or min(32, (12 if lmax > 2048 else 8) * (self.tp.size if self.tp is not None else 1)))
         return self._engines[key]
 
     def _prompt_ids(self, cond_prompt, uncond_prompt, image_size, cfg_on):
