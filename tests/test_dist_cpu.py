@@ -118,3 +118,35 @@ def test_fid_sampler_uint8_and_args():
     assert to_uint8(x)[0, 0, :, 0].tolist() == [0, 0, 128, 255, 255]        # clamp(127.5 x + 128), truncation to uint8
     a = get_args(["--model", "BitDance-B", "--ckpt", "models/BitDance_B_16x.pt", "--cfg-scale", "6.1", "--parallel-num", "16"])
     assert folder_name(a) == "BitDance-B-BitDance_B_16x-size-256-steps-100-cfg-6.1-seed-99"
+
+
+def test_bench_launch_line_for_gpus_n(monkeypatch):
+    """`python bench.py --gpus N` from a plain interpreter re-executes itself as one process per GPU: the launch line is the
+    driver's own (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    <the same arguments>`), the rendezvous is on 127.0.0.1 and the dmabuf IPC switch travels in the environment."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.setenv("BD_BENCH_BACKEND", "gloo")             # (no devices here: the RCCL path refuses before launching)
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    args = bench.parse()
+    assert args.gpus == 4
+    assert bench.spawn_ranks(args) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:5] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4"]
+    assert cmd[5:7] == ["--master-addr", "127.0.0.1"] and cmd[7] == "--master-port" and 1024 < int(cmd[8]) < 65536
+    assert cmd[9] == os.path.join(root, "bench.py") and cmd[10:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.delenv("BD_BENCH_BACKEND")
+    assert bench.spawn_ranks(args) == 2                        # RCCL backend, fewer devices than ranks: refused with a message, nothing launched
