@@ -1,4 +1,4 @@
-"""Native conv decoder of the binary tokenizer: ``Decoder.forward`` (/root/reference/modeling/vision_encoder/autoencoder.py:129-196,
+"""Native conv decoder (and encoder: NativeEncoder, below) of the binary tokenizer: ``Decoder.forward`` (/root/reference/modeling/vision_encoder/autoencoder.py:129-196,
 ResBlock :13-57, Upsampler / depth_to_space :198-250, AdaptiveGroupNorm :251-277) on the hand-written gfx950 kernels of
 csrc/bd_conv.hip -- 3x3 / 1x1 convolutions as implicit GEMMs on the matrix pipe, GroupNorm statistics + fused
 normalise / AdaGN / swish passes, depth-to-space in the upsampling convolution's epilogue -- instead of MIOpen.
@@ -24,12 +24,16 @@ def _st() -> int:
 class _Conv:
     """One nn.Conv2d (3x3 pad 1, or 1x1) packed for bd_conv: [Cout -> 256-multiple][taps * Cin], K ordered (ky, kx, ci)."""
 
-    def __init__(self, conv: torch.nn.Conv2d, device):
+    def __init__(self, conv: torch.nn.Conv2d, device, cin_pad: int = 0):
         w = conv.weight.detach().to(device=device, dtype=torch.float32)
+        if cin_pad > w.shape[1]:                                # the encoder's conv_in: 3 image channels in a 32-channel (zero) operand
+            w = torch.cat([w, w.new_zeros(w.shape[0], cin_pad - w.shape[1], *w.shape[2:])], dim=1)
         self.cout, self.cin, kh, kw = w.shape
         self.taps = kh * kw
-        if (kh, kw) not in ((3, 3), (1, 1)) or self.cin % 32:
-            raise BitDanceHipError(f"native decoder: unsupported convolution {tuple(w.shape)}")
+        self.stride = int(conv.stride[0])
+        if (kh, kw) not in ((3, 3), (1, 1)) or self.cin % 32 or conv.stride[0] != conv.stride[1] or self.stride not in (1, 2) or \
+                (self.stride == 2 and (kh != 3 or tuple(conv.padding) != (1, 1))):
+            raise BitDanceHipError(f"native tokenizer: unsupported convolution {tuple(w.shape)} stride {tuple(conv.stride)}")
         npad = (self.cout + 255) // 256 * 256
         m = torch.zeros(npad, self.taps * self.cin, dtype=BF16, device=device)
         m[: self.cout] = w.permute(0, 2, 3, 1).reshape(self.cout, -1).to(BF16)
@@ -91,9 +95,10 @@ class NativeDecoder:
     # -- operators ---------------------------------------------------------------------------------------------------
     def _conv(self, cv: _Conv, x, out, n, H, W, *, mode=0, res=None):
         l = lib()
-        check(l.bd_conv(x.data_ptr(), cv.w.data_ptr(), None if cv.bias is None else cv.bias.data_ptr(),
-                        None if res is None else res.data_ptr(), int(res is not None and res.dtype == torch.float32),
-                        out.data_ptr(), mode, int(out.dtype == torch.float32), n, H, W, cv.cin, cv.cout, cv.taps, _st()), "bd_conv")
+        check(l.bd_conv_strided(x.data_ptr(), cv.w.data_ptr(), None if cv.bias is None else cv.bias.data_ptr(),
+                                None if res is None else res.data_ptr(), int(res is not None and res.dtype == torch.float32),
+                                out.data_ptr(), mode, int(out.dtype == torch.float32), n, H, W, cv.cin, cv.cout, cv.taps, cv.stride, _st()),
+              "bd_conv_strided")
         return out
 
     def _stats(self, x, n, H, W, C, eps):
@@ -163,3 +168,59 @@ class NativeDecoder:
         img = torch.empty(n, self.conv_out.cout, H, W, dtype=torch.float32, device=self.device)
         self._conv(self.conv_out, pn, img, n, H, W, mode=2)
         return img.to(BF16)
+
+
+class NativeEncoder(NativeDecoder):
+    """``encode(x)`` == ``Encoder.forward(x)`` under ``torch.autocast('cuda', bfloat16)`` (autoencoder.py:59-127: conv_in, per level
+    ResBlocks + a stride-2 3x3 convolution, mid blocks, norm_out -> swish -> 1x1 conv_out).  The dtype flow is simpler than the
+    decoder's: no AdaptiveGroupNorm, so every convolution output and the residual stream are bf16, GroupNorm / swish fp32.
+    The same kernels as the decoder (bd_conv.hip); H, W of the image must be multiples of 2^(levels - 1)."""
+
+    def __init__(self, enc, device):
+        self.device = torch.device(device)
+        self.enc = enc
+        self.nlev = enc.nlev
+        C = lambda m, **k: _Conv(m, self.device, **k)
+        self.conv_in = C(enc.conv_in, cin_pad=32)
+        self.levels = []
+        for lv in range(self.nlev):
+            level = enc.down[lv]
+            self.levels.append({"blocks": [self._block(b) for b in level.block],
+                                "down": C(level.downsample) if lv < self.nlev - 1 else None})
+        self.mid = [self._block(b) for b in enc.mid_block]
+        self.norm_out = _Norm(enc.norm_out, self.device)
+        self.conv_out = C(enc.conv_out)
+        self._buf: dict = {}
+
+    def decode(self, z):                                       # (only the operator helpers are inherited)
+        raise BitDanceHipError("NativeEncoder has no decode()")
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor) -> torch.Tensor:
+        """x [B, 3, H, W] image in [-1, 1] -> h [B, z_channels, H / 2^(levels-1), W / 2^(levels-1)] bf16 (pre-sign latent)."""
+        if not x.is_cuda:
+            raise BitDanceHipError("native encoder: CUDA/HIP tensors only (no CPU path)")
+        n, cimg, H, W = x.shape
+        f = 1 << (self.nlev - 1)
+        if H % f or W % f or cimg > 32:
+            raise BitDanceHipError(f"native encoder: image sides must be multiples of {f}")
+        p0 = self._padded("p.img", n, H, W, 32)                # zero border AND zero channels 3 .. 31 (written once: stay zero)
+        p0[:, 1:-1, 1:-1, :cimg] = x.permute(0, 2, 3, 1).to(BF16)           # the conv's input cast under autocast
+        c = self.conv_in.cout
+        h = self._conv(self.conv_in, p0, self._get("s.in", (n, H, W, c), BF16), n, H, W)
+        for lv in range(self.nlev):
+            L = self.levels[lv]
+            for i, blk in enumerate(L["blocks"]):
+                h = self._resblock(blk, h, n, H, W, f"l{i & 1}")
+            if L["down"] is not None:
+                c = h.shape[-1]
+                ph = self._apply(h, None, self._padded("p.dn", n, H, W, c), 0, False, n, H, W, c)       # re-layout: zero border
+                H, W = H // 2, W // 2
+                h = self._conv(L["down"], ph, self._get("s.dn", (n, H, W, c), BF16), n, H, W)
+        for i, blk in enumerate(self.mid):
+            h = self._resblock(blk, h, n, H, W, f"mid{i & 1}")
+        c = h.shape[-1]
+        st = self._stats(h, n, H, W, c, self.norm_out.eps)
+        a = self._apply(h, st, self._get("a.out", (n, H, W, c), BF16), 2, True, n, H, W, c, gamma=self.norm_out.gamma, beta=self.norm_out.beta)
+        z = self._conv(self.conv_out, a, self._get("z", (n, H, W, self.conv_out.cout), BF16), n, H, W)
+        return z.permute(0, 3, 1, 2).contiguous()

@@ -175,15 +175,28 @@ class VQModel(nn.Module):
         # GPU decode on the native kernels (False: torch / MIOpen, the cross-check path).  Built on first use: the weights have to
         # be loaded first.  The native path implements the bf16-autocast flow the pipelines decode under.
         self.native_decoder = True
+        self.native_encoder = True                            # the same for encode() (image-conditioned generation: mllm.encode_image)
         self._native = None
+        self._native_enc = None
+
+    @staticmethod
+    def _bf16_autocast_on(t) -> bool:
+        return t.is_cuda and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
 
     def encode(self, x):
-        h = self.encoder(x)
+        if self.native_encoder and self._bf16_autocast_on(x) and x.shape[1] <= 32 and \
+                x.shape[-1] % (1 << (self.encoder.nlev - 1)) == 0 and x.shape[-2] % (1 << (self.encoder.nlev - 1)) == 0:
+            if self._native_enc is None or self._native_enc.device != x.device:
+                from .ae_native import NativeEncoder
+                self._native_enc = NativeEncoder(self.encoder, x.device)
+            h = self._native_enc.encode(x)
+        else:
+            h = self.encoder(x)
         one = torch.ones((), dtype=h.dtype, device=h.device)
         return torch.where(h > 0, one, -one)
 
     def decode(self, quant):
-        if self.native_decoder and quant.is_cuda and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        if self.native_decoder and self._bf16_autocast_on(quant):
             if self._native is None or self._native.device != quant.device:
                 from .ae_native import NativeDecoder
                 self._native = NativeDecoder(self.decoder, quant.device)
@@ -191,7 +204,7 @@ class VQModel(nn.Module):
         return self.decoder(quant)
 
     def load_state_dict(self, *a, **k):
-        self._native = None                                   # packed copies of the old weights
+        self._native = self._native_enc = None                # packed copies of the old weights
         return super().load_state_dict(*a, **k)
 
     def forward(self, x):

@@ -41,7 +41,8 @@ struct ConvP {
     const bf16_t* bias;      // [Cout] or null
     const void* res;         // residual, unpadded NHWC [n][H][W][Cout], fp32 or bf16, or null
     void* out;
-    int n, H, W, Cin, Cout, taps, TW;
+    int n, H, W, Cin, Cout, taps, TW;   // H, W: OUTPUT size; the input is [stride * H (+2)][stride * W (+2)]
+    int stride;              // 1, or 2 (3x3, padding 1: the encoder's down-sampling convolution) -- output pixel (y, x) gathers taps around (2y, 2x)
     int res_f32, out_f32;    // dtypes of the residual / of the output (out_mode 0)
     int out_mode;            // 0: unpadded NHWC [n][H][W][Cout]   1: depth-to-space, bf16 NHWC [n][2H][2W][Cout/4], channel = (dy, dx, c)
                              // 2: image, fp32 NCHW [n][Cout][H][W]  3: padded bf16 NHWC [n][H+2][W+2][Cout] (interior)
@@ -70,7 +71,8 @@ __global__ __launch_bounds__(512) void conv_tile_kernel(ConvP p) {
 
     const int spt = p.Cin >> 5;                                 // 32-deep stages per tap
     const int nst = p.taps * spt;
-    const int Wp = p.taps == 9 ? p.W + 2 : p.W, Hp = p.taps == 9 ? p.H + 2 : p.H;
+    const int sd = p.stride;
+    const int Wp = p.taps == 9 ? p.W * sd + 2 : p.W * sd, Hp = p.taps == 9 ? p.H * sd + 2 : p.H * sd;
 
     // ---- DMA sources: waves 0-3 gather A (chunk c = 4 wave + j: k-step c >> 3, row block c & 7), waves 4-7 stream W
     const char* src[4];
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(512) void conv_tile_kernel(ConvP p) {
             const int c = wave * 4 + j, ks = c >> 3, rb = c & 7;
             const int pix = rb * 32 + (lane & 31), ty = pix / TW, tx = pix - ty * TW;
             const int yy = min(y0 + ty, p.H - 1), xx = min(x0 + tx, p.W - 1);      // pixels past the edge of a partial tile: re-read the edge
-            src[j] = reinterpret_cast<const char*>(p.in + (((size_t)img * Hp + yy) * Wp + xx) * p.Cin + ks * 16 + (lane >> 5) * 8);
+            src[j] = reinterpret_cast<const char*>(p.in + (((size_t)img * Hp + yy * sd) * Wp + xx * sd) * p.Cin + ks * 16 + (lane >> 5) * 8);
             dst[j] = (unsigned)c * 1024u;
         }
     } else {
@@ -420,8 +422,9 @@ extern "C" {
 /* 3x3 (taps = 9, `in` padded) or 1x1 (taps = 1, `in` unpadded) convolution; w = bd_pack_weight of [Cout padded to 256][taps * Cin]
  * with K ordered (ky, kx, ci).  The image is covered by 256-pixel tiles of (256 / TW) rows x TW columns, TW in {32, 16, 8} chosen for
  * the least padding (the released sizes have latent grids of any multiple of 8: 16 .. 128); edge tiles may be partial. */
-int bd_conv(const void* in, const void* w_packed, const void* bias, const void* res, int res_f32, void* out, int out_mode, int out_f32,
-            int n, int H, int W, int Cin, int Cout, int taps, void* stream) {
+int bd_conv_strided(const void* in, const void* w_packed, const void* bias, const void* res, int res_f32, void* out, int out_mode, int out_f32,
+                    int n, int H, int W, int Cin, int Cout, int taps, int stride, void* stream) {
+    if (stride != 1 && !(stride == 2 && taps == 9)) return bd_last_error_set("bd_conv_strided: stride 1, or 2 with a 3x3 kernel");
     int TW = 32;
     {
         long long best = -1;
@@ -436,7 +439,7 @@ int bd_conv(const void* in, const void* w_packed, const void* bias, const void* 
         return bd_last_error_set("bd_conv: taps 9 / 1, Cin % 32, Cout % 8 (any Cout for the image output), depth-to-space needs Cout / 4 % 8 == 0");
     ConvP p;
     p.in = (const bf16_t*)in; p.Wt = (const u32x4*)w_packed; p.bias = (const bf16_t*)bias; p.res = res; p.out = out;
-    p.n = n; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.taps = taps; p.TW = TW;
+    p.n = n; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.taps = taps; p.TW = TW; p.stride = stride;
     p.res_f32 = res_f32; p.out_f32 = out_f32; p.out_mode = out_mode;
     p.PS = (size_t)((taps * Cin) >> 4) * 64;
     const int MT = n * ((H + 256 / TW - 1) / (256 / TW)) * ((W + TW - 1) / TW), NT = (Cout + 255) / 256;
@@ -446,6 +449,11 @@ int bd_conv(const void* in, const void* w_packed, const void* bias, const void* 
     if (!bd_lds_optin((const void*)conv_tile_kernel, lds, &optin)) return bd_last_error_set("bd_conv: LDS opt-in failed");
     BD_LAUNCH(conv_tile_kernel, dim3(blocks), dim3(512), lds, (hipStream_t)stream, p);
     return bd_launch_status() == 0 ? 0 : bd_last_error_set("bd_conv: launch failed");
+}
+
+int bd_conv(const void* in, const void* w_packed, const void* bias, const void* res, int res_f32, void* out, int out_mode, int out_f32,
+            int n, int H, int W, int Cin, int Cout, int taps, void* stream) {
+    return bd_conv_strided(in, w_packed, bias, res, res_f32, out, out_mode, out_f32, n, H, W, Cin, Cout, taps, 1, stream);
 }
 
 /* GroupNorm(32) statistics of an unpadded NHWC tensor -> stats [n][32][2] = (mean, rstd); partial: scratch [n][ceil(HW / 256)][32][2] fp32 */

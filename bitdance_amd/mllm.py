@@ -13,7 +13,7 @@ can run: any user text / user image items followed by ONE model-generated image 
 conditioning).  Its text-generation branch does not run in the reference (the first decode step indexes ``past_key_values``
 while it is still None, :796-800; later steps would feed 2-D embeddings), so a plan that asks the model for text raises
 ``NotImplementedError`` here too; the token sampler that branch would call (``sample_codebook`` / ``top_k_top_p_filtering``,
-modeling/utils.py:64-124) is provided and pinned against the reference's outputs all the same.  ``encode_image`` (:899-930) = the tokenizer's conv encoder (MIOpen) -> binary tokens in patch
+modeling/utils.py:64-124) is provided and pinned against the reference's outputs all the same.  ``encode_image`` (:899-930) = the tokenizer's conv encoder (native kernels under bf16 autocast: ae_native.NativeEncoder) -> binary tokens in patch
 order -> the native projector -> + 2-D position embedding.
 
 Out of scope (training): ``forward`` / losses; ``gen_image_full_causal`` (parallel_num == 1 T2I models) -- ``NotImplementedError``.

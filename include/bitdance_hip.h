@@ -154,6 +154,10 @@ int bd_gfq_codes(const int* idx, float* codes, int ntok, int ncodebooks, int bit
  *      (autoencoder.py:198-230, DCR) bf16 NHWC [n][2H][2W][Cout/4], 2: fp32 NCHW image, 3: padded bf16 NHWC. */
 int bd_conv(const void* in, const void* w_packed, const void* bias_bf16, const void* res, int res_f32, void* out, int out_mode, int out_f32,
             int n, int H, int W, int Cin, int Cout, int taps, void* stream);
+/* the same with a stride: 1, or 2 for a 3x3 / padding-1 kernel -- the Encoder's down-sampling convolution (autoencoder.py:59-127:
+ * nn.Conv2d(c, c, 3, stride=2, padding=1)); H, W are the OUTPUT size, the padded input is [n][2H+2][2W+2][Cin] */
+int bd_conv_strided(const void* in, const void* w_packed, const void* bias_bf16, const void* res, int res_f32, void* out, int out_mode,
+                    int out_f32, int n, int H, int W, int Cin, int Cout, int taps, int stride, void* stream);
 /* GroupNorm(32) statistics (nn.GroupNorm(32, C, eps), autoencoder.py:9-11) of an unpadded NHWC tensor: stats [n][32][2] = (mean, rstd);
  * `partial` = scratch [n][ceil(HW / 256)][32][2] fp32; deterministic (no atomics) */
 int bd_gn_stats(const void* x, int x_f32, float* partial, float* stats, int n, int HW, int C, float eps, void* stream);

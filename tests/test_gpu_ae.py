@@ -213,3 +213,59 @@ def test_native_decoder_released_dims_vs_torch():
     scale = ref.abs().mean().item()
     print(f"[ae d16c32 256px] max {d.max().item():.4f} mean {d.mean().item():.5f} (ref mean |x| {scale:.3f})")
     assert torch.isfinite(got).all() and d.mean().item() <= 0.03 * scale + 2e-3
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout", [(8, 8, 32, 64), (16, 24, 64, 64), (37, 19, 128, 128), (64, 64, 256, 256)])
+def test_conv_stride2_vs_torch(H, W, Cin, Cout):
+    """The Encoder's down-sampling convolution (nn.Conv2d(c, c, 3, stride=2, padding=1), autoencoder.py:59-127) as the strided form
+    of the implicit GEMM: output (H, W) from a padded [2H + 2][2W + 2] input; odd output sizes -> partial pixel tiles."""
+    from bitdance_amd._lib import check, lib
+    l = lib()
+    g = torch.Generator(device=DEV).manual_seed(H * 131 + W)
+    n = 2
+    x = torch.randn(n, Cin, 2 * H, 2 * W, device=DEV, generator=g).to(BF16)
+    w = (torch.randn(Cout, Cin, 3, 3, device=DEV, generator=g) / (9 * Cin) ** 0.5).to(BF16)
+    b = (torch.randn(Cout, device=DEV, generator=g) * 0.1).to(BF16)
+    xp = torch.zeros(n, 2 * H + 2, 2 * W + 2, Cin, dtype=BF16, device=DEV)
+    xp[:, 1:-1, 1:-1] = x.permute(0, 2, 3, 1)
+    npad = (Cout + 255) // 256 * 256
+    m = torch.zeros(npad, 9 * Cin, dtype=BF16, device=DEV)
+    m[:Cout] = w.permute(0, 2, 3, 1).reshape(Cout, -1)
+    wp = torch.empty(npad * 9 * Cin, dtype=BF16, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    check(l.bd_pack_weight(wp.data_ptr(), m.data_ptr(), npad, 9 * Cin, 0, npad, st))
+    out = torch.full((n, H, W, Cout), float("nan"), dtype=BF16, device=DEV)
+    check(l.bd_conv_strided(xp.data_ptr(), wp.data_ptr(), b.data_ptr(), None, 0, out.data_ptr(), 0, 0, n, H, W, Cin, Cout, 9, 2, st), "bd_conv_strided")
+    ref = F.conv2d(x.float(), w.float(), b.float(), stride=2, padding=1).permute(0, 2, 3, 1)
+    d = (out.float() - ref).abs()
+    assert torch.isfinite(out.float()).all() and d.max().item() <= 2e-2 * max(1.0, ref.abs().max().item()), d.max().item()
+    assert l.bd_conv_strided(xp.data_ptr(), wp.data_ptr(), None, None, 0, out.data_ptr(), 0, 0, n, H, W, Cin, Cout, 1, 2, st) != 0   # 1x1 has no stride
+
+
+@pytest.mark.parametrize("H,W", [(128, 128), (64, 192)])
+def test_native_encoder_tiny_vs_torch_and_cpu_reference(H, W):
+    """Encoder.forward on the native kernels (bitdance_amd/ae_native.py NativeEncoder) against the torch module under bf16 autocast on the
+    GPU (MIOpen) and against the same module on the CPU with the autocast rounding points emulated; the binary tokens (sign of the latent)
+    agree wherever the latent is not within rounding noise of zero."""
+    import copy
+    from bitdance_amd.ae_native import NativeEncoder
+    from oracle import tiny_models as tm
+    ae, _ = _decoders(tm.TINY_AE, 44)
+    enc = NativeEncoder(ae.encoder, DEV)
+    x = torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(5)) * 2 - 1
+    with torch.no_grad(), torch.autocast("cuda", dtype=BF16):
+        ref_gpu = ae.encoder(x.to(DEV)).float().cpu()
+    ref_cpu = _cpu_autocast_decode(copy.deepcopy(ae.encoder).float().cpu(), x)
+    got = enc.encode(x.to(DEV)).float().cpu()
+    assert got.shape == ref_cpu.shape == (2, 32, H // 16, W // 16)
+    scale = ref_cpu.abs().mean().item()
+    for name, ref in (("torch GPU autocast", ref_gpu), ("CPU emulation", ref_cpu)):
+        d = (got - ref).abs()
+        firm = ref.abs() > 8 * d.mean().item()
+        agree = (torch.sign(got)[firm] == torch.sign(ref)[firm]).float().mean().item()
+        print(f"[enc tiny vs {name}] max {d.max().item():.4f} mean {d.mean().item():.5f} (ref mean |h| {scale:.3f}); tokens equal on firm latents {agree:.4f}")
+        assert d.mean().item() <= 0.03 * scale + 3e-3 and agree >= 0.999
+    assert torch.equal(enc.encode(x.to(DEV)), enc.encode(x.to(DEV)))
+    with torch.no_grad(), torch.autocast("cuda", dtype=BF16):
+        tok = ae.encode(x.to(DEV))                                          # VQModel.encode takes the native path on a GPU under autocast
+    assert torch.equal(tok.float().cpu(), torch.where(got > 0, 1.0, -1.0))
