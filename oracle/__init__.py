@@ -15,9 +15,10 @@ reference executes on the hot path named in SURVEY.md section 8:
   * ``pipeline``   -- AR orchestration, pos-embed, projector, sign binarise
                      (t2i_pipeline.py)
   * ``gfq``        -- bit <-> index math of the group-wise LFQ (imagenet_gen/src/gfq.py)
-  * ``autoencoder`` is NOT restated: the conv tokenizer stays on MIOpen (north star)
-    and the product ships its own torch implementation, checked against the
-    reference module directly through golden vectors.
+  * ``autoencoder`` -- the binary tokenizer's conv encoder / decoder
+                     (vision_encoder/autoencoder.py), functional from the state dict,
+                     fp32 and autocast policies; pinned against ae_roundtrip.npz.  The
+                     native conv kernels (csrc/bd_conv.hip) are checked against it.
 
 Parity pinning: the reference repository ships no tests or golden vectors
 (SURVEY.md section 4), so the oracle is pinned against the reference *itself*:

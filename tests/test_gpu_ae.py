@@ -157,35 +157,30 @@ def test_native_decoder_tiny_vs_torch(gh, gw):
     assert (alt - ref).abs().mean().item() <= 2e-2 * max(1.0, scale)
 
 
-def _cpu_autocast_decode(dec_cpu, z):
-    """The torch decoder (the module tests/test_host_cpu.py pins against the reference's own outputs) on the CPU under an emulation of
-    the CUDA autocast policy: CPU autocast (conv2d / linear -> bf16) with group_norm forced to fp32 as CUDA's fp32 list does."""
-    gn = F.group_norm
-
-    def gn32(x, groups, weight=None, bias=None, eps=1e-5):
-        with torch.autocast("cpu", enabled=False):
-            return gn(x.float(), groups, None if weight is None else weight.float(), None if bias is None else bias.float(), eps)
-    F.group_norm = gn32
-    try:
-        with torch.no_grad(), torch.autocast("cpu", dtype=BF16):
-            return dec_cpu(z).float()
-    finally:
-        F.group_norm = gn
+def _oracle(ae):
+    """oracle/autoencoder.py on the module's own weights: the CPU restatement of the reference's Encoder / Decoder, pinned against the
+    reference's outputs (tests/test_oracle_golden.py::test_autoencoder_oracle_matches_reference), under the autocast policy."""
+    from oracle import autoencoder as oae
+    from oracle.numerics import Policy
+    sd = {k: v.detach().float().cpu() for k, v in ae.state_dict().items()}
+    return oae, Policy("autocast"), sd
 
 
 @pytest.mark.parametrize("gh,gw", [(16, 16), (8, 24)])
 def test_native_decoder_tiny_vs_cpu_reference(gh, gw):
-    """The native decoder against a reference that shares nothing with it: the pinned torch module on the CPU (no MIOpen, no HIP) with
-    the autocast rounding points emulated.  What remains is fp32 summation order inside the convolutions and bf16 ties."""
-    import copy
+    """The native decoder against a reference that shares nothing with it: the CPU oracle (no MIOpen, no HIP, not even the product's
+    torch module) with the autocast rounding points explicit.  What remains is fp32 summation order inside the convolutions and
+    bf16 ties."""
     from oracle import tiny_models as tm
     ae, nat = _decoders(tm.TINY_AE, 44)
+    oae, pol, sd = _oracle(ae)
     z = torch.sign(torch.randn(2, 32, gh, gw, generator=torch.Generator().manual_seed(3)))
-    ref = _cpu_autocast_decode(copy.deepcopy(ae.decoder).float().cpu(), z)
+    with torch.no_grad():
+        ref = oae.decoder_forward(pol, sd, tm.TINY_AE["ddconfig"], z).float()
     got = nat.decode(z.to(DEV)).float().cpu()
     d = (got - ref).abs()
     scale = ref.abs().mean().item()
-    print(f"[ae tiny vs cpu] max {d.max().item():.4f} mean {d.mean().item():.5f} (ref mean |x| {scale:.3f})")
+    print(f"[ae tiny vs oracle] max {d.max().item():.4f} mean {d.mean().item():.5f} (ref mean |x| {scale:.3f})")
     # measured: max 0.047, mean 0.0063 on images of mean magnitude 0.63 -- closer than MIOpen is to it (0.009)
     assert d.mean().item() <= 0.015 * scale + 1e-3 and d.max().item() <= 0.15 * max(1.0, ref.abs().max().item())
 
@@ -247,19 +242,20 @@ def test_native_encoder_tiny_vs_torch_and_cpu_reference(H, W):
     """Encoder.forward on the native kernels (bitdance_amd/ae_native.py NativeEncoder) against the torch module under bf16 autocast on the
     GPU (MIOpen) and against the same module on the CPU with the autocast rounding points emulated; the binary tokens (sign of the latent)
     agree wherever the latent is not within rounding noise of zero."""
-    import copy
     from bitdance_amd.ae_native import NativeEncoder
     from oracle import tiny_models as tm
     ae, _ = _decoders(tm.TINY_AE, 44)
+    oae, pol, sd = _oracle(ae)
     enc = NativeEncoder(ae.encoder, DEV)
     x = torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(5)) * 2 - 1
     with torch.no_grad(), torch.autocast("cuda", dtype=BF16):
         ref_gpu = ae.encoder(x.to(DEV)).float().cpu()
-    ref_cpu = _cpu_autocast_decode(copy.deepcopy(ae.encoder).float().cpu(), x)
+    with torch.no_grad():
+        ref_cpu = oae.encoder_forward(pol, sd, tm.TINY_AE["ddconfig"], x).float()
     got = enc.encode(x.to(DEV)).float().cpu()
     assert got.shape == ref_cpu.shape == (2, 32, H // 16, W // 16)
     scale = ref_cpu.abs().mean().item()
-    for name, ref in (("torch GPU autocast", ref_gpu), ("CPU emulation", ref_cpu)):
+    for name, ref in (("torch GPU autocast", ref_gpu), ("CPU oracle", ref_cpu)):
         d = (got - ref).abs()
         firm = ref.abs() > 8 * d.mean().item()
         agree = (torch.sign(got)[firm] == torch.sign(ref)[firm]).float().mean().item()

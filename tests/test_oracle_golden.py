@@ -401,3 +401,29 @@ def test_mllm_gen_image_is_the_same_loop(golden_dir):
     oracle / one native loop covers both copies of the hot path the north star names."""
     a, b = load(golden_dir, "mllm_equiv"), load(golden_dir, "gen_fp32")
     assert int(a["calls"]) == int(b["calls"]) and torch.equal(a["tokens"], b["tokens"])
+
+
+def test_autoencoder_oracle_matches_reference(golden_dir):
+    """oracle/autoencoder.py (functional restatement of the tokenizer's Encoder / Decoder from the state dict) against the unmodified
+    reference module's outputs on seeded weights (tests/golden/ae_roundtrip.npz: image -> encoder latent -> sign; token map -> decoder
+    image), fp32 policy; the autocast policy stays within bf16 noise of it."""
+    import ast
+    from oracle import autoencoder as oae
+    g = load(golden_dir, "ae_roundtrip")
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["keys"], g["shapes"])}
+    sd = tm.seeded_state(shapes, seed=44, gain=1.4)
+    cfg = tm.TINY_AE["ddconfig"]
+    fp32 = Policy("fp32")
+    with torch.no_grad():
+        h = oae.encoder_forward(fp32, sd, cfg, g["image"])
+        q = oae.encode(fp32, sd, cfg, g["image"])
+        dec = oae.decoder_forward(fp32, sd, cfg, g["quant"])
+        torch.testing.assert_close(h, g["henc"], atol=1e-4, rtol=1e-4)
+        assert (q == g["quant"]).float().mean() >= 0.999
+        torch.testing.assert_close(dec, g["dec"], atol=2e-4, rtol=1e-3)
+        amp = Policy("autocast")
+        ha = oae.encoder_forward(amp, sd, cfg, g["image"])
+        da = oae.decoder_forward(amp, sd, cfg, g["quant"])
+    assert ha.dtype == torch.bfloat16 and da.dtype == torch.bfloat16
+    assert (ha.float() - g["henc"]).abs().mean().item() <= 0.02 * g["henc"].abs().mean().item() + 2e-3
+    assert (da.float() - g["dec"]).abs().mean().item() <= 0.03 * g["dec"].abs().mean().item() + 2e-3
