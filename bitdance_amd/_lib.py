@@ -44,6 +44,8 @@ _PROTOS = {
     "bd_gemm_w8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bd_gemm_swiglu": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bd_gemm_swiglu_splitk": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "bd_ctx_create": (C.c_void_p, []),
     "bd_ctx_destroy": (None, [C.c_void_p]),
     "bd_ctx_set_int": (C.c_int, [C.c_void_p, C.c_char_p, C.c_longlong]),

@@ -341,6 +341,12 @@ int bd_gemm_swiglu(const void* a, int RB, const void* w, const void* bias, int N
     return 0;
 }
 
+int bd_gemm_swiglu_splitk(const void* a, int RB, const void* w, const void* bias, int N2, int K, int S, int nw, float* scratch, int* counters,
+                          void* act, void* stream) {
+    BD_TRY(bdk_gemm(a, RB, w, N2, K, S, nw, BD_EPI_SWIGLU, scratch, act, bias, counters, (hipStream_t)stream));
+    return 0;
+}
+
 bd_ctx* bd_ctx_create(void) { return new bd_ctx(); }
 void bd_ctx_destroy(bd_ctx* c) {
     if (!c) return;

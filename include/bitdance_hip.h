@@ -51,6 +51,10 @@ int bd_gemm_f32(const void* a_frag, int row_blocks, const void* w_packed, int N,
 /* Linear -> chunk(2) -> silu(h1)*h2 (flow_head:250-251) / down_proj input act_fn(gate)*up (HF:82) */
 int bd_gemm_swiglu(const void* a_frag, int row_blocks, const void* w_packed_pairs, const void* bias_packed, int N2, int K,
                    int nwaves, void* act_frag, void* stream);
+/* the same over `splitk` K slices reduced inside the launch (the head's w1 at 128 rows: 2 slices); scratch [splitk][rows][N2] fp32,
+ * counters: zeroed ints, one per output tile (left zero) */
+int bd_gemm_swiglu_splitk(const void* a_frag, int row_blocks, const void* w_packed_pairs, const void* bias_packed, int N2, int K,
+                          int splitk, int nwaves, float* scratch, int* counters, void* act_frag, void* stream);
 
 /* ---- fp8-e4m3 weight storage (BASELINE config 5; a separate precision mode).  src: OCP e4m3 bytes [rows][K] row-major,
  *      already divided by the per-output-channel scale; the GEMM converts to bf16 in registers and multiplies the fp32 scale

@@ -392,3 +392,82 @@ def test_bench_tensor_parallel_failure_ends_in_replicas_not_in_a_crash():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "replicas x2" and "tp" not in d
     assert "RCCL" in d["config"]["tensor_parallel_fallback"] and d["value"] > 0
+
+
+@pytest.mark.parametrize("P", [64, 16])
+@pytest.mark.parametrize("tp", [2, 4, 8])
+def test_planned_tensor_parallel_gemms_launch_and_match(tp, P):
+    """Every GEMM of one rank of the 14B model at tp = 2 / 4 / 8 exactly as the planner configures it (bd_ctx_set_tp + bd_ctx_finalize:
+    per-rank N / K, grid slices, tile form, ring), launched through the epilogue the step uses -- bf16 or slabs for the column-split
+    Linears, the fused SwiGLU for w1 / gate-up, the finished fp32 partial for the row-split ones -- and compared with an fp64 matmul.
+    The planner is host code and tested without a GPU for every size; only tp = 2 engines run end to end on this one-GPU box, so
+    this is where a tile form that is planned but not instantiated (or a slice count a kernel rejects) for tp = 4 / 8 would show."""
+    import ctypes
+    from bitdance_amd import engine as E
+    from bitdance_amd._lib import check, lib
+    l = lib()
+    dims = {"B": 1, "branches": 2, "P": P, "head.D": 5120, "head.C": 32, "head.Dz": 5120, "head.H": 7680, "head.nblocks": 6,
+            "head.nada": 2, "head.T": 4096, "proj.D": 5120, "proj.C": 32, "llm.D": 5120, "llm.L": 40, "llm.nh": 40, "llm.nkv": 8,
+            "llm.F": 17408, "llm.head_dim": 128, "llm.Lmax": 4352, "llm.splits": 8}
+    c = l.bd_ctx_create()
+    for k, v in dims.items():
+        assert l.bd_ctx_set_int(c, k.encode(), int(v)) == 0, k
+    assert l.bd_ctx_set_tp(c, tp - 1, tp) == 0 and l.bd_ctx_finalize(c) == 0, l.bd_last_error()
+
+    def cfg(name):
+        s_, nw = ctypes.c_int(), ctypes.c_int()
+        assert l.bd_gemm_config(c, name.encode(), ctypes.byref(s_), ctypes.byref(nw)) == 0
+        return s_.value, nw.value
+    D, H, F_, nh, nkv = 5120, 7680, 17408, 40, 8
+    M = 2 * P
+    shapes = [  # name, N, K, kind: col = column-split Linear, swiglu, row = row-split (fp32 partial of this rank)
+        ("head.qkv", 3 * D // tp, D, "col"), ("head.wo", D, D // tp, "row"), ("head.w1", 2 * H // tp, D, "swiglu"), ("head.w2", D, H // tp, "row"),
+        ("llm.qkv", (nh + 2 * nkv) * 128 // tp, D, "col"), ("llm.o", D, nh * 128 // tp, "row"), ("llm.gu", 2 * F_ // tp, D, "swiglu"),
+        ("llm.down", D, F_ // tp, "row")]
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=DEV).manual_seed(1000 * tp + P)
+    rb = E.row_blocks(M)
+    cnt = torch.zeros(16384, dtype=torch.int32, device=DEV)
+    for name, N, K, kind in shapes:
+        S, code = cfg(name)
+        x = torch.randn(M, K, device=DEV, generator=g)
+        w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)
+        xf = torch.zeros(rb * 32 * K, dtype=torch.bfloat16, device=DEV)
+        check(l.bd_rows_to_frag(xf.data_ptr(), x.data_ptr(), 1, M, K, rb, st))
+        ref = x.to(torch.bfloat16).double() @ w.double().t()
+        tol = 2e-5 * K ** 0.5 + 1e-5
+        scratch = torch.zeros(max(S, 1), rb * 32, N, device=DEV)
+        tag = f"{name} tp={tp} rows={M} N={N} K={K} S={S} code={code}"
+        if kind == "row":
+            assert S <= 3, tag
+            wp = E.pack_linear([w], DEV)
+            out = torch.full((rb * 32, N), float("nan"), device=DEV)
+            check(l.bd_gemm_f32(xf.data_ptr(), rb, wp.data_ptr(), N, K, S, code, scratch.data_ptr(), cnt.data_ptr(), out.data_ptr(), st), tag)
+            torch.cuda.synchronize()
+            assert (out[:M].double() - ref).abs().max().item() <= tol, tag
+        elif kind == "col":
+            wp = E.pack_linear([w], DEV)
+            if S <= 2:                                         # bd_api.hip linear(): few slices are reduced in the launch
+                outb = torch.zeros(rb * 32, N, dtype=torch.bfloat16, device=DEV)
+                check(l.bd_gemm_bf16(xf.data_ptr(), rb, wp.data_ptr(), None, N, K, S, code, scratch.data_ptr(), cnt.data_ptr(), outb.data_ptr(), st), tag)
+                torch.cuda.synchronize()
+                assert (outb[:M].double() - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item()), tag
+            else:
+                check(l.bd_gemm_partial(xf.data_ptr(), rb, wp.data_ptr(), N, K, S, code, scratch.data_ptr(), st), tag)
+                torch.cuda.synchronize()
+                assert (scratch.sum(0)[:M].double() - ref).abs().max().item() <= tol, tag
+        else:
+            Fh = N // 2
+            wp = E.pack_swiglu(w[:Fh], w[Fh:], DEV)
+            act = torch.zeros(rb * 32 * Fh, dtype=torch.bfloat16, device=DEV)
+            check(l.bd_gemm_swiglu_splitk(xf.data_ptr(), rb, wp.data_ptr(), None, N, K, S, code, scratch.data_ptr(), cnt.data_ptr(),
+                                          act.data_ptr(), st), tag)
+            torch.cuda.synchronize()
+            h = ref.float().to(torch.bfloat16)
+            want = torch.nn.functional.silu(h[:, :Fh]) * h[:, Fh:]
+            a = act.view(Fh // 16, rb, 2, 32, 8).permute(1, 3, 0, 2, 4).reshape(rb * 32, Fh)[:M]
+            d = (a.float() - want.float()).abs()
+            assert (d > 0).float().mean() <= 0.02 and d.max() <= 0.07, tag
+        assert int(cnt.abs().sum()) == 0, tag
+        del w, x, xf, scratch
+    l.bd_ctx_destroy(c)
