@@ -33,7 +33,9 @@ _RANK_STREAMS: list = []
 def _streams(n):
     """One HIP stream per in-process rank, created ONCE for the whole session: the ranks' kernels wait for each other, so two
     rank streams must never share a hardware queue; streams taken from torch's pool at different times can (the pool wraps
-    around the queues the runtime multiplexes them onto), a batch created together does not."""
+    around the queues the runtime multiplexes them onto), a batch created together does not.  (At most 4 ranks this way:
+    the runtime multiplexes streams onto 4 hardware queues by default, and two ranks behind one queue would wait for each other until
+    the exchange's time budget runs out -- tp = 8 is covered by the planner tests and test_planned_tensor_parallel_gemms_launch_and_match.)"""
     while len(_RANK_STREAMS) < 4:
         _RANK_STREAMS.append(torch.cuda.Stream())
     return _RANK_STREAMS[:n]
