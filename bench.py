@@ -19,7 +19,9 @@ imagenet_gen/sample_ddp_parallel.py:199-214); each prints its own metric name --
 
 Rank 0 prints ONE JSON line with the contract fields plus
   "roofline"     : the dominant kernel family (the weight-streaming / MFMA GEMM), measured live with HIP events on the
-                   pipeline's stream: achieved HBM GB/s vs the 8 TB/s peak (M <= 256 rows) or TFLOP/s vs 2.5 PFLOP/s
+                   pipeline's stream: achieved = algorithmic weight bytes (N*K*2 per Linear and evaluation) / time vs the 8 TB/s
+                   peak at M <= 256 rows ("streamed": the bytes physically moved by the one-evaluation launches), or TFLOP/s vs
+                   2.5 PFLOP/s beyond; "traffic": HBM bytes per launch from the committed PMC passes
   "cpu_baseline" : the CPU oracle (a port of the reference algorithm) timed on this box's host cores on a bounded sample at
                    TRUE dimensions (oracle/true_dims.py: a 2-block head evaluation with the full adaLN projection + one
                    Qwen3-14B layer step), extrapolated to one image -- and, from the same sample, "parity": the max / mean
@@ -81,7 +83,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-decode", action="store_true", help="imagenet: skip the conv decoder (MIOpen) in the timed pass")
+    ap.add_argument("--no-decode", action="store_true", help="imagenet: skip the conv decoder in the timed pass")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8", "fp8a"],
                     help="fp8: streamed Linear weights as e4m3 + per-channel scales (BASELINE config 5; a separate precision mode); "
                          "fp8a: also e4m3 activations (per-row scales) on the fp8 matrix pipe for the GEMMs fed by a row kernel")
@@ -382,7 +384,9 @@ def main():
         return tokens_agree(dist, next(iter(pipe._engines.values())).tok_all, dev)
 
     tp_note = None
-    for i in range(args.warmup):
+    # tensor parallel: the first image is always an untimed, verified one (every rank finished, bit-identical tokens; else the
+    # fall-back chain below) -- also with --warmup 0, where it is the only untimed pass
+    for i in range(max(args.warmup, 1) if tp_mode else args.warmup):
         if tp_mode and i == 0:
             if not tp_pass_ok(i):
                 why = None
@@ -464,7 +468,7 @@ def main():
             out["tp"] = {"size": n, "world_size_seen": dist.get_world_size(), "process_group_backend": dist.get_backend(),
                          "exchange_backend": comm.backend, "exchange_buffer_uncached": info["data_uncached"],
                          "flag_block_uncached": info["flags_uncached"], "fallback_reason": getattr(comm, "fallback_reason", None),
-                         "images_checked_bit_identical": args.steps + (1 if args.warmup else 0),
+                         "images_checked_bit_identical": args.steps + 1,
                          "weight_bytes_per_rank": int(wbytes),
                          "exchanges_per_image": n_x, "exchange_payload_bytes_per_rank": int(eng.M * 5120 * 6 * (n - 1) / n),
                          "ranks_bit_identical": True}
