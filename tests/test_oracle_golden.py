@@ -427,3 +427,27 @@ def test_autoencoder_oracle_matches_reference(golden_dir):
     assert ha.dtype == torch.bfloat16 and da.dtype == torch.bfloat16
     assert (ha.float() - g["henc"]).abs().mean().item() <= 0.02 * g["henc"].abs().mean().item() + 2e-3
     assert (da.float() - g["dec"]).abs().mean().item() <= 0.03 * g["dec"].abs().mean().item() + 2e-3
+
+
+def test_autoencoder_oracle_config1(golden_dir):
+    """BASELINE config 1 through the ORACLE: the ae_d16c32 tokenizer (released size: ch 256, ch_mult [1,1,2,2,4], 4 res-blocks) on one
+    256 x 256 image, CPU fp32 -- encode -> binary quantise -> decode reproduces the reference's binary latent bit for bit and its
+    decoded pixels to fp32 conv-order noise (tests/golden/ae_c1.npz, generated by the unmodified reference module)."""
+    from oracle import autoencoder as oae
+    z = np.load(os.path.join(golden_dir, "ae_c1.npz"))
+    from bitdance_amd.autoencoder import VQModel              # (only for the key / shape table of the released architecture)
+    shapes = {k: tuple(v.shape) for k, v in VQModel(**tm.AE_D16C32).state_dict().items()}
+    assert len(shapes) == int(z["n_tensors"])
+    sd = tm.seeded_state(shapes, seed=61, gain=1.4)
+    cfg = tm.AE_D16C32["ddconfig"]
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+    fp32 = Policy("fp32")
+    with torch.no_grad():
+        q = oae.encode(fp32, sd, cfg, img)
+        dec = oae.decoder_forward(fp32, sd, cfg, q)
+    assert tuple(q.shape) == (1, 32, 16, 16)
+    assert np.array_equal(np.packbits((q > 0).numpy().reshape(-1)), z["quant_bits"])          # binary tokens: exact
+    got = dec.reshape(-1)[torch.from_numpy(z["sample_idx"])]
+    torch.testing.assert_close(got, torch.from_numpy(z["dec_samples"]), atol=1e-3, rtol=1e-3)
+    assert abs(float(dec.mean()) - float(z["dec_mean"])) < 1e-3 and abs(float(dec.std()) - float(z["dec_std"])) < 1e-3
