@@ -92,6 +92,14 @@ class NativeDecoder:
     def _padded(self, role, n, H, W, C):
         return self._get(role, (n, H + 2, W + 2, C), BF16, zero=True)
 
+    def _new_call(self, n, H, W) -> None:
+        """Buffers are kept per (role, shape) for the next call of the same size; a different batch / image size drops them, so a
+        process that walks through many aspect ratios (t2i_pipeline.py:27-31) holds one size's activations, not all of them.
+        (Everything runs on the current stream: a freed buffer is only reused behind the launches that read it.)"""
+        if getattr(self, "_call_key", None) != (n, H, W):
+            self._buf.clear()
+            self._call_key = (n, H, W)
+
     # -- operators ---------------------------------------------------------------------------------------------------
     def _conv(self, cv: _Conv, x, out, n, H, W, *, mode=0, res=None):
         l = lib()
@@ -137,6 +145,7 @@ class NativeDecoder:
         if not z.is_cuda:
             raise BitDanceHipError("native decoder: CUDA/HIP tensors only (no CPU path)")
         n, Cz, H, W = z.shape
+        self._new_call(n, H, W)
         zf = z.to(torch.float32).contiguous()
         p0 = self._padded("p.in", n, H, W, Cz)
         check(lib().bd_tokens_to_padded(zf.data_ptr(), p0.data_ptr(), n, Cz, H, W, _st()), "bd_tokens_to_padded")
@@ -204,6 +213,7 @@ class NativeEncoder(NativeDecoder):
         f = 1 << (self.nlev - 1)
         if H % f or W % f or cimg > 32:
             raise BitDanceHipError(f"native encoder: image sides must be multiples of {f}")
+        self._new_call(n, H, W)
         p0 = self._padded("p.img", n, H, W, 32)                # zero border AND zero channels 3 .. 31 (written once: stay zero)
         p0[:, 1:-1, 1:-1, :cimg] = x.permute(0, 2, 3, 1).to(BF16)           # the conv's input cast under autocast
         c = self.conv_in.cout
