@@ -329,3 +329,33 @@ def test_launch_plan_rules_measured_in_round_2():
     assert l.bd_ctx_finalize(c) == 0, l.bd_last_error()
     assert _cfg(l, c, "head.w1")[0] == 6 and _cfg(l, c, "head.w2")[0] == 18
     l.bd_ctx_destroy(c)
+
+
+def test_bench_roofline_accounting():
+    """bench.py's roofline arithmetic on a synthetic profile (no GPU): `achieved` = algorithmic bytes (N*K*2 per Linear AND evaluation:
+    a launch named "<gemm>[xG]" serves G evaluations in one pass) over the summed event time; `streamed` = the bytes physically moved by
+    the one-evaluation launches over their time; the grouped launch carries its TFLOP/s; frac == achieved / peak."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_roofline_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    wq, wa = 15360 * 5120 * 2.0, 71680 * 5120 * 2.0
+
+    class FakeEngine:
+        wdtype = 0
+
+        def profile_gemms(self, run):
+            return {"head.qkv": dict(count=10, ms=10 * 0.040, bytes=10 * wq), "head.ada[x4]": dict(count=2, ms=2 * 0.400, bytes=2 * wa)}
+
+        def gemm_config(self, name):
+            return (2, 4 + 16 * 3) if name == "head.qkv" else (1, 9 + 16 * 2)
+    r = bench.gemm_roofline(FakeEngine(), lambda: None, 128)
+    ms = 10 * 0.040 + 2 * 0.400
+    assert r["bound"] == "hbm" and r["launches"] == 12
+    assert abs(r["achieved"] - (10 * wq + 2 * 4 * wa) / ms / 1e6) < 0.5 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3
+    assert r["streamed"]["launches"] == 10 and abs(r["streamed"]["achieved"] - wq / 0.040 / 1e6) < 0.5
+    grouped = [g for g in r["per_gemm"] if g["name"] == "head.ada[x4]"][0]
+    assert grouped["evaluations_per_launch"] == 4 and grouped["rows_per_pass"] == 512
+    assert abs(grouped["TFLOPs"] - 2.0 * 512 * 71680 * 5120 / 0.400e-3 / 1e12) < 1.0
+    assert abs(grouped["algorithmic_GBs"] - 4 * wa / 0.400 / 1e6) < 0.5 and abs(grouped["GBs"] - wa / 0.400 / 1e6) < 0.5
