@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
         load_w(w[P], j + WR);                 // this slot's MFMAs have all issued
         __syncthreads();
         u32x4* t = cur; cur = nxt; nxt = wr3; wr3 = t;
+        if (j == last) BD_MFMA_DRAIN();       // the last phase is followed, across a branch, by the accumulator reads (bd_common.h)
     };
 
     int j = 0;
@@ -249,7 +250,6 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
         if (j + 1 < nst) phase(std::integral_constant<int, 1>{}, j + 1);
     }
 
-    // (every phase ends in a workgroup barrier behind its MFMAs: no accumulator read can follow them closely)
     // ---- epilogue (same forms as gemm_kernel)
     const int col = nb * 32 + (lane & 31);
     float bias_pn[NPW];
