@@ -176,36 +176,65 @@ class VQModel(nn.Module):
         # be loaded first.  The native path implements the bf16-autocast flow the pipelines decode under.
         self.native_decoder = True
         self.native_encoder = True                            # the same for encode() (image-conditioned generation: mllm.encode_image)
-        self._native = None
-        self._native_enc = None
+        self._native_state = {}                               # {"dec" / "enc": packed twin + the weights it was packed from}
 
     @staticmethod
     def _bf16_autocast_on(t) -> bool:
         return t.is_cuda and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
 
+    @staticmethod
+    def _weights_key(module, device):
+        """Identity of the weights a packed native copy was made from: any load_state_dict (also through a parent module or on the
+        sub-module), ``.to()``, or in-place update changes a parameter's storage pointer or version counter."""
+        return (str(device),) + tuple((p.data_ptr(), p._version) for p in module.parameters())
+
+    def _native_for(self, which, module, device):
+        """The packed native twin of ``module`` on ``device``, rebuilt when the weights changed; None when the native kernels do not
+        cover this configuration (channel counts off the 32-multiples, other GroupNorm groupings, ...) or a gradient is wanted
+        (the native path is inference only) -- the caller then runs the torch module, on the same device."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+            return None
+        key = self._weights_key(module, device)
+        slot = self._native_state.setdefault(which, {"key": None, "obj": None, "why": None})
+        if slot["key"] != key:
+            from . import ae_native
+            from ._lib import BitDanceHipError
+            slot.update(key=key, obj=None, why=None)
+            try:
+                slot["obj"] = (ae_native.NativeDecoder if which == "dec" else ae_native.NativeEncoder)(module, device)
+            except (BitDanceHipError, ValueError, NotImplementedError) as e:
+                slot["why"] = str(e)                          # decided once per set of weights; VQModel.native_fallback_reason reports it
+        return slot["obj"]
+
+    @property
+    def native_fallback_reason(self):
+        """{"dec" / "enc": why the torch module runs instead of the native kernels} for the paths that fell back."""
+        return {k: v["why"] for k, v in self._native_state.items() if v["why"]}
+
     def encode(self, x):
+        nat = None
         if self.native_encoder and self._bf16_autocast_on(x) and x.shape[1] <= 32 and \
                 x.shape[-1] % (1 << (self.encoder.nlev - 1)) == 0 and x.shape[-2] % (1 << (self.encoder.nlev - 1)) == 0:
-            if self._native_enc is None or self._native_enc.device != x.device:
-                from .ae_native import NativeEncoder
-                self._native_enc = NativeEncoder(self.encoder, x.device)
-            h = self._native_enc.encode(x)
-        else:
+            nat = self._native_for("enc", self.encoder, x.device)
+        h = self._run_native("enc", nat, "encode", x) if nat is not None else None
+        if h is None:
             h = self.encoder(x)
         one = torch.ones((), dtype=h.dtype, device=h.device)
         return torch.where(h > 0, one, -one)
 
     def decode(self, quant):
-        if self.native_decoder and self._bf16_autocast_on(quant):
-            if self._native is None or self._native.device != quant.device:
-                from .ae_native import NativeDecoder
-                self._native = NativeDecoder(self.decoder, quant.device)
-            return self._native.decode(quant)
-        return self.decoder(quant)
+        nat = self._native_for("dec", self.decoder, quant.device) if (self.native_decoder and self._bf16_autocast_on(quant)) else None
+        out = self._run_native("dec", nat, "decode", quant) if nat is not None else None
+        return out if out is not None else self.decoder(quant)
 
-    def load_state_dict(self, *a, **k):
-        self._native = self._native_enc = None                # packed copies of the old weights
-        return super().load_state_dict(*a, **k)
+    def _run_native(self, which, nat, method, t):
+        """A launcher that refuses a shape (host-side validation: nothing has been launched) retires the native twin for these weights."""
+        from ._lib import BitDanceHipError
+        try:
+            return getattr(nat, method)(t)
+        except BitDanceHipError as e:
+            self._native_state[which].update(obj=None, why=str(e))
+            return None
 
     def forward(self, x):
         q = self.encode(x)

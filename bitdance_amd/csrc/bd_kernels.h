@@ -129,7 +129,9 @@ struct HeadYAllArgs {       // y_i = silu(time_embed(t_i) + cond_embed(c)) for E
                             //      matrix holds the n_evals % G left-over evaluations only, its row-block count rounded up to 8
     int M, D, RB, Mpad, n_evals;
     int G = 1;              // evaluations per adaLN GEMM (1: one [Mpad][D] matrix per evaluation)
-    float* a8_scale = nullptr;   // not null (G == 1 only): fp8-e4m3 operands (A8 layout) + scales [n_evals][Mpad]
+    float* a8_scale = nullptr;   // not null: fp8-e4m3 operands (A8 layout, any G) + scales [ceil(n_evals / G) * G][Mpad] (a group's rows
+                                 // contiguous).  A short last group's pad rows (row blocks past its evaluations, up to the rounded-up count)
+                                 // are zero-filled by bdk_head_y_all itself, data and scales: the GEMM reads them
 };
 int bdk_head_y_all(const HeadYAllArgs& a, hipStream_t st);
 

@@ -343,6 +343,14 @@ __global__ void head_y_all_kernel(HeadYAllArgs a) {
 int bdk_head_y_all(const HeadYAllArgs& a, hipStream_t st) {
     const int t = row_threads(a.D);
     if (t < 0 || a.D % 8) return -2;
+    if (a.G > 1 && a.n_evals % a.G) {
+        // the last group is short: its matrix keeps a rounded-up row-block count whose pad rows nobody writes below -- zero them
+        // (and their fp8 row scales) here instead of relying on how the caller allocated the buffers
+        const int g = a.n_evals / a.G;
+        bf16_t* base = (bf16_t*)a.y_all + (size_t)g * a.G * a.Mpad * a.D;
+        if (hipMemsetAsync(base, 0, (size_t)a.G * a.Mpad * a.D * sizeof(bf16_t), st) != hipSuccess) return -1;
+        if (a.a8_scale && hipMemsetAsync(a.a8_scale + (size_t)g * a.G * a.Mpad, 0, (size_t)a.G * a.Mpad * sizeof(float), st) != hipSuccess) return -1;
+    }
     BD_LAUNCH(head_y_all_kernel, dim3(a.M, a.n_evals), dim3(t), 0, st, a);
     return bd_launch_status();
 }

@@ -315,11 +315,20 @@ class TPComm:
 
 
 def _device_uuid(device) -> str:
-    """Identifies the physical GPU behind a torch device (ranks that share one GPU share its L2)."""
-    try:
-        return str(torch.cuda.get_device_properties(device).uuid)
-    except Exception:                                         # older torch: fall back to (host pid-independent) index + name
-        return f"{torch.cuda.get_device_name(device)}#{torch.device(device).index}"
+    """Identifies the physical GPU behind a torch device (ranks that share one GPU share its L2).  Without a physical identifier
+    (no ``uuid`` and no PCI address in this torch build) the answer is unique per process: ranks isolated with HIP_VISIBLE_DEVICES
+    all see "device 0", so an index-based fallback would call eight GPUs one device and skip the peer-access and uncached-buffer
+    checks -- unknown identity must read as DIFFERENT devices."""
+    props = torch.cuda.get_device_properties(device)
+    uuid = getattr(props, "uuid", None)
+    if uuid is not None:
+        return str(uuid)
+    pci = [getattr(props, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+    if all(v is not None for v in pci):
+        return "pci-%04x:%02x:%02x" % tuple(int(v) for v in pci)
+    import os
+    import socket
+    return f"unknown-{socket.gethostname()}-{os.getpid()}"
 
 
 def _dist_ready() -> bool:

@@ -1189,8 +1189,9 @@ def test_bench_contract_on_tiny_workload():
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
-    if rf["bound"] == "hbm":                                   # physically streamed bytes next to the algorithmic ones
-        assert rf["streamed"]["frac"] > 0 and rf["streamed"]["launches"] <= rf["launches"]
+    if rf["bound"] == "hbm":                                   # physically streamed bytes; the algorithmic figure beside them
+        assert rf["hbm_bound_launches"]["frac"] > 0 and rf["hbm_bound_launches"]["launches"] <= rf["launches"]
+        assert rf["algorithmic"]["GBs"] >= rf["achieved"] - 0.5 and rf["frac"] <= 1.0
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert cb["parity"]["within_bounds"] is True

@@ -332,9 +332,10 @@ def test_launch_plan_rules_measured_in_round_2():
 
 
 def test_bench_roofline_accounting():
-    """bench.py's roofline arithmetic on a synthetic profile (no GPU): `achieved` = algorithmic bytes (N*K*2 per Linear AND evaluation:
-    a launch named "<gemm>[xG]" serves G evaluations in one pass) over the summed event time; `streamed` = the bytes physically moved by
-    the one-evaluation launches over their time; the grouped launch carries its TFLOP/s; frac == achieved / peak."""
+    """bench.py's roofline arithmetic on a synthetic profile (no GPU): `achieved` = bytes PHYSICALLY streamed by all GEMM launches over the
+    summed event time (a launch named "<gemm>[xG]" serves G evaluations in one pass and moved its weights once), frac == achieved / peak
+    and can never exceed 1 by double counting; `algorithmic` = N*K*2 per Linear AND evaluation over the same time (not a fraction of
+    the peak); `hbm_bound_launches` = the one-evaluation launches alone; the grouped launch carries its TFLOP/s."""
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("bench_roofline_under_test", os.path.join(root, "bench.py"))
@@ -353,8 +354,9 @@ def test_bench_roofline_accounting():
     r = bench.gemm_roofline(FakeEngine(), lambda: None, 128)
     ms = 10 * 0.040 + 2 * 0.400
     assert r["bound"] == "hbm" and r["launches"] == 12
-    assert abs(r["achieved"] - (10 * wq + 2 * 4 * wa) / ms / 1e6) < 0.5 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3
-    assert r["streamed"]["launches"] == 10 and abs(r["streamed"]["achieved"] - wq / 0.040 / 1e6) < 0.5
+    assert abs(r["achieved"] - (10 * wq + 2 * wa) / ms / 1e6) < 0.5 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3
+    assert abs(r["algorithmic"]["GBs"] - (10 * wq + 2 * 4 * wa) / ms / 1e6) < 0.5 and "frac" not in r["algorithmic"]
+    assert r["hbm_bound_launches"]["launches"] == 10 and abs(r["hbm_bound_launches"]["achieved"] - wq / 0.040 / 1e6) < 0.5
     grouped = [g for g in r["per_gemm"] if g["name"] == "head.ada[x4]"][0]
     assert grouped["evaluations_per_launch"] == 4 and grouped["rows_per_pass"] == 512
     assert abs(grouped["TFLOPs"] - 2.0 * 512 * 71680 * 5120 / 0.400e-3 / 1e12) < 1.0
