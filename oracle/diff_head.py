@@ -16,7 +16,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from .numerics import BF16, F32, Policy
+from .numerics import BF16, F32, Policy, fused_kernel
 from . import sampler
 
 
@@ -25,7 +25,7 @@ def timestep_features(t: torch.Tensor, dim: int = 256, max_period: float = 10000
     """flow_head_parallel_x.py:12-27 (cos first, then sin)."""
     half = dim // 2
     t = time_factor * t.float()
-    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=F32) / half)
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=F32, device=t.device) / half)
     args = t[:, None] * freqs[None]
     emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
     if dim % 2:
@@ -61,12 +61,13 @@ def attention(w: dict, pre: str, x: torch.Tensor, n_head: int, pol: Policy) -> t
         out = pol.matmul(att, v)
     else:
         cd = q.dtype
-        s = (q.to(F32) @ k.to(F32).transpose(-1, -2)) * scale
-        m = s.amax(dim=-1, keepdim=True)
-        p = torch.exp(s - m)
-        l = p.sum(dim=-1, keepdim=True)
-        out = (p.to(cd).to(F32) @ v.to(F32)) / l
-        out = out.to(cd)
+        with fused_kernel(q):
+            s = (q.to(F32) @ k.to(F32).transpose(-1, -2)) * scale
+            m = s.amax(dim=-1, keepdim=True)
+            p = torch.exp(s - m)
+            l = p.sum(dim=-1, keepdim=True)
+            out = (p.to(cd).to(F32) @ v.to(F32)) / l
+            out = out.to(cd)
     out = out.transpose(1, 2).contiguous().view(bsz, seqlen, dim)
     return pol.linear(out, w[pre + "wo.weight"], w[pre + "wo.bias"])
 

@@ -91,6 +91,36 @@ class Policy:
         return x.to(BF16) if self.amp else x
 
 
+class fused_kernel:
+    """The body of a FUSED attention kernel (flash_attn_func, F.scaled_dot_product_attention) restated with torch ops: a real
+    ``torch.autocast`` context active around the caller must not re-cast the restated internals (the fused kernel is opaque to
+    autocast: fp32 scores and statistics whatever the policy).  Inert when no autocast context is active -- every CPU golden
+    run -- and what lets tests/test_gpu_autocast.py run this oracle under the DEVICE's own autocast with ``Policy("fp32")``."""
+
+    def __init__(self, t: torch.Tensor):
+        self._ctx = torch.autocast(t.device.type, enabled=False) if torch.is_autocast_enabled(t.device.type) else None
+
+    def __enter__(self):
+        if self._ctx is not None:
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+        return False
+
+
+def autocast_lower(*ts):
+    """What an active device autocast does to the inputs of an op on its lower-precision list (F.scaled_dot_product_attention):
+    cast floating inputs to the autocast dtype.  Identity without an active autocast context."""
+    dev = ts[0].device.type
+    if not torch.is_autocast_enabled(dev):
+        return ts
+    dt = torch.get_autocast_dtype(dev)
+    return tuple(t.to(dt) if t.is_floating_point() else t for t in ts)
+
+
 def bf16_round(x: torch.Tensor) -> torch.Tensor:
     """Round-to-nearest-even to bf16, returned as fp32 (value-preserving)."""
     return x.to(BF16).to(F32)

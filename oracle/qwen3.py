@@ -20,7 +20,7 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
-from .numerics import BF16, F32, Policy
+from .numerics import BF16, F32, Policy, autocast_lower, fused_kernel
 
 
 def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
@@ -35,7 +35,7 @@ def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
 def rope_tables(cfg: dict, position_ids: torch.Tensor, dtype) -> tuple[torch.Tensor, torch.Tensor]:
     """HF:94-137 (default rope): fp32 cos/sin, cast to the hidden-state dtype."""
     hd = cfg["head_dim"]
-    inv_freq = 1.0 / (cfg["rope_theta"] ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))
+    inv_freq = 1.0 / (cfg["rope_theta"] ** (torch.arange(0, hd, 2, dtype=torch.float, device=position_ids.device) / hd))
     freqs = position_ids.float()[:, None] * inv_freq[None, :]       # == the K=1 matmul at HF:131
     emb = torch.cat((freqs, freqs), dim=-1)
     return emb.cos().to(dtype), emb.sin().to(dtype)
@@ -52,18 +52,20 @@ def sdpa(q, k, v, mask, scale: float, pol: Policy):
     the compute dtype before P.V, fp32 accumulation, one rounding of the output."""
     if pol.amp:
         q, k, v = q.to(BF16), k.to(BF16), v.to(BF16)
+    q, k, v = autocast_lower(q, k, v)                      # (a real autocast context: tests/test_gpu_autocast.py; inert otherwise)
     cd = q.dtype
-    rep = q.shape[1] // k.shape[1]
-    k = k.repeat_interleave(rep, dim=1)
-    v = v.repeat_interleave(rep, dim=1)
-    s = (q.to(F32) @ k.to(F32).transpose(-1, -2)) * scale
-    if mask is not None:
-        s = s.masked_fill(~mask, float("-inf"))
-    m = s.amax(dim=-1, keepdim=True)
-    p = torch.exp(s - m)
-    l = p.sum(dim=-1, keepdim=True)
-    out = (p.to(cd).to(F32) @ v.to(F32)) / l
-    return out.to(cd)
+    with fused_kernel(q):
+        rep = q.shape[1] // k.shape[1]
+        k = k.repeat_interleave(rep, dim=1)
+        v = v.repeat_interleave(rep, dim=1)
+        s = (q.to(F32) @ k.to(F32).transpose(-1, -2)) * scale
+        if mask is not None:
+            s = s.masked_fill(~mask, float("-inf"))
+        m = s.amax(dim=-1, keepdim=True)
+        p = torch.exp(s - m)
+        l = p.sum(dim=-1, keepdim=True)
+        out = (p.to(cd).to(F32) @ v.to(F32)) / l
+        return out.to(cd)
 
 
 def model_forward(w: dict, cfg: dict, inputs_embeds: torch.Tensor, cache: list | None,
@@ -81,13 +83,14 @@ def model_forward(w: dict, cfg: dict, inputs_embeds: torch.Tensor, cache: list |
     if cache is None:
         cache = [None] * L
     past = 0 if cache[0] is None else cache[0][0].shape[2]
-    pos = torch.arange(T) + past
+    dev = inputs_embeds.device
+    pos = torch.arange(T, device=dev) + past
     h = inputs_embeds
     cos, sin = rope_tables(cfg, pos, h.dtype)            # [T,hd], dtype of the hidden states
     cos, sin = cos[None, None], sin[None, None]
     if attention_mask is None:
-        i = torch.arange(T)[:, None] + past
-        j = torch.arange(past + T)[None, :]
+        i = torch.arange(T, device=dev)[:, None] + past
+        j = torch.arange(past + T, device=dev)[None, :]
         mask = (j <= i)[None, None]
     else:
         mask = attention_mask[..., : past + T]             # shim 3 of SURVEY 8(c): slice to key length

@@ -104,6 +104,42 @@ def head_case(device="cuda", *, D=5120, Dz=None, C=32, P=64, B=1, branches=2, de
             "gemm_cfg": {k: {"splitk": s, "nwaves": c & 15} for k, (s, c) in cfgs.items()}, "t": t_i, **extra}
 
 
+def head_sample_case(device="cuda", *, D=5120, C=32, P=64, B=1, depth=6, nada=2, head_dim=128, n_steps=4, cfg=1.25, seed=131,
+                     tune: dict | None = None, weights: str = "bf16") -> dict:
+    """``DiffHead.sample`` at true width: n_steps + 1 CHAINED evaluations of the ``depth``-block head with classifier-free
+    guidance ``cfg`` (sampling_x.py:44-97 driving flow_head_parallel_x.py:325-342), device vs oracle on the same noise.  At a
+    guidance scale near 1 the chain is contractive, so the bound is a statement about the implementations, not about chaos
+    (tests/test_gpu_chain_parity.py makes the same point on the tiny model)."""
+    from bitdance_amd import engine as E
+    cfgd = dict(ch_target=C, ch_cond=D, ch_latent=D, depth_latent=depth, depth_adanln=nada)
+    sd_dev = device_seeded_state(tm.head_shapes(cfgd), seed, device)
+    hw = E.HeadWeights.from_state_dict(sd_dev, device, head_dim=head_dim, weights=weights)
+    sd = {k: v.cpu() for k, v in sd_dev.items()}
+    del sd_dev
+    branches = 2 if cfg > 1.0 else 1
+    eng = E.Engine(hw, None, None, num_images=B, branches=branches, device=device, max_tokens=P, parallel_num=P, tune=tune)
+    g = torch.Generator().manual_seed(seed + 1)
+    z = torch.randn(branches * B, P, D, generator=g)
+    noise = torch.randn(n_steps + 1, B, P, C, generator=g)
+    eng.set_schedule(n_steps, cfg, 1)
+    eng.load_noise(noise.view(1, n_steps + 1, B, P, C))
+    eng.reset([0] * min(branches * B, 16))
+    eng.set_cond(z.to(device))
+    eng.head_sample()
+    torch.cuda.synchronize()
+    pred = eng.pred().cpu()
+    tok = eng.tok_cur().cpu()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref = diff_head.sample(sd, z, cfg, n_steps, list(noise), Policy({"fp8": "fp8w", "fp8a": "fp8wa"}.get(weights, "autocast")))[:B]
+    t_cpu = time.perf_counter() - t0
+    err = (pred - ref).abs()
+    agree = (torch.sign(pred) == torch.sign(ref)).float().mean().item()
+    return {"max_err": err.max().item(), "mean_err": err.mean().item(), "ref_abs_mean": ref.abs().mean().item(),
+            "finite": bool(torch.isfinite(pred).all()), "tokens_are_sign_of_pred": bool(torch.equal(tok, torch.sign(pred))),
+            "token_agreement": agree, "evaluations": n_steps + 1, "t_cpu_s": t_cpu}
+
+
 def llm_case(device="cuda", *, layers=1, P=64, past=(1000, 1017), cfg: dict | None = None, seed=202,
              tune: dict | None = None, weights: str = "bf16") -> dict:
     """One native decode step (P new tokens per sequence, ragged cache lengths) at Qwen3-14B width vs the oracle.

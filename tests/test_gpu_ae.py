@@ -210,6 +210,35 @@ def test_native_decoder_released_dims_vs_torch():
     assert torch.isfinite(got).all() and d.mean().item() <= 0.03 * scale + 2e-3
 
 
+@pytest.mark.parametrize("name,grid", [("AE_D16C32", 8), ("AE_D32C256", 4)])
+def test_native_decoder_released_dims_vs_cpu_reference(name, grid):
+    """The decoders of BOTH released tokenizer shapes at their real channel counts (ae_d16c32: z 32, five levels; ae_d32c256 --
+    BASELINE config 5's tokenizer: z 256, six levels, ch_mult as assumed in synthetic.py) on a 128 x 128 crop against the CPU
+    oracle (oracle/autoencoder.py under the autocast policy: no MIOpen, no HIP, not the product's torch module).  A 128-pixel
+    crop runs every layer shape of the 1024-pixel decode (the network is fully convolutional) at a CPU cost of seconds."""
+    from bitdance_amd import synthetic as syn
+    from bitdance_amd.ae_native import NativeDecoder
+    from bitdance_amd.autoencoder import VQModel
+    cfg = getattr(syn, name)
+    ae = VQModel(**cfg).eval()
+    ae.load_state_dict(syn.random_ae_state(cfg, DEV), strict=True, assign=True)
+    ae.to(DEV)
+    nat = NativeDecoder(ae.decoder, DEV)
+    oae, pol, sd = _oracle(ae)
+    zc = cfg["ddconfig"]["z_channels"]
+    z = torch.sign(torch.randn(1, zc, grid, grid, generator=torch.Generator().manual_seed(5)))
+    with torch.no_grad():
+        ref = oae.decoder_forward(pol, sd, cfg["ddconfig"], z).float()
+    got = nat.decode(z.to(DEV)).float().cpu()
+    assert got.shape == ref.shape == (1, 3, 128, 128)
+    d = (got - ref).abs()
+    scale = ref.abs().mean().item()
+    print(f"[{name} 128px vs oracle] max {d.max().item():.4f} mean {d.mean().item():.5f} (ref mean |x| {scale:.3f})")
+    # the tiny-config bound (test_native_decoder_tiny_vs_cpu_reference), with the depth of the released ladders (4 res-blocks per
+    # level instead of 1) in the constant
+    assert torch.isfinite(got).all() and d.mean().item() <= 0.03 * scale + 2e-3 and d.max().item() <= 0.25 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("H,W,Cin,Cout", [(8, 8, 32, 64), (16, 24, 64, 64), (37, 19, 128, 128), (64, 64, 256, 256)])
 def test_conv_stride2_vs_torch(H, W, Cin, Cout):
     """The Encoder's down-sampling convolution (nn.Conv2d(c, c, 3, stride=2, padding=1), autoencoder.py:59-127) as the strided form

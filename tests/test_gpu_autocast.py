@@ -1,0 +1,77 @@
+"""The `*_amp` goldens are the reference run under a CPU EMULATION of CUDA/HIP autocast (oracle/ref_harness.py CudaAutocastOnCpu):
+/root/reference does not exist on the GPU box, so the reference itself cannot run here.  What CAN run here is torch-ROCm's real
+``torch.autocast("cuda", dtype=bfloat16)`` over the same op sequence: the oracle with ``Policy("fp32")`` is plain torch ops (F.linear,
+F.layer_norm, softmax, silu ...; fused attention kernels stay opaque, oracle/numerics.py fused_kernel) -- exactly what the
+reference's modules call.  These tests run it on the device under the device's own autocast and compare NUMBERS with
+
+  * the goldens the emulation produced from the unmodified reference (head_amp / llm_amp), and
+  * the oracle's explicit-cast restatement (Policy("autocast")) on the CPU,
+
+at bf16-noise level: the emulation's rules (tools/probe_autocast.py) and its numbers are both validated on the device."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import diff_head, qwen3
+from oracle import tiny_models as tm
+from oracle.numerics import Policy
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+    return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fiub" and z[k].ndim > 0 else z[k]) for k in z.files}
+
+
+def test_head_under_device_autocast_matches_the_emulated_reference(golden_dir):
+    """DiffHead.net (TransEncoder.forward, 4 blocks) on the device under torch.autocast("cuda", bf16) vs the reference under the
+    CPU emulation (golden) and vs the explicit-cast oracle: same bounds as the CPU pin (tests/test_oracle_golden.py
+    test_head_forward_amp) -- after ONE block only accumulation-order noise, after four a few bf16 ulp."""
+    g = load(golden_dir, "head_amp")
+    w = tm.seeded_state(tm.head_shapes(tm.TINY_HEAD), seed=11)
+    wd = {k: v.to(DEV) for k, v in w.items()}
+    tr = {}
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y = diff_head.net_forward(wd, g["x"].to(DEV), g["t"].to(DEV), g["c"].to(DEV), Policy("fp32"), trace=tr)
+    assert tr["x1"].dtype == torch.bfloat16 and tr["y"].dtype == torch.bfloat16    # Linear outputs and the head's residual stream: bf16
+    y, x1 = y.float().cpu(), tr["x1"].float().cpu()
+    assert (x1 != g["x1"]).float().mean() <= 0.35 and (x1 - g["x1"]).abs().mean() <= 1.5e-3
+    err = (y - g["y"]).abs()
+    assert err.max() <= 5e-2 and err.mean() <= 6e-3, (err.max(), err.mean())
+    with torch.no_grad():
+        yo = diff_head.net_forward(w, g["x"], g["t"], g["c"], Policy("autocast")).float()
+    eo = (y - yo).abs()
+    assert eo.max() <= 5e-2 and eo.mean() <= 6e-3, (eo.max(), eo.mean())
+
+
+def test_llm_under_device_bf16_matches_the_emulated_reference(golden_dir):
+    """Qwen3Model.forward (prefill + two cached 64-token calls, bf16 weights, as t2i_pipeline.py:199-268 drives it) on the device
+    vs the reference's golden and vs the explicit-cast oracle; dtypes of the outputs as on the CPU pin (the decode call's fp32
+    hidden state, K promoted by the type-promoting cache cat)."""
+    g = load(golden_dir, "llm_amp")
+    w = {k: v.to(torch.bfloat16) for k, v in tm.seeded_state(tm.llm_shapes(tm.TINY_LLM), seed=22).items()}
+    wd = {k: v.to(DEV) for k, v in w.items()}
+
+    def run(ws, dev, pol, amp):
+        ctx = torch.autocast("cuda", dtype=torch.bfloat16) if amp else torch.autocast("cpu", enabled=False)
+        with torch.no_grad(), ctx:
+            emb = torch.nn.functional.embedding(g["ids"].long().to(dev), ws["model.embed_tokens.weight"])
+            h1, cache = qwen3.model_forward(ws, tm.TINY_LLM, emb, None, None, pol)
+            past = cache[0][0].shape[2]
+            ones = torch.ones(2, 1, 64, 64 + past + 5, dtype=torch.bool, device=dev)
+            h2, cache = qwen3.model_forward(ws, tm.TINY_LLM, g["blk"].to(dev).to(torch.bfloat16), cache, ones, pol)
+            ones = torch.ones(2, 1, 64, 64 + cache[0][0].shape[2], dtype=torch.bool, device=dev)
+            h3, cache = qwen3.model_forward(ws, tm.TINY_LLM, g["dec"].to(dev), cache, ones, pol)
+        return h1, h2, h3, cache[0][0]
+    h1, h2, h3, k0 = run(wd, DEV, Policy("fp32"), True)
+    assert h1.dtype == torch.bfloat16 and h2.dtype == torch.bfloat16 and h3.dtype == torch.float32 and k0.dtype == torch.float32
+    o1, o2, o3, _ = run(w, "cpu", Policy("autocast"), False)
+    for got, ref, orc in ((h1, g["h1"], o1), (h2, g["h2"], o2), (h3, g["h3"], o3)):
+        e = (got.float().cpu() - ref).abs()
+        assert e.max() <= 0.12 and e.mean() <= 1e-2, (e.max(), e.mean())
+        eo = (got.float().cpu() - orc.float()).abs()
+        assert eo.max() <= 0.12 and eo.mean() <= 1e-2, (eo.max(), eo.mean())

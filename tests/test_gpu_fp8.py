@@ -201,6 +201,8 @@ def test_head_eval_fp8a_vs_oracle(D, P, depth, nada):
     # (measured on an MI355X: D = 5120 max 0.086 / mean 0.014, D = 256 max 0.16 / mean 0.023)
     assert r["finite"] and r["max_err"] <= 0.25 and r["mean_err"] <= 3.5e-2, r
     assert r["vs_bf16_mean"] <= 7e-2 and r["vs_bf16_max"] <= 0.6, r
+    if D == 5120:                                              # the width that matters has its own, tighter bound (the tiny model amplifies)
+        assert r["max_err"] <= 0.15 and r["mean_err"] <= 2.2e-2 and r["vs_bf16_mean"] <= 5e-2, r
 
 
 def test_llm_step_fp8a_vs_oracle_true_dims():

@@ -56,6 +56,19 @@ def test_mlp_head_eval_bitdance_b_1x_dims_vs_oracle():
         r["mean_err"] <= 0.012 * max(1.0, r["ref_abs_mean"]), r
 
 
+def test_head_sample_chain_true_dims_vs_oracle():
+    """FIVE chained evaluations of the full 6-block head at D = 5120 (DiffHead.sample with N = 4, sampling_x.py:44-97) with
+    classifier-free guidance 1.25, device vs oracle on identical noise: the true-width counterpart of the tiny model's chained
+    bound (tests/test_gpu_chain_parity.py, 0.03 at this guidance scale).  The binarised tokens follow the device's own latent bit
+    for bit; against the oracle they may differ only where the latent is within the noise of zero."""
+    from oracle.true_dims import head_sample_case
+    r = head_sample_case(D=5120, depth=6, nada=2, n_steps=4, cfg=1.25)
+    print(f"[head sample chain D=5120, 5 evaluations, cfg 1.25] max {r['max_err']:.4f} mean {r['mean_err']:.5f} "
+          f"token agreement {r['token_agreement']:.4f} (oracle {r['t_cpu_s']:.0f} s)")
+    assert r["finite"] and r["tokens_are_sign_of_pred"], r
+    assert r["mean_err"] <= 0.03 and r["max_err"] <= 0.35 and r["token_agreement"] >= 0.97, r
+
+
 def test_llm_decode_step_qwen3_14b_true_dims():
     """One Qwen3-14B decoder layer + final norm, 2 sequences x 64 new tokens against ~1k cached tokens of DIFFERENT
     lengths: D = 5120, 40 q heads / 8 kv heads (G = 5), FFN 17408."""
