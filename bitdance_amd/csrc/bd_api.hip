@@ -193,7 +193,7 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
 static const char* const kIntKeys[] = {
     "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid", "head.y_evals", "head.variant",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "proj.rows_all", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
-    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async", "tune.ragged", "tune.ragged52", "tune.slab_cap", "tune.slab3",
+    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "rt.in_first", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async", "tune.ragged", "tune.ragged52", "tune.slab_cap", "tune.slab3",
     "tune.ada_group", "tune.ada_group_nw"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
                                          "llm.qkv", "llm.o", "llm.gu", "llm.down"};
@@ -910,10 +910,19 @@ static int llm_step_in(bd_ctx* c, hipStream_t st) {
     const GemmCfg &gq = c->cfg("llm.qkv"), &go = c->cfg("llm.o"), &gg = c->cfg("llm.gu"), &gd = c->cfg("llm.down");
     const size_t layer_elems = (size_t)nseq * nh * c->lLmax * 64;
     Partial br{nullptr, nullptr, 0, 0, 0};
+    // "rt.in_first" = 1: a block of the FIRST forward_model call (model_parallel.py:386-388 / model.py:372-377): llm.R holds the raw
+    // fp32 class-embedding / query-token rows, emb_norm runs here (the decode steps get it from projector_in), the residual stream
+    // stays fp32; "rt.llm_causal": causal mask inside the block (the class tokens); "rt.no_advance": the host sets the cache lengths
+    const int first = (int)c->geti("rt.in_first", 0), causal = (int)c->geti("rt.llm_causal", 0);
     InRmsArgs r1;
     r1.R = (float*)c->wptr("llm.R"); r1.init_from_pend = 0; r1.renorm_to_R = 0;
     r1.a_frag = c->wptr("llm.a_frag"); r1.hidden_out = nullptr; r1.cond_frag = nullptr; r1.pos = nullptr; r1.state = state;
-    r1.M = M; r1.D = D; r1.RB = RB; r1.P = c->Pn; r1.eps = eps;
+    r1.M = M; r1.D = D; r1.RB = RB; r1.P = c->Pn; r1.eps = eps; r1.f32_stream = first;
+    if (first) {
+        InRmsArgs e = r1;
+        e.pend = br; e.renorm_to_R = 1; e.a_frag = nullptr; e.w = (const float*)c->ptr("llm.emb_norm");
+        BD_TRY(bdk_in_rms(e, st));
+    }
     for (int l = 0; l < c->lL; ++l) {
         const std::string pre = "llm.l" + std::to_string(l) + ".";
         r1.pend = br;
@@ -928,6 +937,7 @@ static int llm_step_in(bd_ctx* c, hipStream_t st) {
         qa.state = state; qa.M = M; qa.P = c->Pn; qa.nh = nh; qa.Lmax = c->lLmax;
         BD_TRY(bdk_in_qkv_post(qa, st));
         InAttnArgs aa{c->ptr("llm.q"), qa.k_cache, qa.v_cache, c->wptr("llm.attn_frag"), state, nseq, c->Pn, nh, c->lLmax, RB};
+        aa.causal = causal;
         BD_TRY(bdk_in_attn(aa, st));
         InRmsArgs r2 = r1;
         BD_TRY(linear(c, "llm.o", c->ptr("llm.attn_frag"), RB, wref(c, pre + "wo"), D, D, go, "llm.br_part", "llm.br_bf",
@@ -939,8 +949,10 @@ static int llm_step_in(bd_ctx* c, hipStream_t st) {
         BD_TRY(linear(c, "llm.down", c->ptr("llm.act_frag"), RB, wref(c, pre + "wdown"), D, F, gd, "llm.br_part", "llm.br_bf",
                       nullptr, Mp, &br, st));
     }
-    StepAdvanceArgs sa{state, nseq < BD_MAX_SEQ ? nseq : BD_MAX_SEQ, c->Pn};
-    BD_TRY(bdk_step_advance(sa, st));
+    if (!c->geti("rt.no_advance", 0)) {
+        StepAdvanceArgs sa{state, nseq < BD_MAX_SEQ ? nseq : BD_MAX_SEQ, c->Pn};
+        BD_TRY(bdk_step_advance(sa, st));
+    }
     InRmsArgs rf = r1;
     rf.pend = br; rf.w = (const float*)c->ptr("llm.final_norm"); rf.a_frag = nullptr;
     rf.hidden_out = (float*)c->wptr("llm.hidden");

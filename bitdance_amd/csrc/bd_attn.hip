@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void in_attn_kernel(InAttnArgs a) {
             const int j = jb + 16 * jj;
             float acc = 0.f;
             for (int d = 0; d < 64; ++d) acc += qs[i * 64 + d] * kt[j * 65 + d];
-            if (t0 + j < L) sc[i * LS + t0 + j] = bfr(acc);
+            if (t0 + j < L) sc[i * LS + t0 + j] = (a.causal && t0 + j > L - a.P + i) ? -INFINITY : bfr(acc);   // att + mask
         }
     }
     __syncthreads();
@@ -466,7 +466,10 @@ __global__ __launch_bounds__(256) void in_attn_mfma_kernel(InAttnArgs a, int LS)
                 sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bd_bf16x8v, qa[kk]), __builtin_bit_cast(bd_bf16x8v, kb[u][kk]), sacc, 0, 0, 0);
             const int key = t0 + u * 16 + r16;                      // D layout: row (query) 4 (lane >> 4) + r, column (key) lane & 15
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sc[((lane >> 4) * 4 + r) * LS + key] = (key < L) ? f2bf(sacc[r]) : (bf16_t)0xff80;   // -inf pad
+            for (int r = 0; r < 4; ++r) {
+                const bool vis = key < L && !(a.causal && key > L - a.P + (lane >> 4) * 4 + r);   // causal: keys <= past + query index
+                sc[((lane >> 4) * 4 + r) * LS + key] = vis ? f2bf(sacc[r]) : (bf16_t)0xff80;        // -inf: pad / masked
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

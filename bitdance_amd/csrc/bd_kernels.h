@@ -224,6 +224,8 @@ struct InRmsArgs {          // nn.RMSNorm on a bf16 residual stream: bf16( x * r
     const BdStepState* state;
     int M, D, RB, P;
     float eps;
+    int f32_stream = 0;     // 1: the FIRST forward_model call (class + query tokens, model_parallel.py:386-388): the class embedding is
+                            // fp32, so the residual stream stays fp32 (fp32 + bf16 branch -> fp32, rms_norm of an fp32 tensor returns fp32)
 };
 int bdk_in_rms(const InRmsArgs& a, hipStream_t st);
 
@@ -245,6 +247,8 @@ struct InAttnArgs {         // naive_attention with the reference's rounding poi
     void* o_frag;           // out fragment-major bf16 [Mpad][D]
     const BdStepState* state;
     int nseq, P, nh, Lmax, RB;
+    int causal = 0;         // 1: query i of the block sees keys <= past + i only (the causal part of attn_mask, model_parallel.py:90-101);
+                            // 0: every cached key and the whole block (a decode block, and the first call's last, bidirectional block)
 };
 int bdk_in_attn(const InAttnArgs& a, hipStream_t st);
 

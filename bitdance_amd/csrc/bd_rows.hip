@@ -754,7 +754,7 @@ __global__ void in_rms_kernel(InRmsArgs a) {
                 float o[8];
                 slab8(a.pend, m, d0, o);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = bfr(x[j] + o[j]);   // bf16 residual + bf16 branch -> bf16
+                for (int j = 0; j < 8; ++j) x[j] = a.f32_stream ? x[j] + o[j] : bfr(x[j] + o[j]);   // bf16 residual + bf16 branch -> bf16 (fp32 + bf16 -> fp32)
             }
         }
         if (!a.renorm_to_R && (a.pend.p || a.init_from_pend)) st_f32x8(a.R + (size_t)m * a.D + d0, x);
@@ -766,7 +766,10 @@ __global__ void in_rms_kernel(InRmsArgs a) {
     float w[8], n[8];
     ld_f32x8(a.w + d0, w);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) n[j] = bfr(fmul(fmul(x[j], rs), w[j]));   // rms_norm composite: one rounding to the input dtype
+    for (int j = 0; j < 8; ++j) {                                  // rms_norm composite: one rounding to the input dtype (none for fp32)
+        const float v = fmul(fmul(x[j], rs), w[j]);
+        n[j] = a.f32_stream ? v : bfr(v);
+    }
     if (a.renorm_to_R) st_f32x8(a.R + (size_t)m * a.D + d0, n);
     if (a.a_frag) *reinterpret_cast<u32x4*>((bf16_t*)a.a_frag + afrag_off(m, d0, a.RB)) = pack8(n);
     if (a.hidden_out) st_f32x8(a.hidden_out + (size_t)m * a.D + d0, n);

@@ -16,10 +16,12 @@ What runs where:
     final_sigmoid=False));
   * I2 the KV-cached block-causal transformer: every 16-token decode step (``proj_in`` -> ``forward_model``) on the HIP
     engine (``bd_projector`` / ``bd_llm_step`` in their imagenet variant: bf16 residual stream, fp32 norm weights,
-    interleaved 2-D RoPE, head_dim-64 attention with the reference's rounding points, static K/V cache); the first step
-    (class tokens + query tokens under the mixed causal / block mask, once per image) runs as torch ops and writes the
-    same K/V cache -- like the T2I prefill;
-  * the conv decoder stays on MIOpen (north star).
+    interleaved 2-D RoPE, head_dim-64 attention with the reference's rounding points, static K/V cache).  The FIRST call
+    (class tokens + query tokens under the mixed causal / block mask, once per batch) runs on the same step kernels since round
+    4 (``_first_step_native``: causal blocks of P class tokens, then the last P tokens as a bidirectional block; fp32 residual
+    stream, emb_norm on the raw rows) -- like the T2I prefill; the torch form stays behind ``native_first_step = False`` /
+    ``native_transformer = False`` as a cross-check;
+  * the conv decoder runs on the native kernels under bf16 autocast (autoencoder.VQModel.decode, round 3).
 """
 from __future__ import annotations
 
@@ -127,6 +129,7 @@ class BitDance:
         self.total_tokens = self.h * self.w + cls_token_num
         self.vae = vae
         self.native_transformer = True                       # False: torch ops for every step (reference arithmetic)
+        self.native_first_step = True                        # False: the class / query-token call on torch ops (cross-check)
         sd = {k: v.detach().to(self.device, torch.float32) for k, v in state_dict.items() if not k.startswith("vae.")}
         self.w_ = sd
         head_sd = {k[len("head."):]: v for k, v in sd.items() if k.startswith("head.")}
@@ -207,6 +210,46 @@ class BitDance:
             kc[l, :, :, :T0].copy_(k[:, :, :T0])
             vc[l, :, :, :T0].copy_(v[:, :, :T0])
         eng.reset([T0] * min(bsz, 16))
+
+    def _cache_views(self, eng: Engine, T0: int) -> list:
+        """The first T0 cached positions of every layer of ``eng`` as (K, V) views [bsz, heads, T0, 64] (what _load_cache takes)."""
+        bsz = eng.B * eng.branches
+        shape = (self.n_layer, bsz, self.n_head, eng.Lmax, 64)
+        kc = eng.view("llm.k_cache", torch.bfloat16, shape)
+        vc = eng.view("llm.vt_cache", torch.bfloat16, shape)
+        return [(kc[l][:, :, :T0], vc[l][:, :, :T0]) for l in range(self.n_layer)]
+
+    def _first_step_native(self, eng: Engine, ids: torch.Tensor) -> torch.Tensor:
+        """The first ``forward_model`` call (model_parallel.py:386-388; 1x: model.py:372-377) on the step kernels: the class tokens
+        (+ P - 1 query tokens) of every sequence under ``attn_mask[:T0, :T0]`` -- blocks of P tokens with the causal mask inside the
+        block for the first T0 - P tokens, then the last P tokens as one bidirectional block (exactly a decode block: every cached
+        key plus the block).  The class embedding is fp32, so this call's residual stream is fp32 ("rt.in_first"; the decode steps'
+        is bf16) and emb_norm runs on the raw rows.  K / V land in ``eng``'s static cache.  Returns norm(x) of the last P tokens
+        [bsz, P, D] fp32."""
+        P, n_cls, w = self.P, self.cls_token_num, self.w_
+        bsz = ids.shape[0]
+        T0 = n_cls + P - 1
+        c = F.embedding(ids, w["cls_embedding.weight"]).view(bsz, n_cls, -1)          # a gather: fp32 rows of the table
+        x = torch.cat([c, w["query_token"].repeat(bsz, 1, 1)], dim=1) if P > 1 else c
+        R = eng.residual()[: bsz * P].view(bsz, P, -1)
+        nc = T0 - P                                                                   # tokens ahead of the last block: causal
+
+        def run(rows: torch.Tensor, past: int, causal: bool) -> None:
+            R.zero_()
+            R[:, : rows.shape[1]].copy_(rows)
+            eng.reset([past] * min(bsz, 16))
+            for k, v in (("rt.in_first", 1), ("rt.llm_causal", int(causal)), ("rt.no_advance", 1)):
+                eng.set_int(k, v)
+            try:
+                eng.llm_step()
+            finally:
+                for k in ("rt.in_first", "rt.llm_causal", "rt.no_advance"):
+                    eng.set_int(k, 0)
+        for c0 in range(0, nc, P):
+            run(x[:, c0: min(c0 + P, nc)], c0, True)       # a short last block: its pad rows' K / V are overwritten by the next block
+        run(x[:, nc:], nc, False)
+        eng.reset([T0] * min(bsz, 16))
+        return eng.hidden().view(bsz, P, -1).clone()
 
     def _decode_step(self, eng: Engine, tokens: torch.Tensor) -> torch.Tensor:
         """proj_in + forward_model for one 16-token block on the engine; returns norm(x) [bsz, P, D] (bf16 values)."""
@@ -329,14 +372,19 @@ class BitDance:
         bsz = ids.shape[0]
         act = bsz // 2 if cfg_scale > 1.0 else bsz
         hd = self.dim // self.n_head
+        torch_first = not (self.native_transformer and self.native_first_step)   # the torch cross-check path keeps its own K / V
         caches = [(torch.zeros(bsz, self.n_head, self.total_tokens, hd, device=dev),
-                   torch.zeros(bsz, self.n_head, self.total_tokens, hd, device=dev)) for _ in range(self.n_layer)]
+                   torch.zeros(bsz, self.n_head, self.total_tokens, hd, device=dev)) for _ in range(self.n_layer)] if torch_first else None
         seq_len = self.h * self.w // P
         w = self.w_
         toks, preds, last = [], [], None
         eng_t = self._tr_engine(bsz) if self.native_transformer else None
         for i in range(seq_len):
-            if i == 0:
+            if i == 0 and eng_t is not None and self.native_first_step:
+                T0 = n_cls + P - 1
+                x = self._first_step_native(eng_t, ids)
+                caches = self._cache_views(eng_t, T0)             # (for the combined engine of the graph path)
+            elif i == 0:
                 with torch.autocast("cuda", dtype=torch.bfloat16):
                     T0 = n_cls + P - 1
                     c = F.embedding(ids, w["cls_embedding.weight"]).view(bsz, n_cls, -1)

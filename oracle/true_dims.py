@@ -140,6 +140,33 @@ def head_sample_case(device="cuda", *, D=5120, C=32, P=64, B=1, depth=6, nada=2,
             "token_agreement": agree, "evaluations": n_steps + 1, "t_cpu_s": t_cpu}
 
 
+def ae_case(device="cuda", *, config: str = "AE_D16C32", px: int = 256, seed: int = 5) -> dict:
+    """The tokenizer's conv decoder (autoencoder.py:169-196) at its released channel counts on a ``px`` x ``px`` image: the
+    native kernels (bitdance_amd/ae_native.py) vs oracle/autoencoder.py under the autocast policy, and the oracle's CPU time --
+    SURVEY 8(d)'s ``t_ae256`` (a 1024-pixel decode is 16 such tiles of work: the network is fully convolutional)."""
+    from bitdance_amd import synthetic as syn
+    from bitdance_amd.ae_native import NativeDecoder
+    from bitdance_amd.autoencoder import VQModel
+    from . import autoencoder as oae
+    cfg = getattr(syn, config)
+    ae = VQModel(**cfg).eval()
+    ae.load_state_dict(syn.random_ae_state(cfg, device), strict=True, assign=True)
+    ae.to(device)
+    nat = NativeDecoder(ae.decoder, device)
+    sd = {k: v.detach().float().cpu() for k, v in ae.state_dict().items()}
+    down = 2 ** (len(cfg["ddconfig"]["ch_mult"]) - 1)
+    zc = cfg["ddconfig"]["z_channels"]
+    z = torch.sign(torch.randn(1, zc, px // down, px // down, generator=torch.Generator().manual_seed(seed)))
+    got = nat.decode(z.to(device)).float().cpu()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref = oae.decoder_forward(Policy("autocast"), sd, cfg["ddconfig"], z).float()
+    t_cpu = time.perf_counter() - t0
+    err = (got - ref).abs()
+    return {"max_err": err.max().item(), "mean_err": err.mean().item(), "ref_abs_mean": ref.abs().mean().item(),
+            "finite": bool(torch.isfinite(got).all()), "t_cpu_s": t_cpu, "px": px}
+
+
 def llm_case(device="cuda", *, layers=1, P=64, past=(1000, 1017), cfg: dict | None = None, seed=202,
              tune: dict | None = None, weights: str = "bf16") -> dict:
     """One native decode step (P new tokens per sequence, ragged cache lengths) at Qwen3-14B width vs the oracle.
