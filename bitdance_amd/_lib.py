@@ -75,6 +75,10 @@ _PROTOS = {
     "bd_gfq_codes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "bd_probe_read": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p]),
     "bd_comm_create": (C.c_void_p, [C.c_int, C.c_int, C.c_longlong]),
+    "bd_comm_create2": (C.c_void_p, [C.c_int, C.c_int, C.c_longlong, C.c_longlong]),
+    "bd_comm_gather_ptr": (C.c_void_p, [C.c_void_p]),
+    "bd_comm_gather_bytes": (C.c_longlong, [C.c_void_p]),
+    "bd_comm_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "bd_comm_destroy": (None, [C.c_void_p]),
     "bd_comm_ipc_handles": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bd_comm_open_peer": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

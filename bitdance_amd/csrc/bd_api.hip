@@ -194,7 +194,7 @@ static const char* const kIntKeys[] = {
     "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid", "head.y_evals", "head.variant",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "proj.rows_all", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
     "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "rt.in_first", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async", "tune.ragged", "tune.ragged52", "tune.slab_cap", "tune.slab3",
-    "tune.ada_group", "tune.ada_group_nw"};
+    "tune.ada_group", "tune.ada_group_nw", "tp.ada_split"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
                                          "llm.qkv", "llm.o", "llm.gu", "llm.down"};
 static bool known_int_key(const std::string& k) {
@@ -207,7 +207,7 @@ static bool known_int_key(const std::string& k) {
     return false;
 }
 static const char* const kPtrKeys[] = {
-    "head.cond_w", "head.cond_b", "head.in_w", "head.in_b", "head.ada_w", "head.ada_b", "head.lin_w", "head.lin_b", "head.temb",
+    "head.cond_w", "head.cond_b", "head.in_w", "head.in_b", "head.ada_w", "head.ada_b", "head.ada_w_l", "head.ada_b_l", "head.ada_loc", "head.lin_w", "head.lin_b", "head.temb",
     "head.noise", "head.tok_all", "head.y_all", "head.y_scale_all", "head.cfg_table", "proj.w1", "proj.b1", "proj.w2", "proj.b2", "llm.final_norm", "llm.emb_norm", "llm.rope2d",
     "llm.cos", "llm.sin", "pos",
     // workspaces (the caller allocates them after bd_ctx_finalize; a head-/projector-only context may borrow another's)
@@ -227,7 +227,7 @@ static bool known_ptr_key(const std::string& k) {
         for (const char* f : fields) if (k.compare(i + 1, std::string::npos, f) == 0) return true;
         return false;
     };
-    for (const char* n : {"head.cond_w_s", "head.ada_w_s", "proj.w2_s"}) if (k == n) return true;      // fp8 scales
+    for (const char* n : {"head.cond_w_s", "head.ada_w_s", "head.ada_w_l_s", "proj.w2_s"}) if (k == n) return true;      // fp8 scales
     return indexed("head.blk", {"ln1_w", "ln1_b", "ln2_w", "ln2_b", "wqkv", "bqkv", "wo", "bo", "w1", "b1", "w2", "b2",
                                 "wqkv_s", "wo_s", "w1_s", "w2_s"}) ||
            indexed("llm.l", {"in_norm", "post_norm", "q_norm", "k_norm", "wqkv", "wo", "wgu", "wdown",
@@ -480,6 +480,15 @@ int bd_ctx_finalize(bd_ctx* c) {
             add("head.y_frag", Mp * c->hD * 2);
             add("head.X", Mp * c->hD * 2);
             add("head.ada_bf", Mp * c->hNada * 2 * (c->geti("tune.ada_async", 0) ? 2 : c->adaG));
+            if (c->geti("tp.ada_split", 0)) {
+                // COLUMN-split adaLN projection (reference layout flow_head_parallel_x.py:331): this rank computes hNada / tp
+                // of the output columns of a whole group of evaluations into head.ada_loc and pushes them into every rank's head.ada_bf
+                // (which the caller places in the communicator's gather region) -- instead of every rank streaming all 0.73 GB
+                if (tp < 2 || !c->comm || bdk_comm_mode(c->comm) != 0) return fail("tp.ada_split: a tensor-parallel context on the hand-written exchange only");
+                if (c->adaG < 2) return fail("tp.ada_split: needs the grouped adaLN projection (tune.ada_group > 1)");
+                if (c->hNada % tp || (c->hNada / tp) % 256) return fail("tp.ada_split: the adaLN width must split into multiples of 256 columns");
+                add("head.ada_loc", Mp * (c->hNada / tp) * 2 * c->adaG);
+            }
             add("head.cemb", Mp * c->hD * 2);
             add("head.h_frag", Mp * c->hD * 2);
             add("head.h_scale", Mp * 4);                       // fp8 activations: per-row scales of h / y (wdtype 2)
@@ -712,10 +721,18 @@ static int head_ada_group(bd_ctx* c, int g, hipStream_t st) {
     const bf16_t* y = (const bf16_t*)c->ptr("head.y_all") + (size_t)g * G * c->Mpad * D;
     char name[32];
     std::snprintf(name, sizeof(name), "head.ada[x%d]", Gg);     // profiling: Gg evaluations' worth of rows per weight pass
-    WRef wa = wref(c, "head.ada_w");
+    const bool split = c->tp > 1 && c->geti("tp.ada_split", 0) != 0;
+    WRef wa = wref(c, split ? "head.ada_w_l" : "head.ada_w");
     if (c->fp8a) wa.a = (const float*)c->ptr("head.y_scale_all") + (size_t)g * G * c->Mpad;
-    BD_TRY(gemm(c, name, y, rbg, wa, c->hNada, D, 1, /*8 waves, ring 2: the 256-row / tiled kernels*/ (int)c->geti("tune.ada_group_nw", c->fp8a ? 4 : 8) + 16 * 2,
-                BD_EPI_BF16, nullptr, c->wptr("head.ada_bf"), c->ptr("head.ada_b"), st));
+    const int nw = (int)c->geti("tune.ada_group_nw", c->fp8a ? 4 : 8) + 16 * 2;   // 8 waves, ring 2: the 256-row / tiled kernels
+    if (split) {
+        // this rank's columns of the group's modulation tensor, then one push all-gather into every rank's head.ada_bf
+        const int Nl = c->hNada / c->tp;
+        BD_TRY(gemm(c, name, y, rbg, wa, Nl, D, 1, nw, BD_EPI_BF16, nullptr, c->wptr("head.ada_loc"), c->ptr("head.ada_b_l"), st));
+        BD_TRY(bdk_tp_allgather(c->comm, c->ptr("head.ada_loc"), c->wptr("head.ada_bf"), rbg * 32, Nl, c->hNada, st));
+        return 0;
+    }
+    BD_TRY(gemm(c, name, y, rbg, wa, c->hNada, D, 1, nw, BD_EPI_BF16, nullptr, c->wptr("head.ada_bf"), c->ptr("head.ada_b"), st));
     return 0;
 }
 

@@ -38,8 +38,9 @@
 struct bd_comm {
     int rank = 0, size = 1, mode = 0;
     long long max_elems = 0;                 // rows * N capacity of one exchange
-    char* data = nullptr;                    // local: staging fp32 [max_elems] | result bf16 [max_elems]
-    int* flags = nullptr;                    // local: A [tp][GMAX] | B [tp][GMAX] | err | epoch [GMAX]
+    long long gather_bytes = 0;              // capacity of the all-gather region behind the exchange buffers (bd_comm_create2)
+    char* data = nullptr;                    // local: staging fp32 [max_elems] | result bf16 [max_elems] | gather region [gather_bytes]
+    int* flags = nullptr;                    // local: A [tp][GMAX] | B [tp][GMAX] | err | epoch [GMAX] | C [tp][GMAX] | epoch of C [GMAX]
     bool own = false;
     bool data_uncached = false, flags_uncached = false;   // allocation kinds actually obtained (bd_comm_info): the cross-GPU
                                                           // coherence argument of the hand-written exchange needs both
@@ -50,7 +51,9 @@ struct bd_comm {
     int (*nccl_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     double timeout_s = 20.0;
     long long n_exchanges = 0;               // launches issued (graph captures count once): reporting only
+    long long n_gathers = 0;
 };
+#define BD_TP_FLAG_INTS (3 * BD_TP_MAX * BD_TP_GMAX + 1 + 2 * BD_TP_GMAX)
 
 void bdk_set_error(const std::string& m);    // bd_api.hip
 
@@ -227,19 +230,87 @@ int bdk_tp_allreduce(bd_comm* c, const float* part, const void* bias, int rows, 
     return 0;
 }
 
+// ---- all-gather of a COLUMN-split Linear's output (the adaLN projection under tensor parallelism, flow_head_parallel_x.py:331):
+// rank r holds columns [r * Nl, (r + 1) * Nl) of the bf16 tensor [rows][N] and pushes them into every rank's copy (its own
+// included) in the gather region; one flag round (block b of rank r <-> block b of every peer, its own epoch counters) tells a
+// rank that every slice of ITS copy has landed.  Push-only, 16 B system-scope stores, bounded waits, the same error word.
+struct AgArgs {
+    const u32x4* src;           // this rank's slice [rows][Nl] bf16 row-major
+    char* peer_data[BD_TP_MAX];
+    int* peer_flags[BD_TP_MAX];
+    int* flags;
+    long long gather_off, gather_bytes, timeout_ticks;
+    int rank, size, G, rows, Nl8, N8;          // Nl8 / N8: 16 B units per slice row / per full row
+};
+__global__ __launch_bounds__(256) void tp_allgather_kernel(AgArgs g) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int FC = 2 * BD_TP_MAX * BD_TP_GMAX + 1 + BD_TP_GMAX, ERR = 2 * BD_TP_MAX * BD_TP_GMAX, EPC = FC + BD_TP_MAX * BD_TP_GMAX;
+    const int e = g.flags[EPC + b] + 1;
+    const long long U = (long long)g.rows * g.Nl8, Ub = (U + g.G - 1) / g.G;
+    const long long u0 = b * Ub, u1 = min(U, u0 + Ub);
+    __amdgpu_buffer_rsrc_t dst[BD_TP_MAX];
+#pragma unroll
+    for (int q = 0; q < BD_TP_MAX; ++q) dst[q] = sys_rsrc(g.peer_data[q < g.size ? q : 0] + g.gather_off, g.gather_bytes);
+    for (long long u = u0 + tid; u < u1; u += 256) {
+        const int row = (int)(u / g.Nl8), cu = (int)(u % g.Nl8);
+        const u32x4 v = g.src[u];
+        const unsigned off = (unsigned)(((long long)row * g.N8 + (long long)g.rank * g.Nl8 + cu) * 16);
+#pragma unroll
+        for (int q = 0; q < BD_TP_MAX; ++q)
+            if (q < g.size) __builtin_amdgcn_raw_buffer_store_b128(v, dst[q], off, 0, BD_SYS_AUX);
+    }
+    ArArgs a;                                                    // the signalling helpers take the exchange's argument block
+    for (int p = 0; p < BD_TP_MAX; ++p) a.peer_flags[p] = g.peer_flags[p];
+    a.flags = g.flags; a.rank = g.rank; a.size = g.size; a.timeout_ticks = g.timeout_ticks;
+    tp_signal(a, FC, b, e);
+    (void)tp_wait(a, FC, b, e, ERR);
+    if (tid == 0) g.flags[EPC + b] = e;
+}
+
+// dst_local: where this rank's copy of the gathered tensor lives -- must be bd_comm_gather_ptr(c) (+ an offset every rank uses alike)
+int bdk_tp_allgather(bd_comm* c, const void* slice, void* dst_local, int rows, int Nl, int N, hipStream_t st) {
+    if (!c || c->size < 2 || c->mode == 1) return -2;             // (RCCL mode: the caller keeps the projection replicated)
+    if (Nl % 8 || N != Nl * c->size) return -3;
+    const long long off = (char*)dst_local - c->data, need = (long long)rows * N * 2;
+    const long long g0 = c->max_elems * 6;
+    if (off < g0 || off + need > g0 + c->gather_bytes || off % 16 || need >= (1LL << 31)) return -3;
+    for (int p = 0; p < c->size; ++p)
+        if (!c->peer_data[p] || !c->peer_flags[p]) return -6;
+    AgArgs g;
+    g.src = (const u32x4*)slice; g.flags = c->flags;
+    for (int p = 0; p < BD_TP_MAX; ++p) { g.peer_data[p] = c->peer_data[p]; g.peer_flags[p] = c->peer_flags[p]; }
+    g.gather_off = off; g.gather_bytes = need; g.timeout_ticks = (long long)(c->timeout_s * 1e8);
+    g.rank = c->rank; g.size = c->size; g.rows = rows; g.Nl8 = Nl / 8; g.N8 = N / 8;
+    const long long U = (long long)rows * g.Nl8;
+    g.G = (int)((U + 2047) / 2048);                              // >= 8 units per thread, up to BD_TP_GMAX blocks
+    if (g.G > BD_TP_GMAX) g.G = BD_TP_GMAX;
+    if (g.G < 1) g.G = 1;
+    c->n_gathers++;
+    BD_LAUNCH(tp_allgather_kernel, dim3(g.G), dim3(256), 0, st, g);
+    return bd_launch_status();
+}
+void* bdk_comm_gather_ptr(const bd_comm* c) { return (c && c->gather_bytes > 0) ? c->data + c->max_elems * 6 : nullptr; }
+long long bdk_comm_gather_bytes(const bd_comm* c) { return c ? c->gather_bytes : 0; }
+int bdk_comm_mode(const bd_comm* c) { return c ? c->mode : 0; }
+
 int bdk_comm_rank(const bd_comm* c) { return c ? c->rank : 0; }
 int bdk_comm_size(const bd_comm* c) { return c ? c->size : 1; }
 
 extern "C" {
 
-bd_comm* bd_comm_create(int rank, int size, long long max_elems) {
-    if (size < 1 || size > BD_TP_MAX || rank < 0 || rank >= size || max_elems < 8) { bdk_set_error("bd_comm_create: bad rank/size/capacity"); return nullptr; }
+bd_comm* bd_comm_create(int rank, int size, long long max_elems) { return bd_comm_create2(rank, size, max_elems, 0); }
+
+/* ... with an all-gather region of `gather_bytes` behind the exchange buffers (same allocation, same IPC handle): where the
+ * column-split adaLN projection's output is assembled on every rank (bd_comm_gather_ptr) */
+bd_comm* bd_comm_create2(int rank, int size, long long max_elems, long long gather_bytes) {
+    if (size < 1 || size > BD_TP_MAX || rank < 0 || rank >= size || max_elems < 8 || gather_bytes < 0) { bdk_set_error("bd_comm_create: bad rank/size/capacity"); return nullptr; }
     bd_comm* c = new bd_comm();
     c->rank = rank; c->size = size;
-    c->max_elems = (max_elems + 7) / 8 * 8 + 8 * BD_TP_MAX;     // slices are ceil(units / size): up to one 8-element unit of slack per rank
+    c->max_elems = (max_elems + 127) / 128 * 128 + 128 * BD_TP_MAX;   // slices are ceil(units / size): slack per rank; keeps the gather region 256 B aligned
+    c->gather_bytes = (gather_bytes + 255) / 256 * 256;
     // the kernel addresses an allocation through ONE buffer resource: 32-bit size and offsets
     if (c->max_elems * 6 >= (1LL << 31)) { delete c; bdk_set_error("bd_comm_create: capacity too large (rows * N * 6 must stay below 2^31 bytes)"); return nullptr; }
-    const size_t dbytes = (size_t)c->max_elems * 6, fbytes = (size_t)(2 * BD_TP_MAX * BD_TP_GMAX + 1 + BD_TP_GMAX) * sizeof(int);
+    const size_t dbytes = (size_t)c->max_elems * 6 + (size_t)c->gather_bytes, fbytes = (size_t)BD_TP_FLAG_INTS * sizeof(int);
     // staging / result buffer: written by the PEERS over xGMI and read here inside the same kernel.  Ordinary (coarse-grained)
     // device memory is cached in this GPU's L2 as device-coherent only -- a line kept from the previous exchange could be
     // served instead of what a peer has pushed since (the one-GPU tests cannot show this: all "ranks" share one L2).  Uncached
@@ -309,6 +380,8 @@ int bd_comm_set_peer_ptrs(bd_comm* c, int peer, void* data, void* flags) {
     return 0;
 }
 void* bd_comm_local_data(bd_comm* c) { return c->data; }
+void* bd_comm_gather_ptr(bd_comm* c) { return bdk_comm_gather_ptr(c); }   /* this rank's copy of the all-gather region (null: none) */
+long long bd_comm_gather_bytes(bd_comm* c) { return bdk_comm_gather_bytes(c); }
 void* bd_comm_local_flags(bd_comm* c) { return c->flags; }
 
 int bd_comm_set_rccl(bd_comm* c, void* nccl_comm, void* nccl_allreduce_fn) {
@@ -320,7 +393,7 @@ int bd_comm_set_rccl(bd_comm* c, void* nccl_comm, void* nccl_allreduce_fn) {
 int bd_comm_set_timeout(bd_comm* c, double seconds) { c->timeout_s = seconds; return 0; }
 /* after a failed exchange (all ranks, between two host barriers): clear flags, epochs and the error word */
 int bd_comm_reset(bd_comm* c) {
-    const size_t fbytes = (size_t)(2 * BD_TP_MAX * BD_TP_GMAX + 1 + BD_TP_GMAX) * sizeof(int);
+    const size_t fbytes = (size_t)BD_TP_FLAG_INTS * sizeof(int);
     if (hipDeviceSynchronize() != hipSuccess || hipMemset(c->flags, 0, fbytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
         return cfail("bd_comm_reset failed");
     return 0;
@@ -355,11 +428,18 @@ int bd_comm_allreduce(bd_comm* c, const float* part, const void* bias_bf16, int 
     return 0;
 }
 
+/* standalone all-gather of column slices (tests): slice [rows][Nl] bf16 -> this rank's gather region [rows][Nl * size] */
+int bd_comm_allgather(bd_comm* c, const void* slice_bf16, int rows, int Nl, void* stream) {
+    const int rc = bdk_tp_allgather(c, slice_bf16, bdk_comm_gather_ptr(c), rows, Nl, Nl * (c ? c->size : 1), (hipStream_t)stream);
+    if (rc != 0) return cfail("bd_comm_allgather failed with " + std::to_string(rc));
+    return 0;
+}
+
 /* copy `bytes` of this rank's exchange buffer (offset from its base: 0 = fp32 staging, max_elems*4 = bf16 result) into a
  * caller-owned device buffer -- how tests read a standalone exchange back */
 int bd_comm_copy_out(bd_comm* c, void* dst, long long bytes, int from_result, void* stream) {
-    const long long off = from_result ? c->max_elems * 4 : 0;
-    if (bytes < 0 || off + bytes > c->max_elems * 6) return cfail("bd_comm_copy_out: range");
+    const long long off = from_result == 2 ? c->max_elems * 6 : (from_result ? c->max_elems * 4 : 0);   // 2: the all-gather region
+    if (bytes < 0 || off + bytes > c->max_elems * 6 + c->gather_bytes) return cfail("bd_comm_copy_out: range");
     return hipMemcpyAsync(dst, c->data + off, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess
                ? 0 : cfail("bd_comm_copy_out: hipMemcpyAsync failed");
 }

@@ -263,6 +263,12 @@ struct bd_comm;
 int bdk_tp_allreduce(bd_comm* c, const float* part, const void* bias, int rows, int N, Partial* res, hipStream_t st);
 int bdk_comm_rank(const bd_comm* c);
 int bdk_comm_size(const bd_comm* c);
+// all-gather of a column-split Linear's bf16 output [rows][Nl] into every rank's [rows][Nl * size] copy at `dst_local` (inside the
+// gather region, the same offset on every rank); hand-written exchange only (mode 0)
+int bdk_tp_allgather(bd_comm* c, const void* slice, void* dst_local, int rows, int Nl, int N, hipStream_t st);
+void* bdk_comm_gather_ptr(const bd_comm* c);
+long long bdk_comm_gather_bytes(const bd_comm* c);
+int bdk_comm_mode(const bd_comm* c);            // 0 hand-written exchange, 1 ncclAllReduce
 
 // ---- bd_attn.hip
 struct HeadAttnArgs {       // DiT attention over one patch (seq = P = 64 or 16), non-causal      flow_head:192-220

@@ -186,6 +186,16 @@ class HeadWeights:
         ada_b = [g(f"net.ada_ln_blocks.{j}.bias") for j in range(na)] + [g("net.final_layer.ada_ln_modulation.bias")]
         _put_linear(p, "head.ada_w", ada_w, device, fp8, act8=True)
         p["head.ada_b"] = torch.cat([_bf16(b, device) for b in ada_b]).contiguous()
+        nada_cols = p["head.ada_b"].numel()
+        if tp_size > 1 and not mlp and nada_cols % tp_size == 0 and (nada_cols // tp_size) % 256 == 0:
+            # tensor parallel: ALSO this rank's contiguous slice of the stacked projection's output columns (SURVEY 8e "column-split
+            # ada_ln_blocks"): the engine runs the grouped projection on it and all-gathers the modulation tensor when the communicator
+            # offers a gather region (Engine: "tp.ada_split"); the whole matrix above stays for the modes that keep it replicated
+            nl = nada_cols // tp_size
+            full = torch.cat([_bf16(w_, device) for w_ in ada_w])
+            _put_linear(p, "head.ada_w_l", [full[tp_rank * nl:(tp_rank + 1) * nl].contiguous()], device, fp8, act8=True)
+            p["head.ada_b_l"] = p["head.ada_b"][tp_rank * nl:(tp_rank + 1) * nl].contiguous()
+            del full
         for i in range(nb):
             s, d = f"net.res_blocks.{i}.", f"head.blk{i}."
             for n, src in ((("2", "norm"),) if mlp else (("1", "norm1"), ("2", "norm2"))):
@@ -380,6 +390,16 @@ class Engine:
         for k, v in (tune or {}).items():
             ints["tune." + k] = v
         ints.update(extra_ints or {})
+        # tensor parallel on the hand-written exchange: column-split adaLN projection + push all-gather when this rank holds its
+        # slice and the communicator's gather region takes one group's modulation tensor (G evaluations x Mpad rows x all columns)
+        self.ada_split = False
+        if self.comm is not None and head is not None and "head.ada_w_l" in head.ptrs and self.comm.backend in ("ipc", "none") \
+                and ints.get("tp.ada_split", 1) and not ints.get("tune.ada_async", 0):
+            mp = 32 if self.M <= 32 else (64 if self.M <= 64 else (self.M + 127) // 128 * 128)
+            G = ints.get("tune.ada_group", 512 // mp if mp <= 128 else (1024 // mp if (mp <= 512 and 1024 % mp == 0) else 1))
+            need = G * mp * head.ptrs["head.ada_b"].numel() * 2
+            self.ada_split = G >= 2 and self.comm.gather_bytes >= need and (self.wdtype in (0, 2))
+        ints["tp.ada_split"] = int(self.ada_split)
         for k, v in ints.items():
             check(self.l.bd_ctx_set_int(self.ctx, k.encode(), int(v)))
         if llm is not None:
@@ -395,6 +415,12 @@ class Engine:
         for i in range(self.l.bd_ctx_ws_count(self.ctx)):
             name = self.l.bd_ctx_ws_name(self.ctx, i).decode()
             nbytes = self.l.bd_ctx_ws_bytes(self.ctx, i)
+            if name == "head.ada_bf" and self.ada_split:
+                # the gathered modulation tensor lives in the communicator's exported region: the peers push their columns into it
+                if int(nbytes) > self.comm.gather_bytes:
+                    raise BitDanceHipError("the communicator's gather region is smaller than one group's adaLN modulation tensor")
+                check(self.l.bd_ctx_set_ptr(self.ctx, name.encode(), self.comm.gather_ptr), "bd_ctx_set_ptr")
+                continue
             t = torch.zeros(max(int(nbytes), 16), dtype=torch.uint8, device=self.device)
             self.ws[name] = t
             self.set_ptr(name, t)

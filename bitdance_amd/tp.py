@@ -101,12 +101,14 @@ class _NcclUniqueId(C.Structure):
 class TPComm:
     """One rank's exchange state.  ``max_elems`` = rows * N of the largest exchanged tensor (e.g. 512 * 5120)."""
 
-    def __init__(self, rank: int, size: int, max_elems: int, device=None):
+    def __init__(self, rank: int, size: int, max_elems: int, device=None, gather_bytes: int = 0):
+        """``gather_bytes``: capacity of the all-gather region (the column-split adaLN projection's modulation tensor of one group of
+        evaluations: G x rows x 71 680 x 2 B = 73 MB at one image); 0: none, the projection stays replicated."""
         self.l = lib()
         self.rank, self.size = rank, size
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         with torch.cuda.device(self.device):
-            self.h = self.l.bd_comm_create(rank, size, int(max_elems))
+            self.h = self.l.bd_comm_create2(rank, size, int(max_elems), int(gather_bytes))
         if not self.h:
             raise BitDanceHipError(f"bd_comm_create failed: {self.l.bd_last_error().decode()}")
         self.group = None
@@ -123,11 +125,11 @@ class TPComm:
 
     # -- construction ------------------------------------------------------------------------------------
     @classmethod
-    def from_process_group(cls, max_elems: int, group=None, device=None, backend: str | None = None) -> "TPComm":
+    def from_process_group(cls, max_elems: int, group=None, device=None, backend: str | None = None, gather_bytes: int = 0) -> "TPComm":
         """One process per GPU: exchange the IPC handles through ``torch.distributed`` and map every peer."""
         import torch.distributed as dist
         rank, size = dist.get_rank(group), dist.get_world_size(group)
-        self = cls(rank, size, max_elems, device)
+        self = cls(rank, size, max_elems, device, gather_bytes)
         self.group = group
         backend = backend or os.environ.get("BD_TP_COMM", "ipc")
         if backend not in ("ipc", "rccl"):
@@ -227,10 +229,10 @@ class TPComm:
         self.barrier()
 
     @classmethod
-    def in_process(cls, size: int, max_elems: int, device=None) -> list:
+    def in_process(cls, size: int, max_elems: int, device=None, gather_bytes: int = 0) -> list:
         """``size`` ranks as contexts of THIS process on one device, linked by plain pointers: the exchange protocol can then
         be exercised on a single GPU with one stream per rank (tests/test_gpu_tp.py)."""
-        comms = [cls(r, size, max_elems, device) for r in range(size)]
+        comms = [cls(r, size, max_elems, device, gather_bytes) for r in range(size)]
         for a in comms:
             for b in comms:
                 if a is not b:
@@ -288,6 +290,23 @@ class TPComm:
             gave_up = [p for p in range(self.size) if e > 0 and e & (1 << (8 + p))]
             raise BitDanceHipError(f"tensor-parallel exchange failed on rank {self.rank}: timed out waiting for peers {peers}"
                                    + (f"; ranks {gave_up} reported a timeout" if gave_up else ""))
+
+    @property
+    def gather_bytes(self) -> int:
+        return int(self.l.bd_comm_gather_bytes(self.h))
+
+    @property
+    def gather_ptr(self) -> int:
+        return int(self.l.bd_comm_gather_ptr(self.h) or 0)
+
+    def allgather(self, slice_bf16: torch.Tensor) -> torch.Tensor:
+        """Standalone all-gather of column slices (tests): this rank's [rows, Nl] bf16 -> a copy of the gathered [rows, Nl * size]."""
+        rows, nl = slice_bf16.shape
+        st = torch.cuda.current_stream().cuda_stream
+        check(self.l.bd_comm_allgather(self.h, slice_bf16.contiguous().data_ptr(), rows, nl, st), "bd_comm_allgather")
+        out = torch.empty(rows, nl * self.size, dtype=torch.bfloat16, device=slice_bf16.device)
+        check(self.l.bd_comm_copy_out(self.h, out.data_ptr(), out.numel() * 2, 2, st), "bd_comm_copy_out")
+        return out
 
     def exchanges(self) -> int:
         return int(self.l.bd_comm_exchanges(self.h))

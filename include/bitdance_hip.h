@@ -122,6 +122,13 @@ int bd_step_reset(bd_ctx* c, const int* kv_len, int nseq, void* stream);   /* st
  *      step graphs), or standalone through bd_comm_allreduce.  bd_comm_set_rccl switches the exchange to ncclAllReduce of
  *      the same fp32 partials (host passes the RCCL communicator and the address of ncclAllReduce): fallback and baseline. */
 bd_comm* bd_comm_create(int rank, int size, long long max_elems);
+/* ... plus an all-gather region of gather_bytes in the same exported allocation: where the COLUMN-split adaLN projection
+ * (flow_head_parallel_x.py:331: each rank computes N / size of its 71 680 output columns) is assembled on every rank by pushes
+ * (bd_comm_allgather standalone; inside the step when the context finds "head.ada_w_l" and the region is large enough) */
+bd_comm* bd_comm_create2(int rank, int size, long long max_elems, long long gather_bytes);
+void* bd_comm_gather_ptr(bd_comm* c);                                /* this rank's copy of the region (null: none) */
+long long bd_comm_gather_bytes(bd_comm* c);
+int bd_comm_allgather(bd_comm* c, const void* slice_bf16, int rows, int Nl, void* stream);   /* [rows][Nl] of every rank -> [rows][Nl * size] */
 void bd_comm_destroy(bd_comm* c);
 int bd_comm_ipc_handles(bd_comm* c, void* out128);                   /* 2 x hipIpcMemHandle_t: data, flags */
 int bd_comm_open_peer(bd_comm* c, int peer, const void* handles128);
@@ -140,7 +147,8 @@ long long bd_comm_exchanges(bd_comm* c);                             /* exchange
 int bd_comm_allreduce(bd_comm* c, const float* part, const void* bias_bf16, int rows, int N, void** out_ptr, int* out_is_fp32,
                       void* stream);
 
-int bd_comm_copy_out(bd_comm* c, void* dst, long long bytes, int from_result, void* stream);   /* read a standalone exchange back */
+int bd_comm_copy_out(bd_comm* c, void* dst, long long bytes, int from_result, void* stream);   /* read a standalone exchange back:
+                                                     from_result 0 fp32 staging, 1 bf16 result, 2 the all-gather region */
 
 /* ---- GFQ bit <-> index math of the ImageNet tokenizer (imagenet_gen/src/gfq.py:152-160,217-239): integer, bit exact.
  *      z/codes: [ntok][ncodebooks*bits] fp32 channels-last; idx: [ntok][ncodebooks] int32 (LSB = first channel). */

@@ -41,9 +41,9 @@ def _streams(n):
     return _RANK_STREAMS[:n]
 
 
-def _comms(tp, max_elems):
+def _comms(tp, max_elems, gather_bytes=0):
     from bitdance_amd.tp import TPComm
-    comms = TPComm.in_process(tp, max_elems, DEV)
+    comms = TPComm.in_process(tp, max_elems, DEV, gather_bytes)
     for c in comms:
         c.set_timeout(8.0)                     # a protocol bug must fail the test in seconds, not hang the box
     return comms
@@ -75,6 +75,31 @@ def test_exchange_in_process(tp, rows, N):
         want = acc.to(torch.bfloat16)
         for r in range(tp):
             assert torch.equal(outs[r], want), (rep, r, (outs[r].float() - want.float()).abs().max())
+
+
+@pytest.mark.parametrize("tp,rows,Nl", [(2, 512, 35840), (4, 512, 2048), (4, 96, 256), (3, 64, 8)])
+def test_allgather_in_process(tp, rows, Nl):
+    """The push all-gather of a column-split Linear's output (csrc/bd_comm.hip tp_allgather_kernel; the adaLN projection under
+    tensor parallelism): every rank's [rows, Nl] bf16 slice lands in every rank's [rows, Nl * tp] copy, bit for bit, over many
+    epochs of the same buffers."""
+    comms = _comms(tp, 4096, gather_bytes=rows * Nl * tp * 2)
+    streams = _streams(tp)
+    g = torch.Generator(device=DEV).manual_seed(tp * 77 + rows)
+    base = [torch.randn(rows, Nl, device=DEV, generator=g).to(torch.bfloat16) for _ in range(tp)]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        cur = [(b.float() * (rep + 1)).to(torch.bfloat16) for b in base]
+        torch.cuda.synchronize()
+        outs = []
+        for r in range(tp):
+            with torch.cuda.stream(streams[r]):
+                outs.append(comms[r].allgather(cur[r]))
+        torch.cuda.synchronize()
+        for c in comms:
+            c.check()
+        want = torch.cat(cur, dim=1)
+        for r in range(tp):
+            assert torch.equal(outs[r], want), (rep, r)
 
 
 @pytest.mark.parametrize("M,N,K,S,code", [
@@ -161,8 +186,11 @@ def _head_run(eng, z, x, n_steps=3, eval_index=1):
     eng.head_eval(eval_index)
 
 
-@pytest.mark.parametrize("tp,P", [(2, 64), (4, 64), (4, 16)])
-def test_head_eval_tensor_parallel(tp, P):
+@pytest.mark.parametrize("tp,P,weights,ada_split", [(2, 64, "bf16", 1), (4, 64, "bf16", 1), (4, 16, "bf16", 1), (2, 64, "bf16", 0), (2, 64, "fp8a", 1),
+                                                      (4, 64, "fp8a", 1), (2, 64, "fp8", 0)])
+def test_head_eval_tensor_parallel(tp, P, weights, ada_split):
+    """(weights "fp8a" / "fp8": BASELINE config 5's precision modes under tensor parallelism -- the column-split GEMMs take the fp8
+    operands the row kernels emit, the row-split ones fp8 weights over bf16 activations into the fp32 partial the exchange sums.)"""
     from bitdance_amd import engine as E
     sd_dev = device_seeded_state(tm.head_shapes(HEAD8), 301, DEV)
     sd = {k: v.cpu() for k, v in sd_dev.items()}
@@ -171,19 +199,21 @@ def test_head_eval_tensor_parallel(tp, P):
     z = torch.randn(br * B, P, 1024, generator=g)
     x = torch.randn(B, P, C, generator=g)
     # unsharded engine
-    e1 = E.Engine(E.HeadWeights.from_state_dict(sd_dev, DEV), None, None, num_images=B, branches=br, device=DEV, max_tokens=P,
+    e1 = E.Engine(E.HeadWeights.from_state_dict(sd_dev, DEV, weights=weights), None, None, num_images=B, branches=br, device=DEV, max_tokens=P,
                   parallel_num=P)
     _head_run(e1, z, x)
     torch.cuda.synchronize()
     M = br * B * P
     x1 = e1.view("head.xhat", torch.float32, (e1.Mpad, C))[:M].clone()
     # tp ranks, one stream each
-    comms = _comms(tp, e1.Mpad * 1024)
+    nada = (HEAD8["depth_adanln"] * 6 + 2) * 1024                  # stacked adaLN width: 8192 -> 4096 / 2048 columns per rank
+    comms = _comms(tp, e1.Mpad * 1024, gather_bytes=0 if ada_split == 0 else 512 * nada * 2)
     streams = _streams(tp)
     engs = []
     for r in range(tp):
-        hw = E.HeadWeights.from_state_dict(sd_dev, DEV, tp_rank=r, tp_size=tp)
+        hw = E.HeadWeights.from_state_dict(sd_dev, DEV, tp_rank=r, tp_size=tp, weights=weights)
         engs.append(E.Engine(hw, None, None, num_images=B, branches=br, device=DEV, max_tokens=P, parallel_num=P, comm=comms[r]))
+        assert engs[-1].ada_split == bool(ada_split and weights != "fp8")      # column-split adaLN projection + all-gather (bf16, fp8a)
     torch.cuda.synchronize()
     for r in range(tp):
         with torch.cuda.stream(streams[r]):
@@ -195,16 +225,81 @@ def test_head_eval_tensor_parallel(tp, P):
     for r in range(1, tp):
         assert torch.equal(xs[r], xs[0]), f"rank {r} diverged from rank 0"        # replicated state stays bit-identical
     d1 = (xs[0] - x1).abs()
-    assert d1.max() <= 4e-2 and d1.mean() <= 4e-3, (d1.max(), d1.mean())           # vs unsharded: summation order only
     t_i = float(e1._sc[1, 0])
-    ref = diff_head.net_forward(sd, torch.cat([x] * br), torch.full((br * B,), t_i), z, Policy("autocast")).float().view(M, C)
+    pol = Policy({"fp8": "fp8w", "fp8a": "fp8wa"}.get(weights, "autocast"))
+    ref = diff_head.net_forward(sd, torch.cat([x] * br), torch.full((br * B,), t_i), z, pol).float().view(M, C)
     err = (xs[0].cpu() - ref).abs()
-    assert err.max() <= 5e-2 and err.mean() <= 6e-3, (err.max(), err.mean())       # the tiny-test bounds, vs the oracle
+    if weights == "bf16":
+        assert d1.max() <= 4e-2 and d1.mean() <= 4e-3, (d1.max(), d1.mean())       # vs unsharded: summation order only
+        assert err.max() <= 5e-2 and err.mean() <= 6e-3, (err.max(), err.mean())   # the tiny-test bounds, vs the oracle
+    else:
+        # an 8-bit quantiser downstream of a different summation order: an element on a rounding boundary moves a whole step (the
+        # one-GPU fp8 tests' bounds, tests/test_gpu_fp8.py)
+        print(f"[tp {tp} {weights}] vs unsharded max {d1.max().item():.4f} mean {d1.mean().item():.5f}; vs oracle max {err.max().item():.4f} mean {err.mean().item():.5f}")
+        assert d1.max() <= 0.25 and d1.mean() <= 3.5e-2, (d1.max(), d1.mean())
+        assert err.max() <= 0.25 and err.mean() <= 3.5e-2, (err.max(), err.mean())
     assert comms[0].exchanges() == 2 * HEAD8["depth_latent"]                       # one exchange per wo / w2
 
 
-def test_llm_step_tensor_parallel():
-    """tiny Qwen3 (4 q heads / 2 kv heads, 2 layers) on 2 ranks: kv cache sharded by kv head, o_proj / down_proj exchanged."""
+@pytest.mark.parametrize("tp,weights,split", [(2, "bf16", 1), (4, "bf16", 1), (2, "bf16", 0), (2, "fp8a", 1)])
+def test_head_sample_tensor_parallel_column_split_adaln(tp, weights, split):
+    """DiffHead.sample (N + 1 chained evaluations, grouped adaLN projection) under tensor parallelism with the projection
+    COLUMN-split over the ranks and its modulation tensor all-gathered by pushes (bd_api.hip head_ada_group, "tp.ada_split";
+    reference layout flow_head_parallel_x.py:331), against the replicated projection (split = 0) and the unsharded engine:
+    every rank holds bit-identical latents and tokens; bf16: a column's K sum runs in the same order wherever it is computed, so
+    split and replicated projections give the SAME bits."""
+    from bitdance_amd import engine as E
+    sd_dev = device_seeded_state(tm.head_shapes(HEAD8), 311, DEV)
+    B, br, C, P, n = 1, 2, 32, 64, 4
+    g = torch.Generator().manual_seed(312)
+    z = torch.randn(br * B, P, 1024, generator=g)
+    noise = torch.randn(1, n + 1, B, P, C, generator=g)
+
+    def sample(eng):
+        eng.set_schedule(n, 1.5, 1)
+        eng.load_noise(noise)
+        eng.reset([0] * (br * B))
+        eng.set_cond(z.to(DEV))
+        eng.head_sample()
+
+    e1 = E.Engine(E.HeadWeights.from_state_dict(sd_dev, DEV, weights=weights), None, None, num_images=B, branches=br, device=DEV,
+                  max_tokens=P, parallel_num=P)
+    sample(e1)
+    torch.cuda.synchronize()
+    p1 = e1.pred().clone()
+    nada = (HEAD8["depth_adanln"] * 6 + 2) * 1024
+    outs = {}
+    for sp in sorted({split, 0}):
+        comms = _comms(tp, e1.Mpad * 1024, gather_bytes=512 * nada * 2 if sp else 0)
+        streams = _streams(tp)
+        engs = [E.Engine(E.HeadWeights.from_state_dict(sd_dev, DEV, tp_rank=r, tp_size=tp, weights=weights), None, None, num_images=B,
+                         branches=br, device=DEV, max_tokens=P, parallel_num=P, comm=comms[r]) for r in range(tp)]
+        assert all(e.ada_split == bool(sp) for e in engs)
+        torch.cuda.synchronize()
+        for r in range(tp):
+            with torch.cuda.stream(streams[r]):
+                sample(engs[r])
+        torch.cuda.synchronize()
+        for c in comms:
+            c.check()
+        ps = [e.pred().clone() for e in engs]
+        for r in range(1, tp):
+            assert torch.equal(ps[r], ps[0]) and torch.equal(engs[r].tok_cur(), engs[0].tok_cur()), f"rank {r} diverged (split {sp})"
+        outs[sp] = ps[0]
+        del engs, comms
+    if split and weights == "bf16":
+        assert torch.equal(outs[1], outs[0])                       # the same bits as the replicated projection
+    d = (outs[split] - p1).abs()
+    # vs the unsharded engine: summation order of the row-split Linears, through 5 chained evaluations (8-bit activations: an element
+    # on a rounding boundary moves a whole quantisation step per evaluation -- measured 0.50 / 0.075 on this tiny model)
+    lim = (0.9, 0.12) if weights != "bf16" else (0.15, 1.5e-2)
+    assert d.max() <= lim[0] and d.mean() <= lim[1], (d.max(), d.mean())
+
+
+@pytest.mark.parametrize("weights", ["bf16", "fp8a"])
+def test_llm_step_tensor_parallel(weights):
+    """tiny Qwen3 (4 q heads / 2 kv heads, 2 layers) on 2 ranks: kv cache sharded by kv head, o_proj / down_proj exchanged
+    (also in the fp8-activation mode of BASELINE config 5)."""
     from bitdance_amd import engine as E
     tp, P = 2, 64
     c = tm.TINY_LLM
@@ -230,14 +325,14 @@ def test_llm_step_tensor_parallel():
         eng.residual()[:2 * P].copy_(x.reshape(2 * P, D).to(DEV))
         eng.llm_step()
 
-    e1 = E.Engine(None, None, E.LlmWeights.from_state_dict(sd, c, DEV, keep_for_prefill=False), num_images=2, branches=1,
+    e1 = E.Engine(None, None, E.LlmWeights.from_state_dict(sd, c, DEV, keep_for_prefill=False, weights=weights), num_images=2, branches=1,
                   device=DEV, max_tokens=P, max_kv=256)
     run(e1, 0, 1)
     torch.cuda.synchronize()
     h1 = e1.hidden().clone()
     comms = _comms(tp, e1.Mpad * D)
     streams = _streams(tp)
-    engs = [E.Engine(None, None, E.LlmWeights.from_state_dict(sd, c, DEV, keep_for_prefill=False, tp_rank=r, tp_size=tp),
+    engs = [E.Engine(None, None, E.LlmWeights.from_state_dict(sd, c, DEV, keep_for_prefill=False, tp_rank=r, tp_size=tp, weights=weights),
                      num_images=2, branches=1, device=DEV, max_tokens=P, max_kv=256, comm=comms[r]) for r in range(tp)]
     torch.cuda.synchronize()
     for r in range(tp):
@@ -249,15 +344,16 @@ def test_llm_step_tensor_parallel():
     hs = [e.hidden().clone() for e in engs]
     assert torch.equal(hs[0], hs[1])
     d = (hs[0] - h1).abs()
-    assert d.max() <= 0.08 and d.mean() <= 6e-3, (d.max(), d.mean())
-    pol = Policy("autocast")
+    f8 = weights != "bf16"                                        # (8-bit quantisers behind different summation orders: the one-GPU fp8 bounds)
+    assert d.max() <= (0.3 if f8 else 0.08) and d.mean() <= (2.5e-2 if f8 else 6e-3), (d.max(), d.mean())
+    pol = Policy("fp8wa" if f8 else "autocast")
     refs = []
     for b, Lp in enumerate(past):
         o, _ = qwen3.model_forward(sd, c, x[b:b + 1], [[k.clone(), v.clone()] for k, v in caches[b]],
                                    torch.ones(1, 1, P, Lp + P, dtype=torch.bool), pol)
         refs.append(o.float())
     e = (hs[0].cpu().view(2, P, D) - torch.cat(refs)).abs()
-    assert e.max() <= 0.12 and e.mean() <= 1e-2, (e.max(), e.mean())
+    assert e.max() <= (0.4 if f8 else 0.12) and e.mean() <= (3e-2 if f8 else 1e-2), (e.max(), e.mean())
     assert comms[0].exchanges() == 2 * L
 
 
