@@ -356,7 +356,10 @@ def main():
     if tp_mode:
         from bitdance_amd.tp import TPComm
         rows_max = 2 * num_images * 64
-        comm = TPComm.from_process_group(max(rows_max, 128) * 5120, device=dev, backend=args.tp_comm)
+        # (+ the gather region of the column-split adaLN projection: 14 x 5120 output columns per evaluation row, one group of evaluations)
+        from bitdance_amd.tp import ada_gather_bytes
+        comm = TPComm.from_process_group(max(rows_max, 128) * 5120, device=dev, backend=args.tp_comm,
+                                         gather_bytes=ada_gather_bytes(max(rows_max, 128), 14 * 5120))
     pipe = syn.build_pipeline(size, dev, with_ae=True, tp=comm, weights=args.weights)
     if args.weights == "fp8":
         metric += " (fp8-e4m3 weights)"
@@ -480,10 +483,12 @@ def main():
             n_x = ar_steps * (n_sampling + 1) * 2 * nblk + (ar_steps - 1) * 2 * L
             info = comm.info()
             out["tp"] = {"size": n, "world_size_seen": dist.get_world_size(), "process_group_backend": dist.get_backend(),
-                         "exchange_backend": comm.backend, "exchange_buffer_uncached": info["data_uncached"],
+                         "exchange_backend": comm.backend, "exchange_fences": getattr(comm, "fences", 0), "reduce_scatter_push": "fused into the row-split GEMM epilogue (tune.tp_fuse)",
+                         "exchange_buffer_uncached": info["data_uncached"],
                          "flag_block_uncached": info["flags_uncached"], "fallback_reason": getattr(comm, "fallback_reason", None),
                          "images_checked_bit_identical": args.steps + 1,
                          "weight_bytes_per_rank": int(wbytes),
+                         "adaln_projection": "column-split + push all-gather" if getattr(eng, "ada_split", False) else "replicated",
                          "exchanges_per_image": n_x, "exchange_payload_bytes_per_rank": int(eng.M * 5120 * 6 * (n - 1) / n),
                          "ranks_bit_identical": True}
         if not args.no_roofline:

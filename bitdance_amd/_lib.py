@@ -87,6 +87,8 @@ _PROTOS = {
     "bd_comm_local_flags": (C.c_void_p, [C.c_void_p]),
     "bd_comm_set_rccl": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "bd_comm_set_timeout": (C.c_int, [C.c_void_p, C.c_double]),
+    "bd_comm_set_fences": (C.c_int, [C.c_void_p, C.c_int]),
+    "bd_comm_mark_prepushed": (C.c_int, [C.c_void_p]),
     "bd_comm_reset": (C.c_int, [C.c_void_p]),
     "bd_comm_error": (C.c_int, [C.c_void_p]),
     "bd_comm_exchanges": (C.c_longlong, [C.c_void_p]),

@@ -194,7 +194,7 @@ static const char* const kIntKeys[] = {
     "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid", "head.y_evals", "head.variant",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "proj.rows_all", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
     "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "rt.in_first", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async", "tune.ragged", "tune.ragged52", "tune.slab_cap", "tune.slab3",
-    "tune.ada_group", "tune.ada_group_nw", "tp.ada_split"};
+    "tune.ada_group", "tune.ada_group_nw", "tune.tp_fuse", "tp.ada_split"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
                                          "llm.qkv", "llm.o", "llm.gu", "llm.down"};
 static bool known_int_key(const std::string& k) {
@@ -660,7 +660,13 @@ static int linear_rowsplit(bd_ctx* c, const char* name, const void* A, int RB, W
     if (c->tp <= 1) return linear(c, name, A, RB, W, N, Klocal, g, scratch_ws, out_ws, bias, Mpad, res, st);
     if (!c->comm) return fail(std::string(name) + ": tensor-parallel context without a communicator (bd_ctx_set_comm)");
     if (g.S > 3) return fail(std::string(name) + ": a tensor-parallel partial needs at most 3 grid slices");
+    // phase 1 of the exchange (every peer's slice of the partial into that peer's staging row) fused into the GEMM's epilogue where
+    // the shape allows it: the exchange kernel then only signals, waits, reduces and pushes the result ("tune.tp_fuse" = 0: unfused)
+    BdTpPush push;
+    const bool want = c->geti("tune.tp_fuse", 1) != 0 && bdk_tp_push_target(c->comm, rows, N, &push);
+    bdk_gemm_set_push(want ? &push : nullptr);
     BD_TRY(gemm(c, name, A, RB, W, N, Klocal, g.S, g.code(), BD_EPI_F32, (float*)c->wptr(scratch_ws), c->wptr(tp_ws), nullptr, st));
+    if (bdk_gemm_push_used()) bdk_tp_mark_prepushed(c->comm);
     BD_TRY(bdk_tp_allreduce(c->comm, (const float*)c->ptr(tp_ws), bias, rows, N, res, st));
     return 0;
 }

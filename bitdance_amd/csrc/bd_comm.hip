@@ -50,8 +50,12 @@ struct bd_comm {
     void* nccl_comm = nullptr;
     int (*nccl_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     double timeout_s = 20.0;
+    int fences = 0;                          // 1: system-scope fences around every flag (bd_comm_set_fences): belt and braces on a node whose
+                                             // self-test fails without them; the payload is write-through sc0 sc1 stores drained by vmcnt(0) and
+                                             // read back with sc0 sc1 loads, which needs no fence (MI355X_MICROARCH.md, hand-off recipe R1)
     long long n_exchanges = 0;               // launches issued (graph captures count once): reporting only
     long long n_gathers = 0;
+    int prepushed_next = 0;                  // set by bdk_tp_push_target: the next exchange finds its staging rows already pushed
 };
 #define BD_TP_FLAG_INTS (3 * BD_TP_MAX * BD_TP_GMAX + 1 + 2 * BD_TP_GMAX)
 
@@ -69,6 +73,8 @@ struct ArArgs {
     long long data_bytes;       // size of a data allocation (staging + result)
     long long timeout_ticks;    // wall_clock64 ticks (100 MHz)
     int rank, size, G, U, Us, N8;
+    int fences = 0;
+    int prepushed = 0;          // 1: the producing GEMM's epilogue already pushed every peer's slice into its staging row (bdk_tp_push_target)
 };
 
 // all of this block's pushes are at their destination, then the epoch goes to every peer's flag row of this rank
@@ -77,7 +83,7 @@ BD_DEV void tp_signal(const ArArgs& a, int base, int b, int e) {
     __syncthreads();
     const int t = threadIdx.x;
     if (t < a.size && t != a.rank) {
-        __threadfence_system();
+        if (a.fences) __threadfence_system();
         __hip_atomic_store(a.peer_flags[t] + base + a.rank * BD_TP_GMAX + b, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -95,7 +101,7 @@ BD_DEV bool tp_wait(const ArArgs& a, int base, int b, int e, int err_index) {
         const long long t0 = wall_clock64();
         bool dead = __hip_atomic_load(a.flags + err_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
         while (!dead && (int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
-            __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_s_sleep(2);
             if (wall_clock64() - t0 > a.timeout_ticks) {
                 __hip_atomic_fetch_or(a.flags + err_index, 1 << t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 for (int p = 0; p < a.size; ++p)             // tell everyone: bit 8 + rank = "rank r gave up"
@@ -107,7 +113,7 @@ BD_DEV bool tp_wait(const ArArgs& a, int base, int b, int e, int err_index) {
             dead = __hip_atomic_load(a.flags + err_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
         }
         if (dead) alive_sh = 0;
-        __threadfence_system();
+        if (a.fences) __threadfence_system();
     }
     __syncthreads();
     return alive_sh != 0;
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(256) void tp_allreduce_kernel(ArArgs a) {
     const int Ub = (a.Us + a.G - 1) / a.G;
     const int c0 = b * Ub, c1 = min(a.Us, c0 + Ub);
     // ---- phase 1: push my partial of every peer's slice into that peer's staging row [rank]
-    for (int p = 0; p < a.size; ++p) {
+    for (int p = 0; p < a.size && !a.prepushed; ++p) {
         if (p == a.rank) continue;
         const __amdgpu_buffer_rsrc_t dst = sys_rsrc(a.peer_data[p], a.data_bytes);
         for (int u = c0 + tid; u < c1; u += 256) {
@@ -217,7 +223,8 @@ int bdk_tp_allreduce(bd_comm* c, const float* part, const void* bias, int rows, 
     a.stage_bytes = c->max_elems * 4;
     a.data_bytes = c->max_elems * 6;
     a.timeout_ticks = (long long)(c->timeout_s * 1e8);
-    a.rank = c->rank; a.size = c->size;
+    a.rank = c->rank; a.size = c->size; a.fences = c->fences; a.prepushed = c->prepushed_next;
+    c->prepushed_next = 0;
     a.U = rows * (N / 8); a.Us = (a.U + c->size - 1) / c->size; a.N8 = N / 8;
     a.G = (a.Us + 255) / 256;
     if (a.G > BD_TP_GMAX) a.G = BD_TP_GMAX;
@@ -241,6 +248,7 @@ struct AgArgs {
     int* flags;
     long long gather_off, gather_bytes, timeout_ticks;
     int rank, size, G, rows, Nl8, N8;          // Nl8 / N8: 16 B units per slice row / per full row
+    int fences;
 };
 __global__ __launch_bounds__(256) void tp_allgather_kernel(AgArgs g) {
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(256) void tp_allgather_kernel(AgArgs g) {
     }
     ArArgs a;                                                    // the signalling helpers take the exchange's argument block
     for (int p = 0; p < BD_TP_MAX; ++p) a.peer_flags[p] = g.peer_flags[p];
-    a.flags = g.flags; a.rank = g.rank; a.size = g.size; a.timeout_ticks = g.timeout_ticks;
+    a.flags = g.flags; a.rank = g.rank; a.size = g.size; a.timeout_ticks = g.timeout_ticks; a.fences = g.fences;
     tp_signal(a, FC, b, e);
     (void)tp_wait(a, FC, b, e, ERR);
     if (tid == 0) g.flags[EPC + b] = e;
@@ -280,7 +288,7 @@ int bdk_tp_allgather(bd_comm* c, const void* slice, void* dst_local, int rows, i
     g.src = (const u32x4*)slice; g.flags = c->flags;
     for (int p = 0; p < BD_TP_MAX; ++p) { g.peer_data[p] = c->peer_data[p]; g.peer_flags[p] = c->peer_flags[p]; }
     g.gather_off = off; g.gather_bytes = need; g.timeout_ticks = (long long)(c->timeout_s * 1e8);
-    g.rank = c->rank; g.size = c->size; g.rows = rows; g.Nl8 = Nl / 8; g.N8 = N / 8;
+    g.rank = c->rank; g.size = c->size; g.rows = rows; g.Nl8 = Nl / 8; g.N8 = N / 8; g.fences = c->fences;
     const long long U = (long long)rows * g.Nl8;
     g.G = (int)((U + 2047) / 2048);                              // >= 8 units per thread, up to BD_TP_GMAX blocks
     if (g.G > BD_TP_GMAX) g.G = BD_TP_GMAX;
@@ -289,6 +297,20 @@ int bdk_tp_allgather(bd_comm* c, const void* slice, void* dst_local, int rows, i
     BD_LAUNCH(tp_allgather_kernel, dim3(g.G), dim3(256), 0, st, g);
     return bd_launch_status();
 }
+bool bdk_tp_push_target(bd_comm* c, int rows, int N, BdTpPush* out) {
+    if (!c || c->size < 2 || c->mode != 0 || N % 8 || rows % c->size || (rows / c->size) % 8) return false;
+    const long long U = (long long)rows * (N / 8), Us = U / c->size;          // whole rows per slice: U % size == 0
+    if (Us * c->size * 8 > c->max_elems) return false;
+    for (int p = 0; p < c->size; ++p)
+        if (!c->peer_data[p]) return false;
+    BdTpPush t;
+    for (int p = 0; p < c->size; ++p) t.stage[p] = c->peer_data[p];
+    t.Us = Us; t.rank = c->rank; t.size = c->size; t.rows_per_rank = rows / c->size;
+    *out = t;
+    return true;
+}
+void bdk_tp_mark_prepushed(bd_comm* c) { if (c) c->prepushed_next = 1; }
+
 void* bdk_comm_gather_ptr(const bd_comm* c) { return (c && c->gather_bytes > 0) ? c->data + c->max_elems * 6 : nullptr; }
 long long bdk_comm_gather_bytes(const bd_comm* c) { return c ? c->gather_bytes : 0; }
 int bdk_comm_mode(const bd_comm* c) { return c ? c->mode : 0; }
@@ -391,6 +413,10 @@ int bd_comm_set_rccl(bd_comm* c, void* nccl_comm, void* nccl_allreduce_fn) {
     return 0;
 }
 int bd_comm_set_timeout(bd_comm* c, double seconds) { c->timeout_s = seconds; return 0; }
+int bd_comm_set_fences(bd_comm* c, int on) { c->fences = on != 0; return 0; }
+/* the NEXT exchange finds its staging rows already written (the producing GEMM's epilogue pushed them: BdTpPush); standalone use:
+ * protocol micro-benchmarks of phase 2 alone */
+int bd_comm_mark_prepushed(bd_comm* c) { bdk_tp_mark_prepushed(c); return 0; }
 /* after a failed exchange (all ranks, between two host barriers): clear flags, epochs and the error word */
 int bd_comm_reset(bd_comm* c) {
     const size_t fbytes = (size_t)BD_TP_FLAG_INTS * sizeof(int);

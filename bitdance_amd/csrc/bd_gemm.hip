@@ -288,6 +288,12 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
 static int g_wide_keep = -1;                              // weight loads of the 256-row kernel: -1 = default policy when > 1 row tile, 0 = always nt, 1 = never nt
 static int g_wide_ring = 2, g_wide_xcd = -1;            // xcd: -1 = by shape (on when the weights outweigh the rows), 0 / 1 forced
 void bdk_gemm_tile_debug(int v);
+// tensor parallelism: the push target of the NEXT bdk_gemm call with the fp32-partial epilogue on the 128-row bf16 kernel (set by
+// bd_api.hip linear_rowsplit through bd_comm.hip bdk_tp_push_target; consumed and reported by bdk_gemm_push_used)
+static thread_local BdTpPush g_push;
+static thread_local bool g_push_set = false, g_push_used = false;
+void bdk_gemm_set_push(const BdTpPush* t) { g_push_set = t != nullptr; if (t) g_push = *t; g_push_used = false; }
+bool bdk_gemm_push_used() { const bool u = g_push_used; g_push_used = false; g_push_set = false; return u; }
 static int g_tile = 1;                                   // >= 512 rows: the LDS-tiled MFMA-bound kernel (bd_gemm_tile.hip); 0 = 256-row kernel
 int bdk_set_gemm_option(const char* name, int v) {
     const std::string n(name);
@@ -352,6 +358,11 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
     size_t PS, SS;
     bdk_w_strides(N / 32, K, &PS, &SS);
     GemmP p{(const u32x4*)A, (const u32x4*)W, out_partial, (bf16_t*)out_act, (const bf16_t*)bias, cnt, nullptr, RB, N, K, S, RB * 32, PS, SS};
+    if (g_push_set && epi == BD_EPI_F32 && RB % 4 == 0 && RB < 8 && g_push.size > 1 && g_push.rows_per_rank % 8 == 0 && N % 32 == 0) {
+        p.push = g_push;                               // the 128-row kernel's epilogue pushes the peers' slices itself (bd_gemm_kernel.h)
+        g_push_used = true;
+    }
+    g_push_set = false;
     // rows per pass over the weights: 256 (two images with CFG: W streamed once for both) when the row count allows,
     // else 128 / 64 / 32
     const int MB = (RB % 8 == 0 && nw >= 4 && kw == 1) ? 8 : ((RB % 4 == 0) ? 4 : RB);

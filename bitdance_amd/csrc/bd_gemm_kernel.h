@@ -46,6 +46,7 @@ struct GemmP {
     size_t PS, SS;       // packed-W strides in 16 B units: panel stride, 64-deep-K-stage stride
     const float* ascale = nullptr;   // fp8 ACTIVATIONS (WT = 2): per row [Mpad] fp32 dequantisation scale
     int w_keep = 0;                  // 256-row kernel: 1 = default-policy weight loads (several row tiles read each slice: let L2 keep it)
+    BdTpPush push;                   // BD_EPI_F32 under tensor parallelism: the epilogue pushes the peers' slices (size > 1)
 };
 
 // MFMA-bound form for >= 512 rows: both operands through LDS, 256 x 256 workgroup tiles (bd_gemm_tile.hip)
@@ -330,6 +331,31 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = a[r];
         } else if (EPI == BD_EPI_F32) {    // the finished fp32 sum (no bias, no rounding): one rank's partial of a row-split Linear
+            if (p.push.size > 1) {
+                // the accumulator holds a COLUMN per lane; a store over the fabric should be 16 B of ONE row: turn the 32 x 32 block
+                // through this wave's LDS patch ([32 rows][36 floats]: conflict-free writes, 16 B aligned reads), then lane L holds
+                // columns 4 (L & 7) .. + 3 of rows (L >> 3) + 8 j -- eight consecutive rows per store, all reduced by ONE rank
+                // (rows_per_rank % 8 == 0, checked by the launcher)
+                float* const tb = reinterpret_cast<float*>(smem + 256) + pw * (32 * 36);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tb[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 36 + (lane & 31)] = a[r];
+                const int c4 = nbl * 32 + (lane & 7) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int rr = (lane >> 3) + 8 * j;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(tb + rr * 36 + (lane & 7) * 4);
+                    const int row = (mt * MB + m) * 32 + rr;
+                    const int q = __builtin_amdgcn_readfirstlane(((mt * MB + m) * 32 + 8 * j) / p.push.rows_per_rank);
+                    if (q == p.push.rank || q >= p.push.size) {            // mine (or a pad row past the last rank's rows): local
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.act) + (size_t)row * p.N + c4) = v;
+                    } else {
+                        const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(p.push.stage[q], 0, (int)(p.push.Us * p.push.size * 32), 0x00020000);
+                        const unsigned off = (unsigned)((p.push.rank * p.push.Us + (size_t)(row - q * p.push.rows_per_rank) * (p.N >> 3)) * 32 + (size_t)c4 * 4);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst, off, 0, 17 /* sc0 sc1: system scope */);
+                    }
+                }
+                return;
+            }
             float* o = reinterpret_cast<float*>(p.act) + (size_t)(mt * MB + m) * 32 * p.N + col;
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = a[r];
@@ -407,6 +433,7 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
             }
 #pragma unroll
             for (int m = 0; m < MB; ++m) finalize(m);
+            if (EPI == BD_EPI_F32 && p.push.size > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
@@ -426,13 +453,16 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
             finalize(m);                                                  // row-block by row-block: short live ranges
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (EPI == BD_EPI_F32 && p.push.size > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
         return;
     }
+    if (EPI == BD_EPI_F32 && p.push.size > 1) __syncthreads();           // every wave is done with the A tiles (the patches overlay them)
     if (owner) {
 #pragma unroll
         for (int m = 0; m < MB; ++m) finalize(m);
     }
+    if (EPI == BD_EPI_F32 && p.push.size > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the pushes are at their destinations before the kernel ends
 }
 
 template <int NP, int KW, int MB, int EPI, int R, bool RED, int MODE = 0, int WT = 0>
@@ -448,7 +478,9 @@ static int launch_one(const GemmP& p, hipStream_t st) {
     }
     // two A-stage buffers; with KW > 1 the same LDS is re-used for the accumulators of K parts 1..KW-1
     constexpr size_t lds_a = (size_t)2 * MB * 256 * KW * 16, lds_r = (size_t)(KW - 1) * NP * MB * 4096;
-    constexpr size_t lds = lds_a > lds_r ? lds_a : lds_r;
+    constexpr size_t lds_e = (EPI == BD_EPI_F32) ? 256 + (size_t)NP * 32 * 36 * 4 : 0;   // the pushing epilogue's transposition patches, one per panel wave
+    constexpr size_t lds_ar = lds_a > lds_r ? lds_a : lds_r;
+    constexpr size_t lds = lds_ar > lds_e ? lds_ar : lds_e;
     if constexpr (lds > 64 * 1024) {                               // beyond 64 KiB of dynamic LDS needs the opt-in
         static unsigned long long optin = 0;                      // per device (bd_kernels.h)
         if (!bd_lds_optin((const void*)gemm_kernel<NP, KW, MB, EPI, R, RED, MODE, WT>, (int)lds, &optin)) return -8;

@@ -269,6 +269,22 @@ int bdk_tp_allgather(bd_comm* c, const void* slice, void* dst_local, int rows, i
 void* bdk_comm_gather_ptr(const bd_comm* c);
 long long bdk_comm_gather_bytes(const bd_comm* c);
 int bdk_comm_mode(const bd_comm* c);            // 0 hand-written exchange, 1 ncclAllReduce
+// the exchange of a [rows][N] partial with phase 1 fused into the producing GEMM: fills the GEMM's push target (false: this
+// shape / mode keeps the unfused form) and marks the NEXT bdk_tp_allreduce as pre-pushed once the GEMM confirms it took the target
+// Tensor parallelism: where the finished fp32 partial of a ROW-split Linear goes (BD_EPI_F32).  With size > 1 the epilogue itself
+// is phase 1 of the all-reduce (bd_comm.hip): the rows rank q reduces are written straight into q's staging row [rank] over the
+// fabric (16 B system-scope stores), the rows this rank reduces into its own partial buffer as before -- the exchange kernel
+// that follows only signals, waits and reduces.
+struct BdTpPush {
+    char* stage[8] = {};        // every rank's staging area (peer_data[q]); [rank] unused
+    long long Us = 0;           // 32 B units per rank slice = rows_per_rank * N / 8
+    int rank = 0, size = 0, rows_per_rank = 0;
+};
+
+bool bdk_tp_push_target(bd_comm* c, int rows, int N, BdTpPush* out);
+void bdk_tp_mark_prepushed(bd_comm* c);
+void bdk_gemm_set_push(const BdTpPush* t);      // bd_gemm.hip
+bool bdk_gemm_push_used();
 
 // ---- bd_attn.hip
 struct HeadAttnArgs {       // DiT attention over one patch (seq = P = 64 or 16), non-causal      flow_head:192-220

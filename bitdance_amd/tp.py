@@ -30,7 +30,7 @@ import torch
 
 from ._lib import BitDanceHipError, check, lib
 
-__all__ = ["TPComm", "shard_head_state", "shard_llm_state", "shard_rows", "shard_cols"]
+__all__ = ["TPComm", "ada_gather_bytes", "shard_head_state", "shard_llm_state", "shard_rows", "shard_cols"]
 
 
 # ----------------------------------------------------------------------------------------------- slicing
@@ -93,6 +93,15 @@ def shard_llm_state(sd: dict, cfg: dict, rank: int, size: int) -> dict:
     return out
 
 
+def ada_gather_bytes(rows: int, ada_cols: int, group: int | None = None) -> int:
+    """Capacity a communicator's gather region needs for the column-split adaLN projection: one GROUP of evaluations' modulation
+    tensors, [G * padded rows][ada_cols] bf16, with the engine's default grouping (512 rows per projection GEMM up to 128 rows per
+    evaluation, 1024 up to 512: csrc/bd_api.hip ``tune.ada_group``).  rows = branches * num_images * parallel_num."""
+    mp = 32 if rows <= 32 else (64 if rows <= 64 else (rows + 127) // 128 * 128)
+    g = group or (512 // mp if mp <= 128 else (1024 // mp if (mp <= 512 and 1024 % mp == 0) else 1))
+    return g * mp * ada_cols * 2 if g >= 2 else 0
+
+
 # ----------------------------------------------------------------------------------------------- communicator
 class _NcclUniqueId(C.Structure):
     _fields_ = [("internal", C.c_ubyte * 128)]          # c_ubyte: a c_char field would be read back truncated at the first NUL
@@ -113,6 +122,7 @@ class TPComm:
             raise BitDanceHipError(f"bd_comm_create failed: {self.l.bd_last_error().decode()}")
         self.group = None
         self.backend = "ipc"
+        self.fences = 0
         self._nccl = None
 
     def __del__(self):
@@ -174,13 +184,20 @@ class TPComm:
             # one-time cross-rank self-test of the hand-written exchange (known pattern, every rank checks every element):
             # a node on which the IPC mapping 'works' but remote writes are not seen must not find out 44 000 exchanges later
             if backend == "ipc":
-                ok = self._self_test()
-                oks = [None] * size
-                dist.all_gather_object(oks, ok, group=group)
-                if not all(oks):
-                    self.fallback_reason = f"exchange self-test failed on ranks {[r for r, o in enumerate(oks) if not o]}"
+                # first without system-scope fences around the flags (write-through payload, drained before the flag, read with
+                # system-scope loads: no fence needed by the hand-off recipe), then -- every rank together -- with them, then RCCL
+                for fences in (0, 1):
+                    self.set_fences(fences)
+                    ok = self._self_test()
+                    oks = [None] * size
+                    dist.all_gather_object(oks, ok, group=group)
+                    if all(oks):
+                        break
                     dist.barrier(group=group)
                     check(self.l.bd_comm_reset(self.h), "bd_comm_reset")
+                    dist.barrier(group=group)
+                if not all(oks):
+                    self.fallback_reason = f"exchange self-test failed on ranks {[r for r, o in enumerate(oks) if not o]}"
                     backend = "rccl"
             if self.fallback_reason and rank == 0:
                 print(f"[bitdance_amd.tp] {self.fallback_reason}: exchanges go through RCCL (ncclAllReduce)", flush=True)
@@ -310,6 +327,12 @@ class TPComm:
 
     def exchanges(self) -> int:
         return int(self.l.bd_comm_exchanges(self.h))
+
+    def set_fences(self, on: int) -> None:
+        """System-scope fences around every flag of the hand-written exchange (default off; from_process_group turns them on when the
+        self-test only passes with them)."""
+        check(self.l.bd_comm_set_fences(self.h, int(on)))
+        self.fences = int(on)
 
     def set_timeout(self, seconds: float) -> None:
         check(self.l.bd_comm_set_timeout(self.h, float(seconds)))

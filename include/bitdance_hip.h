@@ -137,6 +137,10 @@ void* bd_comm_local_data(bd_comm* c);
 void* bd_comm_local_flags(bd_comm* c);
 int bd_comm_set_rccl(bd_comm* c, void* nccl_comm, void* nccl_allreduce_fn);
 int bd_comm_set_timeout(bd_comm* c, double seconds);                 /* budget of every in-kernel wait (default 20 s) */
+int bd_comm_set_fences(bd_comm* c, int on);                          /* 1: system-scope fences around every flag (default 0: the payload is
+                                                                        write-through stores drained before the flag, read with system-scope loads) */
+int bd_comm_mark_prepushed(bd_comm* c);                              /* the next exchange skips its push phase: the producing GEMM's epilogue
+                                                                        wrote every peer's slice of the partial into that peer's staging row */
 int bd_comm_reset(bd_comm* c);                                       /* all ranks, between host barriers: clear flags / epochs / error */
 int bd_comm_error(bd_comm* c);                                       /* after a sync: bit p = this rank's wait for peer p timed out;
                                                                         bit 8+r = rank r reported a timed-out wait (all ranks raise together) */

@@ -296,6 +296,50 @@ def test_head_sample_tensor_parallel_column_split_adaln(tp, weights, split):
     assert d.max() <= lim[0] and d.mean() <= lim[1], (d.max(), d.mean())
 
 
+@pytest.mark.parametrize("tp,P", [(2, 64), (4, 64), (4, 16)])
+def test_fused_reduce_scatter_push_equals_unfused_exchange(tp, P):
+    """Phase 1 of the all-reduce (every peer's slice of the row-split Linear's fp32 partial into that peer's staging row) fused into
+    the GEMM's epilogue (bd_gemm_kernel.h BD_EPI_F32 with a push target; 16 B system-scope stores of whole rows through a per-wave
+    LDS transposition) against the unfused form (the GEMM writes its partial locally, the exchange kernel pushes it;
+    "tune.tp_fuse" = 0): the same fp32 values reach the same staging words and are summed in the same rank order, so the
+    sampled latents are BIT-identical -- on every rank."""
+    import time
+    from bitdance_amd import engine as E
+    sd_dev = device_seeded_state(tm.head_shapes(HEAD8), 321, DEV)
+    B, br, C, n = 1, 2, 32, 6
+    g = torch.Generator().manual_seed(322)
+    z = torch.randn(br * B, P, 1024, generator=g)
+    noise = torch.randn(1, n + 1, B, P, C, generator=g)
+    outs, times = {}, {}
+    for fuse in (1, 0):
+        comms = _comms(tp, 128 * 1024)
+        streams = _streams(tp)
+        engs = [E.Engine(E.HeadWeights.from_state_dict(sd_dev, DEV, tp_rank=r, tp_size=tp), None, None, num_images=B, branches=br,
+                         device=DEV, max_tokens=P, parallel_num=P, comm=comms[r], tune={"tp_fuse": fuse}) for r in range(tp)]
+        for rep in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for r in range(tp):
+                with torch.cuda.stream(streams[r]):
+                    engs[r].set_schedule(n, 1.5, 1)
+                    engs[r].load_noise(noise)
+                    engs[r].reset([0] * (br * B))
+                    engs[r].set_cond(z.to(DEV))
+                    engs[r].head_sample()
+            torch.cuda.synchronize()
+            times[fuse] = time.perf_counter() - t0
+        for c in comms:
+            c.check()
+        ps = [e.pred().clone() for e in engs]
+        for r in range(1, tp):
+            assert torch.equal(ps[r], ps[0]), f"rank {r} diverged (fuse {fuse})"
+        outs[fuse] = ps[0]
+        assert comms[0].exchanges() == 2 * (n + 1) * 2 * HEAD8["depth_latent"]
+        del engs, comms
+    print(f"[tp {tp} P {P}] head_sample of {n + 1} evaluations, ranks as streams of one GPU: fused {times[1] * 1e3:.2f} ms, unfused {times[0] * 1e3:.2f} ms")
+    assert torch.equal(outs[1], outs[0])
+
+
 @pytest.mark.parametrize("weights", ["bf16", "fp8a"])
 def test_llm_step_tensor_parallel(weights):
     """tiny Qwen3 (4 q heads / 2 kv heads, 2 layers) on 2 ranks: kv cache sharded by kv head, o_proj / down_proj exchanged
@@ -369,7 +413,8 @@ def _proc(rank, world, port, q):
         from bitdance_amd.autoencoder import VQModel
         from bitdance_amd.t2i_pipeline import BitDanceT2IPipeline
         from bitdance_amd.tp import TPComm
-        comm = TPComm.from_process_group(256 * 256, device="cuda:0", backend="ipc")
+        from bitdance_amd.tp import ada_gather_bytes
+        comm = TPComm.from_process_group(256 * 256, device="cuda:0", backend="ipc", gather_bytes=ada_gather_bytes(128, 14 * 256))
         comm.set_timeout(15.0)
         llm_sd = {k: v.to(torch.bfloat16) for k, v in tm.seeded_state(tm.llm_shapes(tm.TINY_LLM), seed=22).items()}
         ae_shapes = {k: tuple(v.shape) for k, v in VQModel(**tm.TINY_AE).state_dict().items()}
