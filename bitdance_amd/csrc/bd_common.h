@@ -14,7 +14,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // hipcc (ROCm 7.2, gfx950) under-counts the MFMA -> accumulator-read wait states across a TAKEN BRANCH: a guarded loop tail whose last
 // executed phase ends in MFMAs jumps to a join that reads the last accumulator registers 6 instructions later (one `s_nop 0` inserted,
 // >= 11 needed for an 8-pass MFMA).  Observed: acc[MB-1][15] stale -- rows 27 / 31 of the last row block wrong -- exactly when the K
-// stages fill the whole tail (tools/ring_debug.py: gemm_kernel<2,2,4,..,R=3> at 14 stages, <4,1,4,..,R=4> at 15 / 27).  The forms the
+// stages fill the whole tail (found by a ring-depth sweep in round 3: gemm_kernel<2,2,4,..,R=3> at 14 stages, <4,1,4,..,R=4> at 15 / 27).  The forms the
 // engine launches never hit that stage count, but nothing guaranteed it.  The accumulator copies are emitted at the very top of the
 // join block, ahead of anything the source can place there, so the drain (32 wait states: a 16-pass MFMA needs 19) goes at the END of
 // the block that holds the last MFMAs: the final guarded phase of a K loop, the last statement of an MFMA loop body.

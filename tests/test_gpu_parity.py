@@ -74,7 +74,7 @@ def test_gemm_every_stage_count(eng_mod, nw, kw, ring):
     """Every K-stage count 1 .. 30 through every tile form / register-ring depth: the guarded tail of the K loop runs 1 .. U + R - 1
     phases.  Regression for a compiler hazard (bd_common.h BD_MFMA_DRAIN): when the LAST tail phase executed, its final MFMA was
     followed across a taken branch by the accumulator copies with too few wait states -- acc[3][15] (rows 27 / 31 of the last row
-    block) stale at exactly 14 stages (ring 3, K-part tiles) or 15 / 27 (ring 4); tools/ring_debug.py."""
+    block) stale at exactly 14 stages (ring 3, K-part tiles) or 15 / 27 (ring 4); the regression below runs every stage count."""
     from bitdance_amd._lib import check, lib
     M, N = 128, 32 * (nw // kw) * 2
     g = torch.Generator(device=DEV).manual_seed(100 * nw + 10 * kw + ring)
@@ -844,8 +844,7 @@ def test_imagenet_released_variants_real_dims_run(variant):
     if variant == "h1x":                                       # 40 layers as torch ops: covered at B width
         return
     # decode steps of the HIP transformer against the same steps as torch ops (the reference's arithmetic), compared where
-    # they differ -- norm(x), before the head's sampler amplifies bf16 noise (measured: rel. error 0.010-0.017 at every variant,
-    # tools/diag_imagenet_decode.py)
+    # they differ -- norm(x), before the head's sampler amplifies bf16 noise (measured in round 3: rel. error 0.010-0.017 at every variant)
     import torch.nn.functional as F
     n_cls, bsz, hd = m.cls_token_num, 8, m.dim // m.n_head
     cls_ids = torch.arange(bsz, device=DEV)
