@@ -41,12 +41,6 @@ struct bd_ctx {
     std::vector<ProfRec> prof;
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     hipGraph_t graph[2] = {nullptr, nullptr};
-    // "tune.ada_async": the adaLN projection of evaluation i+1 (a function of (t_{i+1}, cond) only) runs on a second,
-    // low-priority stream beside evaluation i's chain; fork / join through events, also inside the captured graph
-    hipStream_t side = nullptr;
-    std::vector<hipEvent_t> ev_ada, ev_done;
-    hipEvent_t ev_fork = nullptr;
-    bool ada_async = false;
     bool y_ready = false;                 // head.y_all holds y_i of every evaluation for the current cond (set by head_cond)
 
     // derived
@@ -88,8 +82,6 @@ struct bd_ctx {
     void* wptr(const std::string& k) const { return const_cast<void*>(ptr(k)); }
     const void* optr(const std::string& k) const { auto it = P.find(k); return it == P.end() ? nullptr : it->second; }
 };
-
-static int async_setup(bd_ctx* c, int n_evals);
 
 static int pad_rows(int m) { return m <= 32 ? 32 : (m <= 64 ? 64 : ((m + 127) / 128) * 128); }
 
@@ -193,7 +185,7 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
 static const char* const kIntKeys[] = {
     "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid", "head.y_evals", "head.variant",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "proj.rows_all", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
-    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "rt.in_first", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ada_async", "tune.ragged", "tune.ragged52", "tune.slab_cap", "tune.slab3",
+    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "rt.in_first", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ragged", "tune.ragged52", "tune.slab_cap", "tune.slab3",
     "tune.ada_group", "tune.ada_group_nw", "tune.tp_fuse", "tp.ada_split"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
                                          "llm.qkv", "llm.o", "llm.gu", "llm.down"};
@@ -354,10 +346,6 @@ void bd_ctx_destroy(bd_ctx* c) {
         if (c->gexec[i]) hipGraphExecDestroy(c->gexec[i]);
         if (c->graph[i]) hipGraphDestroy(c->graph[i]);
     }
-    for (hipEvent_t e : c->ev_ada) hipEventDestroy(e);
-    for (hipEvent_t e : c->ev_done) hipEventDestroy(e);
-    if (c->ev_fork) hipEventDestroy(c->ev_fork);
-    if (c->side) hipStreamDestroy(c->side);
     delete c;
 }
 // unknown keys are rejected: a typo must not silently fall back to a default (keys: DESIGN.md / the tables above)
@@ -466,12 +454,12 @@ int bd_ctx_finalize(bd_ctx* c) {
             {
                 long long g = c->geti("tune.ada_group", -1);
                 // (fp8 weights with bf16 activations have no 256-row form; fp8 weights + activations do: bd_gemm8.hip)
-                const bool can = (!c->wfp8 || c->fp8a) && c->hNada % 256 == 0 && c->geti("tune.ada_async", 0) == 0;
+                const bool can = (!c->wfp8 || c->fp8a) && c->hNada % 256 == 0;
                 // 128 rows and fewer: 512 rows per GEMM; 256 / 512 rows (num_images 2 / 4): 1024 rows per GEMM, where the LDS-tiled
                 // MFMA-bound kernel takes over (bd_gemm_tile.hip: adaLN at 1024 rows 694 vs 786 us on the 256-row kernel)
                 if (g < 0) g = !can ? 1 : (Mp <= 128 ? 512 / Mp : (Mp <= 512 && 1024 % Mp == 0 ? 1024 / Mp : 1));
                 if (g < 1 || g > 64 || (g > 1 && ((c->RB * g) % 8 != 0 || !can)))
-                    return fail("tune.ada_group: 1..64 evaluations, rows a multiple of 256, adaLN width a multiple of 256, bf16 weights or fp8 weights + activations, no ada_async");
+                    return fail("tune.ada_group: 1..64 evaluations, rows a multiple of 256, adaLN width a multiple of 256, bf16 weights or fp8 weights + activations");
                 c->adaG = (int)g;
             }
             add("head.cond_frag", Mp * c->hDz * 2);
@@ -479,7 +467,7 @@ int bd_ctx_finalize(bd_ctx* c) {
             add("head.xt", (long long)c->BP * c->hC * 4);
             add("head.y_frag", Mp * c->hD * 2);
             add("head.X", Mp * c->hD * 2);
-            add("head.ada_bf", Mp * c->hNada * 2 * (c->geti("tune.ada_async", 0) ? 2 : c->adaG));
+            add("head.ada_bf", Mp * c->hNada * 2 * c->adaG);
             if (c->geti("tp.ada_split", 0)) {
                 // COLUMN-split adaLN projection (reference layout flow_head_parallel_x.py:331): this rank computes hNada / tp
                 // of the output columns of a whole group of evaluations into head.ada_loc and pushes them into every rank's head.ada_bf
@@ -583,8 +571,6 @@ int bd_head_set_schedule(bd_ctx* c, int n_steps, const float* s, float cfg) {
         q.is_final = (i == n_steps); q.cfg_mult = c->branches;
         c->sched.push_back(q);
     }
-    c->ada_async = c->has_head && c->geti("tune.ada_async", 0) != 0;
-    if (c->ada_async && async_setup(c, n_steps + 1) != 0) return -1;
     return 0;
 }
 
@@ -691,7 +677,7 @@ static int head_cond(bd_ctx* c, hipStream_t st) {   // cond_embed(c) is constant
 }
 
 // y = silu(time_embed(t_i) + cond_embed(c)) and the stacked adaLN projection of evaluation i into half `buf` of head.ada_bf
-static int head_ada(bd_ctx* c, int i, int buf, bool light, hipStream_t st) {
+static int head_ada(bd_ctx* c, int i, int buf, hipStream_t st) {
     const int D = c->hD, RB = c->RB;
     const void* y = c->ptr("head.y_frag");
     const float* ysc = c->fp8a ? (const float*)c->ptr("head.y_scale") : nullptr;
@@ -709,11 +695,10 @@ static int head_ada(bd_ctx* c, int i, int buf, bool light, hipStream_t st) {
         BD_TRY(bdk_head_prologue(pa, st));
     }
     GemmCfg ga = c->cfg("head.ada");
-    if (light) { ga.nw = 4; ga.kw = 1; ga.ring = 2; }
     bf16_t* out = (bf16_t*)c->wptr("head.ada_bf") + (size_t)buf * c->Mpad * c->hNada;
     WRef wa = wref(c, "head.ada_w");
     wa.a = ysc;
-    BD_TRY(gemm(c, "head.ada", y, RB, wa, c->hNada, D, 1, ga.code() + (light ? 8192 : 0), BD_EPI_BF16,
+    BD_TRY(gemm(c, "head.ada", y, RB, wa, c->hNada, D, 1, ga.code(), BD_EPI_BF16,
                 nullptr, out, c->ptr("head.ada_b"), st));
     return 0;
 }
@@ -742,8 +727,8 @@ static int head_ada_group(bd_ctx* c, int g, hipStream_t st) {
     return 0;
 }
 
-// `ada_buf` < 0: compute y and the adaLN projection here, in line (the plain path); >= 0: they were produced ahead of time
-// into that half of head.ada_bf (head_sample with tune.ada_async)
+// `ada_buf` < 0: compute y and the adaLN projection here, in line (the plain path); >= 0: this evaluation's rows of a grouped
+// projection (head_ada_group) are slot `ada_buf` of head.ada_bf
 static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0_ready = false, bool chain_next = false) {
     if (i < 0 || i >= (int)c->sched.size()) return fail("bd_head_eval: eval index outside the schedule");
     const int D = c->hD, Mp = c->Mpad, RB = c->RB, M = c->M;
@@ -751,7 +736,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0
     const int n_steps = (int)c->sched.size() - 1;
     const BdStepState* state = (const BdStepState*)c->ptr("state");
     if (ada_buf < 0) {
-        BD_TRY(head_ada(c, i, 0, false, st));
+        BD_TRY(head_ada(c, i, 0, st));
         ada_buf = 0;
     }
     if (!x0_ready) {                                           // x0 = input_proj(x_t): the previous evaluation's final kernel wrote it
@@ -839,22 +824,6 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0
     return 0;
 }
 
-static int async_setup(bd_ctx* c, int n_evals) {          // streams / events are created OUTSIDE any capture
-    if (!c->side) {
-        int least = 0, greatest = 0;
-        hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least) != hipSuccess) return fail("side stream creation failed");
-        if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail("event creation failed");
-    }
-    while ((int)c->ev_ada.size() < n_evals) {
-        hipEvent_t a, d;
-        if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d, hipEventDisableTiming) != hipSuccess)
-            return fail("event creation failed");
-        c->ev_ada.push_back(a); c->ev_done.push_back(d);
-    }
-    return 0;
-}
-
 static int head_sample(bd_ctx* c, hipStream_t st) {
     if (c->sched.empty()) return fail("bd_head_sample: no schedule set");
     const int n_steps = (int)c->sched.size() - 1;
@@ -862,28 +831,14 @@ static int head_sample(bd_ctx* c, hipStream_t st) {
                       (long long)(n_steps + 1) * c->BP * c->hC, (const BdStepState*)c->ptr("state"), c->BP * c->hC};
     BD_TRY(bdk_init_latent(ia, st));
     BD_TRY(head_cond(c, st));
-    if (!c->ada_async || c->prof_on) {
-        const int G = c->adaG;
-        for (int i = 0; i <= n_steps; ++i) {
-            if (G > 1 && c->y_ready) {
-                if (i % G == 0) BD_TRY(head_ada_group(c, i / G, st));
-                BD_TRY(head_eval(c, i, st, i % G, /*x0_ready=*/i > 0, /*chain_next=*/true));
-            } else {
-                BD_TRY(head_eval(c, i, st, -1, /*x0_ready=*/i > 0, /*chain_next=*/true));
-            }
-        }
-        return 0;
-    }
-    // fork: the side stream produces y / adaLN(i) into half i & 1 as soon as evaluation i-2 has released it; the chain of
-    // evaluation i waits for adaLN(i) only.  The last side operation is joined by the chain of the last evaluation.
-    if ((int)c->ev_ada.size() <= n_steps || !c->side) return fail("bd_head_sample: async state not set up (bd_head_set_schedule)");
-    if (hipEventRecord(c->ev_fork, st) != hipSuccess || hipStreamWaitEvent(c->side, c->ev_fork, 0) != hipSuccess) return fail("fork failed");
+    const int G = c->adaG;
     for (int i = 0; i <= n_steps; ++i) {
-        if (i >= 2 && hipStreamWaitEvent(c->side, c->ev_done[i - 2], 0) != hipSuccess) return fail("side wait failed");
-        BD_TRY(head_ada(c, i, i & 1, true, c->side));
-        if (hipEventRecord(c->ev_ada[i], c->side) != hipSuccess || hipStreamWaitEvent(st, c->ev_ada[i], 0) != hipSuccess) return fail("join failed");
-        BD_TRY(head_eval(c, i, st, i & 1, i > 0, true));
-        if (hipEventRecord(c->ev_done[i], st) != hipSuccess) return fail("event record failed");
+        if (G > 1 && c->y_ready) {
+            if (i % G == 0) BD_TRY(head_ada_group(c, i / G, st));
+            BD_TRY(head_eval(c, i, st, i % G, /*x0_ready=*/i > 0, /*chain_next=*/true));
+        } else {
+            BD_TRY(head_eval(c, i, st, -1, /*x0_ready=*/i > 0, /*chain_next=*/true));
+        }
     }
     return 0;
 }

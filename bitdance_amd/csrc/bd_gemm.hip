@@ -345,8 +345,6 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
     int ring = (nw_ring >> 4) & 15;
     const int kw = ((nw_ring >> 8) & 3) + 1;
     const bool pipe = (nw_ring >> 11) & 1;             // + 2048: software-pipelined LDS reads (4-wave workgroups, ring 2)
-    const bool light = (nw_ring >> 13) & 1;            // + 8192: low-register 4-wave variant for a GEMM that runs BESIDE the step's
-                                                       //         chain on a second stream (the adaLN projection, bd_api.hip)
     if (ring == 0) ring = 2;
     if (ring < 2 || ring > 4 || kw > 2 || nw % kw) return -7;
     const int np = nw / kw;
@@ -379,7 +377,6 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
         return launch_gemm_wide(p, epi, st);
     }
 #define BD_CASE(NPV, KWV, MBV, RV) if (np == NPV && kw == KWV && MB == MBV && ring == RV) return launch_gemm<NPV, KWV, MBV, RV>(p, epi, st);
-    if (light && np == 4 && kw == 1 && MB == 4) return launch_gemm<4, 1, 4, 2, 2>(p, epi, st);
 #define BD_CASE_PIPE(NPV, KWV, MBV) if (pipe && np == NPV && kw == KWV && MB == MBV) return launch_gemm<NPV, KWV, MBV, 2, 1>(p, epi, st);
     BD_CASE_PIPE(4, 1, 4) BD_CASE_PIPE(2, 1, 4) BD_CASE_PIPE(2, 2, 4) BD_CASE_PIPE(4, 1, 2) BD_CASE_PIPE(4, 1, 1)
 #undef BD_CASE_PIPE

@@ -76,8 +76,7 @@ int bdk_gemm_tile(const GemmP& p, int epi, hipStream_t st);
 template <int NP, int KW, int MB, int EPI, int R, bool RED, int MODE = 0, int WT = 0>
 __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
     constexpr int WL = (WT != 0) ? 2 : 4;                 // 16 B loads per lane and 64-deep stage
-    constexpr bool PIPE = (MODE == 1);                    // MODE 2 ("light"): one k-step of fragments resident at a time -- a
-                                                          // ~170-register wave that fits NEXT to a 300-register one on a SIMD
+    constexpr bool PIPE = (MODE == 1);
     constexpr int NW = NP * KW, NT = NW * 64;
     constexpr int UNITS = MB * (WT == 2 ? 128 : 256) * KW; // 16 B units per (64*KW)-deep A stage
     constexpr int XL = (UNITS + NT - 1) / NT;             // A loads per thread per stage
@@ -146,7 +145,7 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
     // This wave's 64-deep part of the A stage goes LDS -> registers in one burst (16 ds_read_b128 for 128 rows), then the
     // MFMAs issue back to back: with the reads interleaved two-at-a-time the matrix pipe idled on LDS latency (the loop
     // was bound by the ds_read -> MFMA chain, not by HBM).
-    constexpr int KG = (MODE != 2 && MB <= 4 && NW <= 8) ? 4 : 1;      // k-steps whose A fragments are resident at once (VGPR budget)
+    constexpr int KG = (MB <= 4 && NW <= 8) ? 4 : 1;      // k-steps whose A fragments are resident at once (VGPR budget)
     auto compute = [&](const u32x4* stage, const u32x4(&wr)[WL]) {
         if constexpr (WT == 2) {                                          // one fp8 MFMA (K = 64) per row block
             const u32x4* buf8 = stage + kg * MB * 128;

@@ -394,7 +394,7 @@ class Engine:
         # slice and the communicator's gather region takes one group's modulation tensor (G evaluations x Mpad rows x all columns)
         self.ada_split = False
         if self.comm is not None and head is not None and "head.ada_w_l" in head.ptrs and self.comm.backend in ("ipc", "none") \
-                and ints.get("tp.ada_split", 1) and not ints.get("tune.ada_async", 0):
+                and ints.get("tp.ada_split", 1):
             mp = 32 if self.M <= 32 else (64 if self.M <= 64 else (self.M + 127) // 128 * 128)
             G = ints.get("tune.ada_group", 512 // mp if mp <= 128 else (1024 // mp if (mp <= 512 and 1024 % mp == 0) else 1))
             need = G * mp * head.ptrs["head.ada_b"].numel() * 2

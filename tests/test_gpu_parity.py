@@ -1053,37 +1053,6 @@ def test_pipeline_from_model_dir_and_mllm_surface(tmp_path, golden_dir):
         m.gen_image_full_causal("x")
 
 
-def test_adaln_side_stream_equals_inline(eng_mod, golden_dir):
-    """tune.ada_async: the adaLN projection of evaluation i+1 runs on a second stream beside evaluation i (fork / join by
-    events, double-buffered output, a low-register GEMM variant).  Same arithmetic per output element -> bit-identical
-    samples, eagerly and from the captured graph."""
-    g = load(golden_dir, "head_amp")
-    sd = tm.seeded_state(tm.head_shapes(tm.TINY_HEAD), seed=11)
-    hw = eng_mod.HeadWeights.from_state_dict(sd, DEV)
-    n, cfg = 3, 2.5
-    outs = []
-    side = torch.cuda.Stream()                                   # graphs cannot be captured on the legacy default stream
-    torch.cuda.set_stream(side)
-    for tune in (None, {"ada_async": 1}):
-        eng = eng_mod.Engine(hw, None, None, num_images=2, branches=2, device=DEV, max_tokens=64, tune=tune)
-        eng.set_schedule(n, cfg, 1)
-        eng.load_noise(g["noise"].view(1, n + 1, 2, 64, 32))
-        eng.reset([0, 0, 0, 0])
-        eng.set_cond(g["z"].to(DEV))
-        eng.head_sample()
-        torch.cuda.synchronize()
-        outs.append(eng.pred().clone())
-        if tune:
-            eng.capture(0)
-            eng.reset([0, 0, 0, 0])
-            eng.launch(0)
-            eng.launch(0)                                     # replay twice: events / buffers are re-usable
-            torch.cuda.synchronize()
-            outs.append(eng.pred().clone())
-    torch.cuda.set_stream(torch.cuda.default_stream())
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-
-
 def test_native_prefill_vs_reference_and_oracle(eng_mod, golden_dir):
     """The prompt passes on the step kernels (causal block + bf16 hidden-state flow) against the reference's own outputs
     (golden llm_amp: h1 = causal call over 11 tokens, h2 = all-visible call over the next 64) with the bounds of the torch

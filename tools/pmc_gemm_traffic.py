@@ -26,8 +26,11 @@ SHAPES = [("head.ada", 71680, 5120, 1, 9, 1, 2), ("head.qkv", 15360, 5120, 2, 4,
           ("head.w1", 15360, 5120, 2, 4, 1, 3), ("head.w2", 5120, 7680, 3, 4, 2, 2), ("head.cond", 5120, 5120, 3, 4, 2, 2),
           ("proj.fc2", 5120, 5120, 3, 4, 2, 2), ("llm.qkv", 7168, 5120, 4, 8, 2, 2), ("llm.o", 5120, 5120, 3, 4, 2, 2),
           ("llm.gu", 34816, 5120, 1, 8, 1, 2), ("llm.down", 5120, 17408, 9, 8, 1, 2),
-          # the grouped adaLN projection as the pipeline launches it: 4 evaluations x 128 rows on the 256-row kernel
-          ("head.ada[x4]", 71680, 5120, 1, 4, 1, 2, 512)]
+          # the grouped adaLN projection as the pipeline launches it: 4 evaluations x 128 rows, launch code 8 waves / ring 2 = the 256-row
+          # kernel (gemm_wide_kernel: default-policy weight loads and XCD placement with two row tiles, bd_gemm.hip launch_gemm_wide).
+          # (Round 3 listed it with launch code 4 waves, which selects gemm_kernel<4,1,8> -- a different kernel: its 2.16x read ratio and
+          # 514 us were not the engine's launch.)
+          ("head.ada[x4]", 71680, 5120, 1, 8, 1, 2, 512)]
 
 
 def _shape(sh):

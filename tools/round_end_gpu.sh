@@ -1,12 +1,12 @@
 #!/bin/bash
 # One GPU-box pass for the numbers a round commits under profiles/ (run from the repo root on the box):
-#   PMC passes over the GEMM shapes -> profiles/r03_pmc_gemm_traffic.json (bench.py's roofline.traffic reads it), the default
+#   PMC passes over the GEMM shapes -> profiles/r04_pmc_gemm_traffic.json (bench.py's roofline.traffic reads it), the default
 #   bench line, the full -m gpu suite, and the rocprofv3 kernel summary of the bench command at 1024 px.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-timeout 180 bash tools/run_pmc_passes.sh > $O/c6_pmc.log 2>&1 && cp $O/pmc/pmc_gemm_traffic.json profiles/r03_pmc_gemm_traffic.json && cp $O/pmc/pmc_gemm_traffic.json $O/c6_pmc_gemm_traffic.json
+timeout 180 bash tools/run_pmc_passes.sh > $O/c6_pmc.log 2>&1 && cp $O/pmc/pmc_gemm_traffic.json profiles/r04_pmc_gemm_traffic.json && cp $O/pmc/pmc_gemm_traffic.json $O/c6_pmc_gemm_traffic.json
 timeout 200 python bench.py > $O/c6_bench_default.json 2> $O/c6_bench_default.err
 timeout 480 python -m pytest tests -m gpu -q > $O/c6_pytest_full.log 2>&1
 timeout 150 python bench.py --num-images 4 --steps 1 --warmup 1 --no-cpu-baseline > $O/c6_bench_b4.json 2> $O/c6_bench_b4.err
