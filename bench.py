@@ -86,6 +86,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="imagenet: skip the conv decoder in the timed pass")
+    ap.add_argument("--tp-ada-split", default="auto", choices=["auto", "0", "1"],
+                    help="tensor parallel: column-split the adaLN projection and all-gather its output (auto: from 4 ranks up)")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8", "fp8a"],
                     help="fp8: streamed Linear weights as e4m3 + per-channel scales (BASELINE config 5; a separate precision mode); "
                          "fp8a: also e4m3 activations (per-row scales) on the fp8 matrix pipe for the GEMMs fed by a row kernel")
@@ -366,6 +368,8 @@ def main():
     elif args.weights == "fp8a":
         metric += " (fp8-e4m3 weights + activations, fp8 MFMA)"
     pipe.tune = tune or None
+    if tp_mode and args.tp_ada_split != "auto":
+        pipe.extra_ints = {"tp.ada_split": int(args.tp_ada_split)}
     if args.attn_splits:
         pipe.attn_splits = args.attn_splits
     pipe.use_graph = not args.no_graph

@@ -393,8 +393,11 @@ class Engine:
         # tensor parallel on the hand-written exchange: column-split adaLN projection + push all-gather when this rank holds its
         # slice and the communicator's gather region takes one group's modulation tensor (G evaluations x Mpad rows x all columns)
         self.ada_split = False
+        # Default from tp = 4 up: a rank receives (tp - 1) / tp of the group's tensor over tp - 1 links, i.e. 73 MB / tp per link and
+        # group -- at tp = 2 that is 36 MB over ONE link (more time than streaming the 0.73 GB locally saves), at tp = 4 / 8 18 / 9 MB.
+        # "tp.ada_split" = 1 / 0 in ``extra_ints`` forces it either way (the in-process tests run it at tp = 2).
         if self.comm is not None and head is not None and "head.ada_w_l" in head.ptrs and self.comm.backend in ("ipc", "none") \
-                and ints.get("tp.ada_split", 1):
+                and ints.get("tp.ada_split", 1 if self.comm.size >= 4 else 0):
             mp = 32 if self.M <= 32 else (64 if self.M <= 64 else (self.M + 127) // 128 * 128)
             G = ints.get("tune.ada_group", 512 // mp if mp <= 128 else (1024 // mp if (mp <= 512 and 1024 % mp == 0) else 1))
             need = G * mp * head.ptrs["head.ada_b"].numel() * 2

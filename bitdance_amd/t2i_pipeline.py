@@ -182,6 +182,7 @@ class BitDanceT2IPipeline:
             self._engines[key] = Engine(self.head_w, self.proj_w, self.llm_w, num_images=num_images,
                                         branches=branches, device=self.device, max_tokens=tokens, max_kv=lmax,
                                         tune=getattr(self, "tune", None), parallel_num=self.parallel_num, comm=self.tp,
+                                        extra_ints=getattr(self, "extra_ints", None),      # e.g. {"tp.ada_split": 1} (engine.Engine)
                                         # flash-decode splits of the KV cache: 12 once the cache passes ~2k tokens (a 1024 px image ends
                                         # at 4.4k): 248 vs 265 us per layer at 4096 cached tokens, no difference below 1k
                                         # (profiles/r03_llm_attn_splits.log); more splits only add partial-output traffic

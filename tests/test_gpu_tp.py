@@ -212,7 +212,8 @@ def test_head_eval_tensor_parallel(tp, P, weights, ada_split):
     engs = []
     for r in range(tp):
         hw = E.HeadWeights.from_state_dict(sd_dev, DEV, tp_rank=r, tp_size=tp, weights=weights)
-        engs.append(E.Engine(hw, None, None, num_images=B, branches=br, device=DEV, max_tokens=P, parallel_num=P, comm=comms[r]))
+        engs.append(E.Engine(hw, None, None, num_images=B, branches=br, device=DEV, max_tokens=P, parallel_num=P, comm=comms[r],
+                             extra_ints={"tp.ada_split": ada_split}))
         assert engs[-1].ada_split == bool(ada_split and weights != "fp8")      # column-split adaLN projection + all-gather (bf16, fp8a)
     torch.cuda.synchronize()
     for r in range(tp):
@@ -273,7 +274,8 @@ def test_head_sample_tensor_parallel_column_split_adaln(tp, weights, split):
         comms = _comms(tp, e1.Mpad * 1024, gather_bytes=512 * nada * 2 if sp else 0)
         streams = _streams(tp)
         engs = [E.Engine(E.HeadWeights.from_state_dict(sd_dev, DEV, tp_rank=r, tp_size=tp, weights=weights), None, None, num_images=B,
-                         branches=br, device=DEV, max_tokens=P, parallel_num=P, comm=comms[r]) for r in range(tp)]
+                         branches=br, device=DEV, max_tokens=P, parallel_num=P, comm=comms[r], extra_ints={"tp.ada_split": sp})
+                for r in range(tp)]
         assert all(e.ada_split == bool(sp) for e in engs)
         torch.cuda.synchronize()
         for r in range(tp):
@@ -423,6 +425,7 @@ def _proc(rank, world, port, q):
                   head_sd=tm.seeded_state(tm.head_shapes(tm.TINY_HEAD), seed=11),
                   proj_sd=tm.seeded_state(tm.proj_shapes(32, 256), seed=33), device="cuda:0")
         pipe = BitDanceT2IPipeline.from_components(**kw, tp=comm)
+        pipe.extra_ints = {"tp.ada_split": 1}               # the column-split adaLN projection + push all-gather through the IPC mapping too
         n, steps = 3, 2
         noise = torch.randn(steps, n + 1, 1, 64, 32, generator=torch.Generator().manual_seed(7))
         args = dict(guidance_scale=3.0, num_sampling_steps=n, max_length=128, num_images=1, image_size=[256, 128], noise=noise)
@@ -433,6 +436,7 @@ def _proc(rank, world, port, q):
         if rank == 0:
             single = BitDanceT2IPipeline.from_components(**kw).gen_image("a red fox", "<|", return_tokens=True, **args).cpu()
         dist.barrier()
+        assert next(iter(pipe._engines.values())).ada_split
         q.put((rank, tok.numpy(), bool(torch.equal(tok, tok2)), tuple(img.shape), bool(torch.isfinite(img).all()),
                None if single is None else single.numpy(), comm.exchanges()))
         dist.barrier()
