@@ -164,6 +164,42 @@ def gemm_roofline(eng, run, rows: int) -> dict:
     algorithmic = {"GBs": round(alg_b / all_ms / 1e6, 1), "bytes_per_launch": int(alg_b / all_n),
                    "note": "N*K*2 per Linear and evaluation (what the reference streams) / the same time: a grouped launch counts G x its weights; not a fraction of the HBM peak"}
     common.update(launches=all_n, avg_launch_us=round(all_ms / all_n * 1e3, 2))
+    # The path that actually binds the 128-row GEMMs (profiles/r04_probe_mix.log, r04_probe_gemmlike.log): a CU's
+    # vector-memory path carries the weights AND every column tile's re-read of the activations AND the split-K slabs.  Bytes through
+    # that path per launch = W + (N / tile columns) x rows x K x 2 + S x rows x N x 4 (S > 1); the bound is what a kernel that ONLY
+    # issues the qkv GEMM's loads reaches on this chip (10.4 TB/s: 314 MB in 30.2 us, no LDS / MFMA / barrier / epilogue).  Reported
+    # beside the HBM figure, never instead of it.
+    vpath = None
+    kdim = {}
+    if getattr(eng, "head", None) is not None:
+        h = eng.head
+        kdim.update({"head.qkv": h.D, "head.wo": h.D // max(1, h.tp_size), "head.w1": h.D, "head.w2": h.H // max(1, h.tp_size), "head.cond": h.Dz, "head.ada": h.D})
+    if getattr(eng, "llm", None) is not None:
+        c = eng.llm.cfg
+        tpl = max(1, getattr(eng.llm, "tp_size", 1))
+        kdim.update({"llm.qkv": c["hidden_size"], "llm.gu": c["hidden_size"], "llm.o": c["num_attention_heads"] * c["head_dim"] // tpl,
+                     "llm.down": c["intermediate_size"] // tpl})
+    if getattr(eng, "proj", None) is not None:
+        kdim["proj.fc2"] = eng.proj.D
+    if rows <= 256 and not eng.wdtype:
+        pb = pt = 0.0
+        rows_pad = 32 if rows <= 32 else (64 if rows <= 64 else (rows + 127) // 128 * 128)
+        for q in per:
+            name, r = q["name"], allg[q["name"]]
+            if name not in kdim or r["G"] != 1:
+                continue
+            K = kdim[name]
+            N = int(round(r["bytes"] / r["count"] / 2 / K))
+            cols = 32 * max(1, q["nwaves"] // q["kparts"])
+            a_bytes = -(-N // cols) * rows_pad * K * 2
+            slab = q["splitk"] * rows_pad * N * 4 if q["splitk"] > 1 else 0
+            q["path_GBs"] = round((r["bytes"] / r["count"] + a_bytes + slab) * r["count"] / r["ms"] / 1e6, 1)
+            pb += (r["bytes"] / r["count"] + a_bytes + slab) * r["count"]
+            pt += r["ms"]
+        if pt > 0:
+            vpath = {"achieved": round(pb / pt / 1e6, 1), "bound": 10400.0, "unit": "GB/s", "frac": round(pb / pt / 1e6 / 10400.0, 4),
+                     "note": "weights + per-tile activation re-reads + split-K slab writes through the CUs' vector-memory path / time, over the "
+                             "one-evaluation launches; bound = the same traffic as bare loads (tools/probe_gemmlike.hip, profiles/r04_probe_gemmlike.log)"}
     # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own runs, gfx950 x2
     # wide-read correction: tools/pmc_gemm_traffic.py -> profiles/r0*_pmc_gemm_traffic.json), weighted by this step's
     # launch mix; only valid for the shapes / launch configs that pass measured, else null
@@ -189,7 +225,8 @@ def gemm_roofline(eng, run, rows: int) -> dict:
             break
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "bytes_per_launch": int(all_b / all_n), "hbm_bound_launches": streamed, "algorithmic": algorithmic, **common}
+            "bytes_per_launch": int(all_b / all_n), "hbm_bound_launches": streamed, "algorithmic": algorithmic,
+            "vector_memory_path": vpath, **common}
 
 
 # ---------------------------------------------------------------------------------------------------------
