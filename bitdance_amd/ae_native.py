@@ -60,6 +60,7 @@ class NativeDecoder:
         self.device = torch.device(device)
         self.dec = dec
         self.nlev, self.nres = dec.nlev, dec.nres
+        self.gan = bool(getattr(dec, "gan", False))          # GANDecoder (autoencoder.py:279-351): conv_in over [tokens | fresh noise]
         C = lambda m: _Conv(m, self.device)
         self.conv_in = C(dec.conv_in)
         self.mid = [self._block(b) for b in dec.mid_block]
@@ -147,8 +148,12 @@ class NativeDecoder:
         n, Cz, H, W = z.shape
         self._new_call(n, H, W)
         zf = z.to(torch.float32).contiguous()
-        p0 = self._padded("p.in", n, H, W, Cz)
-        check(lib().bd_tokens_to_padded(zf.data_ptr(), p0.data_ptr(), n, Cz, H, W, _st()), "bd_tokens_to_padded")
+        zin, Cin = zf, Cz
+        if self.gan:                                         # the reference's draw: torch.randn_like(z) from the global generator, :329
+            zin = torch.cat([zf, torch.randn_like(z).to(torch.float32)], dim=1).contiguous()
+            Cin = 2 * Cz
+        p0 = self._padded("p.in", n, H, W, Cin)
+        check(lib().bd_tokens_to_padded(zin.data_ptr(), p0.data_ptr(), n, Cin, H, W, _st()), "bd_tokens_to_padded")
         c = self.conv_in.cout
         x = self._conv(self.conv_in, p0, self._get("s.in", (n, H, W, c), BF16), n, H, W)
         for i, blk in enumerate(self.mid):

@@ -124,14 +124,17 @@ class AdaptiveGroupNorm(nn.Module):
 
 
 class Decoder(nn.Module):
-    """autoencoder.py:129-196"""
+    """autoencoder.py:129-196; ``gan=True``: the ``GANDecoder`` variant (:279-351) -- the same ladder with ``conv_in`` taking the
+    token map concatenated with a fresh ``torch.randn_like`` noise map (one more normal draw from the global generator per decode,
+    :329-330), same state-dict keys."""
 
     def __init__(self, *, ch, out_ch, in_channels, num_res_blocks, z_channels, ch_mult=(1, 2, 2, 4),
-                 resolution=None, double_z=False):
+                 resolution=None, double_z=False, gan: bool = False):
         super().__init__()
         self.nlev, self.nres = len(ch_mult), num_res_blocks
+        self.gan = bool(gan)
         cin = ch * ch_mult[-1]
-        self.conv_in = nn.Conv2d(z_channels, cin, 3, padding=1, bias=True)
+        self.conv_in = nn.Conv2d(z_channels * (2 if gan else 1), cin, 3, padding=1, bias=True)
         self.mid_block = nn.ModuleList([ResBlock(cin, cin) for _ in range(num_res_blocks)])
         self.up = nn.ModuleList()
         self.adaptive = nn.ModuleList()
@@ -151,6 +154,8 @@ class Decoder(nn.Module):
 
     def forward(self, z):
         tokens = z
+        if self.gan:
+            z = torch.cat([z, torch.randn_like(z).to(z.device)], dim=1)      # GANDecoder.forward :329-330
         z = self.conv_in(z)
         for blk in self.mid_block:
             z = blk(z)
@@ -164,14 +169,12 @@ class Decoder(nn.Module):
 
 
 class VQModel(nn.Module):
-    """encode -> where(h>0,+1,-1) ; decode.  autoencoder.py:354-521 (the ``gan_decoder`` variant is not supported)."""
+    """encode -> where(h>0,+1,-1) ; decode.  autoencoder.py:354-521 (``gan_decoder=True``: the GANDecoder ladder, :279-351)."""
 
     def __init__(self, ddconfig, checkpoint=None, gan_decoder=False):
         super().__init__()
-        if gan_decoder:
-            raise NotImplementedError("gan_decoder=True tokenizers are outside the T2I hot path")
         self.encoder = Encoder(**ddconfig)
-        self.decoder = Decoder(**ddconfig)
+        self.decoder = Decoder(**ddconfig, gan=bool(gan_decoder))
         # GPU decode on the native kernels (False: torch / MIOpen, the cross-check path).  Built on first use: the weights have to
         # be loaded first.  The native path implements the bf16-autocast flow the pipelines decode under.
         self.native_decoder = True

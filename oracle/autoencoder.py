@@ -91,12 +91,16 @@ def adaptive_group_norm(pol: Policy, sd: dict, pre: str, x, tokens, eps: float =
     return scale * group_norm(pol, x, None, None, eps) + bias
 
 
-def decoder_forward(pol: Policy, sd: dict, cfg: dict, z):
+def decoder_forward(pol: Policy, sd: dict, cfg: dict, z, noise=None):
     """Decoder.forward (autoencoder.py:169-196): conv_in, mid blocks, then from the coarsest level up: AdaptiveGroupNorm on the
-    token map, ResBlocks, Upsampler (3x3 conv to 4x channels + depth-to-space, :232-250); norm_out -> swish -> conv_out."""
+    token map, ResBlocks, Upsampler (3x3 conv to 4x channels + depth-to-space, :232-250); norm_out -> swish -> conv_out.
+    A ``conv_in`` of twice the token channels is the GANDecoder (:279-351): its input is the token map concatenated with
+    ``torch.randn_like(z)`` (:329-330) -- drawn here from the global generator like the reference does, or given as ``noise``."""
     nlev, nres = len(cfg["ch_mult"]), cfg["num_res_blocks"]
     p = "decoder."
     tokens = z
+    if sd[p + "conv_in.weight"].shape[1] == 2 * z.shape[1]:
+        z = torch.cat([z, torch.randn_like(z) if noise is None else noise], dim=1)
     h = conv2d(pol, z, sd[p + "conv_in.weight"], sd[p + "conv_in.bias"], padding=1)
     for i in range(nres):
         h = res_block(pol, sd, f"{p}mid_block.{i}.", h)

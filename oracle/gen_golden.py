@@ -352,6 +352,24 @@ def gen_ae_c1():
          n_tensors=np.int64(len(shapes)), n_params=np.int64(sum(int(np.prod(v)) for v in shapes.values())))
 
 
+def gen_ae_gan():
+    """The GAN-decoder variant of the tokenizer (VQModel(gan_decoder=True), autoencoder.py:279-351): one decode of a +-1 token map on
+    CPU (fp32) with the global generator seeded right before it -- the decoder draws its noise map with torch.randn_like(z)."""
+    from modeling.vision_encoder.autoencoder import VQModel
+    ae = VQModel(**tm.TINY_AE, gan_decoder=True).eval()
+    shapes = {k: tuple(v.shape) for k, v in ae.state_dict().items()}
+    ae.load_state_dict(tm.seeded_state(shapes, seed=47, gain=1.4))
+    g = torch.Generator().manual_seed(5)
+    q = torch.sign(torch.randn(2, 32, 4, 6, generator=g))
+    torch.manual_seed(77)
+    with torch.no_grad():
+        dec = ae.decode(q)
+    torch.manual_seed(77)
+    noise = torch.randn_like(q)                                  # what the decoder drew (first draw after the seed)
+    save("ae_gan", quant=q, dec=dec, noise=noise, seed=np.int64(77),
+         keys=np.array(sorted(shapes)), shapes=np.array([str(shapes[k]) for k in sorted(shapes)]))
+
+
 def gen_misc():
     pipe = build_pipeline(torch.float32)
     save("posembed", table=pipe.pos_embed_1d, e_4_6_2=pipe.get_2d_embed(4, 6, ps=2),
@@ -495,6 +513,8 @@ def main():
         return gen_ae_c1()
     if len(sys.argv) > 1 and sys.argv[1] == "misc":
         return gen_misc()
+    if len(sys.argv) > 1 and sys.argv[1] == "ae_gan":
+        return gen_ae_gan()
     gen_sampler()
     gen_head()
     gen_llm()
@@ -506,6 +526,7 @@ def main():
     gen_interleaved()
     gen_text_sampling()
     gen_ae_c1()
+    gen_ae_gan()
 
 
 if __name__ == "__main__":

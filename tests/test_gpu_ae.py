@@ -157,6 +157,43 @@ def test_native_decoder_tiny_vs_torch(gh, gw):
     assert (alt - ref).abs().mean().item() <= 2e-2 * max(1.0, scale)
 
 
+def test_native_gan_decoder_vs_torch_and_oracle():
+    """The GAN-decoder variant (VQModel(gan_decoder=True), autoencoder.py:279-351) on the native kernels: conv_in over [tokens | noise]
+    with the noise drawn by the reference's own call (torch.randn_like from the global generator) -- same seed, same noise, so the
+    native decode equals the torch module's under autocast to bf16 noise, and the CPU oracle fed that noise."""
+    from bitdance_amd.ae_native import NativeDecoder
+    from bitdance_amd.autoencoder import VQModel
+    from oracle import autoencoder as oae
+    from oracle import tiny_models as tm
+    from oracle.numerics import Policy
+    ae = VQModel(**tm.TINY_AE, gan_decoder=True).eval()
+    shapes = {k: tuple(v.shape) for k, v in ae.state_dict().items()}
+    ae.load_state_dict(tm.seeded_state(shapes, seed=47, gain=1.4))
+    ae = ae.to(DEV)
+    nat = NativeDecoder(ae.decoder, DEV)
+    assert nat.gan and nat.conv_in.cin == 64
+    z = torch.sign(torch.randn(2, 32, 8, 12, generator=torch.Generator().manual_seed(9))).to(DEV)
+    torch.manual_seed(123)
+    with torch.no_grad(), torch.autocast("cuda", dtype=BF16):
+        ref = ae.decoder(z).float()
+    torch.manual_seed(123)
+    noise = torch.randn_like(z)
+    torch.manual_seed(123)
+    got = nat.decode(z).float()
+    d = (got - ref).abs()
+    scale = ref.abs().mean().item()
+    assert d.mean().item() <= 0.02 * scale + 2e-3 and d.max().item() <= 0.25 * max(1.0, ref.abs().max().item()), (d.mean(), d.max())
+    torch.manual_seed(123)
+    with torch.no_grad(), torch.autocast("cuda", dtype=BF16):
+        via = ae.decode(z)                                                   # VQModel.decode takes the native path, same draw
+    assert torch.equal(via.float(), got)
+    sd = {k: v.detach().float().cpu() for k, v in ae.state_dict().items()}
+    with torch.no_grad():
+        orc = oae.decoder_forward(Policy("autocast"), sd, tm.TINY_AE["ddconfig"], z.cpu(), noise=noise.cpu()).float()
+    do = (got.cpu() - orc).abs()
+    assert do.mean().item() <= 0.015 * orc.abs().mean().item() + 1e-3, do.mean()
+
+
 def _oracle(ae):
     """oracle/autoencoder.py on the module's own weights: the CPU restatement of the reference's Encoder / Decoder, pinned against the
     reference's outputs (tests/test_oracle_golden.py::test_autoencoder_oracle_matches_reference), under the autocast policy."""

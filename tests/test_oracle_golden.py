@@ -429,6 +429,32 @@ def test_autoencoder_oracle_matches_reference(golden_dir):
     assert (da.float() - g["dec"]).abs().mean().item() <= 0.03 * g["dec"].abs().mean().item() + 2e-3
 
 
+def test_gan_decoder_variant_matches_reference(golden_dir):
+    """VQModel(gan_decoder=True) (autoencoder.py:279-351: conv_in over the token map concatenated with a fresh torch.randn_like noise
+    map): the product's torch module (checkpoint-compatible: the reference's state-dict keys and shapes) and the oracle restatement
+    against the unmodified reference's decode with the global generator seeded the same way (tests/golden/ae_gan.npz) -- the noise
+    draw comes out of the same generator in the same order (one normal of the token map's shape per decode)."""
+    import ast
+    from bitdance_amd.autoencoder import VQModel
+    from oracle import autoencoder as oae
+    g = load(golden_dir, "ae_gan")
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["keys"], g["shapes"])}
+    ae = VQModel(**tm.TINY_AE, gan_decoder=True).eval()
+    assert {k: tuple(v.shape) for k, v in ae.state_dict().items()} == shapes          # drop-in for the reference checkpoint
+    sd = tm.seeded_state(shapes, seed=47, gain=1.4)
+    ae.load_state_dict(sd)
+    torch.manual_seed(int(g["seed"]))
+    with torch.no_grad():
+        dec = ae.decode(g["quant"])
+    torch.testing.assert_close(dec, g["dec"], atol=2e-4, rtol=1e-3)
+    torch.manual_seed(int(g["seed"]))
+    with torch.no_grad():
+        od = oae.decoder_forward(Policy("fp32"), sd, tm.TINY_AE["ddconfig"], g["quant"])      # draws its own noise, like the reference
+        on = oae.decoder_forward(Policy("fp32"), sd, tm.TINY_AE["ddconfig"], g["quant"], noise=g["noise"])
+    torch.testing.assert_close(od, g["dec"], atol=2e-4, rtol=1e-3)
+    assert torch.equal(od, on)
+
+
 def test_autoencoder_oracle_config1(golden_dir):
     """BASELINE config 1 through the ORACLE: the ae_d16c32 tokenizer (released size: ch 256, ch_mult [1,1,2,2,4], 4 res-blocks) on one
     256 x 256 image, CPU fp32 -- encode -> binary quantise -> decode reproduces the reference's binary latent bit for bit and its
