@@ -73,8 +73,10 @@ int bdk_gemm_tile(const GemmP& p, int epi, hipStream_t st);
 // of four bf16 ones at twice the rate, and half the LDS bytes for the activations.  Weights: 2 KiB per (panel, 64-deep stage) as
 // two lane-linear 1 KiB halves (bytes 0-15 / 16-31 of every lane's 32); activations: the same chunk shape per (stage, row block),
 // produced by the row kernels together with one fp32 scale per row (bd_rows.hip quant8_store).
+// The kernel's body as a device function (the __global__ wrapper follows it): tools/persist_pair.hip runs two bodies inside ONE launch
+// with a grid barrier between them, to price a persistent chain against two launches on this code.
 template <int NP, int KW, int MB, int EPI, int R, bool RED, int MODE = 0, int WT = 0>
-__global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
+BD_DEV void gemm_body(const GemmP& p) {
     constexpr int WL = (WT != 0) ? 2 : 4;                 // 16 B loads per lane and 64-deep stage
     constexpr bool PIPE = (MODE == 1);
     constexpr int NW = NP * KW, NT = NW * 64;
@@ -462,6 +464,11 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
         for (int m = 0; m < MB; ++m) finalize(m);
     }
     if (EPI == BD_EPI_F32 && p.push.size > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the pushes are at their destinations before the kernel ends
+}
+
+template <int NP, int KW, int MB, int EPI, int R, bool RED, int MODE = 0, int WT = 0>
+__global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
+    gemm_body<NP, KW, MB, EPI, R, RED, MODE, WT>(p);
 }
 
 template <int NP, int KW, int MB, int EPI, int R, bool RED, int MODE = 0, int WT = 0>
