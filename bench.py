@@ -564,6 +564,8 @@ def bench_imagenet(args, dist, world, rank, dev, metric, barrier, max_over_ranks
     mcfg = syn.IMAGENET_MODELS[variant]
     P = mcfg["parallel_num"]
     m = syn.build_imagenet(dev, cfg=mcfg, with_vae=not args.no_decode)
+    tune = {k: int(v) for k, v in (kv.split("=") for kv in filter(None, args.tune.split(",")))}
+    m.tune = tune or None
     ids = (torch.arange(n_cls) + rank * n_cls) % 1000
 
     def one_pass(i):

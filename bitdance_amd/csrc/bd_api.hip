@@ -186,7 +186,7 @@ static const char* const kIntKeys[] = {
     "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid", "head.y_evals", "head.variant",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "proj.rows_all", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
     "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "rt.in_first", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ragged", "tune.ragged52", "tune.slab_cap", "tune.slab3",
-    "tune.ada_group", "tune.ada_group_nw", "tune.tp_fuse", "tp.ada_split"};
+    "tune.ada_group", "tune.ada_group_nw", "tune.tp_fuse", "tune.ln_rows", "tp.ada_split"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
                                          "llm.qkv", "llm.o", "llm.gu", "llm.down"};
 static bool known_int_key(const std::string& k) {
@@ -406,11 +406,8 @@ int bd_ctx_finalize(bd_ctx* c) {
         // length); head-only contexts read just the step counter, imagenet sequences all share slot 0
         if (c->branches * c->B > BD_MAX_SEQ && c->has_llm && c->geti("llm.variant", 0) == 0)
             return fail("too many sequences for the Qwen3 decode path (max 64: num_images <= 32 with CFG)");
-        if (c->Pn < 16 && c->has_llm && c->geti("llm.variant", 0) == 0)
-            return fail("the Qwen3 decode path takes 64 or 16 tokens per step");
         c->hMlp = c->has_head ? (int)c->geti("head.variant", 0) : 0;
         if (c->hMlp != 0 && c->hMlp != 1) return fail("head.variant: 0 (transformer blocks) or 1 (MLP blocks)");
-        if (c->has_head && !c->hMlp && c->Pn == 1) return fail("the transformer head needs at least 4 tokens per step (head.variant = 1 for the 1x models)");
         c->ws.clear();
         auto add = [&](const std::string& n, long long bytes) { c->ws.push_back({n, bytes}); };
         add("state", sizeof(BdStepState));
@@ -766,6 +763,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0
         l1.scale_off = base; l1.shift_off = base + D;
         l1.h_frag = c->wptr("head.h_frag"); l1.M = M; l1.D = D; l1.RB = RB; l1.eps = 1e-6f;
         if (c->fp8a) l1.a8_scale = (float*)c->wptr("head.h_scale");
+        l1.wave_rows = (int)c->geti("tune.ln_rows", M >= 1024 ? 1 : 0);   // the ImageNet batch: a wave per row (bd_rows.hip)
         LnModArgs l2 = l1;
         if (!mlp) {
             l1.ln_w = (const float*)c->ptr(pre + "ln1_w"); l1.ln_b = (const float*)c->ptr(pre + "ln1_b");

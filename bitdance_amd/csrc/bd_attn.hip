@@ -348,7 +348,7 @@ int bdk_head_attn(const HeadAttnArgs& a, hipStream_t st) {
         if (a.dh == 64) BD_LAUNCH(head_attn16_mfma_kernel<64>, dim3(blocks), dim3(256), 0, st, a);
         else BD_LAUNCH(head_attn16_mfma_kernel<128>, dim3(blocks), dim3(256), 0, st, a);
     }
-    else if (a.P <= 16 && a.P >= 2) BD_LAUNCH(head_attn16_kernel, dim3(a.nseq * a.nhead), dim3(256), 0, st, a);   // 16x from slabs; 4x
+    else if (a.P <= 16 && a.P >= 1) BD_LAUNCH(head_attn16_kernel, dim3(a.nseq * a.nhead), dim3(256), 0, st, a);   // 16x from slabs; 4x; 1 (out = v)
     else return -2;
     return bd_launch_status();
 }
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256) void llm_attn_combine_kernel(LlmAttnArgs a) {
 int bdk_llm_attn(const LlmAttnArgs& a, hipStream_t st) {
     const int G = a.nh / a.nkv;
     const int halves = (a.P + 31) / 32;
-    if ((a.P != 64 && a.P != 16) || G * halves * 64 > 640 || a.nh % a.nkv) return -2;   // G <= 5 (Qwen3-14B: 40/8)
+    if (a.P < 1 || a.P > 64 || G * halves * 64 > 640 || a.nh % a.nkv) return -2;   // G <= 5 (Qwen3-14B: 40/8); P = 1 / 4: a mostly padded half
     BD_LAUNCH(llm_attn_kernel, dim3(a.splits, a.nkv, a.nseq), dim3(G * halves * 64), 0, st, a);
     BD_LAUNCH(llm_attn_combine_kernel, dim3(a.nseq * a.P, (a.nh + 3) / 4), dim3(256), 0, st, a);
     return bd_launch_status();

@@ -83,6 +83,7 @@ struct LnModArgs {          // x (+= pending branch * gate) ; h = LN(x)*(1+scale
     int M, D, RB;
     float eps;
     float* a8_scale = nullptr;   // not null: h goes out as fp8-e4m3 in the A8 layout + one fp32 scale per row (fp8 x fp8 GEMMs)
+    int wave_rows = 0;           // 1: one wave per row, eight rows per workgroup (many rows of a narrow model; D <= 1024, bf16 output)
 };
 int bdk_ln_mod(const LnModArgs& a, hipStream_t st);
 

@@ -290,9 +290,77 @@ __global__ void ln_mod_kernel(LnModArgs a) {
     }
     *reinterpret_cast<u32x4*>((bf16_t*)a.h_frag + afrag_off(m, d0, a.RB)) = pack8(h);   // cast by the next Linear
 }
+// Many rows of a narrow model (the ImageNet batch: 12 288 rows of D = 768): one workgroup per row is 12 288 two-wave workgroups with
+// two LDS block reductions each, and the eight rows that share every 128 B line of the fragment-major output are written from
+// eight workgroups on eight XCDs (eight partial lines per L2).  Here a WAVE owns a row -- statistics by cross-lane sums only, no
+// LDS, no barrier -- and the eight waves of a workgroup own the eight consecutive rows of one output line group.  Same arithmetic
+// per element as ln_mod_kernel; the LayerNorm sums are taken in a different order (fp32, last-bit differences in mean / rstd).
+template <int NPASS>
+__global__ __launch_bounds__(512) void ln_mod_rows_kernel(LnModArgs a) {
+    const int lane = threadIdx.x & 63, m = blockIdx.x * 8 + (threadIdx.x >> 6);
+    if (m >= a.M) return;
+    const bf16_t* ada = (const bf16_t*)a.ada + (size_t)m * a.ada_ld;
+    bf16_t* const Xr = (bf16_t*)a.X + (size_t)m * a.D;
+    float x[NPASS][8];
+    u32x4 scr[NPASS], sfr[NPASS];
+    float s = 0.f;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int d0 = (p * 64 + lane) * 8;
+        if (d0 < a.D) {
+            const u32x4 xr = ld_raw8(Xr + d0);
+            scr[p] = ld_raw8(ada + a.scale_off + d0);
+            sfr[p] = ld_raw8(ada + a.shift_off + d0);
+            unpack8(xr, x[p]);
+            if (a.pend.p) {
+                float o[8], g[8];
+                const u32x4 gr = ld_raw8(ada + a.gate_off + d0);
+                slab8(a.pend, m, d0, o);
+                unpack8(gr, g);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[p][j] = bfr(x[p][j] + bfr(o[j] * g[j]));
+                *reinterpret_cast<u32x4*>(Xr + d0) = pack8(x[p]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += x[p][j];
+        }
+    }
+    const float mean = wave_sum(s) / (float)a.D;
+    float v = 0.f;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p)
+        if ((p * 64 + lane) * 8 < a.D) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float c = x[p][j] - mean; v += c * c; }
+        }
+    const float rstd = rsqrtf(wave_sum(v) / (float)a.D + a.eps);
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int d0 = (p * 64 + lane) * 8;
+        if (d0 < a.D) {
+            float sc[8], sf[8], w[8], b[8], h[8];
+            unpack8(scr[p], sc);
+            unpack8(sfr[p], sf);
+            if (a.ln_w) { ld_f32x8(a.ln_w + d0, w); ld_f32x8(a.ln_b + d0, b); }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float ln = (x[p][j] - mean) * rstd;
+                if (a.ln_w) ln = ln * w[j] + b[j];
+                h[j] = fadd(fmul(ln, bfr(1.0f + sc[j])), sf[j]);
+            }
+            *reinterpret_cast<u32x4*>((bf16_t*)a.h_frag + afrag_off(m, d0, a.RB)) = pack8(h);
+        }
+    }
+}
 int bdk_ln_mod(const LnModArgs& a, hipStream_t st) {
     const int t = row_threads(a.D);
     if (t < 0 || a.D % 8) return -2;
+    if (a.wave_rows && !a.a8_scale && a.D <= 1024) {
+        const dim3 grid((a.M + 7) / 8);
+        if (a.D <= 512) BD_LAUNCH(ln_mod_rows_kernel<1>, grid, dim3(512), 0, st, a);
+        else BD_LAUNCH(ln_mod_rows_kernel<2>, grid, dim3(512), 0, st, a);
+        return bd_launch_status();
+    }
     BD_LAUNCH(ln_mod_kernel, dim3(a.M), dim3(t), 0, st, a);
     return bd_launch_status();
 }

@@ -364,7 +364,7 @@ class Engine:
         self.device = torch.device(device)
         self.head, self.proj, self.llm = head, proj, llm
         if parallel_num not in (1, 4, 16, 64):
-            raise BitDanceHipError("parallel_num must be 64 / 16 (T2I 64x / 16x, ImageNet 16x), 4 or 1 (ImageNet 4x / 1x)")
+            raise BitDanceHipError("parallel_num must be 64 / 16 (T2I 64x / 16x, ImageNet 16x), 4 or 1 (ImageNet 4x / 1x; the full-causal T2I loop)")
         self.B, self.branches, self.P = num_images, branches, parallel_num
         self.BP = self.B * self.P
         self.M = self.branches * self.BP

@@ -268,7 +268,8 @@ class BitDance:
         key = (n, branches)
         if key not in self._comb:
             eng = Engine(self.head_w, self.proj_w, self.tr_w, num_images=n, branches=branches, device=self.device,
-                         max_tokens=self.h * self.w, max_kv=self.total_tokens, parallel_num=self.P, extra_ints={"proj.rows_all": 1})
+                         max_tokens=self.h * self.w, max_kv=self.total_tokens, parallel_num=self.P, extra_ints={"proj.rows_all": 1},
+                         tune=getattr(self, "tune", None))
             eng.pos[: self.h * self.w].copy_(self.w_["pos_for_diff.weight"])
             eng.cfg_table = torch.ones(self.h * self.w // self.P + 1, dtype=torch.float32, device=self.device)
             eng.set_ptr("head.cfg_table", eng.cfg_table)

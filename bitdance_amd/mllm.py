@@ -16,7 +16,8 @@ while it is still None, :796-800; later steps would feed 2-D embeddings), so a p
 modeling/utils.py:64-124) is provided and pinned against the reference's outputs all the same.  ``encode_image`` (:899-930) = the tokenizer's conv encoder (native kernels under bf16 autocast: ae_native.NativeEncoder) -> binary tokens in patch
 order -> the native projector -> + 2-D position embedding.
 
-Out of scope (training): ``forward`` / losses; ``gen_image_full_causal`` (parallel_num == 1 T2I models) -- ``NotImplementedError``.
+``gen_image_full_causal`` (mllm.py:274-384, parallel_num == 1 models: one token per AR step) is the same native loop at P = 1
+(golden ``full_causal_*.npz``).  Out of scope (training): ``forward`` / losses.
 """
 from __future__ import annotations
 
@@ -71,8 +72,22 @@ class MLLModel:
         return self._p.gen_image(cond_prompt, uncond_prompt, guidance_scale, num_sampling_steps, max_length, num_images,
                                  image_size, show_progress, **native_kw)
 
-    def gen_image_full_causal(self, *a, **k):
-        raise NotImplementedError("parallel_num == 1 models (token-by-token loop, mllm.py:274-384) are not part of the native path")
+    @torch.no_grad()
+    def gen_image_full_causal(self, cond_prompt, uncond_prompt=None, guidance_scale: float = 1.0, num_sampling_steps: int = 50,
+                              max_length: int = 64, num_images: int = 1, image_size=[256, 256], show_progress: bool = False,
+                              **native_kw):
+        """mllm.py:274-384, what ``gen_image`` dispatches to when the head's parallel_num is 1 (:268-272): one token per AR step
+        (``step_width`` = parallel_num), a plain causal prefill, no query tokens, ps = 1.  That is the block-causal loop with blocks
+        of one token -- the reference's two loops produce identical tokens from identical components and noise at
+        parallel_num = 1 (asserted when tests/golden/full_causal_*.npz are generated) -- so the same native loop serves it.  The
+        reference can only run it with the diffusion_parallel_x head (the one head that builds ``vision_diffusion_head``,
+        :133-150); with parallel_num > 1 its ``last_hidden_state[:, -step_width:]`` / query-token variant is
+        gen_image_block_causal's prefill without the block mask, which no released model uses."""
+        if self.parallel_num != 1:
+            raise NotImplementedError("gen_image_full_causal is the loop of parallel_num == 1 models (mllm.py:268-272); "
+                                      f"this model has parallel_num = {self.parallel_num}: use gen_image / gen_image_block_causal")
+        return self._p.gen_image(cond_prompt, uncond_prompt, guidance_scale, num_sampling_steps, max_length, num_images,
+                                 image_size, show_progress, **native_kw)
 
     def decode_image(self, image_latents, image_size=None, ps=1):
         """mllm.py:503-512."""

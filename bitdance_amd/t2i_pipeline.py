@@ -120,8 +120,9 @@ class BitDanceT2IPipeline:
         self.vision_head_config = head_config
         self.head_w = HeadWeights.from_state_dict(head_sd, device, tp_rank=tpr, tp_size=tps, weights=weights)
         self.parallel_num = head_config["parallel_num"]
-        if self.parallel_num not in (16, 64):
-            raise NotImplementedError("the native path implements the 64x and 16x models (parallel_num 64 / 16)")
+        if self.parallel_num not in (1, 4, 16, 64):
+            raise NotImplementedError("the native path implements parallel_num 64 / 16 (the released 64x / 16x models), 4 and 1 "
+                                      "(one token per AR step: the loop of MLLModel.gen_image_full_causal, mllm.py:274-384)")
         self.ps = int(self.parallel_num ** 0.5)
         self.proj_w = ProjWeights.from_state_dict(proj_sd, device, weights=weights)
         # the reference's operator seams (same attribute names), each backed by the native engine

@@ -245,6 +245,65 @@ def gen_mllm_equiv():
     save("mllm_equiv", tokens=captured["tokens"], calls=rn.calls)
 
 
+def gen_full_causal():
+    """MLLModel.gen_image_full_causal (modeling/mllm.py:274-384): the loop gen_image dispatches to when the head's
+    parallel_num is 1 (mllm.py:268-272) -- one token per AR step, plain causal prefill, no query tokens, ps = 1.  Only the
+    diffusion_parallel_x head builds ``vision_diffusion_head`` (mllm.py:133-150), so that is the head it can run with.  Tiny
+    components of gen_fp32 with a parallel_num = 1 head, 64 x 64 px = 4 x 4 tokens = 16 AR steps, CFG 4, 4 sampling steps;
+    fp32 as on CPU and under the emulated CUDA autocast.  The reference's t2i_pipeline.gen_image on the same components has
+    to produce the same tokens with the same RNG draws (block-causal with blocks of one token IS causal)."""
+    from types import SimpleNamespace
+    import modeling.mllm as mm
+
+    class Tiny(mm.MLLModel):
+        device = "cpu"
+
+    head1 = dict(tm.TINY_HEAD, parallel_num=1)
+    for tag, dtype in (("fp32", torch.float32), ("amp", torch.bfloat16)):
+        base = build_pipeline(dtype, head1)
+        tok = tm.FakeTokenizer()
+        tk = SimpleNamespace(encode=tok.encode, start_of_image_id=tm.VISION_START)
+        for n in range(1, 129):
+            setattr(tk, f"res_{n}_id", tm.RES_BASE + n)
+        m = object.__new__(Tiny)
+        torch.nn.Module.__init__(m)
+        m.tokenizer = tk
+        m.config = SimpleNamespace(vit_patch_size=16)
+        m.llm_model = base.llm_model
+        m.hidden_size = base.hidden_size
+        m.vision_head_type = "diffusion_parallel_x"
+        m.parallel_num, m.ps = 1, 1
+        m.vision_diffusion_head = base.vision_head
+        m.embed_vision_mlp = base.embed_vision_mlp
+        m.register_buffer("pos_embed_1d", m._get_1d_sincos_pos_embed(m.hidden_size // 2, 256), persistent=False)
+        captured = {}
+        m.decode_image = lambda lat, image_size=None, ps=1: captured.setdefault("tokens", lat.clone())
+        preds = []
+        orig_sample = base.vision_head.sample
+
+        def rec_sample(*a, **k):
+            o = orig_sample(*a, **k)
+            preds.append(o.detach().clone())
+            return o
+
+        base.vision_head.sample = rec_sample
+        ctx = rh.CudaAutocastOnCpu() if tag == "amp" else torch.no_grad()
+        with torch.no_grad(), ctx, rh.ReplayNoise(seed=17) as rn:
+            m.gen_image_full_causal("a red fox", "<|", 4.0, 4, 16, 1, [64, 64], False)
+        n_model = len(preds)
+        # the same loop through the T2I pipeline's block-causal code at parallel_num = 1, same injected noise
+        cap2 = {}
+        base.decode_image = lambda lat, image_size=None, ps=1: cap2.setdefault("tokens", lat.clone())
+        ctx = rh.CudaAutocastOnCpu() if tag == "amp" else torch.no_grad()
+        with torch.no_grad(), ctx, rh.ReplayNoise(seq=[t.clone() for t in rn.record]) as rn2:
+            base.gen_image(cond_prompt="a red fox", uncond_prompt="<|", guidance_scale=4.0, num_sampling_steps=4,
+                           max_length=16, num_images=1, image_size=[64, 64])
+        assert rn2.calls == rn.calls and torch.equal(cap2["tokens"], captured["tokens"]), \
+            "mllm.gen_image_full_causal and t2i_pipeline.gen_image (parallel_num = 1) disagree"
+        save(f"full_causal_{tag}", tokens=captured["tokens"], preds=torch.stack(preds[:n_model]), noise=torch.stack(rn.record),
+             calls=rn.calls, cfg=np.float32(4.0), n_steps=4)
+
+
 def gen_interleaved():
     """MLLModel.forward_inference_block_causal (modeling/mllm.py:695-897) for an image-EDITING plan: a user text, a user image
     (encode_image :899-930 = VQModel.vt_forward -> MLPconnector -> + 2-D pos embed) and a model-generated image, CFG on (the
@@ -509,6 +568,8 @@ def main():
         return gen_pipeline()
     if len(sys.argv) > 1 and sys.argv[1] == "mllm":
         return gen_mllm_equiv()
+    if len(sys.argv) > 1 and sys.argv[1] == "full_causal":
+        return gen_full_causal()
     if len(sys.argv) > 1 and sys.argv[1] == "ae_c1":
         return gen_ae_c1()
     if len(sys.argv) > 1 and sys.argv[1] == "misc":
@@ -523,6 +584,7 @@ def main():
     gen_imagenet()
     gen_imagenet_variants()
     gen_mllm_equiv()
+    gen_full_causal()
     gen_interleaved()
     gen_text_sampling()
     gen_ae_c1()

@@ -1053,6 +1053,44 @@ def test_pipeline_from_model_dir_and_mllm_surface(tmp_path, golden_dir):
         m.gen_image_full_causal("x")
 
 
+@pytest.mark.parametrize("native_prefill", [True, False])
+def test_full_causal_loop_vs_reference(golden_dir, native_prefill):
+    """MLLModel.gen_image_full_causal (modeling/mllm.py:274-384: parallel_num == 1, one token per AR step, causal prefill, no
+    query tokens) on the native loop at P = 1 against the reference's own run (golden full_causal_amp, 16 AR steps of one token,
+    CFG 4): teacher-forced with the reference's tokens the pre-sign latents stay within the loops' bf16 bound and the firm signs
+    agree; hipGraph replay == eager launches; the dispatch of gen_image (mllm.py:268-272) reaches it; decode runs."""
+    from bitdance_amd.mllm import MLLModel
+    g = load(golden_dir, "full_causal_amp")
+    pipe = tiny_pipeline(dict(tm.TINY_HEAD, parallel_num=1), native_prefill=native_prefill)
+    m = MLLModel(pipe)
+    assert m.parallel_num == 1 and m.ps == 1
+    n, cfg = int(g["n_steps"]), float(g["cfg"])
+    noise = g["noise"].view(16, n + 1, 1, 1, 32)
+    cond_ids, uncond_ids = pipe._prompt_ids("a red fox", "<|", [64, 64], True)
+    assert len(cond_ids) == len(tm.FakeTokenizer().encode("a red fox")) + 3          # <|vision_start|>, res_h, res_w: no query tokens
+    embed = pipe.llm_w.sd["model.embed_tokens.weight"]
+    ctx = [torch.nn.functional.embedding(torch.tensor(ids, device=DEV), embed) for ids in (cond_ids, uncond_ids)]
+    tr = {}
+    pipe.gen_image_from_context(ctx[0], ctx[1], guidance_scale=cfg, num_sampling_steps=n, num_images=1, image_size=[64, 64],
+                                noise=noise, return_tokens=True, force_tokens=g["tokens"], trace=tr)
+    pred, ref = torch.stack(tr["pred"]).cpu(), g["preds"][:, :1]
+    err = (pred - ref).abs()
+    assert err.mean() <= 0.25, err.mean()
+    firm = ref.abs() > 0.5
+    assert (torch.sign(pred)[firm] == torch.sign(ref)[firm]).float().mean() >= 0.95
+    kw = dict(guidance_scale=cfg, num_sampling_steps=n, max_length=16, num_images=1, image_size=[64, 64])
+    pipe.use_graph = False
+    t_eager = m.gen_image_full_causal("a red fox", "<|", noise=noise, return_tokens=True, **kw).cpu()
+    pipe.use_graph = True
+    t_graph = m.gen_image_full_causal("a red fox", "<|", noise=noise, return_tokens=True, **kw).cpu()
+    assert torch.equal(t_eager, t_graph) and t_graph.shape == (1, 16, 32) and set(t_graph.unique().tolist()) <= {-1.0, 0.0, 1.0}
+    assert (t_graph == g["tokens"]).float().mean() >= 0.7                             # free-running: flips propagate (SURVEY 7)
+    img = m.gen_image("a red fox", "<|", **kw)                                        # parallel_num == 1 -> gen_image_full_causal
+    assert img.shape == (1, 3, 64, 64) and torch.isfinite(img).all()
+    with pytest.raises(NotImplementedError):
+        MLLModel(tiny_pipeline()).gen_image_full_causal("x")                          # a parallel_num = 64 model: the block-causal loop
+
+
 def test_native_prefill_vs_reference_and_oracle(eng_mod, golden_dir):
     """The prompt passes on the step kernels (causal block + bf16 hidden-state flow) against the reference's own outputs
     (golden llm_amp: h1 = causal call over 11 tokens, h2 = all-visible call over the next 64) with the bounds of the torch

@@ -403,6 +403,27 @@ def test_mllm_gen_image_is_the_same_loop(golden_dir):
     assert int(a["calls"]) == int(b["calls"]) and torch.equal(a["tokens"], b["tokens"])
 
 
+def test_full_causal_loop_fp32_and_amp(golden_dir):
+    """MLLModel.gen_image_full_causal (modeling/mllm.py:274-384: the loop of parallel_num == 1 models -- one token per AR step,
+    causal prefill, no query tokens, ps = 1) on the reference with a parallel_num = 1 head (goldens full_causal_*; the generator
+    also asserts the reference's t2i_pipeline.gen_image gives the same tokens at parallel_num = 1).  The oracle's one loop with
+    P = 1 reproduces it: fp32 every token identical and the pre-sign latents to 2e-4; under the emulated autocast teacher-forced
+    within the loops' bf16 bound.  So the full-causal entry point is the same native loop at P = 1 (bitdance_amd/mllm.py)."""
+    g = load(golden_dir, "full_causal_fp32")
+    assert int(g["calls"]) == 16 * (int(g["n_steps"]) + 1) and g["tokens"].shape == (1, 16, 32)
+    tr = {}
+    out = run_gen(g, "fp32", torch.float32, trace=tr, P=1, hw=4)
+    assert torch.equal(out, g["tokens"])
+    torch.testing.assert_close(torch.stack(tr["pred"]), g["preds"][:, :1], atol=2e-4, rtol=1e-3)
+    g = load(golden_dir, "full_causal_amp")
+    tr = {}
+    run_gen(g, "autocast", torch.bfloat16, force=g["tokens"], trace=tr, P=1, hw=4)
+    pred, ref = torch.stack(tr["pred"]), g["preds"][:, :1]
+    assert (pred - ref).abs().mean() <= 0.25, (pred - ref).abs().mean()
+    firm = ref.abs() > 0.5
+    assert (torch.sign(pred)[firm] == torch.sign(ref)[firm]).float().mean() >= 0.95
+
+
 def test_autoencoder_oracle_matches_reference(golden_dir):
     """oracle/autoencoder.py (functional restatement of the tokenizer's Encoder / Decoder from the state dict) against the unmodified
     reference module's outputs on seeded weights (tests/golden/ae_roundtrip.npz: image -> encoder latent -> sign; token map -> decoder
