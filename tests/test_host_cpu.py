@@ -247,8 +247,8 @@ def test_context_planning_tensor_parallel(tp):
 def test_context_planning_imagenet_1x_and_4x_variants():
     """Host-only planning of the other ImageNet variants: the MLP head (head.variant = 1) at BitDance-B-1x
     dimensions with one token per step -- 2 adaLN blocks of THREE chunks + the final layer's two = 8 x 768 adaLN columns -- and
-    the 4-token parallel variant; a transformer head with P = 1, the Qwen3 path below 16 tokens per step and an unknown variant
-    are rejected."""
+    the 4-token parallel variant; the transformer head and the Qwen3 path also plan at 4 / 1 tokens per step (the full-causal T2I
+    loop); an unknown head variant and a token count outside {1, 4, 16, 64} are rejected."""
     head_b = {"head.D": 768, "head.C": 32, "head.Dz": 768, "head.H": 1152, "head.nblocks": 6, "head.nada": 2, "head.dh": 64,
               "head.sigmoid": 0}
     l, c = _ctx({"B": 384, "branches": 2, "P": 1, "head.variant": 1, **head_b})
@@ -261,14 +261,18 @@ def test_context_planning_imagenet_1x_and_4x_variants():
     ws = {l.bd_ctx_ws_name(c, i).decode(): l.bd_ctx_ws_bytes(c, i) for i in range(l.bd_ctx_ws_count(c))}
     assert ws["head.ada_bf"] == 3072 * (2 * 6 + 2) * 768 * 2
     l.bd_ctx_destroy(c)
-    l, c = _ctx({"B": 2, "branches": 2, "P": 1, **head_b})
-    assert l.bd_ctx_finalize(c) != 0 and b"head.variant" in l.bd_last_error()
+    l, c = _ctx({"B": 2, "branches": 2, "P": 1, **head_b})                  # a transformer head with one token per step: attention
+    assert l.bd_ctx_finalize(c) == 0, l.bd_last_error()                      # over one key (out = v) -- the full-causal T2I loop
     l.bd_ctx_destroy(c)
     l, c = _ctx({"B": 2, "branches": 2, "P": 1, "head.variant": 2, **head_b})
     assert l.bd_ctx_finalize(c) != 0
     l.bd_ctx_destroy(c)
-    l, c = _ctx({**DIMS_14B, "P": 4})
-    assert l.bd_ctx_finalize(c) != 0 and b"Qwen3" in l.bd_last_error()
+    for P in (4, 1):                                                         # the Qwen3 decode path at 4 / 1 tokens per step
+        l, c = _ctx({**DIMS_14B, "P": P})                                    # (MLLModel.gen_image_full_causal, mllm.py:274-384)
+        assert l.bd_ctx_finalize(c) == 0, (P, l.bd_last_error())
+        l.bd_ctx_destroy(c)
+    l, c = _ctx({**DIMS_14B, "P": 8})
+    assert l.bd_ctx_finalize(c) != 0 and b"parallel_num" in l.bd_last_error()
     l.bd_ctx_destroy(c)
     tr = {"llm.D": 768, "llm.L": 24, "llm.nh": 12, "llm.nkv": 12, "llm.F": 2048, "llm.head_dim": 64, "llm.variant": 1,
           "llm.Lmax": 320, "llm.splits": 8, "proj.D": 768, "proj.C": 32, "proj.hid": 1152, "proj.variant": 1}
