@@ -533,8 +533,105 @@ __global__ __launch_bounds__(256) void in_attn_mfma_kernel(InAttnArgs a, int LS)
                     pack2(o[g8 * 8 + 6], o[g8 * 8 + 7])};
 }
 
+// The 1x / 4x checkpoints (one or four queries per sequence and step): the 16-query forms above spend a 256-thread workgroup and
+// scalar bf16 loads on a row or four (795 us per call at the ImageNet batch of B-1x: a third of its AR step).  Here a WAVE owns a
+// (sequence, head): a lane scores its own key (the 128 B row in eight 16 B loads, q broadcast from wave-private LDS), softmax
+// across the wave, then lane = channel for P V with the probabilities broadcast from LDS.  Same arithmetic and the same
+// summation order as in_attn_kernel for the scores and for P V (fp32, separate multiply and add, ascending d / key); the
+// softmax denominator is summed in a different order.
+template <int P>
+__global__ __launch_bounds__(256) void in_attn_small_kernel(InAttnArgs a, int LS) {
+    extern __shared__ float smem_f[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= a.nseq * a.nh) return;                              // wave-private LDS: no block-wide barrier below
+    const int seq = pair / a.nh, h = pair % a.nh;
+    const int L = a.state->kv_len[0] + P;
+    float* qs = smem_f + (size_t)wave * (P * 64 + P * LS);          // [P][64]
+    float* sc = qs + P * 64;                                        // [P][LS]
+    const int D = a.nh * 64;
+    const bf16_t* Q = (const bf16_t*)a.q + (size_t)seq * P * D + h * 64;
+    const bf16_t* Kc = a.k_cache + ((size_t)seq * a.nh + h) * a.Lmax * 64;
+    const bf16_t* Vc = a.v_cache + ((size_t)seq * a.nh + h) * a.Lmax * 64;
+#pragma unroll
+    for (int i = 0; i < P; ++i) qs[i * 64 + lane] = bf2f(Q[(size_t)i * D + lane]);
+    __builtin_amdgcn_wave_barrier();
+    for (int t0 = 0; t0 < L; t0 += 64) {
+        const int j = t0 + lane;
+        u32x4 kr[8];
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc)
+            kr[pc] = (j < L) ? *reinterpret_cast<const u32x4*>(Kc + (size_t)j * 64 + pc * 8) : (u32x4){0, 0, 0, 0};
+        float acc[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) {
+            float kf[8];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { kf[2 * t] = bf2f((bf16_t)(kr[pc][t] & 0xffff)); kf[2 * t + 1] = bf2f((bf16_t)(kr[pc][t] >> 16)); }
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(qs + i * 64 + pc * 8);
+                const f32x4 q1 = *reinterpret_cast<const f32x4*>(qs + i * 64 + pc * 8 + 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[i] = fadd(acc[i], fmul(q0[t], kf[t]));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[i] = fadd(acc[i], fmul(q1[t], kf[4 + t]));
+            }
+        }
+        if (j < L) {
+#pragma unroll
+            for (int i = 0; i < P; ++i) sc[i * LS + j] = (a.causal && j > L - P + i) ? -INFINITY : bfr(acc[i]);   // att + mask
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < P; ++i) {                                   // softmax over the row in fp32, P = bf16(e / sum)
+        float mx = -INFINITY;
+        for (int j = lane; j < L; j += 64) mx = fmaxf(mx, sc[i * LS + j]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int j = lane; j < L; j += 64) { const float e = expf(sc[i * LS + j] - mx); sc[i * LS + j] = e; sum += e; }
+        sum = wave_sum(sum);
+        for (int j = lane; j < L; j += 64) sc[i * LS + j] = bfr(sc[i * LS + j] / sum);
+    }
+    __builtin_amdgcn_wave_barrier();
+    float o[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) o[i] = 0.f;
+    int j = 0;
+    for (; j + 8 <= L; j += 8) {                                    // lane = channel: eight keys of loads in flight
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = bf2f(Vc[(size_t)(j + u) * 64 + lane]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < P; ++i) o[i] = fadd(o[i], fmul(sc[i * LS + j + u], v[u]));
+    }
+    for (; j < L; ++j) {
+        const float v = bf2f(Vc[(size_t)j * 64 + lane]);
+#pragma unroll
+        for (int i = 0; i < P; ++i) o[i] = fadd(o[i], fmul(sc[i * LS + j], v));
+    }
+    bf16_t* O = (bf16_t*)a.o_frag;
+#pragma unroll
+    for (int i = 0; i < P; ++i) O[afrag_off(seq * P + i, h * 64 + lane, a.RB)] = f2bf(o[i]);
+}
+
 int bdk_in_attn(const InAttnArgs& a, hipStream_t st) {
     if (a.P > 16) return -2;
+    if (a.P == 1 || a.P == 4) {                                    // the 1x / 4x checkpoints: a wave per (sequence, head)
+        const int LS = ((a.Lmax + 64 + 63) & ~63) + 4;             // row stride in floats
+        const size_t lds_s = (size_t)4 * (a.P * 64 + a.P * LS) * sizeof(float);
+        if (lds_s <= 64 * 1024) {
+            const dim3 grid((a.nseq * a.nh + 3) / 4);
+            if (a.P == 1) BD_LAUNCH(in_attn_small_kernel<1>, grid, dim3(256), lds_s, st, a, LS);
+            else BD_LAUNCH(in_attn_small_kernel<4>, grid, dim3(256), lds_s, st, a, LS);
+            return bd_launch_status();
+        }
+    }
     {   // matrix-pipe form: whole 16-token blocks, score rows that fit the per-wave LDS budget
         const int LS = ((a.Lmax + 64 + 63) & ~63) + 8;             // row stride in bf16: multiple of 8 (16 B reads), off the bank period
         const size_t lds_m = (size_t)4 * (16 * LS + 64 * 64) * sizeof(bf16_t);
