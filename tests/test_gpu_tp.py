@@ -432,6 +432,14 @@ def _proc(rank, world, port, q):
         tok = pipe.gen_image("a red fox", "<|", return_tokens=True, **args).cpu()
         tok2 = pipe.gen_image("a red fox", "<|", return_tokens=True, **args).cpu()     # graph replay, epochs keep counting
         img = pipe.gen_image("a red fox", "<|", **args).cpu()
+        # three images per call: each rank decodes its share of the batch (2 + 1), summed into place == every image decoded locally
+        lat = torch.sign(torch.randn(3, 128, 32, generator=torch.Generator().manual_seed(3))).to("cuda:0")
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):  # (the native decoder: per-image results do not depend on the batch)
+            split = pipe.decode_image(lat, [16, 8], ps=8).float().cpu()
+            pipe.tp_split_decode = False
+            whole = pipe.decode_image(lat, [16, 8], ps=8).float().cpu()
+            pipe.tp_split_decode = True
+        assert split.shape == (3, 3, 256, 128) and torch.equal(split, whole), (split - whole).abs().max()
         single = None
         if rank == 0:
             single = BitDanceT2IPipeline.from_components(**kw).gen_image("a red fox", "<|", return_tokens=True, **args).cpu()
