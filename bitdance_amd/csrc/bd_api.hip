@@ -164,6 +164,19 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
         if (S > 3) S = 3;
         if (S < 1) S = 1;
     }
+    // Small weights under a few thousand rows (the ImageNet 1x / 4x batches: 768 / 3072 rows, 1.2 - 3.5 MB per Linear): 256 x 256
+    // tiles leave most CUs idle at one K slice (B-4x qkv: 108 workgroups; B-1x w1: 27) and splitting K to fill the chip parks
+    // 12 - 18 fp32 slabs (B-1x w1: 85 MB of slabs for 3.5 MB of weights, then a separate swiglu_rows pass).  Smaller tiles
+    // instead, re-reading the tiny weight matrix from L2 per row tile: 256 x 128 (4 waves) when that fills the chip, else
+    // 128 x 64 (2 waves), one slice with the fused epilogue wherever that gives ~200 workgroups.  Measured (same box, no decode):
+    // B-1x 36.3 -> 49.9 images/s (w1 13.2 + 12.5 (swiglu_rows) -> 17.3 us, w2 15.5 (18 slabs) -> 11.8 (3)), B-4x 50.6 -> 58.8.
+    if (two_images && c->Mpad <= (int)c->geti("tune.small_tiles_rows", 4096) && (double)N * K * 2 <= 12e6 && !c->wfp8 && c->tp <= 1 &&
+        N % 64 == 0 && !reduce3) {
+        int nw = 4, wgs = (N % 128 == 0) ? (N / 128) * (c->Mpad / 256) : 0;
+        if (wgs < 200) { nw = 2; wgs = (N / 64) * (c->Mpad / 128); }
+        g.nw = nw; g.kw = 1;
+        S = swiglu ? 1 : std::max(1, std::min(4, (int)std::lround(240.0 / wgs)));
+    }
     g.S = S;
     // K stages in flight per wave: 2; 3 for the 4-wave tiles of the 128-row passes (qkv / w1: only 32 KiB per CU in flight at ring 2;
     // in situ on one box, profiles/r03_bench_b1_ring*.json: qkv 39.4 vs 41.6 us, w1 42.5 vs 44.8, image 0.2597 vs 0.2552 /s; ring 4 and
@@ -186,7 +199,7 @@ static const char* const kIntKeys[] = {
     "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid", "head.y_evals", "head.variant",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "proj.rows_all", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
     "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "rt.in_first", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ragged", "tune.ragged52", "tune.slab_cap", "tune.slab3",
-    "tune.ada_group", "tune.ada_group_nw", "tune.tp_fuse", "tune.ln_rows", "tp.ada_split"};
+    "tune.ada_group", "tune.ada_group_nw", "tune.tp_fuse", "tune.ln_rows", "tune.small_tiles_rows", "tp.ada_split"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
                                          "llm.qkv", "llm.o", "llm.gu", "llm.down"};
 static bool known_int_key(const std::string& k) {
