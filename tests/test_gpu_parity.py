@@ -601,6 +601,44 @@ def test_imagenet_head_eval_dh64_vs_oracle(eng_mod):
     assert d.max() <= 0.08 * ref.abs().max() + 0.02 and d.mean() <= 0.01 * ref.abs().mean() + 2e-3, (d.max(), d.mean())
 
 
+def test_ln_mod_wave_per_row_matches_workgroup_per_row(eng_mod):
+    """From 1024 rows up the head's ``ln_mod`` runs one WAVE per row, eight rows per workgroup (bd_rows.hip ln_mod_rows_kernel; the
+    ImageNet batch) instead of one workgroup per row: same arithmetic per element, the LayerNorm sums in a different order.  One
+    evaluation of the tiny ImageNet head (D = 256: the one-pass form) at 1024 rows with ``tune.ln_rows`` 1 / 0: the predictions agree
+    to bf16 noise of the statistics (a last-bit difference in mean / rstd moves an output by <= 1 bf16 ulp before the next
+    Linear), and the first sequences match the oracle within the bound of the small-batch test."""
+    c = tm.TINY_IN
+    sd = tm.seeded_state(tm.imagenet_shapes(c), seed=29)
+    hsd = {k[len("head."):]: v for k, v in sd.items() if k.startswith("head.")}
+    hw = eng_mod.HeadWeights.from_state_dict(hsd, DEV, head_dim=64, final_sigmoid=False)
+    B, P, C, D = 32, 16, c["latent_dim"], c["dim"]                          # 2 * 32 * 16 = 1024 rows
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(2 * B, P, D, generator=g)
+    noise = torch.randn(1, 4, B, P, C, generator=g)
+    x0 = noise[0, 0]
+    outs = []
+    for rows_mode in (1, 0):
+        eng = eng_mod.Engine(hw, None, None, num_images=B, branches=2, device=DEV, max_tokens=P, parallel_num=P,
+                             tune={"ln_rows": rows_mode})
+        eng.set_schedule(3, 2.0, 1)
+        eng.load_noise(noise.to(DEV))
+        eng.reset([0] * (2 * B))
+        eng.set_int("rt.dump_xhat", 1)
+        eng.set_cond(z.to(DEV))
+        eng.view("head.xt", torch.float32, (B * P, C)).copy_(x0.reshape(B * P, C))
+        eng.head_cond()
+        eng.head_eval(0)
+        torch.cuda.synchronize()
+        outs.append(eng.view("head.xhat", torch.float32, (eng.Mpad, C))[: 2 * B * P].cpu().view(2 * B, P, C).clone())
+    d = (outs[0] - outs[1]).abs()
+    assert d.max() <= 0.03 * outs[1].abs().max() and d.mean() <= 2e-3 * outs[1].abs().mean() + 1e-4, (d.max(), d.mean())
+    sel = [0, 1, B, B + 1]                                                  # two cond + the matching uncond sequences
+    ref = diff_head.net_forward(hsd, torch.cat([x0[:2], x0[:2]]), torch.zeros(4), z[sel], Policy("autocast"),
+                                final_sigmoid=False, head_dim=64).float()
+    e = (outs[0][sel] - ref).abs()
+    assert e.max() <= 0.08 * ref.abs().max() + 0.02 and e.mean() <= 0.01 * ref.abs().mean() + 2e-3, (e.max(), e.mean())
+
+
 def test_imagenet_sample_teacher_forced_vs_reference(golden_dir):
     """BitDance.sample (model_parallel.py:371-419) with the reference's noise and tokens fed back: per-AR-step pre-sign
     latents against the reference's own (golden imagenet_amp).  Bound per step: the oracle-vs-reference bf16 noise

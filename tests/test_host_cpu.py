@@ -244,6 +244,35 @@ def test_context_planning_tensor_parallel(tp):
     l3.bd_ctx_destroy(c3)
 
 
+def test_small_weight_tile_rule_for_the_imagenet_batches():
+    """choose_cfg (bd_api.hip): small weights under a few thousand rows run 256 x 128 (4 waves) or 128 x 64 (2 waves) tiles at one K
+    slice with the fused epilogues instead of 256 x 256 tiles split 12-18 ways (B-1x: 768 rows; B-4x: 3072 rows); the 12 288-row
+    batch of B-16x and the 14B shapes at two / four images keep the 256-row kernels."""
+    tr = {"llm.D": 768, "llm.L": 12, "llm.nh": 12, "llm.nkv": 12, "llm.F": 2048, "llm.head_dim": 64, "llm.variant": 1,
+          "llm.Lmax": 320, "llm.splits": 8, "proj.D": 768, "proj.C": 32, "proj.hid": 1152, "proj.variant": 1}
+    head = {"head.D": 768, "head.C": 32, "head.Dz": 768, "head.H": 1152, "head.nblocks": 6, "head.nada": 2, "head.dh": 64,
+            "head.sigmoid": 0}
+    l, c = _ctx({"B": 384, "branches": 2, "P": 1, "head.variant": 1, **head, **tr})          # B-1x: 768 rows
+    assert l.bd_ctx_finalize(c) == 0, l.bd_last_error()
+    assert _cfg(l, c, "head.w1") == (1, 2, 1)              # 36 x 6 = 216 tiles of 128 x 64, SwiGLU in the epilogue
+    assert _cfg(l, c, "head.w2") == (3, 2, 1)              # 12 x 6 tiles x 3 slices (was 18 slabs)
+    assert _cfg(l, c, "llm.o") == (3, 2, 1) and _cfg(l, c, "llm.qkv") == (1, 2, 1)
+    l.bd_ctx_destroy(c)
+    l, c = _ctx({"B": 384, "branches": 2, "P": 4, **head, **tr})                             # B-4x: 3072 rows
+    assert l.bd_ctx_finalize(c) == 0, l.bd_last_error()
+    assert _cfg(l, c, "head.qkv") == (1, 4, 1) and _cfg(l, c, "head.w1") == (1, 4, 1)      # 18 x 12 = 216 tiles of 256 x 128
+    assert _cfg(l, c, "head.wo") == (1, 2, 1) and _cfg(l, c, "head.w2") == (1, 2, 1)       # 12 x 24 = 288 tiles of 128 x 64
+    l.bd_ctx_destroy(c)
+    l, c = _ctx({"B": 384, "branches": 2, "P": 16, **head, **tr})                            # B-16x: 12 288 rows stay on 256 x 256
+    assert l.bd_ctx_finalize(c) == 0, l.bd_last_error()
+    assert all(_cfg(l, c, n) == (1, 8, 1) for n in ("head.qkv", "head.w1", "head.wo", "head.w2"))
+    l.bd_ctx_destroy(c)
+    l, c = _ctx({**DIMS_14B, "B": 4})                                                        # 14B, four images: 52-356 MB weights
+    assert l.bd_ctx_finalize(c) == 0, l.bd_last_error()
+    assert _cfg(l, c, "head.qkv")[1] == 8 and _cfg(l, c, "head.wo")[1] == 8
+    l.bd_ctx_destroy(c)
+
+
 def test_context_planning_imagenet_1x_and_4x_variants():
     """Host-only planning of the other ImageNet variants: the MLP head (head.variant = 1) at BitDance-B-1x
     dimensions with one token per step -- 2 adaLN blocks of THREE chunks + the final layer's two = 8 x 768 adaLN columns -- and
