@@ -655,8 +655,9 @@ int bdk_in_attn(const InAttnArgs& a, hipStream_t st) {
 // LLM decode attention (flash-decode over the static KV cache) + combine
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(640) void llm_attn_kernel(LlmAttnArgs a) {
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * KSTR];
-    __shared__ __attribute__((aligned(16))) bf16_t Vs[128 * VSTR];
+    extern __shared__ __attribute__((aligned(16))) char smem_la[];
+    bf16_t* const Ks = reinterpret_cast<bf16_t*>(smem_la);            // [64 keys][KSTR]
+    bf16_t* const Vs = Ks + 64 * KSTR;                                // [128 d][VSTR]
     const int split = blockIdx.x, kvh = blockIdx.y, seq = blockIdx.z;
     const int G = a.nh / a.nkv;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = blockDim.x;
@@ -674,12 +675,14 @@ __global__ __launch_bounds__(640) void llm_attn_kernel(LlmAttnArgs a) {
     const bf16_t* Kc = (const bf16_t*)a.k_cache + ((size_t)seq * a.nkv + kvh) * a.Lmax * 128;
     const bf16_t* Vc = (const bf16_t*)a.vt_cache + ((size_t)seq * a.nkv + kvh) * 128 * a.Lmax;
 
-    u32x4 qf[8];
+    // the wave's Q fragments (8 k-steps x 16 B per lane) live in LDS, each lane reading back exactly what it parked: 32 registers
+    // freed for the K / V prefetch below (the kernel sits at the 168-register line of 3 waves per SIMD)
+    u32x4* const Qs = reinterpret_cast<u32x4*>(Vs + 128 * VSTR) + (size_t)wave * 512 + lane;
     {
         const int qrow = qvalid ? half * 32 + (lane & 31) : 0;   // padded lanes recompute row 0, never stored
         const bf16_t* qp = (const bf16_t*)a.q + ((size_t)(seq * a.P + qrow) * a.nh + head) * 128 + (lane >> 5) * 8;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qp + ks * 16);
+        for (int ks = 0; ks < 8; ++ks) Qs[ks * 64] = *reinterpret_cast<const u32x4*>(qp + ks * 16);
     }
     const float scale = 0.08838834764831845f;
     float m_run = -INFINITY, l_run = 0.f;
@@ -689,23 +692,16 @@ __global__ __launch_bounds__(640) void llm_attn_kernel(LlmAttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[nb][r] = 0.f;
 
-    for (int t = t_beg; t < t_end; ++t) {
-        const int key_base = t * 64;
-        __syncthreads();
-        for (int u = tid; u < 1024; u += NT) {               // K tile: 64 keys x 16 pieces of 8 d
-            const int key = u >> 4, dp = (u & 15) * 8;
-            *reinterpret_cast<u32x4*>(&Ks[key * KSTR + dp]) =
-                *reinterpret_cast<const u32x4*>(Kc + (size_t)(key_base + key) * 128 + dp);
-        }
-        for (int u = tid; u < 1024; u += NT) {               // V^T tile: 128 d x 8 pieces of 8 keys
-            const int d = u >> 3, kp = (u & 7) * 8;
-            *reinterpret_cast<u32x4*>(&Vs[d * VSTR + kp]) =
-                *reinterpret_cast<const u32x4*>(Vc + (size_t)d * a.Lmax + key_base + kp);
-        }
-        __syncthreads();
+    // One 64-key tile = a K phase (scores + online softmax, from Ks) and a V phase (P V, from Vs).  With two 16 B units per thread
+    // and tile (NT >= 512: the 14B model's 10 waves) the tile's V^T is requested before its K phase and the NEXT tile's K before its
+    // V phase, each parked in the same 8 registers and written to LDS behind the phase that hides it: the loop used to load K and V,
+    // wait, and only then compute -- 2 exposed HBM / L2 round trips per tile of a kernel that runs 3-5 tiles.
+    float p[2][16];
+    auto k_phase = [&](int key_base) {
         f32x16 sacc[2];
-        float p[2][16];
         float tmax = -INFINITY;
+        int qi = 0;
+        asm volatile("" : "+v"(qi));                          // opaque zero: keeps the Q fragment reads inside the tile loop (not hoisted back into registers)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -713,7 +709,7 @@ __global__ __launch_bounds__(640) void llm_attn_kernel(LlmAttnArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 const u32x4 kf = *reinterpret_cast<const u32x4*>(&Ks[(kb * 32 + (lane & 31)) * KSTR + ks * 16 + (lane >> 5) * 8]);
-                sacc[kb] = mfma32(kf, qf[ks], sacc[kb]);
+                sacc[kb] = mfma32(kf, Qs[ks * 64 + qi], sacc[kb]);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -739,6 +735,8 @@ __global__ __launch_bounds__(640) void llm_attn_kernel(LlmAttnArgs a) {
         for (int r = 0; r < 16; ++r)
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) oacc[nb][r] *= alpha;     // O^T layout: the lane's own query
+    };
+    auto v_phase = [&]() {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             u32x4 pa[2];
@@ -753,7 +751,58 @@ __global__ __launch_bounds__(640) void llm_attn_kernel(LlmAttnArgs a) {
                 }
             }
         }
-        BD_MFMA_DRAIN();                                     // the loop's exit edge leads straight to the accumulator reads (bd_common.h)
+        BD_MFMA_DRAIN();                                     // the accumulators are read (scaled) right after, across a loop edge (bd_common.h)
+    };
+    if (NT >= 512) {
+        const int u0 = tid, u1 = tid + NT;
+        const bool two = u1 < 1024;
+        u32x4 r0, r1 = {0, 0, 0, 0};
+        auto ld_k = [&](int kb_) {
+            r0 = *reinterpret_cast<const u32x4*>(Kc + (size_t)(kb_ + (u0 >> 4)) * 128 + (u0 & 15) * 8);
+            if (two) r1 = *reinterpret_cast<const u32x4*>(Kc + (size_t)(kb_ + (u1 >> 4)) * 128 + (u1 & 15) * 8);
+        };
+        auto st_k = [&]() {
+            *reinterpret_cast<u32x4*>(&Ks[(u0 >> 4) * KSTR + (u0 & 15) * 8]) = r0;
+            if (two) *reinterpret_cast<u32x4*>(&Ks[(u1 >> 4) * KSTR + (u1 & 15) * 8]) = r1;
+        };
+        auto ld_v = [&](int kb_) {
+            r0 = *reinterpret_cast<const u32x4*>(Vc + (size_t)(u0 >> 3) * a.Lmax + kb_ + (u0 & 7) * 8);
+            if (two) r1 = *reinterpret_cast<const u32x4*>(Vc + (size_t)(u1 >> 3) * a.Lmax + kb_ + (u1 & 7) * 8);
+        };
+        auto st_v = [&]() {
+            *reinterpret_cast<u32x4*>(&Vs[(u0 >> 3) * VSTR + (u0 & 7) * 8]) = r0;
+            if (two) *reinterpret_cast<u32x4*>(&Vs[(u1 >> 3) * VSTR + (u1 & 7) * 8]) = r1;
+        };
+        if (t_beg < t_end) { ld_k(t_beg * 64); st_k(); }
+        for (int t = t_beg; t < t_end; ++t) {
+            const int key_base = t * 64;
+            ld_v(key_base);                                  // in flight under the K phase
+            __syncthreads();                                 // Ks(t) visible; Vs(t - 1) consumed
+            k_phase(key_base);
+            st_v();
+            __syncthreads();                                 // Vs(t) visible; Ks(t) consumed
+            if (t + 1 < t_end) ld_k(key_base + 64);          // in flight under the V phase
+            v_phase();
+            if (t + 1 < t_end) st_k();
+        }
+    } else {
+        for (int t = t_beg; t < t_end; ++t) {
+            const int key_base = t * 64;
+            __syncthreads();
+            for (int u = tid; u < 1024; u += NT) {               // K tile: 64 keys x 16 pieces of 8 d
+                const int key = u >> 4, dp = (u & 15) * 8;
+                *reinterpret_cast<u32x4*>(&Ks[key * KSTR + dp]) =
+                    *reinterpret_cast<const u32x4*>(Kc + (size_t)(key_base + key) * 128 + dp);
+            }
+            for (int u = tid; u < 1024; u += NT) {               // V^T tile: 128 d x 8 pieces of 8 keys
+                const int d = u >> 3, kp = (u & 7) * 8;
+                *reinterpret_cast<u32x4*>(&Vs[d * VSTR + kp]) =
+                    *reinterpret_cast<const u32x4*>(Vc + (size_t)d * a.Lmax + key_base + kp);
+            }
+            __syncthreads();
+            k_phase(key_base);
+            v_phase();
+        }
     }
     // partial results: [seq][kvh][split][G*P rows][128] and (m, l) per row
     const size_t blk = ((size_t)seq * a.nkv + kvh) * a.splits + split;
@@ -838,7 +887,10 @@ int bdk_llm_attn(const LlmAttnArgs& a, hipStream_t st) {
     const int G = a.nh / a.nkv;
     const int halves = (a.P + 31) / 32;
     if (a.P < 1 || a.P > 64 || G * halves * 64 > 640 || a.nh % a.nkv) return -2;   // G <= 5 (Qwen3-14B: 40/8); P = 1 / 4: a mostly padded half
-    BD_LAUNCH(llm_attn_kernel, dim3(a.splits, a.nkv, a.nseq), dim3(G * halves * 64), 0, st, a);
+    const int lds = (64 * KSTR + 128 * VSTR) * (int)sizeof(bf16_t) + G * halves * 8192;     // K / V^T tiles + 8 KiB of Q fragments per wave
+    static unsigned long long optin = 0;
+    if (!bd_lds_optin((const void*)llm_attn_kernel, 160 * 1024, &optin)) return -8;
+    BD_LAUNCH(llm_attn_kernel, dim3(a.splits, a.nkv, a.nseq), dim3(G * halves * 64), lds, st, a);
     BD_LAUNCH(llm_attn_combine_kernel, dim3(a.nseq * a.P, (a.nh + 3) / 4), dim3(256), 0, st, a);
     return bd_launch_status();
 }
