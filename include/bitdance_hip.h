@@ -75,7 +75,7 @@ int bd_quant_rows8(void* a8, float* ascale, const float* src_rows_f32, int M, in
 int bd_gemm_w8a8(const void* a8, const float* ascale, int RB, const void* w8k, const float* wscale, const void* bias, int N, int K, int S, int nw,
                  int epi, float* scratch, int* counters, void* out, void* stream);
 
-/* ---- context: named ints / floats / device pointers, then finalize.  Keys are listed in DESIGN.md; an unknown key is an
+/* ---- context: named ints / floats / device pointers, then finalize.  Keys are listed in INTEGRATION.md (appendix) / bd_api.hip kIntKeys, kPtrKeys; an unknown key is an
  *      error (-1, text in bd_last_error()), never a silent default. */
 bd_ctx* bd_ctx_create(void);
 void bd_ctx_destroy(bd_ctx* c);
