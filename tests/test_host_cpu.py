@@ -355,10 +355,16 @@ def test_launch_plan_rules_measured_in_round_2():
     assert l.bd_ctx_finalize(c) == 0, l.bd_last_error()
     assert all(_cfg(l, c, "head." + n)[0] == 1 for n in ("qkv", "wo", "w1", "w2", "ada"))
     l.bd_ctx_destroy(c)
-    l, c = _ctx({"B": 384, "branches": 2, "P": 4, "head.H": 2048, "tune.slab_cap": 0, **head_b})
+    # (round 4: these batches now take the small-weight tile rule, test_small_weight_tile_rule_for_the_imagenet_batches;
+    #  tune.small_tiles_rows = 0 keeps the 256 x 256 tiles whose rules are pinned here)
+    old = {"tune.small_tiles_rows": 0}
+    l, c = _ctx({"B": 384, "branches": 2, "P": 4, "head.H": 2048, "tune.slab_cap": 0, **old, **head_b})
     assert l.bd_ctx_finalize(c) == 0 and _cfg(l, c, "head.w2")[0] > 1
     l.bd_ctx_destroy(c)
-    l, c = _ctx({"B": 384, "branches": 2, "P": 1, "head.variant": 1, "head.H": 1152, **head_b})   # B-1x: 768 rows = 3 row tiles
+    l, c = _ctx({"B": 384, "branches": 2, "P": 4, "head.H": 2048, **old, **head_b})
+    assert l.bd_ctx_finalize(c) == 0 and all(_cfg(l, c, "head." + n) == (1, 8, 1) for n in ("qkv", "wo", "w1", "w2"))
+    l.bd_ctx_destroy(c)
+    l, c = _ctx({"B": 384, "branches": 2, "P": 1, "head.variant": 1, "head.H": 1152, **old, **head_b})   # B-1x: 768 rows = 3 row tiles
     assert l.bd_ctx_finalize(c) == 0, l.bd_last_error()
     assert _cfg(l, c, "head.w1")[0] == 6 and _cfg(l, c, "head.w2")[0] == 18
     l.bd_ctx_destroy(c)
