@@ -442,6 +442,7 @@ def main():
         return tokens_agree(dist, next(iter(pipe._engines.values())).tok_all, dev)
 
     tp_note = None
+    tp_fused_check = None
     # tensor parallel: the first image is always an untimed, verified one (every rank finished, bit-identical tokens; else the
     # fall-back chain below) -- also with --warmup 0, where it is the only untimed pass
     for i in range(max(args.warmup, 1) if tp_mode else args.warmup):
@@ -482,6 +483,29 @@ def main():
                         pipe.attn_splits = args.attn_splits
                     pipe.use_graph = not args.no_graph
                     one_pass(i)
+            if tp_mode and comm.backend != "rccl" and "tp_fuse" not in tune:
+                # The construction-time self-test covers the exchange kernel; the push fused into the GEMM epilogues and the push
+                # all-gather of the column-split adaLN projection first meet real links here.  Both are bit-identical to the
+                # conservative forms by construction (tests/test_gpu_tp.py), so the same image is generated once more with
+                # tune.tp_fuse = 0 / tp.ada_split = 0 and the tokens compared on every rank: equal -> the fused forms are timed;
+                # different -> the conservative forms are, and the line says so.
+                eng0 = next(iter(pipe._engines.values()))
+                fused_sum, was_split = token_checksum(eng0.tok_all).clone(), bool(getattr(eng0, "ada_split", False))
+                keep = (pipe.tune, getattr(pipe, "extra_ints", None))
+                pipe.tune = dict(tune, tp_fuse=0)
+                pipe.extra_ints = {"tp.ada_split": 0}
+                pipe._engines.clear()
+                same = tp_pass_ok(i) and bool(torch.equal(token_checksum(next(iter(pipe._engines.values())).tok_all), fused_sum))
+                flag = torch.tensor([1 if same else 0], device="cpu" if dist.get_backend() == "gloo" else dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                tp_fused_check = bool(int(flag.item()))
+                if tp_fused_check:
+                    pipe.tune, pipe.extra_ints = keep
+                    pipe._engines.clear()
+                    one_pass(i)                                # engines and graphs of the timed configuration are built untimed
+                elif rank == 0:
+                    print("[bench] fused reduce-scatter push / column-split adaLN disagree with the unfused exchange on this node "
+                          f"(adaLN split was {'on' if was_split else 'off'}): timing the unfused forms", file=sys.stderr, flush=True)
         else:
             one_pass(i)
     barrier()
@@ -524,7 +548,10 @@ def main():
             n_x = ar_steps * (n_sampling + 1) * 2 * nblk + (ar_steps - 1) * 2 * L
             info = comm.info()
             out["tp"] = {"size": n, "world_size_seen": dist.get_world_size(), "process_group_backend": dist.get_backend(),
-                         "exchange_backend": comm.backend, "exchange_fences": getattr(comm, "fences", 0), "reduce_scatter_push": "fused into the row-split GEMM epilogue (tune.tp_fuse)",
+                         "exchange_backend": comm.backend, "exchange_fences": getattr(comm, "fences", 0),
+                         "reduce_scatter_push": ("in the exchange kernel" if (tune.get("tp_fuse", 1) == 0 or tp_fused_check is False or comm.backend == "rccl")
+                                                 else "fused into the row-split GEMM epilogue (tune.tp_fuse)"),
+                         "fused_forms_equal_unfused_on_this_node": tp_fused_check,
                          "exchange_buffer_uncached": info["data_uncached"],
                          "flag_block_uncached": info["flags_uncached"], "fallback_reason": getattr(comm, "fallback_reason", None),
                          "images_checked_bit_identical": args.steps + 1,

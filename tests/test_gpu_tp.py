@@ -526,6 +526,8 @@ def test_bench_gpus2_from_plain_python_starts_its_own_ranks():
     tp = d["tp"]
     assert tp["size"] == 2 and tp["world_size_seen"] == 2 and tp["exchange_backend"] == "ipc" and tp["ranks_bit_identical"] is True
     assert tp["exchange_buffer_uncached"] in (True, False) and tp["images_checked_bit_identical"] == 2
+    # the warm-up image is generated once more with the push in the exchange kernel and the adaLN projection replicated: same tokens
+    assert tp["fused_forms_equal_unfused_on_this_node"] is True and tp["reduce_scatter_push"].startswith("fused")
 
 
 def test_bench_tensor_parallel_failure_ends_in_replicas_not_in_a_crash():
