@@ -51,6 +51,7 @@ struct GemmP {
 
 // MFMA-bound form for >= 512 rows: both operands through LDS, 256 x 256 workgroup tiles (bd_gemm_tile.hip)
 int bdk_gemm_tile(const GemmP& p, int epi, hipStream_t st);
+void bdk_gemm_tile_stg(int v);
 
 // R = depth of the per-wave W register ring = number of K stages a wave keeps in flight.  The A stage is
 // prefetched equally far ahead (R-1 register slots, then one ds_write into the double-buffered LDS tile): vmcnt retires

@@ -147,6 +147,54 @@ def test_gemm_wide_options(eng_mod, M, N, K, S, ring, xcd):
     assert err <= 2e-5 * K ** 0.5 + 1e-5, err
 
 
+@pytest.mark.parametrize("K,S", [(64, 1), (128, 1), (192, 1), (448, 1), (768, 1), (1024, 1), (5120, 1), (1024, 2), (2048, 3)])
+def test_gemm_tile_kernel_both_fetch_forms(eng_mod, K, S):
+    """The LDS-tiled 256 x 256 kernel (bd_gemm_tile.hip: from 1024 rows on N >= 4096) in both operand-fetch forms -- LDS-DMA
+    (option "tile" = 3) and register-staged global loads, three stages ahead in three register sets (= 2) -- against the 256-row
+    weight-streaming kernel (= 0): every accumulator sees its K steps in the same order through the same MFMA, so the fp32 slabs,
+    the bf16(+bias) output and the fused SwiGLU operand are bit-identical; and right against fp64.  K covers 32-deep stage counts
+    2 .. 160 with every residue mod 3 (the register sets rotate over whole triples; the last 1-3 stages run behind conditions)
+    and split-K slices."""
+    from bitdance_amd._lib import check, lib
+    M, N = 1024, 4096
+    g = torch.Generator(device=DEV).manual_seed(K + S)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = (torch.randn(N, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+    xf, rb = frag(eng_mod, x)
+    wp = eng_mod.pack_linear([w], DEV)
+    ws = eng_mod.pack_swiglu(w[: N // 2], w[N // 2:], DEV)
+    bs = eng_mod.pack_swiglu_bias(b[: N // 2], b[N // 2:], DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+    try:
+        for tile in (0, 3, 2):
+            check(lib().bd_set_gemm_option(b"tile", tile))
+            slabs = torch.full((S, rb * 32, N), float("nan"), device=DEV)
+            check(lib().bd_gemm_partial(xf.data_ptr(), rb, wp.data_ptr(), N, K, S, 8, slabs.data_ptr(), st))
+            outs = [slabs]
+            if S == 1:
+                o16 = torch.zeros(rb * 32, N, dtype=torch.bfloat16, device=DEV)
+                check(lib().bd_gemm_bf16(xf.data_ptr(), rb, wp.data_ptr(), b.data_ptr(), N, K, 1, 8, None, None, o16.data_ptr(), st))
+                act = torch.zeros(rb * 32 * (N // 2), dtype=torch.bfloat16, device=DEV)
+                check(lib().bd_gemm_swiglu(xf.data_ptr(), rb, ws.data_ptr(), bs.data_ptr(), N, K, 8, act.data_ptr(), st))
+                outs += [o16, act]
+            torch.cuda.synchronize()
+            res[tile] = outs
+    finally:
+        check(lib().bd_set_gemm_option(b"tile", 1))
+    for tile in (3, 2):
+        for a, c in zip(res[0], res[tile]):
+            assert torch.equal(a.view(torch.int32 if a.dtype == torch.float32 else torch.int16),
+                               c.view(torch.int32 if c.dtype == torch.float32 else torch.int16)), (tile, a.dtype)
+    ref = x.to(torch.bfloat16).double() @ w.double().t()
+    err = (res[2][0].sum(0)[:M].double() - ref).abs().max().item()
+    assert err <= 2e-5 * K ** 0.5 + 1e-5, err
+    if S == 1:
+        d = (res[2][1][:M].double() - (ref + b.double())).abs().max().item()
+        assert d <= 0.05, d                                                  # one bf16 rounding of values of O(1)
+
+
 # ----------------------------------------------------------------------------------------------- head
 def tiny_head_engine(eng_mod, B=2, branches=2):
     sd = tm.seeded_state(tm.head_shapes(tm.TINY_HEAD), seed=11)

@@ -50,7 +50,7 @@ def main():
         bias = (torch.randn(N, device=DEV, generator=g) * 0.1).to(BF16)
         outs = {}
         res = {}
-        for tile in (0, 1):
+        for tile in ((0, 1) if keep_mode else (0, 3, 2)):
             if keep_mode:                                   # slot 0: nt loads, slot 1: default-policy loads, both on the 256-row kernel
                 check(l.bd_set_gemm_option(b"tile", 0))
                 check(l.bd_set_gemm_option(b"wide.keep", tile))
@@ -72,11 +72,17 @@ def main():
             outs[tile] = out.clone()
             reps = 3 if RB >= 128 else 10
             res[tile] = timed(launch, reps)
-        same = torch.equal(outs[0].view(torch.int16 if form != "p" else torch.int32), outs[1].view(torch.int16 if form != "p" else torch.int32))
+        vw = torch.int16 if form != "p" else torch.int32
+        same = torch.equal(outs[0].view(vw), outs[1 if keep_mode else 3].view(vw))
         fl = 2.0 * M * N * K
-        la, lb = ("nt loads      ", "default loads") if keep_mode else ("256-row kernel", "tile kernel")
-        print(f"{name:16s} N={N:6d} K={K:5d} rows={M:6d} S={S}  {la} {res[0]:9.1f} us {fl / res[0] / 1e6:7.0f} TFLOP/s | "
-              f"{lb} {res[1]:9.1f} us {fl / res[1] / 1e6:7.0f} TFLOP/s ({fl / res[1] / 1e6 / 2500:.3f} of peak) | bit-identical {same}", flush=True)
+        la, lb = ("nt loads      ", "default loads") if keep_mode else ("256-row kernel", "tile kernel (LDS-DMA)")
+        t1 = 1 if keep_mode else 3
+        line = (f"{name:16s} N={N:6d} K={K:5d} rows={M:6d} S={S}  {la} {res[0]:9.1f} us {fl / res[0] / 1e6:7.0f} TFLOP/s | "
+                f"{lb} {res[t1]:9.1f} us {fl / res[t1] / 1e6:7.0f} TFLOP/s ({fl / res[t1] / 1e6 / 2500:.3f} of peak) | bit-identical {same}")
+        if 2 in res:                                            # the tile kernel with register-staged operand fetch (option "tile" = 2)
+            same2 = torch.equal(outs[0].view(vw), outs[2].view(vw))
+            line += f" | register-staged {res[2]:9.1f} us {fl / res[2] / 1e6:7.0f} TFLOP/s | bit-identical {same2}"
+        print(line, flush=True)
         del ws, a, outs
         torch.cuda.empty_cache()
     check(l.bd_set_gemm_option(b"tile", 1))
