@@ -16,6 +16,8 @@
 //     j + 3 is issued right behind the barrier that opens stage j, so three stages (~1.3 us of MFMA time) of L2 / HBM latency
 //     are covered.  The DMAs are inline asm with hand-counted s_waitcnt vmcnt: hipcc counts an LDS-DMA builtin as a store to
 //     all of LDS and drains the queue before the next ds_read (no pipelining at all);
+//     (second form, STG = true, default from 64 stages per slice: the same chunks by plain 16 B global loads into three rotating
+//     register sets, written to their slot one stage ahead -- 2-6 % faster on long K, see the main-loop comment);
 //   * the two waves of every SIMD run half a stage apart (ping-pong): while one issues its 16 MFMAs of a stage from registers
 //     the other reads its next fragments from LDS and issues / awaits its DMAs, one s_barrier per half-step (main-loop comment);
 //   * workgroup -> tile map: block b runs on XCD b % 8 (observed placement, used for speed only).  The 32 blocks an XCD runs
