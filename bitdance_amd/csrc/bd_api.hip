@@ -459,8 +459,8 @@ int bd_ctx_finalize(bd_ctx* c) {
             // consecutive evaluations are ONE GEMM over G * Mpad rows (the 256-row kernel: weights streamed once per G
             // evaluations instead of once per evaluation -- 21 % of the head's weight bytes; every row's K sum runs in the same
             // order through the same MFMA, so the result is bit-identical to G separate launches).  Default: 512 rows per GEMM
-            // (4 evaluations at 128 rows); larger groups measured no further gain in situ (profiles/r03_head_sweep2.log: 974 us
-            // per evaluation at G = 4, 8 and 16 against 1006 at G = 1).  The last group of a schedule is short.
+            // (4 evaluations at 128 rows; round 3, profiles/r03_head_sweep2.log: 974 us per evaluation at G = 4, 8 and 16 against
+            // 1006 at G = 1), 2048 rows for the single-GPU 14B head since round 4 (below).  The last group of a schedule is short.
             {
                 long long g = c->geti("tune.ada_group", -1);
                 // (fp8 weights with bf16 activations have no 256-row form; fp8 weights + activations do: bd_gemm8.hip)
@@ -468,6 +468,12 @@ int bd_ctx_finalize(bd_ctx* c) {
                 // 128 rows and fewer: 512 rows per GEMM; 256 / 512 rows (num_images 2 / 4): 1024 rows per GEMM, where the LDS-tiled
                 // MFMA-bound kernel takes over (bd_gemm_tile.hip: adaLN at 1024 rows 694 vs 786 us on the 256-row kernel)
                 if (g < 0) g = !can ? 1 : (Mp <= 128 ? 512 / Mp : (Mp <= 512 && 1024 % Mp == 0 ? 1024 / Mp : 1));
+                // round 4: one image on one GPU, bf16, a wide projection (the 14B head): 2048 rows per GEMM -- the tiled kernel with
+                // register-staged operand fetch (bd_gemm_tile.hip) runs 16 evaluations' projections in 1204 us (75 us each) against 92-96 us
+                // each for 4 on the 256-row kernel; in situ on one box (profiles/r04_head_sweep_ada_group.log) 987.9 us per evaluation at
+                // G = 16 against 1003.7 / 1007.0 at G = 4, 998.3 at 8, 990.8 at 26.  293 MB of modulation tensor instead of 73.
+                // Tensor-parallel contexts keep 512 rows (the gather region and the all-gather payload scale with G).
+                if (c->geti("tune.ada_group", -1) < 0 && can && Mp == 128 && tp <= 1 && !c->wfp8 && c->hNada >= 4096 && c->hD >= 2048) g = 16;
                 if (g < 1 || g > 64 || (g > 1 && ((c->RB * g) % 8 != 0 || !can)))
                     return fail("tune.ada_group: 1..64 evaluations, rows a multiple of 256, adaLN width a multiple of 256, bf16 weights or fp8 weights + activations");
                 c->adaG = (int)g;
