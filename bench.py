@@ -132,7 +132,7 @@ def gemm_roofline(eng, run, rows: int) -> dict:
             peak = MFMA_PEAK_TFS * (2 if eng.wdtype == 2 else 1)  # fp8 x fp8 MFMA: twice the bf16 rate
             rec["TFLOPs"] = round(r["bytes"] * (2 / bpw) * G * rows / r["ms"] / 1e9, 1)
             rec["frac_of_mfma_peak"] = round(rec["TFLOPs"] / peak, 4)
-            rec["note"] = (f"ONE pass over the weights serves {G} evaluations (256-row kernel, MFMA-bound at {G * rows} rows): GBs = bytes "
+            rec["note"] = (f"ONE pass over the weights serves {G} evaluations ({'LDS-tiled 256 x 256 kernel' if G * rows >= 1024 else '256-row kernel'}, MFMA-bound at {G * rows} rows): GBs = bytes "
                            f"physically streamed / time, algorithmic_GBs = {G} x N*K*2 (the reference streams them once per evaluation) / time")
             grouped.append(rec)
         else:
@@ -141,7 +141,7 @@ def gemm_roofline(eng, run, rows: int) -> dict:
     tot_b = sum(r["bytes"] for r in fam.values())
     tot_ms = sum(r["ms"] for r in fam.values())
     n_launch = sum(r["count"] for r in fam.values())
-    common = {"kernel": "gemm_kernel<NP,KW,MB,EPI,R,RED> / gemm_wide_kernel (bd_gemm.hip): every GEMM launch of one AR step, in situ",
+    common = {"kernel": "gemm_kernel<NP,KW,MB,EPI,R,RED> / gemm_wide_kernel (bd_gemm.hip) / gemm_tile_kernel (bd_gemm_tile.hip: grouped adaLN): every GEMM launch of one AR step, in situ",
               "launches": n_launch, "avg_launch_us": round(tot_ms / n_launch * 1e3, 2), "per_gemm": per}
     prof = fam
     if rows > 256:

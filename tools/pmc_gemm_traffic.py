@@ -30,7 +30,10 @@ SHAPES = [("head.ada", 71680, 5120, 1, 9, 1, 2), ("head.qkv", 15360, 5120, 2, 4,
           # kernel (gemm_wide_kernel: default-policy weight loads and XCD placement with two row tiles, bd_gemm.hip launch_gemm_wide).
           # (Round 3 listed it with launch code 4 waves, which selects gemm_kernel<4,1,8> -- a different kernel: its 2.16x read ratio and
           # 514 us were not the engine's launch.)
-          ("head.ada[x4]", 71680, 5120, 1, 8, 1, 2, 512)]
+          ("head.ada[x4]", 71680, 5120, 1, 8, 1, 2, 512),
+          # round 4 default for one image on one GPU: 16 evaluations x 128 rows = 2048 rows on the LDS-tiled kernel (bd_gemm_tile.hip,
+          # register-staged operand fetch): the same 734 MB of weights, 293 MB of bf16 modulation tensor written
+          ("head.ada[x16]", 71680, 5120, 1, 8, 1, 2, 2048)]
 
 
 def _shape(sh):
@@ -82,7 +85,7 @@ def _rows(db_path, counter):
 
 def parse(out_path, fetch_db, write_db=None, sq_db=None):
     def gemms(rows):
-        g = [r for r in rows if "gemm_kernel" in r[1] or "gemm_wide" in r[1]]
+        g = [r for r in rows if "gemm_kernel" in r[1] or "gemm_wide" in r[1] or "gemm_tile" in r[1]]
         assert len(g) == REPS * len(SHAPES), (len(g), REPS * len(SHAPES))
         return g
 
