@@ -23,6 +23,11 @@ BD_DEV f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
                                                    __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
 }
 
+BD_DEV void ld_bf16x8_attn(const bf16_t* p, float* v) {
+    const u32x4 q = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[2 * j] = bf2f((bf16_t)(q[j] & 0xffff)); v[2 * j + 1] = bf2f((bf16_t)(q[j] >> 16)); }
+}
 #define KSTR 136   // K tile row stride (bf16): 128 + 8 -> conflict-free ds_read_b128 across 16 rows
 #define VSTR 72    // V^T tile row stride (bf16): 64 + 8
 
@@ -535,10 +540,13 @@ __global__ __launch_bounds__(256) void in_attn_mfma_kernel(InAttnArgs a, int LS)
 
 // The 1x / 4x checkpoints (one or four queries per sequence and step): the 16-query forms above spend a 256-thread workgroup and
 // scalar bf16 loads on a row or four (795 us per call at the ImageNet batch of B-1x: a third of its AR step).  Here a WAVE owns a
-// (sequence, head): a lane scores its own key (the 128 B row in eight 16 B loads, q broadcast from wave-private LDS), softmax
-// across the wave, then lane = channel for P V with the probabilities broadcast from LDS.  Same arithmetic and the same
-// summation order as in_attn_kernel for the scores and for P V (fp32, separate multiply and add, ascending d / key); the
-// softmax denominator is summed in a different order.
+// (sequence, head) and every global access is one contiguous KiB: lane = (key of a group of 8, 16 B piece of its 128 B row).
+//   scores: a lane's 8-channel partial of q . k (fp32, separate multiply and add), summed over the row's 8 lanes by three xor
+//           steps, rounded to bf16 (the autocast matmul output), masked, parked in wave-private LDS;
+//   softmax over the whole row in fp32, P = bf16(e / sum) (the reference rounds P only after the full-row sum);
+//   P V:    the same lane map on V -- a lane accumulates its 8 channels over the keys of its residue class, the 8 classes are
+//           summed by three xor steps, the class-0 lanes store 16 B of the fragment-major output.
+// Rounding points as in in_attn_kernel; the fp32 sums run in a different (tree) order.
 template <int P>
 __global__ __launch_bounds__(256) void in_attn_small_kernel(InAttnArgs a, int LS) {
     extern __shared__ float smem_f[];
@@ -547,42 +555,38 @@ __global__ __launch_bounds__(256) void in_attn_small_kernel(InAttnArgs a, int LS
     if (pair >= a.nseq * a.nh) return;                              // wave-private LDS: no block-wide barrier below
     const int seq = pair / a.nh, h = pair % a.nh;
     const int L = a.state->kv_len[0] + P;
-    float* qs = smem_f + (size_t)wave * (P * 64 + P * LS);          // [P][64]
-    float* sc = qs + P * 64;                                        // [P][LS]
+    float* sc = smem_f + (size_t)wave * (P * LS);                   // [P][LS]
     const int D = a.nh * 64;
-    const bf16_t* Q = (const bf16_t*)a.q + (size_t)seq * P * D + h * 64;
-    const bf16_t* Kc = a.k_cache + ((size_t)seq * a.nh + h) * a.Lmax * 64;
-    const bf16_t* Vc = a.v_cache + ((size_t)seq * a.nh + h) * a.Lmax * 64;
+    const int g = lane >> 3, pc = lane & 7;
+    const bf16_t* Q = (const bf16_t*)a.q + (size_t)seq * P * D + h * 64 + pc * 8;
+    const bf16_t* Kc = a.k_cache + ((size_t)seq * a.nh + h) * a.Lmax * 64 + pc * 8;
+    const bf16_t* Vc = a.v_cache + ((size_t)seq * a.nh + h) * a.Lmax * 64 + pc * 8;
+    float q[P][8];
 #pragma unroll
-    for (int i = 0; i < P; ++i) qs[i * 64 + lane] = bf2f(Q[(size_t)i * D + lane]);
-    __builtin_amdgcn_wave_barrier();
-    for (int t0 = 0; t0 < L; t0 += 64) {
-        const int j = t0 + lane;
-        u32x4 kr[8];
+    for (int i = 0; i < P; ++i) ld_bf16x8_attn(Q + (size_t)i * D, q[i]);
+    for (int t0 = 0; t0 < L; t0 += 32) {                            // 4 groups of 8 keys: four loads in flight per lane
+        u32x4 kr[4];
 #pragma unroll
-        for (int pc = 0; pc < 8; ++pc)
-            kr[pc] = (j < L) ? *reinterpret_cast<const u32x4*>(Kc + (size_t)j * 64 + pc * 8) : (u32x4){0, 0, 0, 0};
-        float acc[P];
+        for (int u = 0; u < 4; ++u) {
+            const int j = t0 + u * 8 + g;
+            kr[u] = (j < L) ? *reinterpret_cast<const u32x4*>(Kc + (size_t)j * 64) : (u32x4){0, 0, 0, 0};
+        }
 #pragma unroll
-        for (int i = 0; i < P; ++i) acc[i] = 0.f;
-#pragma unroll
-        for (int pc = 0; pc < 8; ++pc) {
+        for (int u = 0; u < 4; ++u) {
+            const int j = t0 + u * 8 + g;
             float kf[8];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { kf[2 * t] = bf2f((bf16_t)(kr[pc][t] & 0xffff)); kf[2 * t + 1] = bf2f((bf16_t)(kr[pc][t] >> 16)); }
+            for (int t = 0; t < 4; ++t) { kf[2 * t] = bf2f((bf16_t)(kr[u][t] & 0xffff)); kf[2 * t + 1] = bf2f((bf16_t)(kr[u][t] >> 16)); }
 #pragma unroll
             for (int i = 0; i < P; ++i) {
-                const f32x4 q0 = *reinterpret_cast<const f32x4*>(qs + i * 64 + pc * 8);
-                const f32x4 q1 = *reinterpret_cast<const f32x4*>(qs + i * 64 + pc * 8 + 4);
+                float acc = 0.f;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[i] = fadd(acc[i], fmul(q0[t], kf[t]));
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[i] = fadd(acc[i], fmul(q1[t], kf[4 + t]));
+                for (int t = 0; t < 8; ++t) acc = fadd(acc, fmul(q[i][t], kf[t]));
+                acc = fadd(acc, __shfl_xor(acc, 1));
+                acc = fadd(acc, __shfl_xor(acc, 2));
+                acc = fadd(acc, __shfl_xor(acc, 4));
+                if (pc == 0 && j < L) sc[i * LS + j] = (a.causal && j > L - P + i) ? -INFINITY : bfr(acc);   // att + mask
             }
-        }
-        if (j < L) {
-#pragma unroll
-            for (int i = 0; i < P; ++i) sc[i * LS + j] = (a.causal && j > L - P + i) ? -INFINITY : bfr(acc[i]);   // att + mask
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -597,34 +601,56 @@ __global__ __launch_bounds__(256) void in_attn_small_kernel(InAttnArgs a, int LS
         for (int j = lane; j < L; j += 64) sc[i * LS + j] = bfr(sc[i * LS + j] / sum);
     }
     __builtin_amdgcn_wave_barrier();
-    float o[P];
+    float o[P][8];
 #pragma unroll
-    for (int i = 0; i < P; ++i) o[i] = 0.f;
-    int j = 0;
-    for (; j + 8 <= L; j += 8) {                                    // lane = channel: eight keys of loads in flight
-        float v[8];
+    for (int i = 0; i < P; ++i)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = bf2f(Vc[(size_t)(j + u) * 64 + lane]);
+        for (int t = 0; t < 8; ++t) o[i][t] = 0.f;
+    for (int t0 = 0; t0 < L; t0 += 32) {
+        u32x4 vr[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 4; ++u) {
+            const int j = t0 + u * 8 + g;
+            vr[u] = (j < L) ? *reinterpret_cast<const u32x4*>(Vc + (size_t)j * 64) : (u32x4){0, 0, 0, 0};
+        }
 #pragma unroll
-            for (int i = 0; i < P; ++i) o[i] = fadd(o[i], fmul(sc[i * LS + j + u], v[u]));
-    }
-    for (; j < L; ++j) {
-        const float v = bf2f(Vc[(size_t)j * 64 + lane]);
+        for (int u = 0; u < 4; ++u) {
+            const int j = t0 + u * 8 + g;
+            if (j < L) {
+                float vf[8];
 #pragma unroll
-        for (int i = 0; i < P; ++i) o[i] = fadd(o[i], fmul(sc[i * LS + j], v));
+                for (int t = 0; t < 4; ++t) { vf[2 * t] = bf2f((bf16_t)(vr[u][t] & 0xffff)); vf[2 * t + 1] = bf2f((bf16_t)(vr[u][t] >> 16)); }
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    const float pj = sc[i * LS + j];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) o[i][t] = fadd(o[i][t], fmul(pj, vf[t]));
+                }
+            }
+        }
     }
     bf16_t* O = (bf16_t*)a.o_frag;
 #pragma unroll
-    for (int i = 0; i < P; ++i) O[afrag_off(seq * P + i, h * 64 + lane, a.RB)] = f2bf(o[i]);
+    for (int i = 0; i < P; ++i) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            float v = o[i][t];
+            v = fadd(v, __shfl_xor(v, 8));
+            v = fadd(v, __shfl_xor(v, 16));
+            v = fadd(v, __shfl_xor(v, 32));
+            o[i][t] = v;
+        }
+        if (g == 0)
+            *reinterpret_cast<u32x4*>(O + afrag_off(seq * P + i, h * 64 + pc * 8, a.RB)) =
+                (u32x4){pack2(o[i][0], o[i][1]), pack2(o[i][2], o[i][3]), pack2(o[i][4], o[i][5]), pack2(o[i][6], o[i][7])};
+    }
 }
 
 int bdk_in_attn(const InAttnArgs& a, hipStream_t st) {
     if (a.P > 16) return -2;
     if (a.P == 1 || a.P == 4) {                                    // the 1x / 4x checkpoints: a wave per (sequence, head)
         const int LS = ((a.Lmax + 64 + 63) & ~63) + 4;             // row stride in floats
-        const size_t lds_s = (size_t)4 * (a.P * 64 + a.P * LS) * sizeof(float);
+        const size_t lds_s = (size_t)4 * (a.P * LS) * sizeof(float);
         if (lds_s <= 64 * 1024) {
             const dim3 grid((a.nseq * a.nh + 3) / 4);
             if (a.P == 1) BD_LAUNCH(in_attn_small_kernel<1>, grid, dim3(256), lds_s, st, a, LS);
