@@ -28,7 +28,9 @@ int bd_pack_weight(void* dst_packed, const void* src_bf16, int rows, int K, int 
 int bd_set_weight_layout(int stage_major);
 /* process-wide A/B switches of the GEMM kernels, for measurement (tools/, bench.py --gemm-opt); every setting computes the same
  * values.  "wide.ring" 2|3 = weight stages a wave of the 256-row kernel keeps in flight; "wide.xcd" -1|0|1 = row tiles of one
- * weight slice on one XCD (by shape / off / on). */
+ * weight slice on one XCD (by shape / off / on); "wide.keep" -1|0|1 = default-policy instead of non-temporal weight loads when
+ * several row tiles read a slice; "tile" 0|1|2|3 = from 1024 rows on N >= 4096: the 256-row kernel / the LDS-tiled 256 x 256
+ * kernel with its operand fetch chosen by shape / register-staged fetch forced / LDS-DMA fetch forced (bd_gemm_tile.hip). */
 int bd_set_gemm_option(const char* name, int value);
 int bd_pack_weight_swiglu(void* dst_packed, const void* gate_bf16, const void* up_bf16, int F, int K, void* stream);
 int bd_rows_to_frag(void* dst_frag, const void* src, int src_is_fp32, int M, int K, int row_blocks, void* stream);
