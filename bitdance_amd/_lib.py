@@ -21,6 +21,15 @@ class BitDanceHipError(RuntimeError):
     pass
 
 
+class BitDanceUnsupported(BitDanceHipError):
+    """A shape / mode the native kernels do not cover, refused on the host BEFORE anything was launched (the C ABI's
+    BD_ERR_UNSUPPORTED = -22, or a host-side validation in the wrappers): the only error a caller may answer by taking another
+    path.  Launch and runtime failures are plain BitDanceHipError and must propagate."""
+
+
+BD_ERR_UNSUPPORTED = -22
+
+
 _PROTOS = {
     "bd_version": (C.c_int, []),
     "bd_last_error": (C.c_char_p, []),
@@ -133,4 +142,5 @@ def lib() -> C.CDLL:
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = lib().bd_last_error()
-        raise BitDanceHipError(f"{what or 'libbitdance_hip'} failed ({rc}): {msg.decode() if msg else ''}")
+        raise (BitDanceUnsupported if rc == BD_ERR_UNSUPPORTED else BitDanceHipError)(
+            f"{what or 'libbitdance_hip'} failed ({rc}): {msg.decode() if msg else ''}")

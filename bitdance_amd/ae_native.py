@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import torch
 
-from ._lib import BitDanceHipError, check, lib
+from ._lib import BitDanceHipError, BitDanceUnsupported, check, lib
 
 BF16 = torch.bfloat16
 
@@ -33,7 +33,7 @@ class _Conv:
         self.stride = int(conv.stride[0])
         if (kh, kw) not in ((3, 3), (1, 1)) or self.cin % 32 or conv.stride[0] != conv.stride[1] or self.stride not in (1, 2) or \
                 (self.stride == 2 and (kh != 3 or tuple(conv.padding) != (1, 1))):
-            raise BitDanceHipError(f"native tokenizer: unsupported convolution {tuple(w.shape)} stride {tuple(conv.stride)}")
+            raise BitDanceUnsupported(f"native tokenizer: unsupported convolution {tuple(w.shape)} stride {tuple(conv.stride)}")
         npad = (self.cout + 255) // 256 * 256
         m = torch.zeros(npad, self.taps * self.cin, dtype=BF16, device=device)
         m[: self.cout] = w.permute(0, 2, 3, 1).reshape(self.cout, -1).to(BF16)
@@ -46,7 +46,7 @@ class _Conv:
 class _Norm:
     def __init__(self, gn: torch.nn.GroupNorm, device):
         if gn.num_groups != 32:
-            raise BitDanceHipError("native decoder: GroupNorm(32) only")
+            raise BitDanceUnsupported("native decoder: GroupNorm(32) only")
         self.eps = float(gn.eps)
         self.gamma = None if gn.weight is None else gn.weight.detach().to(device, torch.float32).contiguous()
         self.beta = None if gn.bias is None else gn.bias.detach().to(device, torch.float32).contiguous()
@@ -144,7 +144,7 @@ class NativeDecoder:
     def decode(self, z: torch.Tensor) -> torch.Tensor:
         """z [B, C, h, w] (the +-1 token map) -> [B, 3, H, W] bf16 (what ``Decoder.forward`` returns under bf16 autocast)."""
         if not z.is_cuda:
-            raise BitDanceHipError("native decoder: CUDA/HIP tensors only (no CPU path)")
+            raise BitDanceUnsupported("native decoder: CUDA/HIP tensors only (no CPU path)")
         n, Cz, H, W = z.shape
         self._new_call(n, H, W)
         zf = z.to(torch.float32).contiguous()
@@ -213,11 +213,11 @@ class NativeEncoder(NativeDecoder):
     def encode(self, x: torch.Tensor) -> torch.Tensor:
         """x [B, 3, H, W] image in [-1, 1] -> h [B, z_channels, H / 2^(levels-1), W / 2^(levels-1)] bf16 (pre-sign latent)."""
         if not x.is_cuda:
-            raise BitDanceHipError("native encoder: CUDA/HIP tensors only (no CPU path)")
+            raise BitDanceUnsupported("native encoder: CUDA/HIP tensors only (no CPU path)")
         n, cimg, H, W = x.shape
         f = 1 << (self.nlev - 1)
         if H % f or W % f or cimg > 32:
-            raise BitDanceHipError(f"native encoder: image sides must be multiples of {f}")
+            raise BitDanceUnsupported(f"native encoder: image sides must be multiples of {f}")
         self._new_call(n, H, W)
         p0 = self._padded("p.img", n, H, W, 32)                # zero border AND zero channels 3 .. 31 (written once: stay zero)
         p0[:, 1:-1, 1:-1, :cimg] = x.permute(0, 2, 3, 1).to(BF16)           # the conv's input cast under autocast

@@ -201,11 +201,11 @@ class VQModel(nn.Module):
         slot = self._native_state.setdefault(which, {"key": None, "obj": None, "why": None})
         if slot["key"] != key:
             from . import ae_native
-            from ._lib import BitDanceHipError
+            from ._lib import BitDanceUnsupported
             slot.update(key=key, obj=None, why=None)
             try:
                 slot["obj"] = (ae_native.NativeDecoder if which == "dec" else ae_native.NativeEncoder)(module, device)
-            except (BitDanceHipError, ValueError, NotImplementedError) as e:
+            except (BitDanceUnsupported, ValueError, NotImplementedError) as e:   # a configuration the kernels do not cover; launch failures propagate
                 slot["why"] = str(e)                          # decided once per set of weights; VQModel.native_fallback_reason reports it
         return slot["obj"]
 
@@ -231,11 +231,14 @@ class VQModel(nn.Module):
         return out if out is not None else self.decoder(quant)
 
     def _run_native(self, which, nat, method, t):
-        """A launcher that refuses a shape (host-side validation: nothing has been launched) retires the native twin for these weights."""
-        from ._lib import BitDanceHipError
+        """A launcher that refuses a shape (host-side validation, nothing has been launched: BitDanceUnsupported / the C ABI's
+        BD_ERR_UNSUPPORTED) retires the native twin for these weights and the torch module runs; every other native error -- a
+        failed launch, a runtime fault after kernels were issued -- propagates (it must not turn into a silent change of path,
+        speed and numerics)."""
+        from ._lib import BitDanceUnsupported
         try:
             return getattr(nat, method)(t)
-        except BitDanceHipError as e:
+        except BitDanceUnsupported as e:
             self._native_state[which].update(obj=None, why=str(e))
             return None
 

@@ -416,6 +416,9 @@ __global__ void tokens_to_padded_kernel(const float* z, bf16_t* out, int n, int 
 
 void bdk_set_error(const std::string& m);                        // bd_api.hip
 static int bd_last_error_set(const char* m) { bdk_set_error(m); return -1; }
+// a shape / mode the kernels do not cover, refused BEFORE anything is launched (include/bitdance_hip.h BD_ERR_UNSUPPORTED): the one
+// error a caller may answer by taking another path; launch / runtime failures keep -1 and must propagate
+static int bd_unsupported(const char* m) { bdk_set_error(m); return -22; }
 
 extern "C" {
 
@@ -424,7 +427,7 @@ extern "C" {
  * the least padding (the released sizes have latent grids of any multiple of 8: 16 .. 128); edge tiles may be partial. */
 int bd_conv_strided(const void* in, const void* w_packed, const void* bias, const void* res, int res_f32, void* out, int out_mode, int out_f32,
                     int n, int H, int W, int Cin, int Cout, int taps, int stride, void* stream) {
-    if (stride != 1 && !(stride == 2 && taps == 9)) return bd_last_error_set("bd_conv_strided: stride 1, or 2 with a 3x3 kernel");
+    if (stride != 1 && !(stride == 2 && taps == 9)) return bd_unsupported("bd_conv_strided: stride 1, or 2 with a 3x3 kernel");
     int TW = 32;
     {
         long long best = -1;
@@ -436,7 +439,7 @@ int bd_conv_strided(const void* in, const void* w_packed, const void* bias, cons
     }
     if ((taps != 9 && taps != 1) || Cin % 32 || (Cout % 8 && out_mode != 2) || H < 1 || W < 1 || out_mode < 0 || out_mode > 3 ||
         (out_mode == 1 && (Cout % 4 || (Cout / 4) % 8)))
-        return bd_last_error_set("bd_conv: taps 9 / 1, Cin % 32, Cout % 8 (any Cout for the image output), depth-to-space needs Cout / 4 % 8 == 0");
+        return bd_unsupported("bd_conv: taps 9 / 1, Cin % 32, Cout % 8 (any Cout for the image output), depth-to-space needs Cout / 4 % 8 == 0");
     ConvP p;
     p.in = (const bf16_t*)in; p.Wt = (const u32x4*)w_packed; p.bias = (const bf16_t*)bias; p.res = res; p.out = out;
     p.n = n; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.taps = taps; p.TW = TW; p.stride = stride;
@@ -458,7 +461,7 @@ int bd_conv(const void* in, const void* w_packed, const void* bias, const void* 
 
 /* GroupNorm(32) statistics of an unpadded NHWC tensor -> stats [n][32][2] = (mean, rstd); partial: scratch [n][ceil(HW / 256)][32][2] fp32 */
 int bd_gn_stats(const void* x, int x_f32, float* partial, float* stats, int n, int HW, int C, float eps, void* stream) {
-    if (C % 32 || C < 32 || C > 2048 || (256 % (C / 8)) != 0) return bd_last_error_set("bd_gn_stats: C must be a power-of-two multiple of 32, <= 2048");
+    if (C % 32 || C < 32 || C > 2048 || (256 % (C / 8)) != 0) return bd_unsupported("bd_gn_stats: C must be a power-of-two multiple of 32, <= 2048");
     GnStatsP p{x, x_f32, partial, n, HW, C, (HW + 255) / 256};
     BD_LAUNCH(gn_stats_kernel, dim3(p.chunks, n), dim3(256), 0, (hipStream_t)stream, p);
     GnFinalP f{partial, stats, n, HW, C, p.chunks, eps};
@@ -468,9 +471,9 @@ int bd_gn_stats(const void* x, int x_f32, float* partial, float* stats, int n, i
 
 int bd_gn_apply(const void* x, int x_f32, const float* stats, const float* gamma, const float* beta, const float* scale, const float* bias,
                 void* out, int out_mode, int swish, int n, int H, int W, int C, void* stream) {
-    if (C % 32) return bd_last_error_set("bd_gn_apply: C % 32");
+    if (C % 32) return bd_unsupported("bd_gn_apply: C % 32");
     GnApplyP p{x, x_f32, stats, gamma, beta, scale, bias, out, out_mode, swish, n, H, W, C};
-    if ((C / 8) < 256 ? (256 % (C / 8)) != 0 : ((C / 8) % 256) != 0) return bd_last_error_set("bd_gn_apply: C / 8 must divide, or be a multiple of, 256");
+    if ((C / 8) < 256 ? (256 % (C / 8)) != 0 : ((C / 8) % 256) != 0) return bd_unsupported("bd_gn_apply: C / 8 must divide, or be a multiple of, 256");
     BD_LAUNCH(gn_apply_kernel, dim3(n * H), dim3(256), 0, (hipStream_t)stream, p);
     return bd_launch_status() == 0 ? 0 : bd_last_error_set("bd_gn_apply: launch failed");
 }

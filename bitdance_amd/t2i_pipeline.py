@@ -354,7 +354,11 @@ class BitDanceT2IPipeline:
         prev = torch.backends.cudnn.benchmark
         torch.backends.cudnn.benchmark = True
         try:
-            if self.tp is not None and b > 1 and getattr(self, "tp_split_decode", True):
+            # (a GAN decoder draws torch.randn_like from the GLOBAL device generator: ranks decoding different numbers of images
+            # would leave the group with diverged generator offsets, and the next image's sampling noise -- engine.draw_noise, same
+            # generator -- would differ across ranks.  Every rank decodes the whole batch there: the replicated state stays replicated.)
+            gan = bool(getattr(getattr(self.ae, "decoder", None), "gan", False))
+            if self.tp is not None and b > 1 and getattr(self, "tp_split_decode", True) and not gan:
                 per = (b + self.tp.size - 1) // self.tp.size
                 lo = self.tp.rank * per
                 mine = x[lo:lo + per]

@@ -19,6 +19,11 @@ typedef struct bd_comm bd_comm;      /* tensor-parallel exchange state of one ra
 
 int bd_version(void);
 const char* bd_last_error(void);
+/* Return codes: 0 = ok; BD_ERR_UNSUPPORTED = a shape / mode the kernels do not cover, refused by host-side validation BEFORE anything
+ * was launched (the convolution / GroupNorm entries: the caller -- autoencoder.VQModel -- may answer it, and only it, by running the
+ * torch module, which is what the reference runs: autoencoder.py:129-277); any other negative value = a failed launch or a misuse,
+ * which must propagate. */
+#define BD_ERR_UNSUPPORTED (-22)
 
 /* ---- weight / activation layout conversion (load time; replaces nothing in the reference: the reference
  *      keeps nn.Linear weights [N][K] row-major, t2i_pipeline.py:50-74 -- we re-pack once into MFMA order) */

@@ -32,6 +32,22 @@ QWEN3_14B = dict(hidden_size=5120, num_attention_heads=40, num_key_value_heads=8
                  intermediate_size=17408, vocab_size=64, rms_norm_eps=1e-6, rope_theta=1000000.0)
 
 
+def _timed(fn, repeats: int):
+    """Run ``fn`` ``repeats`` times; returns (last result, [seconds per run]) -- SURVEY 8(d) asks for >= 3 repeats per CPU leg."""
+    out, ts = None, []
+    for _ in range(max(1, repeats)):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            out = fn()
+        ts.append(time.perf_counter() - t0)
+    return out, ts
+
+
+def _tstats(ts: list) -> dict:
+    s = sorted(ts)
+    return {"t_cpu_s": s[0], "t_cpu_median_s": s[len(s) // 2], "t_cpu_runs_s": [round(t, 4) for t in ts]}
+
+
 def device_seeded_state(shapes: dict, seed: int, device, gain: float = 1.0) -> dict:
     """tiny_models.seeded_state's distribution (matrices N(0, gain/sqrt(fan_in)), norm scales 1+0.1N, biases 0.1N, all
     rounded to bf16) drawn on the device: 0.8 B parameters take seconds instead of minutes.  Returns fp32 tensors on
@@ -53,7 +69,7 @@ def device_seeded_state(shapes: dict, seed: int, device, gain: float = 1.0) -> d
 
 def head_case(device="cuda", *, D=5120, Dz=None, C=32, P=64, B=1, branches=2, depth=2, nada=2, head_dim=128,
               sigmoid=True, n_steps=3, eval_index=1, seed=101, tune: dict | None = None, weights: str = "bf16",
-              mlp: bool = False) -> dict:
+              mlp: bool = False, repeats: int = 1) -> dict:
     """One head evaluation at width D: device x_hat vs oracle x_hat.  eval_index > 0 exercises a non-zero timestep
     embedding; the latent is a fixed random tensor written straight into the engine's state.  ``mlp``: the MLP head of the
     1x ImageNet models (imagenet_gen/src/diff_head.py:228-253) instead of the transformer head."""
@@ -81,14 +97,12 @@ def head_case(device="cuda", *, D=5120, Dz=None, C=32, P=64, B=1, branches=2, de
     xhat = eng.view("head.xhat", torch.float32, (eng.Mpad, C))[:M].cpu().view(branches * B, P, C)
     t_i = float(eng._sc[eval_index, 0])
     comb = torch.cat([x] * branches)
-    t0 = time.perf_counter()
-    with torch.no_grad():
+    def cpu():
         if mlp:
-            ref = diff_head.mlp_net_forward(sd, comb, torch.full((branches * B,), t_i), z, Policy("autocast")).float()
-        else:
-            ref = diff_head.net_forward(sd, comb, torch.full((branches * B,), t_i), z, Policy({"fp8": "fp8w", "fp8a": "fp8wa"}.get(weights, "autocast")),
-                                        final_sigmoid=sigmoid, head_dim=head_dim).float()
-    t_cpu = time.perf_counter() - t0
+            return diff_head.mlp_net_forward(sd, comb, torch.full((branches * B,), t_i), z, Policy("autocast")).float()
+        return diff_head.net_forward(sd, comb, torch.full((branches * B,), t_i), z, Policy({"fp8": "fp8w", "fp8a": "fp8wa"}.get(weights, "autocast")),
+                                     final_sigmoid=sigmoid, head_dim=head_dim).float()
+    ref, ts = _timed(cpu, repeats)
     err = (xhat - ref).abs()
     extra = {}
     if weights in ("fp8", "fp8a"):                          # how far the fp8 modes are from the bf16 reference flow
@@ -100,7 +114,7 @@ def head_case(device="cuda", *, D=5120, Dz=None, C=32, P=64, B=1, branches=2, de
     cfgs = {n: eng.gemm_config("head." + n) for n in (("ada", "w1", "w2") if mlp else ("ada", "qkv", "wo", "w1", "w2"))}
     macs_per_row = (D * C + D * cfgd["ch_cond"] + (nada * 6 + 2) * D * D + depth * (3 * D * D + D * D + 3 * D * D + 1.5 * D * D) + D * C)
     return {"max_err": err.max().item(), "mean_err": err.mean().item(), "ref_abs_mean": ref.abs().mean().item(),
-            "finite": bool(torch.isfinite(xhat).all()), "t_cpu_s": t_cpu, "rows": M, "macs_per_row": macs_per_row,
+            "finite": bool(torch.isfinite(xhat).all()), **_tstats(ts), "rows": M, "macs_per_row": macs_per_row,
             "gemm_cfg": {k: {"splitk": s, "nwaves": c & 15} for k, (s, c) in cfgs.items()}, "t": t_i, **extra}
 
 
@@ -140,7 +154,7 @@ def head_sample_case(device="cuda", *, D=5120, C=32, P=64, B=1, depth=6, nada=2,
             "token_agreement": agree, "evaluations": n_steps + 1, "t_cpu_s": t_cpu}
 
 
-def ae_case(device="cuda", *, config: str = "AE_D16C32", px: int = 256, seed: int = 5) -> dict:
+def ae_case(device="cuda", *, config: str = "AE_D16C32", px: int = 256, seed: int = 5, repeats: int = 1) -> dict:
     """The tokenizer's conv decoder (autoencoder.py:169-196) at its released channel counts on a ``px`` x ``px`` image: the
     native kernels (bitdance_amd/ae_native.py) vs oracle/autoencoder.py under the autocast policy, and the oracle's CPU time --
     SURVEY 8(d)'s ``t_ae256`` (a 1024-pixel decode is 16 such tiles of work: the network is fully convolutional)."""
@@ -158,17 +172,14 @@ def ae_case(device="cuda", *, config: str = "AE_D16C32", px: int = 256, seed: in
     zc = cfg["ddconfig"]["z_channels"]
     z = torch.sign(torch.randn(1, zc, px // down, px // down, generator=torch.Generator().manual_seed(seed)))
     got = nat.decode(z.to(device)).float().cpu()
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        ref = oae.decoder_forward(Policy("autocast"), sd, cfg["ddconfig"], z).float()
-    t_cpu = time.perf_counter() - t0
+    ref, ts = _timed(lambda: oae.decoder_forward(Policy("autocast"), sd, cfg["ddconfig"], z).float(), repeats)
     err = (got - ref).abs()
     return {"max_err": err.max().item(), "mean_err": err.mean().item(), "ref_abs_mean": ref.abs().mean().item(),
-            "finite": bool(torch.isfinite(got).all()), "t_cpu_s": t_cpu, "px": px}
+            "finite": bool(torch.isfinite(got).all()), **_tstats(ts), "px": px}
 
 
 def llm_case(device="cuda", *, layers=1, P=64, past=(1000, 1017), cfg: dict | None = None, seed=202,
-             tune: dict | None = None, weights: str = "bf16") -> dict:
+             tune: dict | None = None, weights: str = "bf16", repeats: int = 1) -> dict:
     """One native decode step (P new tokens per sequence, ragged cache lengths) at Qwen3-14B width vs the oracle.
     The K/V cache is filled with seeded random post-RoPE keys / values on both sides."""
     from bitdance_amd import engine as E
@@ -202,17 +213,16 @@ def llm_case(device="cuda", *, layers=1, P=64, past=(1000, 1017), cfg: dict | No
     torch.cuda.synchronize()
     got = eng.hidden().cpu().view(nseq, P, D)
     pol = Policy({"fp8": "fp8w", "fp8a": "fp8wa"}.get(weights, "autocast"))
-    t0 = time.perf_counter()
-    refs = []
-    with torch.no_grad():
+    def cpu():
+        refs = []
         for b, L in enumerate(past):
             ones = torch.ones(1, 1, P, L + P, dtype=torch.bool)
-            o, _ = qwen3.model_forward(w, c, x[b:b + 1], caches[b], ones, pol)
+            o, _ = qwen3.model_forward(w, c, x[b:b + 1], list(caches[b]), ones, pol)     # (the forward replaces the list's entries)
             refs.append(o.float())
-    t_cpu = time.perf_counter() - t0
-    ref = torch.cat(refs)
+        return torch.cat(refs)
+    ref, ts = _timed(cpu, repeats)
     err = (got - ref).abs()
     cfgs = {n: eng.gemm_config("llm." + n) for n in ("qkv", "o", "gu", "down")}
     return {"max_err": err.max().item(), "mean_err": err.mean().item(), "ref_abs_mean": ref.abs().mean().item(),
-            "finite": bool(torch.isfinite(got).all()), "t_cpu_s": t_cpu, "rows": nseq * P, "layers": layers,
+            "finite": bool(torch.isfinite(got).all()), **_tstats(ts), "rows": nseq * P, "layers": layers,
             "gemm_cfg": {k: {"splitk": s, "nwaves": c_ & 15} for k, (s, c_) in cfgs.items()}}

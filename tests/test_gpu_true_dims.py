@@ -66,7 +66,8 @@ def test_head_sample_chain_true_dims_vs_oracle():
     print(f"[head sample chain D=5120, 5 evaluations, cfg 1.25] max {r['max_err']:.4f} mean {r['mean_err']:.5f} "
           f"token agreement {r['token_agreement']:.4f} (oracle {r['t_cpu_s']:.0f} s)")
     assert r["finite"] and r["tokens_are_sign_of_pred"], r
-    assert r["mean_err"] <= 0.03 and r["max_err"] <= 0.35 and r["token_agreement"] >= 0.97, r
+    # measured (round 4): max 0.139 / mean 0.023 / tokens 0.987 -- bounds at <= 1.5 x what is measured
+    assert r["mean_err"] <= 0.03 and r["max_err"] <= 0.21 and r["token_agreement"] >= 0.975, r
 
 
 def test_llm_decode_step_qwen3_14b_true_dims():
