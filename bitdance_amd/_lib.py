@@ -85,6 +85,14 @@ _PROTOS = {
     "bd_probe_read": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p]),
     "bd_comm_create": (C.c_void_p, [C.c_int, C.c_int, C.c_longlong]),
     "bd_comm_create2": (C.c_void_p, [C.c_int, C.c_int, C.c_longlong, C.c_longlong]),
+    "bd_comm_create3": (C.c_void_p, [C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong]),
+    "bd_comm_ipc_handles3": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bd_comm_open_peer3": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "bd_comm_set_peer_ptrs3": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bd_comm_local_hbuf": (C.c_void_p, [C.c_void_p]),
+    "bd_comm_hbuf_bytes": (C.c_longlong, [C.c_void_p]),
+    "bd_comm_set_loopback": (C.c_int, [C.c_void_p]),
+    "bd_comm_prepushed": (C.c_longlong, [C.c_void_p]),
     "bd_comm_gather_ptr": (C.c_void_p, [C.c_void_p]),
     "bd_comm_gather_bytes": (C.c_longlong, [C.c_void_p]),
     "bd_comm_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

@@ -60,6 +60,12 @@ struct bd_ctx {
     int hDl = 0, hHl = 0, lnhl = 0, lnkvl = 0, lFl = 0;
     // "tune.ada_group": evaluations whose adaLN projections run as ONE GEMM (head_ada_group); 1 = one GEMM per evaluation
     int adaG = 1;
+    // "tp.seq": sequence-parallel row kernels under tensor parallelism (bd_sp.hip): a rank owns rows / tp rows of the head's residual
+    // stream; no stand-alone exchange kernel inside an evaluation.  sp_fseq: sequence number of the final latent hand-off of the
+    // sampling run being issued (tok_finish waits for it)
+    bool sp = false;
+    int sp_fseq = 0;
+    int ada_slots = 1;                    // column-split adaLN: the gathered modulation tensor is double-buffered by group parity
 
     const GemmCfg& cfg(const char* name) const {
         auto it = g.find(name);
@@ -199,7 +205,7 @@ static const char* const kIntKeys[] = {
     "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid", "head.y_evals", "head.variant",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "proj.rows_all", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
     "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "rt.in_first", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ragged", "tune.ragged52", "tune.slab_cap", "tune.slab3",
-    "tune.ada_group", "tune.ada_group_nw", "tune.tp_fuse", "tune.ln_rows", "tune.small_tiles_rows", "tp.ada_split"};
+    "tune.ada_group", "tune.ada_group_nw", "tune.tp_fuse", "tune.ln_rows", "tune.small_tiles_rows", "tp.ada_split", "tp.seq", "tune.sp_wait", "tune.sp_inv"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
                                          "llm.qkv", "llm.o", "llm.gu", "llm.down"};
 static bool known_int_key(const std::string& k) {
@@ -483,7 +489,11 @@ int bd_ctx_finalize(bd_ctx* c) {
             add("head.xt", (long long)c->BP * c->hC * 4);
             add("head.y_frag", Mp * c->hD * 2);
             add("head.X", Mp * c->hD * 2);
-            add("head.ada_bf", Mp * c->hNada * 2 * c->adaG);
+            // column-split projection: the peers push group g + 1 while a slower rank may still read group g's gate / scale / shift in its
+            // last head_final -> two slots, selected by the group's parity (a rank can only be TWO groups ahead of another after a whole
+            // group of exchanges with it, i.e. after that rank has left the slot)
+            c->ada_slots = c->geti("tp.ada_split", 0) ? 2 : 1;
+            add("head.ada_bf", Mp * c->hNada * 2 * c->adaG * c->ada_slots);
             if (c->geti("tp.ada_split", 0)) {
                 // COLUMN-split adaLN projection (reference layout flow_head_parallel_x.py:331): this rank computes hNada / tp
                 // of the output columns of a whole group of evaluations into head.ada_loc and pushes them into every rank's head.ada_bf
@@ -508,6 +518,18 @@ int bd_ctx_finalize(bd_ctx* c) {
             add("head.tok_cur", (long long)(c->geti("proj.rows_all", 0) ? c->M : c->BP) * c->hC * 4);
             add("head.xhat", Mp * c->hC * 4);
             if (tp > 1) add("head.tp_part", Mp * c->hD * 4);   // this rank's fp32 partial of a row-split Linear (wo / w2)
+            c->sp = false;
+            if (c->geti("tp.seq", 0)) {
+                // sequence-parallel row kernels: 128 real rows (one image, 64-token patches, the headline shape: the fused push exists
+                // for the 128-row kernel), whole 8-row groups per rank with the cond / uncond rows of a patch position on one rank,
+                // bf16 operand rows (bf16 or fp8 weights, not the fp8-activation mode), the hand-written exchange with a landing buffer
+                BdSpLink L;
+                if (tp < 2 || !c->comm || !bdk_sp_link(c->comm, &L)) return fail("tp.seq: needs a tensor-parallel communicator created with an operand landing buffer (bd_comm_create3)");
+                if (c->M != 128 || Mp != 128 || c->hMlp || c->fp8a || (c->BP / 8) % tp || c->BP % 8 || c->branches > 2)
+                    return fail("tp.seq: 128 rows (one image, parallel_num 64), patch positions in whole 8-row groups per rank, bf16 activations");
+                if (bdk_sp_hbuf_bytes(c->comm) < Mp * c->hD * 2) return fail("tp.seq: the communicator's operand landing buffer is smaller than rows x head.D x 2");
+                c->sp = true;
+            }
         }
         if (c->has_proj) {
             const int D = (int)c->geti("proj.D");
@@ -673,7 +695,35 @@ static int linear_rowsplit(bd_ctx* c, const char* name, const void* A, int RB, W
     return 0;
 }
 
+// Sequence-parallel form of a ROW-split Linear (wo / w2): the GEMM's epilogue pushes every owner its rows of the fp32 partial (8-row
+// groups round-robin, BdTpPush::il); nothing else is launched -- the owner's row kernel (ln_mod_sp / head_final_sp) reduces.
+// Returns the sequence number of the hand-off in *seq.
+static int linear_rowsplit_sp(bd_ctx* c, const char* name, const void* A, int RB, WRef W, int N, int Klocal, const GemmCfg& g,
+                              const char* scratch_ws, const char* tp_ws, int rows, int* seq, hipStream_t st) {
+    if (g.S > 3) return fail(std::string(name) + ": a tensor-parallel partial needs at most 3 grid slices");
+    BdTpPush push;
+    if (!bdk_tp_push_target_sp(c->comm, rows, N, &push)) return fail(std::string(name) + ": no sequence-parallel push target for this shape");
+    bdk_gemm_set_push(&push);
+    BD_TRY(gemm(c, name, A, RB, W, N, Klocal, g.S, g.code(), BD_EPI_F32, (float*)c->wptr(scratch_ws), c->wptr(tp_ws), nullptr, st));
+    if (!bdk_gemm_push_used()) return fail(std::string(name) + ": the GEMM did not take the push target");
+    bdk_comm_count_exchange(c->comm);
+    *seq = bdk_sp_next_seq(c->comm);
+    if (*seq < 0) return fail("sequence-parallel exchange: more than 4095 hand-offs since the last bd_head_cond / bd_head_sample");
+    return 0;
+}
+// the consumer GEMM of the operand rows pushed with sequence number `seq`: waits in its prologue ("tune.sp_wait" = 0: a one-workgroup
+// wait kernel in front of it instead)
+static int sp_arm_wait(bd_ctx* c, int seq, hipStream_t st) {
+    if (c->geti("tune.sp_wait", 1) == 0) { BD_TRY(bdk_sp_wait_rows(c->comm, seq, c->M, st)); return 0; }
+    BdHWait w;
+    if (!bdk_sp_hwait(c->comm, seq, c->M, &w)) return fail("sequence-parallel exchange: no flag block");
+    w.inv = (int)c->geti("tune.sp_inv", 0);
+    bdk_gemm_set_hwait(&w);
+    return 0;
+}
+
 static int head_cond(bd_ctx* c, hipStream_t st) {   // cond_embed(c) is constant over the N+1 evals of this AR step
+    if (c->sp) BD_TRY(bdk_sp_begin(c->comm, st));   // sequence numbers of the hand-offs restart with every sampling run
     const GemmCfg& g = c->cfg("head.cond");
     Partial unused;
     BD_TRY(linear(c, "head.cond", c->ptr("head.cond_frag"), c->RB, wref(c, "head.cond_w"), c->hD, c->hDz, g, "head.cond_part",
@@ -736,7 +786,8 @@ static int head_ada_group(bd_ctx* c, int g, hipStream_t st) {
         // this rank's columns of the group's modulation tensor, then one push all-gather into every rank's head.ada_bf
         const int Nl = c->hNada / c->tp;
         BD_TRY(gemm(c, name, y, rbg, wa, Nl, D, 1, nw, BD_EPI_BF16, nullptr, c->wptr("head.ada_loc"), c->ptr("head.ada_b_l"), st));
-        BD_TRY(bdk_tp_allgather(c->comm, c->ptr("head.ada_loc"), c->wptr("head.ada_bf"), rbg * 32, Nl, c->hNada, st));
+        bf16_t* dst = (bf16_t*)c->wptr("head.ada_bf") + (size_t)(g & 1) * G * c->Mpad * c->hNada;      // the group's slot (double-buffered by parity)
+        BD_TRY(bdk_tp_allgather(c->comm, c->ptr("head.ada_loc"), dst, rbg * 32, Nl, c->hNada, st));
         return 0;
     }
     BD_TRY(gemm(c, name, y, rbg, wa, c->hNada, D, 1, nw, BD_EPI_BF16, nullptr, c->wptr("head.ada_bf"), c->ptr("head.ada_b"), st));
@@ -770,6 +821,88 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0
     const bool mlp = c->hMlp != 0;
     const int nc = mlp ? 3 : 6;                               // adaLN chunks per adaLN block; the block's last gate is chunk nc - 1
     const GemmCfg &gq = c->cfg("head.qkv"), &go = c->cfg("head.wo"), &g1 = c->cfg("head.w1"), &g2 = c->cfg("head.w2");
+    if (c->sp) {
+        // ---- sequence-parallel evaluation (bd_sp.hip): per block  ln_mod_sp -> qkv (waits for the rows) -> attention -> wo (pushes
+        // partial rows) -> ln_mod_sp -> w1 (waits) -> w2 (pushes) ; head_final_sp.  12 GEMMs + 6 attention + 13 row kernels, no exchange kernel.
+        BdSpLink L;
+        if (!bdk_sp_link(c->comm, &L)) return fail("sequence-parallel exchange: the communicator lost its peers");
+        const int rows_local = M / c->tp;
+        int seq_p = 0;                                         // pending row-split Linear's hand-off (0: none)
+        const void* pend_bias = nullptr;
+        for (int b = 0; b < c->hNB; ++b) {
+            const std::string pre = "head.blk" + std::to_string(b) + ".";
+            const int base = (b / sw) * nc * D;
+            LnModSpArgs l1;
+            l1.ln.X = c->wptr("head.X");
+            l1.ln.ada = ada; l1.ln.ada_ld = c->hNada;
+            l1.ln.gate_off = ((b - 1 < 0 ? 0 : b - 1) / sw) * nc * D + (nc - 1) * D;
+            l1.ln.scale_off = base; l1.ln.shift_off = base + D;
+            l1.ln.h_frag = nullptr; l1.ln.M = M; l1.ln.D = D; l1.ln.RB = RB; l1.ln.eps = 1e-6f;
+            l1.ln.ln_w = (const float*)c->ptr(pre + "ln1_w"); l1.ln.ln_b = (const float*)c->ptr(pre + "ln1_b");
+            l1.L = L; l1.rows_local = rows_local;
+            l1.part = seq_p ? (const float*)c->ptr("head.tp_part") : nullptr; l1.bias = pend_bias; l1.seq_p = seq_p;
+            l1.seq_h = bdk_sp_next_seq(c->comm);
+            if (l1.seq_h < 0) return fail("sequence-parallel exchange: more than 4095 hand-offs since the last bd_head_cond / bd_head_sample");
+            BD_TRY(bdk_ln_mod_sp(l1, st));
+            HeadAttnArgs at;
+            BD_TRY(sp_arm_wait(c, l1.seq_h, st));
+            BD_TRY(linear(c, "head.qkv", bdk_sp_hbuf(c->comm), RB, wref(c, pre + "wqkv"), 3 * Dl, D, gq, "head.qkv_part", "head.qkv_bf",
+                          c->ptr(pre + "bqkv"), Mp, &at.qkv, st));
+            at.o_frag = c->wptr("head.attn_frag"); at.nseq = M / c->Pn; at.dh = (int)c->geti("head.dh", 128); at.nhead = Dl / at.dh; at.D = Dl; at.RB = RB; at.P = c->Pn;
+            BD_TRY(bdk_head_attn(at, st));
+            BD_TRY(linear_rowsplit_sp(c, "head.wo", c->ptr("head.attn_frag"), RB, wref(c, pre + "wo"), D, Dl, go, "head.br_part", "head.tp_part", M, &seq_p, st));
+            LnModSpArgs l2 = l1;
+            l2.ln.gate_off = base + 2 * D; l2.ln.scale_off = base + 3 * D; l2.ln.shift_off = base + 4 * D;
+            l2.ln.ln_w = (const float*)c->ptr(pre + "ln2_w"); l2.ln.ln_b = (const float*)c->ptr(pre + "ln2_b");
+            l2.part = (const float*)c->ptr("head.tp_part"); l2.bias = c->ptr(pre + "bo"); l2.seq_p = seq_p;
+            l2.seq_h = bdk_sp_next_seq(c->comm);
+            if (l2.seq_h < 0) return fail("sequence-parallel exchange: more than 4095 hand-offs since the last bd_head_cond / bd_head_sample");
+            BD_TRY(bdk_ln_mod_sp(l2, st));
+            BD_TRY(sp_arm_wait(c, l2.seq_h, st));
+            if (!(g1.S == 1 || c->geti("tune.w1_fused", 1))) return fail("tp.seq: the fused SwiGLU epilogue only");
+            BD_TRY(gemm(c, "head.w1", bdk_sp_hbuf(c->comm), RB, wref(c, pre + "w1"), 2 * Hl, D, g1.S, g1.code(), BD_EPI_SWIGLU,
+                        (float*)c->wptr("head.w1_part"), c->wptr("head.act_frag"), c->ptr(pre + "b1"), st));
+            BD_TRY(linear_rowsplit_sp(c, "head.w2", c->ptr("head.act_frag"), RB, wref(c, pre + "w2"), D, Hl, g2, "head.br_part", "head.tp_part", M, &seq_p, st));
+            pend_bias = c->ptr(pre + "b2");
+        }
+        HeadFinalSpArgs fs;
+        HeadFinalArgs& fa = fs.f;
+        fa.X = c->ptr("head.X");
+        fa.pend = Partial{nullptr, nullptr, 0, 0, 0};
+        fa.ada = ada; fa.ada_ld = c->hNada;
+        fa.gate_off = ((c->hNB - 1) / sw) * nc * D + (nc - 1) * D;
+        fa.scale_off = c->hNA * nc * D; fa.shift_off = c->hNA * nc * D + D;
+        fa.lin_w = c->ptr("head.lin_w"); fa.lin_b = c->ptr("head.lin_b");
+        fa.xt = (float*)c->wptr("head.xt");
+        fa.noise = (const float*)c->ptr("head.noise");
+        fa.noise_step_stride = (long long)(n_steps + 1) * c->BP * c->hC;
+        fa.eval_index = i; fa.state = state;
+        fa.pred_out = nullptr; fa.tok_cur = nullptr; fa.tok_all = nullptr;       // written by tok_finish, on every rank
+        fa.T = c->hT; fa.P = c->Pn;
+        fa.xhat_out = c->geti("rt.dump_xhat", 0) ? (float*)c->wptr("head.xhat") : nullptr;
+        fa.sc = c->sched[i];
+        fa.BP = c->BP; fa.D = D; fa.C = c->hC; fa.M = M; fa.eps_ln = 1e-6f; fa.sigmoid = (int)c->geti("head.sigmoid", 1);
+        fa.cfg_table = (const float*)c->optr("head.cfg_table");
+        fa.tok_branches = 1;
+        if (chain_next) { fa.X_next = c->wptr("head.X"); fa.in_w = c->ptr("head.in_w"); fa.in_b = c->ptr("head.in_b"); }
+        fs.L = L; fs.part = (const float*)c->ptr("head.tp_part"); fs.bias = pend_bias; fs.seq_p = seq_p; fs.bp_local = c->BP / c->tp;
+        fs.seq_f = 0;
+        if (fa.sc.is_final) {
+            fs.seq_f = bdk_sp_next_seq(c->comm);
+            if (fs.seq_f < 0) return fail("sequence-parallel exchange: more than 4095 hand-offs since the last bd_head_cond / bd_head_sample");
+        }
+        BD_TRY(bdk_head_final_sp(fs, st));
+        if (fa.sc.is_final) {
+            TokFinishArgs tf;
+            tf.L = L; tf.seq_f = fs.seq_f;
+            tf.xt = (float*)c->wptr("head.xt"); tf.pred_out = (float*)c->wptr("head.pred"); tf.tok_cur = (float*)c->wptr("head.tok_cur");
+            tf.tok_all = (float*)const_cast<void*>(c->optr("head.tok_all"));
+            tf.state = state; tf.BP = c->BP; tf.C = c->hC; tf.T = c->hT; tf.P = c->Pn;
+            tf.tok_branches = (c->geti("proj.rows_all", 0) && c->has_proj) ? c->branches : 1;
+            BD_TRY(bdk_tok_finish(tf, st));
+        }
+        return 0;
+    }
     Partial br{nullptr, nullptr, 0, 0, 0};                    // pending gated branch output (wo / w2)
     for (int b = 0; b < c->hNB; ++b) {
         const std::string pre = "head.blk" + std::to_string(b) + ".";
@@ -852,7 +985,8 @@ static int head_sample(bd_ctx* c, hipStream_t st) {
     for (int i = 0; i <= n_steps; ++i) {
         if (G > 1 && c->y_ready) {
             if (i % G == 0) BD_TRY(head_ada_group(c, i / G, st));
-            BD_TRY(head_eval(c, i, st, i % G, /*x0_ready=*/i > 0, /*chain_next=*/true));
+            // (column-split projection: the group's slot of the double-buffered modulation tensor)
+            BD_TRY(head_eval(c, i, st, (c->ada_slots == 2 ? ((i / G) & 1) * G : 0) + i % G, /*x0_ready=*/i > 0, /*chain_next=*/true));
         } else {
             BD_TRY(head_eval(c, i, st, -1, /*x0_ready=*/i > 0, /*chain_next=*/true));
         }

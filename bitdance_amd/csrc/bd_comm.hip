@@ -55,9 +55,24 @@ struct bd_comm {
                                              // read back with sc0 sc1 loads, which needs no fence (MI355X_MICROARCH.md, hand-off recipe R1)
     long long n_exchanges = 0;               // launches issued (graph captures count once): reporting only
     long long n_gathers = 0;
+    long long n_prepushed = 0;               // exchanges whose phase 1 ran in the producing GEMM's epilogue (tests assert the fusion engaged)
     int prepushed_next = 0;                  // set by bdk_tp_push_target: the next exchange finds its staging rows already pushed
+    // sequence-parallel row kernels (bd_sp.hip): a second, CACHEABLE exported allocation where the peers land the bf16 operand rows the
+    // consuming GEMM re-reads from L2 (an uncached buffer would make each of its 240 workgroups fetch the 1.3 MB operand from memory),
+    // a small landing area for the final latent rows behind the gather region, and the flag block BD_SP_* behind the exchange's flags
+    char* hbuf = nullptr;
+    long long hbuf_bytes = 0, aux_bytes = 0;
+    char* peer_hbuf[BD_TP_MAX] = {};
+    bool ipc_open_h[BD_TP_MAX] = {};
+    int sp_seq = 0;                          // host-side sequence number of the next hand-off since the last bdk_sp_begin
+    // loop-back: ONE rank of a `size`-rank group alone on a GPU (tools/head_sweep.py --tp-shard): the peers' buffers are scratch copies,
+    // every flag a peer would write is written locally -- the rank's launches, traffic and waits without the links
+    int loopback = 0;
+    char* scratch_data[BD_TP_MAX] = {};
+    char* scratch_hbuf[BD_TP_MAX] = {};
 };
 #define BD_TP_FLAG_INTS (3 * BD_TP_MAX * BD_TP_GMAX + 1 + 2 * BD_TP_GMAX)
+#define BD_SP_AUX_BYTES 65536
 
 void bdk_set_error(const std::string& m);    // bd_api.hip
 
@@ -75,8 +90,15 @@ struct ArArgs {
     int rank, size, G, U, Us, N8;
     int fences = 0;
     int prepushed = 0;          // 1: the producing GEMM's epilogue already pushed every peer's slice into its staging row (bdk_tp_push_target)
+    int loopback = 0;           // 1: no peers (bd_comm_set_loopback): the flag a peer t would write here is written by this rank itself
 };
 
+// The fence-less hand-off (payload: sc0 sc1 write-through stores drained by vmcnt(0); flag: relaxed system-scope store; reader: sc0 sc1
+// loads) relies on gfx950's cache-policy semantics, not on a release / acquire edge of the memory model -- like the in-launch
+// split-K reduction (bd_gemm_kernel.h) it must not be compiled for another target unnoticed.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "bd_comm.hip: the sc0 sc1 / vmcnt(0) flag hand-off is validated for gfx950 only"
+#endif
 // all of this block's pushes are at their destination, then the epoch goes to every peer's flag row of this rank
 BD_DEV void tp_signal(const ArArgs& a, int base, int b, int e) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -84,7 +106,8 @@ BD_DEV void tp_signal(const ArArgs& a, int base, int b, int e) {
     const int t = threadIdx.x;
     if (t < a.size && t != a.rank) {
         if (a.fences) __threadfence_system();
-        __hip_atomic_store(a.peer_flags[t] + base + a.rank * BD_TP_GMAX + b, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        int* const dst = a.loopback ? a.flags + base + t * BD_TP_GMAX + b : a.peer_flags[t] + base + a.rank * BD_TP_GMAX + b;
+        __hip_atomic_store(dst, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 // returns false (block-uniform) when the exchange is dead: a wait of THIS rank ran out of its budget now or earlier, or a
@@ -223,7 +246,8 @@ int bdk_tp_allreduce(bd_comm* c, const float* part, const void* bias, int rows, 
     a.stage_bytes = c->max_elems * 4;
     a.data_bytes = c->max_elems * 6;
     a.timeout_ticks = (long long)(c->timeout_s * 1e8);
-    a.rank = c->rank; a.size = c->size; a.fences = c->fences; a.prepushed = c->prepushed_next;
+    a.rank = c->rank; a.size = c->size; a.fences = c->fences; a.prepushed = c->prepushed_next; a.loopback = c->loopback;
+    c->n_prepushed += c->prepushed_next;
     c->prepushed_next = 0;
     a.U = rows * (N / 8); a.Us = (a.U + c->size - 1) / c->size; a.N8 = N / 8;
     a.G = (a.Us + 255) / 256;
@@ -248,7 +272,7 @@ struct AgArgs {
     int* flags;
     long long gather_off, gather_bytes, timeout_ticks;
     int rank, size, G, rows, Nl8, N8;          // Nl8 / N8: 16 B units per slice row / per full row
-    int fences;
+    int fences, loopback;
 };
 __global__ __launch_bounds__(256) void tp_allgather_kernel(AgArgs g) {
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -269,7 +293,7 @@ __global__ __launch_bounds__(256) void tp_allgather_kernel(AgArgs g) {
     }
     ArArgs a;                                                    // the signalling helpers take the exchange's argument block
     for (int p = 0; p < BD_TP_MAX; ++p) a.peer_flags[p] = g.peer_flags[p];
-    a.flags = g.flags; a.rank = g.rank; a.size = g.size; a.timeout_ticks = g.timeout_ticks; a.fences = g.fences;
+    a.flags = g.flags; a.rank = g.rank; a.size = g.size; a.timeout_ticks = g.timeout_ticks; a.fences = g.fences; a.loopback = g.loopback;
     tp_signal(a, FC, b, e);
     (void)tp_wait(a, FC, b, e, ERR);
     if (tid == 0) g.flags[EPC + b] = e;
@@ -288,7 +312,7 @@ int bdk_tp_allgather(bd_comm* c, const void* slice, void* dst_local, int rows, i
     g.src = (const u32x4*)slice; g.flags = c->flags;
     for (int p = 0; p < BD_TP_MAX; ++p) { g.peer_data[p] = c->peer_data[p]; g.peer_flags[p] = c->peer_flags[p]; }
     g.gather_off = off; g.gather_bytes = need; g.timeout_ticks = (long long)(c->timeout_s * 1e8);
-    g.rank = c->rank; g.size = c->size; g.rows = rows; g.Nl8 = Nl / 8; g.N8 = N / 8; g.fences = c->fences;
+    g.rank = c->rank; g.size = c->size; g.rows = rows; g.Nl8 = Nl / 8; g.N8 = N / 8; g.fences = c->fences; g.loopback = c->loopback;
     const long long U = (long long)rows * g.Nl8;
     g.G = (int)((U + 2047) / 2048);                              // >= 8 units per thread, up to BD_TP_GMAX blocks
     if (g.G > BD_TP_GMAX) g.G = BD_TP_GMAX;
@@ -310,6 +334,12 @@ bool bdk_tp_push_target(bd_comm* c, int rows, int N, BdTpPush* out) {
     return true;
 }
 void bdk_tp_mark_prepushed(bd_comm* c) { if (c) c->prepushed_next = 1; }
+// the same push target with the sequence-parallel row ownership (8-row groups dealt round-robin to the ranks, BdTpPush::il)
+bool bdk_tp_push_target_sp(bd_comm* c, int rows, int N, BdTpPush* out) {
+    if (!bdk_tp_push_target(c, rows, N, out) || (rows / 8) % c->size) return false;
+    out->il = 1;
+    return true;
+}
 
 void* bdk_comm_gather_ptr(const bd_comm* c) { return (c && c->gather_bytes > 0) ? c->data + c->max_elems * 6 : nullptr; }
 long long bdk_comm_gather_bytes(const bd_comm* c) { return c ? c->gather_bytes : 0; }
@@ -318,21 +348,94 @@ int bdk_comm_mode(const bd_comm* c) { return c ? c->mode : 0; }
 int bdk_comm_rank(const bd_comm* c) { return c ? c->rank : 0; }
 int bdk_comm_size(const bd_comm* c) { return c ? c->size : 1; }
 
+
+// ---- sequence-parallel exchange: host side (kernels: bd_sp.hip; the consumer's wait: bd_gemm_kernel.h)
+bool bdk_sp_link(bd_comm* c, BdSpLink* out) {
+    if (!c || c->size < 2 || c->mode != 0 || !c->hbuf || c->size > 8) return false;
+    BdSpLink L;
+    const long long aux_off = c->max_elems * 6 + c->gather_bytes;
+    for (int p = 0; p < c->size; ++p) {
+        if (!c->peer_data[p] || !c->peer_flags[p] || !c->peer_hbuf[p]) return false;
+        L.stage[p] = c->peer_data[p];
+        L.hbuf[p] = c->peer_hbuf[p];
+        L.aux[p] = c->peer_data[p] + aux_off;
+        L.spf[p] = c->peer_flags[p] + BD_TP_FLAG_INTS;
+    }
+    L.spf_local = c->flags + BD_TP_FLAG_INTS;
+    L.err = c->flags + 2 * BD_TP_MAX * BD_TP_GMAX;
+    L.stage_bytes = c->max_elems * 4; L.hbuf_bytes = c->hbuf_bytes; L.aux_bytes = c->aux_bytes;
+    L.timeout_ticks = (long long)(c->timeout_s * 1e8);
+    L.rank = c->rank; L.size = c->size; L.loopback = c->loopback;
+    *out = L;
+    return true;
+}
+long long bdk_sp_hbuf_bytes(const bd_comm* c) { return c ? c->hbuf_bytes : 0; }
+void* bdk_sp_hbuf(const bd_comm* c) { return c ? c->hbuf : nullptr; }
+int bdk_sp_next_seq(bd_comm* c) { return (c && c->sp_seq < 4095) ? ++c->sp_seq : -1; }
+void bdk_comm_count_exchange(bd_comm* c) { if (c) { c->n_exchanges++; c->n_prepushed++; } }
+bool bdk_sp_hwait(bd_comm* c, int seq, int rows, BdHWait* out) {
+    if (!c || !c->hbuf || rows > BD_SP_MAXROWS) return false;
+    BdHWait w;
+    w.flags = c->flags + BD_TP_FLAG_INTS + BD_SP_H;
+    w.rc = c->flags + BD_TP_FLAG_INTS + BD_SP_RC;
+    w.err = c->flags + 2 * BD_TP_MAX * BD_TP_GMAX;
+    w.timeout_ticks = (long long)(c->timeout_s * 1e8);
+    w.seq = seq; w.n = rows;
+    *out = w;
+    return true;
+}
+__global__ void sp_begin_kernel(int* spf) {
+    if (threadIdx.x == 0) __hip_atomic_store(spf + BD_SP_RC, __hip_atomic_load(spf + BD_SP_RC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1,
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+int bdk_sp_begin(bd_comm* c, hipStream_t st) {
+    if (!c || !c->hbuf) return -2;
+    c->sp_seq = 0;
+    BD_LAUNCH(sp_begin_kernel, dim3(1), dim3(64), 0, st, c->flags + BD_TP_FLAG_INTS);
+    return bd_launch_status();
+}
+// the consumer's wait as its own one-workgroup kernel: the following GEMM then starts behind a kernel boundary (whose acquire
+// invalidates the caches) instead of polling in 240 workgroups -- the form for several ranks sharing ONE GPU, where a chip full of
+// polling GEMM workgroups would starve the peer rank's row kernel they are waiting for (tests), and an A/B for the in-GEMM wait
+__global__ void sp_wait_rows_kernel(BdHWait w) {
+    const int e = __hip_atomic_load(w.rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) * 4096 + w.seq;
+    const long long t0 = wall_clock64();
+    for (int i = threadIdx.x; i < w.n; i += blockDim.x) {
+        while ((int)(__hip_atomic_load(w.flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+            if (__hip_atomic_load(w.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
+            if (wall_clock64() - t0 > w.timeout_ticks) { __hip_atomic_fetch_or(w.err, 1 << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+}
+int bdk_sp_wait_rows(bd_comm* c, int seq, int rows, hipStream_t st) {
+    BdHWait w;
+    if (!bdk_sp_hwait(c, seq, rows, &w)) return -2;
+    BD_LAUNCH(sp_wait_rows_kernel, dim3(1), dim3(256), 0, st, w);
+    return bd_launch_status();
+}
+
 extern "C" {
 
-bd_comm* bd_comm_create(int rank, int size, long long max_elems) { return bd_comm_create2(rank, size, max_elems, 0); }
+bd_comm* bd_comm_create(int rank, int size, long long max_elems) { return bd_comm_create3(rank, size, max_elems, 0, 0); }
+bd_comm* bd_comm_create2(int rank, int size, long long max_elems, long long gather_bytes) { return bd_comm_create3(rank, size, max_elems, gather_bytes, 0); }
 
 /* ... with an all-gather region of `gather_bytes` behind the exchange buffers (same allocation, same IPC handle): where the
  * column-split adaLN projection's output is assembled on every rank (bd_comm_gather_ptr) */
-bd_comm* bd_comm_create2(int rank, int size, long long max_elems, long long gather_bytes) {
-    if (size < 1 || size > BD_TP_MAX || rank < 0 || rank >= size || max_elems < 8 || gather_bytes < 0) { bdk_set_error("bd_comm_create: bad rank/size/capacity"); return nullptr; }
+/* ... and, with hbuf_bytes > 0, the sequence-parallel exchange's buffers (bd_sp.hip): a cacheable exported landing buffer of
+ * hbuf_bytes (rows x D x 2: the bf16 operand rows every rank pushes to every rank) and a 64 KiB landing area for the final latent rows */
+bd_comm* bd_comm_create3(int rank, int size, long long max_elems, long long gather_bytes, long long hbuf_bytes) {
+    if (size < 1 || size > BD_TP_MAX || rank < 0 || rank >= size || max_elems < 8 || gather_bytes < 0 || hbuf_bytes < 0 || hbuf_bytes >= (1LL << 31)) { bdk_set_error("bd_comm_create: bad rank/size/capacity"); return nullptr; }
     bd_comm* c = new bd_comm();
     c->rank = rank; c->size = size;
     c->max_elems = (max_elems + 127) / 128 * 128 + 128 * BD_TP_MAX;   // slices are ceil(units / size): slack per rank; keeps the gather region 256 B aligned
     c->gather_bytes = (gather_bytes + 255) / 256 * 256;
     // the kernel addresses an allocation through ONE buffer resource: 32-bit size and offsets
     if (c->max_elems * 6 >= (1LL << 31)) { delete c; bdk_set_error("bd_comm_create: capacity too large (rows * N * 6 must stay below 2^31 bytes)"); return nullptr; }
-    const size_t dbytes = (size_t)c->max_elems * 6 + (size_t)c->gather_bytes, fbytes = (size_t)BD_TP_FLAG_INTS * sizeof(int);
+    c->hbuf_bytes = (hbuf_bytes + 255) / 256 * 256;
+    c->aux_bytes = c->hbuf_bytes > 0 ? BD_SP_AUX_BYTES : 0;
+    const size_t dbytes = (size_t)c->max_elems * 6 + (size_t)c->gather_bytes + (size_t)c->aux_bytes;
+    const size_t fbytes = (size_t)(BD_TP_FLAG_INTS + BD_SP_FLAG_INTS) * sizeof(int);
     // staging / result buffer: written by the PEERS over xGMI and read here inside the same kernel.  Ordinary (coarse-grained)
     // device memory is cached in this GPU's L2 as device-coherent only -- a line kept from the previous exchange could be
     // served instead of what a peer has pushed since (the one-GPU tests cannot show this: all "ranks" share one L2).  Uncached
@@ -356,20 +459,33 @@ bd_comm* bd_comm_create2(int rank, int size, long long max_elems, long long gath
         (void)hipGetLastError();
         if (hipMalloc((void**)&c->flags, fbytes) != hipSuccess) { hipFree(c->data); delete c; bdk_set_error("bd_comm_create: flag allocation failed"); return nullptr; }
     }
+    if (c->hbuf_bytes > 0) {
+        // ordinary (cacheable) device memory, exportable like any hipMalloc: the consuming GEMM invalidates its caches after the flag
+        // wait and then re-reads the operand from L2 like any other activation (bd_gemm_kernel.h)
+        if (hipMalloc((void**)&c->hbuf, (size_t)c->hbuf_bytes) != hipSuccess) {
+            hipFree(c->data); hipFree(c->flags); delete c; bdk_set_error("bd_comm_create: operand landing buffer allocation failed"); return nullptr;
+        }
+        hipMemset(c->hbuf, 0, (size_t)c->hbuf_bytes);
+    }
     hipMemset(c->data, 0, dbytes);
     hipMemset(c->flags, 0, fbytes);
     hipDeviceSynchronize();
     c->own = true;
     c->peer_data[rank] = c->data;
     c->peer_flags[rank] = c->flags;
+    c->peer_hbuf[rank] = c->hbuf;
     return c;
 }
 
 void bd_comm_destroy(bd_comm* c) {
     if (!c) return;
-    for (int p = 0; p < BD_TP_MAX; ++p)
+    for (int p = 0; p < BD_TP_MAX; ++p) {
         if (c->ipc_open[p]) { hipIpcCloseMemHandle(c->peer_data[p]); hipIpcCloseMemHandle(c->peer_flags[p]); }
-    if (c->own) { hipFree(c->data); hipFree(c->flags); }
+        if (c->ipc_open_h[p]) hipIpcCloseMemHandle(c->peer_hbuf[p]);
+        if (c->scratch_data[p]) hipFree(c->scratch_data[p]);
+        if (c->scratch_hbuf[p]) hipFree(c->scratch_hbuf[p]);
+    }
+    if (c->own) { hipFree(c->data); hipFree(c->flags); if (c->hbuf) hipFree(c->hbuf); }
     delete c;
 }
 
@@ -419,12 +535,14 @@ int bd_comm_set_fences(bd_comm* c, int on) { c->fences = on != 0; return 0; }
 int bd_comm_mark_prepushed(bd_comm* c) { bdk_tp_mark_prepushed(c); return 0; }
 /* after a failed exchange (all ranks, between two host barriers): clear flags, epochs and the error word */
 int bd_comm_reset(bd_comm* c) {
-    const size_t fbytes = (size_t)BD_TP_FLAG_INTS * sizeof(int);
+    const size_t fbytes = (size_t)(BD_TP_FLAG_INTS + BD_SP_FLAG_INTS) * sizeof(int);
     if (hipDeviceSynchronize() != hipSuccess || hipMemset(c->flags, 0, fbytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
         return cfail("bd_comm_reset failed");
     return 0;
 }
 long long bd_comm_exchanges(bd_comm* c) { return c->n_exchanges; }
+/* exchanges whose reduce-scatter phase ran in the producing GEMM's epilogue (fused push): tests assert that the fusion engaged */
+long long bd_comm_prepushed(bd_comm* c) { return c->n_prepushed; }
 /* out[0] = exchange buffer is uncached (fine-grained) device memory, out[1] = flag block is, out[2] = mode (0 hand-written
  * exchange, 1 ncclAllReduce), out[3] = capacity in elements */
 int bd_comm_info(bd_comm* c, long long* out4) {
@@ -465,9 +583,64 @@ int bd_comm_allgather(bd_comm* c, const void* slice_bf16, int rows, int Nl, void
  * caller-owned device buffer -- how tests read a standalone exchange back */
 int bd_comm_copy_out(bd_comm* c, void* dst, long long bytes, int from_result, void* stream) {
     const long long off = from_result == 2 ? c->max_elems * 6 : (from_result ? c->max_elems * 4 : 0);   // 2: the all-gather region
-    if (bytes < 0 || off + bytes > c->max_elems * 6 + c->gather_bytes) return cfail("bd_comm_copy_out: range");
+    if (bytes < 0 || off + bytes > c->max_elems * 6 + c->gather_bytes + c->aux_bytes) return cfail("bd_comm_copy_out: range");
     return hipMemcpyAsync(dst, c->data + off, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess
                ? 0 : cfail("bd_comm_copy_out: hipMemcpyAsync failed");
 }
 
+
+/* 3 x hipIpcMemHandle_t (64 B each): data, flags, operand landing buffer (zeros when there is none) */
+int bd_comm_ipc_handles3(bd_comm* c, void* out192) {
+    std::memset(out192, 0, 192);
+    if (bd_comm_ipc_handles(c, out192) != 0) return -1;
+    if (c->hbuf) {
+        hipIpcMemHandle_t h;
+        if (hipIpcGetMemHandle(&h, c->hbuf) != hipSuccess) return cfail(std::string("hipIpcGetMemHandle(hbuf): ") + hipGetErrorString(hipGetLastError()));
+        std::memcpy((char*)out192 + 128, &h, sizeof(h));
+    }
+    return 0;
+}
+int bd_comm_open_peer3(bd_comm* c, int peer, const void* handles192) {
+    if (bd_comm_open_peer(c, peer, handles192) != 0) return -1;
+    if (c->hbuf) {
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, (const char*)handles192 + 128, sizeof(h));
+        void* d = nullptr;
+        if (hipIpcOpenMemHandle(&d, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess)
+            return cfail(std::string("hipIpcOpenMemHandle(hbuf): ") + hipGetErrorString(hipGetLastError()));
+        c->peer_hbuf[peer] = (char*)d; c->ipc_open_h[peer] = true;
+    }
+    return 0;
+}
+int bd_comm_set_peer_ptrs3(bd_comm* c, int peer, void* data, void* flags, void* hbuf) {
+    if (bd_comm_set_peer_ptrs(c, peer, data, flags) != 0) return -1;
+    c->peer_hbuf[peer] = (char*)hbuf;
+    return 0;
+}
+void* bd_comm_local_hbuf(bd_comm* c) { return c->hbuf; }
+long long bd_comm_hbuf_bytes(bd_comm* c) { return c->hbuf_bytes; }
+
+/* ONE rank of a `size`-rank group alone on this GPU: every peer's buffers become scratch allocations of this process, every flag a
+ * peer would write is written locally by the block that plays the same role.  The rank's kernels then launch, stream, push and wait
+ * exactly as on a node -- minus the links -- so that its critical path can be timed on one GPU (tools/head_sweep.py --tp-shard).
+ * Results are meaningless (the peers' contributions are zeros). */
+int bd_comm_set_loopback(bd_comm* c) {
+    if (!c || c->size < 2 || c->mode != 0) return cfail("bd_comm_set_loopback: a multi-rank communicator on the hand-written exchange");
+    const size_t dbytes = (size_t)c->max_elems * 6 + (size_t)c->gather_bytes + (size_t)c->aux_bytes;
+    for (int p = 0; p < c->size; ++p) {
+        if (p == c->rank) continue;
+        if (!c->scratch_data[p] && hipMalloc((void**)&c->scratch_data[p], dbytes) != hipSuccess) return cfail("bd_comm_set_loopback: hipMalloc failed");
+        hipMemset(c->scratch_data[p], 0, dbytes);
+        if (c->hbuf_bytes > 0) {
+            if (!c->scratch_hbuf[p] && hipMalloc((void**)&c->scratch_hbuf[p], (size_t)c->hbuf_bytes) != hipSuccess) return cfail("bd_comm_set_loopback: hipMalloc failed");
+            hipMemset(c->scratch_hbuf[p], 0, (size_t)c->hbuf_bytes);
+        }
+        c->peer_data[p] = c->scratch_data[p];
+        c->peer_hbuf[p] = c->scratch_hbuf[p];
+        c->peer_flags[p] = c->flags;
+    }
+    hipDeviceSynchronize();
+    c->loopback = 1;
+    return 0;
+}
 }  // extern "C"

@@ -293,6 +293,18 @@ void bdk_gemm_tile_debug(int v);
 static thread_local BdTpPush g_push;
 static thread_local bool g_push_set = false, g_push_used = false;
 void bdk_gemm_set_push(const BdTpPush* t) { g_push_set = t != nullptr; if (t) g_push = *t; g_push_used = false; }
+// sequence-parallel tensor parallelism: the NEXT bdk_gemm / bdk_gemm8 / bdk_gemm8a call on the 128-row kernel waits for its operand rows
+static thread_local BdHWait g_hwait;
+static thread_local bool g_hwait_set = false;
+void bdk_gemm_set_hwait(const BdHWait* w) { g_hwait_set = w != nullptr; if (w) g_hwait = *w; }
+bool bdk_gemm_take_hwait(BdHWait* out) { const bool s = g_hwait_set; if (s) *out = g_hwait; g_hwait_set = false; return s; }
+// the pending push target, if this launch can take it (fp32-partial epilogue of the 128-row kernel, whole 8-row groups per rank)
+bool bdk_gemm_claim_push(int epi, int RB, int N, BdTpPush* out) {
+    const bool ok = g_push_set && epi == BD_EPI_F32 && RB % 4 == 0 && RB < 8 && g_push.size > 1 && g_push.rows_per_rank % 8 == 0 && N % 32 == 0;
+    if (ok) { *out = g_push; g_push_used = true; }
+    g_push_set = false;
+    return ok;
+}
 bool bdk_gemm_push_used() { const bool u = g_push_used; g_push_used = false; g_push_set = false; return u; }
 static int g_tile = 1;                                   // >= 512 rows: the LDS-tiled MFMA-bound kernel (bd_gemm_tile.hip); 0 = 256-row kernel
 int bdk_set_gemm_option(const char* name, int v) {
@@ -357,11 +369,8 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
     size_t PS, SS;
     bdk_w_strides(N / 32, K, &PS, &SS);
     GemmP p{(const u32x4*)A, (const u32x4*)W, out_partial, (bf16_t*)out_act, (const bf16_t*)bias, cnt, nullptr, RB, N, K, S, RB * 32, PS, SS};
-    if (g_push_set && epi == BD_EPI_F32 && RB % 4 == 0 && RB < 8 && g_push.size > 1 && g_push.rows_per_rank % 8 == 0 && N % 32 == 0) {
-        p.push = g_push;                               // the 128-row kernel's epilogue pushes the peers' slices itself (bd_gemm_kernel.h)
-        g_push_used = true;
-    }
-    g_push_set = false;
+    (void)bdk_gemm_claim_push(epi, RB, N, &p.push);    // the 128-row kernel's epilogue pushes the peers' slices itself (bd_gemm_kernel.h)
+    if (bdk_gemm_take_hwait(&p.hw) && (RB % 8 == 0 || ((nw_ring >> 11) & 1))) return -10;     // (the 128-row plain-loop kernel only)
     // rows per pass over the weights: 256 (two images with CFG: W streamed once for both) when the row count allows,
     // else 128 / 64 / 32
     const int MB = (RB % 8 == 0 && nw >= 4 && kw == 1) ? 8 : ((RB % 4 == 0) ? 4 : RB);

@@ -79,6 +79,7 @@ int bdk_gemm8a(const void* A8, const float* ascale, int RB, const void* W8k, con
     const size_t PS = (size_t)(K >> 6) * 128, SS = 128;
     GemmP p{(const u32x4*)A8, (const u32x4*)W8k, out_partial, (bf16_t*)out_act, (const bf16_t*)bias, cnt, wscale, RB, N, K, S, RB * 32, PS, SS};
     p.ascale = ascale;
+    { BdHWait none; if (bdk_gemm_take_hwait(&none)) return -10; }   // (the sequence-parallel hand-off carries bf16 operand rows only)
     // 256-row passes (the adaLN projection of a group of evaluations, bd_api.hip head_ada_group): one pass over the weights per 256
     // rows, same MFMA and K order per row as the 128-row form -> bit-identical rows.  Only that call shape (one slice, bf16 epilogue):
     // everything else keeps the 128-row forms the parity tests cover
@@ -109,6 +110,8 @@ int bdk_gemm8(const void* A, int RB, const void* W8, const float* wscale, int N,
     GemmP p{(const u32x4*)A, (const u32x4*)W8, out_partial, (bf16_t*)out_act, (const bf16_t*)bias, cnt, wscale, RB, N, K, S, RB * 32, PS, SS};
     const int MB = (RB % 4 == 0) ? 4 : RB;                     // 128-row passes (row blocks beyond 4: grid.y)
     if (MB != 4 && MB != 2 && MB != 1) return -5;
+    (void)bdk_gemm_claim_push(epi, RB, N, &p.push);            // tensor parallelism: the fp32-partial epilogue pushes the peers' rows (as in bdk_gemm)
+    (void)bdk_gemm_take_hwait(&p.hw);                          // sequence-parallel: the operand comes from the peers' row kernels
     // ring 2 (two 2 KiB stages per wave in flight).  Ring 4 was measured SLOWER (adaLN 125 vs 97 us, profiles/r02_bench_fp8_v2.json):
     // at 128 rows and half the bytes per weight the workgroup is bound by its LDS-read + MFMA work per stage (256 FLOP per weight
     // byte, at the ridge), not by bytes in flight.

@@ -47,7 +47,28 @@ struct GemmP {
     const float* ascale = nullptr;   // fp8 ACTIVATIONS (WT = 2): per row [Mpad] fp32 dequantisation scale
     int w_keep = 0;                  // 256-row kernel: 1 = default-policy weight loads (several row tiles read each slice: let L2 keep it)
     BdTpPush push;                   // BD_EPI_F32 under tensor parallelism: the epilogue pushes the peers' slices (size > 1)
+    BdHWait hw;                      // sequence-parallel tensor parallelism: the A operand is pushed by the peers' row kernels -- poll its row flags
+                                     // after the first weight stages are in flight, then invalidate and load it (flags == nullptr: no wait)
 };
+
+// The consumer side of the sequence-parallel hand-off (bd_sp.hip): the weights do not depend on the peers, so the first R stages are
+// requested BEFORE this; the operand rows were written into cacheable local memory by sc0 sc1 write-through stores from other GPUs
+// (or, in the one-GPU tests, other XCDs), so after the flags this CU's L1 and this XCD's L2 may still hold lines of the PREVIOUS
+// operand: one `buffer_inv sc0 sc1` (system-scope invalidate of non-coherent lines) ahead of the barrier, then plain loads.
+BD_DEV void gemm_hwait(const BdHWait& w, int tid, int nthreads) {
+    const int e = __hip_atomic_load(w.rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) * 4096 + w.seq;
+    const long long t0 = wall_clock64();
+    for (int i = tid; i < w.n; i += nthreads) {
+        while ((int)(__hip_atomic_load(w.flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+            if (__hip_atomic_load(w.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;      // a dead exchange: run on (garbage in, the host raises)
+            if (wall_clock64() - t0 > w.timeout_ticks) { __hip_atomic_fetch_or(w.err, 1 << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    if (w.inv == 0 && tid < 64) asm volatile("buffer_inv sc0 sc1" ::: "memory");
+    __syncthreads();
+    if (w.inv == 1) asm volatile("buffer_inv sc0 sc1" ::: "memory");
+}
 
 // MFMA-bound form for >= 512 rows: both operands through LDS, 256 x 256 workgroup tiles (bd_gemm_tile.hip)
 int bdk_gemm_tile(const GemmP& p, int epi, hipStream_t st);
@@ -243,12 +264,25 @@ BD_DEV void gemm_body(const GemmP& p) {
     }
   } else {
     // prologue: stages 0..R-1 of A and W in flight; stage q of A lives in ring slot q % XR
-    load_x(xr[0], 0);
-    load_w(w[0], 0);
-    store_x(lds, xr[0]);
+    if (p.hw.flags) {                                          // block-uniform: the operand comes from the peers (bd_sp.hip)
+        load_w(w[0], 0);
 #pragma unroll
-    for (int r = 1; r < R; ++r)
-        if (r < nst) { load_x(xr[r % XR], r); load_w(w[r], r); }
+        for (int r = 1; r < R; ++r)
+            if (r < nst) load_w(w[r], r);                      // the weight stream starts before the wait ...
+        gemm_hwait(p.hw, tid, NT);                             // ... which ends when every operand row has landed
+        load_x(xr[0], 0);
+        store_x(lds, xr[0]);
+#pragma unroll
+        for (int r = 1; r < R; ++r)
+            if (r < nst) load_x(xr[r % XR], r);
+    } else {
+        load_x(xr[0], 0);
+        load_w(w[0], 0);
+        store_x(lds, xr[0]);
+#pragma unroll
+        for (int r = 1; r < R; ++r)
+            if (r < nst) { load_x(xr[r % XR], r); load_w(w[r], r); }
+    }
     __syncthreads();
 
     int i = 0;
@@ -347,12 +381,15 @@ BD_DEV void gemm_body(const GemmP& p) {
                     const int rr = (lane >> 3) + 8 * j;
                     const f32x4 v = *reinterpret_cast<const f32x4*>(tb + rr * 36 + (lane & 7) * 4);
                     const int row = (mt * MB + m) * 32 + rr;
-                    const int q = __builtin_amdgcn_readfirstlane(((mt * MB + m) * 32 + 8 * j) / p.push.rows_per_rank);
+                    const int g8 = (mt * MB + m) * 4 + j;                  // the 8-row group of this store (rr >> 3 == j)
+                    // owner of the group: contiguous slices, or (sequence parallel, push.il) groups dealt round-robin to the ranks
+                    const int q = __builtin_amdgcn_readfirstlane(p.push.il ? g8 % p.push.size : (g8 * 8) / p.push.rows_per_rank);
+                    const int lrow = p.push.il ? (g8 / p.push.size) * 8 + (rr & 7) : row - q * p.push.rows_per_rank;
                     if (q == p.push.rank || q >= p.push.size) {            // mine (or a pad row past the last rank's rows): local
                         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.act) + (size_t)row * p.N + c4) = v;
                     } else {
                         const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(p.push.stage[q], 0, (int)(p.push.Us * p.push.size * 32), 0x00020000);
-                        const unsigned off = (unsigned)((p.push.rank * p.push.Us + (size_t)(row - q * p.push.rows_per_rank) * (p.N >> 3)) * 32 + (size_t)c4 * 4);
+                        const unsigned off = (unsigned)((p.push.rank * p.push.Us + (size_t)lrow * (p.N >> 3)) * 32 + (size_t)c4 * 4);
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst, off, 0, 17 /* sc0 sc1: system scope */);
                     }
                 }

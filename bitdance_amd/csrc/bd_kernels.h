@@ -280,12 +280,85 @@ struct BdTpPush {
     char* stage[8] = {};        // every rank's staging area (peer_data[q]); [rank] unused
     long long Us = 0;           // 32 B units per rank slice = rows_per_rank * N / 8
     int rank = 0, size = 0, rows_per_rank = 0;
+    int il = 0;                 // 1: sequence-parallel row ownership -- 8-row group g of the tensor belongs to rank g % size (its local
+                                //    row (g / size) * 8 + row % 8), so that a rank owns the cond row AND the uncond row of the same patch
+                                //    position (rows bp and BP + bp) and the final layer / sampler step need no exchange; 0: contiguous slices
 };
 
+// ---- sequence-parallel row kernels under tensor parallelism (bd_sp.hip, bd_comm.hip): one rank's view of the exchange.  A rank owns
+// rows / size rows of the residual stream.  The row-split GEMM's epilogue pushes every owner its rows of the fp32 partial (BdTpPush);
+// the row kernel of the owner sums them, applies gate / residual / LayerNorm / modulation for ITS rows only and pushes the bf16
+// operand rows to every rank's landing buffer; the consuming GEMM polls the per-row flags before its first activation load.
+#define BD_SP_MAXROWS 512
+#define BD_SP_RC 0            /* replay counter: epoch = RC * 4096 + sequence number of the hand-off inside the replayed graph */
+#define BD_SP_P 8             /* [8]  "the partials of rank p are pushed" epochs */
+#define BD_SP_G 16            /* [8]  "the adaLN columns of rank p are pushed" epochs (split all-gather: push early, wait late) */
+#define BD_SP_H 32            /* [BD_SP_MAXROWS] "operand row m is pushed" epochs (also: final latent row bp) */
+#define BD_SP_FLAG_INTS (32 + BD_SP_MAXROWS)
+struct BdSpLink {
+    char* stage[8] = {};       // every rank's staging area [src rank][local row][N] fp32 (uncached)
+    char* hbuf[8] = {};        // every rank's operand landing buffer, fragment-major bf16 [Mpad][D] (cacheable: the GEMM re-reads it from L2)
+    char* aux[8] = {};         // every rank's landing area of the final latent rows [BP][C] fp32 (uncached)
+    int* spf[8] = {};          // every rank's sequence-parallel flag block
+    int* spf_local = nullptr;
+    int* err = nullptr;        // local error word (shared with the all-reduce exchange)
+    long long stage_bytes = 0, hbuf_bytes = 0, aux_bytes = 0, timeout_ticks = 0;
+    int rank = 0, size = 0;
+    int loopback = 0;          // 1: no peers exist (one rank's critical path timed on one GPU): pushes go to scratch copies, every flag a
+                               //    peer would write is written locally by the block that plays the same role
+};
+struct BdHWait {               // the consumer GEMM's wait for the pushed operand rows (bd_gemm_kernel.h prologue)
+    const int* flags = nullptr;   // local BD_SP_H block; null: no wait
+    const int* rc = nullptr;      // local replay counter
+    int* err = nullptr;
+    long long timeout_ticks = 0;
+    int seq = 0, n = 0;           // epoch = *rc * 4096 + seq; rows to wait for
+    int inv = 0;                  // 0: wave 0 invalidates (buffer_inv sc0 sc1) before the barrier; 1: every wave after it
+};
+int bdk_sp_begin(bd_comm* c, hipStream_t st);          // once per replayed graph / eager sequence: RC += 1, sequence numbers restart
+int bdk_sp_next_seq(bd_comm* c);                        // the next hand-off's sequence number (1 .. 4095); -1: exhausted
+bool bdk_sp_link(bd_comm* c, BdSpLink* out);            // false: no sequence-parallel exchange on this communicator
+bool bdk_sp_hwait(bd_comm* c, int seq, int rows, BdHWait* out);
+int bdk_sp_wait_rows(bd_comm* c, int seq, int rows, hipStream_t st);   // the wait as its own tiny kernel ("tune.sp_wait" = 0)
+long long bdk_sp_hbuf_bytes(const bd_comm* c);
+void* bdk_sp_hbuf(const bd_comm* c);
+void bdk_gemm_set_hwait(const BdHWait* w);              // bd_gemm.hip: the NEXT bdk_gemm / bdk_gemm8 call waits in its prologue
+bool bdk_gemm_take_hwait(BdHWait* out);
+void bdk_comm_count_exchange(bd_comm* c);
+
+struct LnModSpArgs {           // ln_mod for this rank's rows only, fed by the peers' partial pushes, feeding every rank's operand buffer
+    LnModArgs ln;              // X, ada, offsets, LayerNorm affine, M, D, RB, eps (pend / h_frag / a8_scale unused)
+    BdSpLink L;
+    const float* part = nullptr;   // this rank's own fp32 partial [Mpad][D] of the pending row-split Linear (rows at their global index); null: no pending branch
+    const void* bias = nullptr;    // its bias [D] bf16 (added once, by the reducing rank) or null
+    int seq_p = 0, seq_h = 0;      // sequence numbers of the partial hand-off (0: none) and of this kernel's operand rows
+    int rows_local = 0;
+};
+int bdk_ln_mod_sp(const LnModSpArgs& a, hipStream_t st);
+struct HeadFinalSpArgs {
+    HeadFinalArgs f;           // pend unused: the last block's w2 partials come through the staging area
+    BdSpLink L;
+    const float* part = nullptr;
+    const void* bias = nullptr;
+    int seq_p = 0, seq_f = 0;  // seq_f: the final evaluation's latent rows (pushed to every rank's aux area); 0 otherwise
+    int bp_local = 0;          // patch positions this rank owns (BP / size)
+};
+int bdk_head_final_sp(const HeadFinalSpArgs& a, hipStream_t st);
+struct TokFinishArgs {         // after the final evaluation: every rank assembles pred / tokens of ALL patch positions from the gathered latent rows
+    BdSpLink L;
+    int seq_f = 0;
+    float* xt; float* pred_out; float* tok_cur; float* tok_all;
+    const BdStepState* state;
+    int BP, C, T, P, tok_branches;
+};
+int bdk_tok_finish(const TokFinishArgs& a, hipStream_t st);
+
 bool bdk_tp_push_target(bd_comm* c, int rows, int N, BdTpPush* out);
+bool bdk_tp_push_target_sp(bd_comm* c, int rows, int N, BdTpPush* out);
 void bdk_tp_mark_prepushed(bd_comm* c);
 void bdk_gemm_set_push(const BdTpPush* t);      // bd_gemm.hip
 bool bdk_gemm_push_used();
+bool bdk_gemm_claim_push(int epi, int RB, int N, BdTpPush* out);
 
 // ---- bd_attn.hip
 struct HeadAttnArgs {       // DiT attention over one patch (seq = P = 64 or 16), non-causal      flow_head:192-220

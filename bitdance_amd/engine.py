@@ -400,9 +400,26 @@ class Engine:
                 and ints.get("tp.ada_split", 1 if self.comm.size >= 4 else 0):
             mp = 32 if self.M <= 32 else (64 if self.M <= 64 else (self.M + 127) // 128 * 128)
             G = ints.get("tune.ada_group", 512 // mp if mp <= 128 else (1024 // mp if (mp <= 512 and 1024 % mp == 0) else 1))
-            need = G * mp * head.ptrs["head.ada_b"].numel() * 2
+            need = 2 * G * mp * head.ptrs["head.ada_b"].numel() * 2          # two slots (double-buffered by group parity)
             self.ada_split = G >= 2 and self.comm.gather_bytes >= need and (self.wdtype in (0, 2))
         ints["tp.ada_split"] = int(self.ada_split)
+        # sequence-parallel row kernels (csrc/bd_sp.hip): every rank owns rows / tp rows of the head's residual stream and no stand-alone
+        # exchange kernel is left in an evaluation.  Default wherever the form applies: the hand-written exchange with an operand landing
+        # buffer, 128 rows (one image, 64-token patches), the cond / uncond rows of a patch position on one rank, bf16 activations.
+        # "tp.seq" = 0 in ``extra_ints`` keeps the all-reduce form.  Ranks that share ONE GPU (in-process tests) wait in a tiny kernel in
+        # front of the consuming GEMM ("tune.sp_wait" = 0) from 3 ranks up: a chip full of polling GEMM workgroups of two ranks could
+        # starve the third rank's row kernel they are waiting for.
+        self.seq_parallel = False
+        if self.comm is not None and head is not None and not head.mlp and self.comm.backend in ("ipc", "none") and self.comm.hbuf_bytes > 0:
+            ok = (self.M == 128 and self.branches == 2 and (self.BP // 8) % self.comm.size == 0 and self.wdtype in (0, 1)
+                  and self.comm.hbuf_bytes >= 128 * head.D * 2)
+            self.seq_parallel = bool(ints.get("tp.seq", 1)) and ok
+            if ints.get("tp.seq", 0) and not ok:
+                raise BitDanceHipError("tp.seq: sequence-parallel row kernels need 128 rows (one image with CFG, parallel_num 64), whole 8-row "
+                                       "groups of patch positions per rank, bf16 activations and a communicator with an operand landing buffer")
+        ints["tp.seq"] = int(self.seq_parallel)
+        if self.seq_parallel and "tune.sp_wait" not in ints and getattr(self.comm, "in_process_peers", False) and self.comm.size > 2:
+            ints["tune.sp_wait"] = 0
         for k, v in ints.items():
             check(self.l.bd_ctx_set_int(self.ctx, k.encode(), int(v)))
         if llm is not None:

@@ -30,7 +30,7 @@ import torch
 
 from ._lib import BitDanceHipError, check, lib
 
-__all__ = ["TPComm", "ada_gather_bytes", "shard_head_state", "shard_llm_state", "shard_rows", "shard_cols"]
+__all__ = ["TPComm", "ada_gather_bytes", "seq_hbuf_bytes", "shard_head_state", "shard_llm_state", "shard_rows", "shard_cols"]
 
 
 # ----------------------------------------------------------------------------------------------- slicing
@@ -99,7 +99,15 @@ def ada_gather_bytes(rows: int, ada_cols: int, group: int | None = None) -> int:
     evaluation, 1024 up to 512: csrc/bd_api.hip ``tune.ada_group``).  rows = branches * num_images * parallel_num."""
     mp = 32 if rows <= 32 else (64 if rows <= 64 else (rows + 127) // 128 * 128)
     g = group or (512 // mp if mp <= 128 else (1024 // mp if (mp <= 512 and 1024 % mp == 0) else 1))
-    return g * mp * ada_cols * 2 if g >= 2 else 0
+    # two slots: the gathered tensor is double-buffered by group parity (a peer may push group g + 1 while this rank still reads g)
+    return 2 * g * mp * ada_cols * 2 if g >= 2 else 0
+
+
+def seq_hbuf_bytes(rows: int, width: int) -> int:
+    """Capacity of the operand landing buffer of the sequence-parallel exchange (csrc/bd_sp.hip): the bf16 operand rows every rank
+    pushes to every rank, [padded rows][width].  rows = branches * num_images * parallel_num; 0 where that form does not apply (it is
+    built for 128-row passes: one image, 64-token patches)."""
+    return rows * width * 2 if rows == 128 else 0
 
 
 # ----------------------------------------------------------------------------------------------- communicator
@@ -110,14 +118,17 @@ class _NcclUniqueId(C.Structure):
 class TPComm:
     """One rank's exchange state.  ``max_elems`` = rows * N of the largest exchanged tensor (e.g. 512 * 5120)."""
 
-    def __init__(self, rank: int, size: int, max_elems: int, device=None, gather_bytes: int = 0):
+    def __init__(self, rank: int, size: int, max_elems: int, device=None, gather_bytes: int = 0, hbuf_bytes: int = 0):
         """``gather_bytes``: capacity of the all-gather region (the column-split adaLN projection's modulation tensor of one group of
-        evaluations: G x rows x 71 680 x 2 B = 73 MB at one image); 0: none, the projection stays replicated."""
+        evaluations, two slots: 2 x G x rows x 71 680 x 2 B = 147 MB at one image); 0: none, the projection stays replicated.
+        ``hbuf_bytes``: the operand landing buffer of the sequence-parallel row kernels (``seq_hbuf_bytes``); 0: the all-reduce form only."""
         self.l = lib()
         self.rank, self.size = rank, size
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.in_process_peers = False
+        self.loopback = False
         with torch.cuda.device(self.device):
-            self.h = self.l.bd_comm_create2(rank, size, int(max_elems), int(gather_bytes))
+            self.h = self.l.bd_comm_create3(rank, size, int(max_elems), int(gather_bytes), int(hbuf_bytes))
         if not self.h:
             raise BitDanceHipError(f"bd_comm_create failed: {self.l.bd_last_error().decode()}")
         self.group = None
@@ -135,11 +146,12 @@ class TPComm:
 
     # -- construction ------------------------------------------------------------------------------------
     @classmethod
-    def from_process_group(cls, max_elems: int, group=None, device=None, backend: str | None = None, gather_bytes: int = 0) -> "TPComm":
+    def from_process_group(cls, max_elems: int, group=None, device=None, backend: str | None = None, gather_bytes: int = 0,
+                           hbuf_bytes: int = 0) -> "TPComm":
         """One process per GPU: exchange the IPC handles through ``torch.distributed`` and map every peer."""
         import torch.distributed as dist
         rank, size = dist.get_rank(group), dist.get_world_size(group)
-        self = cls(rank, size, max_elems, device, gather_bytes)
+        self = cls(rank, size, max_elems, device, gather_bytes, hbuf_bytes)
         self.group = group
         backend = backend or os.environ.get("BD_TP_COMM", "ipc")
         if backend not in ("ipc", "rccl"):
@@ -148,8 +160,8 @@ class TPComm:
         if size > 1:
             # map the peers' buffers; if ANY rank cannot (IPC export / open refused on this node), every rank falls back to RCCL
             ok, why = True, ""
-            buf = C.create_string_buffer(128)
-            if self.l.bd_comm_ipc_handles(self.h, buf) != 0:
+            buf = C.create_string_buffer(192)                # data, flags, operand landing buffer (zeros when there is none)
+            if self.l.bd_comm_ipc_handles3(self.h, buf) != 0:
                 ok, why = False, self.l.bd_last_error().decode()
             handles = [None] * size
             my_dev = torch.device(self.device).index if self.device is not None else None
@@ -165,7 +177,7 @@ class TPComm:
                         ok, why = False, f"device {my_dev} cannot access device {handles[p][3]} (no peer-to-peer path)"
             if ok:
                 for p in range(size):
-                    if p != rank and self.l.bd_comm_open_peer(self.h, p, C.create_string_buffer(handles[p][0], 128)) != 0:
+                    if p != rank and self.l.bd_comm_open_peer3(self.h, p, C.create_string_buffer(handles[p][0], 192)) != 0:
                         ok, why = False, self.l.bd_last_error().decode()
             flags = [None] * size
             dist.all_gather_object(flags, (ok, why), group=group)
@@ -246,15 +258,36 @@ class TPComm:
         self.barrier()
 
     @classmethod
-    def in_process(cls, size: int, max_elems: int, device=None, gather_bytes: int = 0) -> list:
+    def in_process(cls, size: int, max_elems: int, device=None, gather_bytes: int = 0, hbuf_bytes: int = 0) -> list:
         """``size`` ranks as contexts of THIS process on one device, linked by plain pointers: the exchange protocol can then
         be exercised on a single GPU with one stream per rank (tests/test_gpu_tp.py)."""
-        comms = [cls(r, size, max_elems, device, gather_bytes) for r in range(size)]
+        comms = [cls(r, size, max_elems, device, gather_bytes, hbuf_bytes) for r in range(size)]
         for a in comms:
+            a.in_process_peers = True
             for b in comms:
                 if a is not b:
-                    check(a.l.bd_comm_set_peer_ptrs(a.h, b.rank, a.l.bd_comm_local_data(b.h), a.l.bd_comm_local_flags(b.h)))
+                    check(a.l.bd_comm_set_peer_ptrs3(a.h, b.rank, a.l.bd_comm_local_data(b.h), a.l.bd_comm_local_flags(b.h),
+                                                     a.l.bd_comm_local_hbuf(b.h)))
         return comms
+
+    @classmethod
+    def loopback_rank(cls, rank: int, size: int, max_elems: int, device=None, gather_bytes: int = 0, hbuf_bytes: int = 0) -> "TPComm":
+        """ONE rank of a ``size``-rank group alone on this GPU (bd_comm_set_loopback): the peers' buffers are scratch copies and every
+        flag a peer would write is written locally, so the rank's launches, weight shards, pushes and waits run as on a node minus
+        the links -- for timing its critical path on one GPU (tools/head_sweep.py --tp-shard).  Results are meaningless."""
+        self = cls(rank, size, max_elems, device, gather_bytes, hbuf_bytes)
+        with torch.cuda.device(self.device):
+            check(self.l.bd_comm_set_loopback(self.h), "bd_comm_set_loopback")
+        self.loopback = True
+        return self
+
+    @property
+    def hbuf_bytes(self) -> int:
+        return int(self.l.bd_comm_hbuf_bytes(self.h))
+
+    def prepushed(self) -> int:
+        """Exchanges whose reduce-scatter push ran in the producing GEMM's epilogue."""
+        return int(self.l.bd_comm_prepushed(self.h))
 
     def _init_rccl(self, dist, group) -> None:
         """ncclCommInitRank on the librccl torch itself uses; the per-Linear exchange then is ncclAllReduce(fp32 partials)."""

@@ -133,6 +133,24 @@ bd_comm* bd_comm_create(int rank, int size, long long max_elems);
  * (flow_head_parallel_x.py:331: each rank computes N / size of its 71 680 output columns) is assembled on every rank by pushes
  * (bd_comm_allgather standalone; inside the step when the context finds "head.ada_w_l" and the region is large enough) */
 bd_comm* bd_comm_create2(int rank, int size, long long max_elems, long long gather_bytes);
+/* ... plus, with hbuf_bytes > 0, the buffers of the SEQUENCE-PARALLEL form of the exchange (round 5; csrc/bd_sp.hip; "tp.seq" in the
+ * context): what one DiT block computes (flow_head_parallel_x.py:242-252: x += gate * branch; h = LN(x) * (1 + scale) + shift) is done
+ * for rows / size rows per rank -- the row-split GEMM's epilogue pushes each owner its rows of the fp32 partial, the owner's row kernel
+ * sums them in rank order (+ bias, one bf16 rounding: the same value the all-reduce form computes), normalises / modulates and pushes
+ * the bf16 operand rows into EVERY rank's landing buffer (hbuf_bytes = rows x D x 2, a second, cacheable exported allocation: the
+ * consuming GEMM re-reads it from L2), and the consuming GEMM polls per-row flags after issuing its first weight loads.  No stand-alone
+ * exchange kernel is left in the evaluation.  A 64 KiB landing area for the final latent rows sits behind the gather region. */
+bd_comm* bd_comm_create3(int rank, int size, long long max_elems, long long gather_bytes, long long hbuf_bytes);
+int bd_comm_ipc_handles3(bd_comm* c, void* out192);                  /* 3 x hipIpcMemHandle_t: data, flags, operand landing buffer */
+int bd_comm_open_peer3(bd_comm* c, int peer, const void* handles192);
+int bd_comm_set_peer_ptrs3(bd_comm* c, int peer, void* data, void* flags, void* hbuf);   /* peers inside this process */
+void* bd_comm_local_hbuf(bd_comm* c);
+long long bd_comm_hbuf_bytes(bd_comm* c);
+/* ONE rank of a `size`-rank group alone on this GPU: the peers' buffers become scratch copies, every flag a peer would write is written
+ * locally -- the rank's launches, weight shards, pushes and waits minus the links, for timing its critical path on one GPU
+ * (tools/head_sweep.py --tp-shard).  The results are meaningless (the peers contribute zeros). */
+int bd_comm_set_loopback(bd_comm* c);
+long long bd_comm_prepushed(bd_comm* c);                             /* exchanges whose reduce-scatter push ran in the producing GEMM's epilogue */
 void* bd_comm_gather_ptr(bd_comm* c);                                /* this rank's copy of the region (null: none) */
 long long bd_comm_gather_bytes(bd_comm* c);
 int bd_comm_allgather(bd_comm* c, const void* slice_bf16, int rows, int Nl, void* stream);   /* [rows][Nl] of every rank -> [rows][Nl * size] */

@@ -337,9 +337,168 @@ def test_fused_reduce_scatter_push_equals_unfused_exchange(tp, P):
             assert torch.equal(ps[r], ps[0]), f"rank {r} diverged (fuse {fuse})"
         outs[fuse] = ps[0]
         assert comms[0].exchanges() == 2 * (n + 1) * 2 * HEAD8["depth_latent"]
+        # the fusion must actually have engaged where it is claimed: every exchange of the 128-row passes (P = 64) found its staging rows
+        # pushed by the producing GEMM's epilogue; the 32-row passes (P = 16: one row block, the push epilogue is instantiated for
+        # four) keep the exchange kernel's own push phase, fused or not
+        want_pre = comms[0].exchanges() if (fuse and P == 64) else 0
+        assert comms[0].prepushed() == want_pre, (fuse, P, comms[0].prepushed(), comms[0].exchanges())
         del engs, comms
     print(f"[tp {tp} P {P}] head_sample of {n + 1} evaluations, ranks as streams of one GPU: fused {times[1] * 1e3:.2f} ms, unfused {times[0] * 1e3:.2f} ms")
     assert torch.equal(outs[1], outs[0])
+
+
+# ----------------------------------------------------------------------------------------------- sequence-parallel row kernels
+def _sp_comms(tp, D, nada, split=False):
+    from bitdance_amd.tp import TPComm, ada_gather_bytes, seq_hbuf_bytes
+    comms = TPComm.in_process(tp, 128 * D, DEV, gather_bytes=ada_gather_bytes(128, nada) if split else 0, hbuf_bytes=seq_hbuf_bytes(128, D))
+    for c in comms:
+        c.set_timeout(8.0)
+    return comms
+
+
+@pytest.mark.parametrize("tp,tune,split", [(2, {}, 0), (2, {"sp_wait": 0}, 0), (2, {"sp_inv": 1}, 1), (4, {}, 0), (4, {}, 1)])
+def test_head_sample_sequence_parallel_equals_allreduce_form(tp, tune, split):
+    """The sequence-parallel form of the tensor-parallel head (csrc/bd_sp.hip: a rank owns rows / tp rows of the residual stream; the
+    row-split GEMM's epilogue pushes each owner its rows of the fp32 partial, the owner's row kernel reduces in rank order, normalises,
+    modulates and pushes bf16 operand rows to every rank, the consuming GEMM polls per-row flags; final layer / sampler step on the
+    owner, latent rows gathered after the last evaluation) against the all-reduce form (tp.seq = 0): every element is computed by
+    exactly one rank from the same partials in the same order, so the sampled latents and tokens are BIT-identical -- between the
+    forms and between the ranks -- eagerly and as replayed hipGraphs (epochs = replay counter x 4096 + sequence number)."""
+    from bitdance_amd import engine as E
+    sd_dev = device_seeded_state(tm.head_shapes(HEAD8), 331, DEV)
+    B, br, C, P, n = 1, 2, 32, 64, 5
+    g = torch.Generator().manual_seed(332)
+    z = torch.randn(br * B, P, 1024, generator=g)
+    noise = torch.randn(2, n + 1, B, P, C, generator=g)
+    nada = (HEAD8["depth_adanln"] * 6 + 2) * 1024
+    hws = [E.HeadWeights.from_state_dict(sd_dev, DEV, tp_rank=r, tp_size=tp) for r in range(tp)]
+
+    def prep(eng, step):
+        eng.set_schedule(n, 1.5, 2)
+        eng.load_noise(noise)
+        eng.reset([0] * (br * B))
+        if step:
+            eng.view("state", torch.int32, (1,)).fill_(step)        # AR step 1: the second set of noise draws
+        eng.set_cond(z.to(DEV))
+
+    outs = {}
+    for seq in (0, 1):
+        comms = _sp_comms(tp, 1024, nada, split)
+        streams = _streams(tp)
+        engs = [E.Engine(hws[r], None, None, num_images=B, branches=br, device=DEV, max_tokens=2 * P, parallel_num=P, comm=comms[r],
+                         tune=dict(tune) if seq else None, extra_ints={"tp.seq": seq, "tp.ada_split": split}) for r in range(tp)]
+        assert all(e.seq_parallel == bool(seq) and e.ada_split == bool(split) for e in engs)
+        torch.cuda.synchronize()
+        res = []
+        for mode in ("eager", "graph", "graph"):                   # the same graph replayed twice: epochs advance, flags are never reset
+            step = len(res) % 2
+            if mode == "graph":
+                for r in range(tp):
+                    with torch.cuda.stream(streams[r]):
+                        prep(engs[r], step)
+                        engs[r].capture(0)
+                torch.cuda.synchronize()
+            for r in range(tp):
+                with torch.cuda.stream(streams[r]):
+                    prep(engs[r], step)
+                    engs[r].head_sample() if mode == "eager" else engs[r].launch(0)
+            torch.cuda.synchronize()
+            for c in comms:
+                c.check()
+            ps = [e.pred().clone() for e in engs]
+            ts = [e.tok_cur().clone() for e in engs]
+            for r in range(1, tp):
+                assert torch.equal(ps[r], ps[0]) and torch.equal(ts[r], ts[0]), f"rank {r} diverged (seq {seq}, {mode})"
+            assert torch.equal(ts[0], torch.sign(ps[0]))
+            assert torch.equal(engs[0].tok_all[:, step * P:(step + 1) * P], ts[0])
+            res.append(ps[0])
+        assert torch.equal(res[0], res[2]) and not torch.equal(res[0], res[1])      # step 0 eager == step 0 replayed; step 1 differs (other noise)
+        n_ex = comms[0].exchanges()
+        assert comms[0].prepushed() == n_ex                                         # every hand-off's push ran in a GEMM epilogue
+        outs[seq] = res
+        del engs, comms
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b), (a - b).abs().max()                               # sequence-parallel == all-reduce form, bit for bit
+
+
+@pytest.mark.parametrize("tp", [2, 4])
+def test_head_eval_sequence_parallel_rows_vs_oracle(tp):
+    """One evaluation in the sequence-parallel form: every rank produces x_hat for the patch positions it owns (8-row groups dealt
+    round-robin: rank r owns positions 8 (j tp + r) .. + 7 and their unconditional rows) -- the union over the ranks equals the
+    all-reduce form's x_hat bit for bit and sits inside the tiny-model bounds against the CPU oracle."""
+    from bitdance_amd import engine as E
+    sd_dev = device_seeded_state(tm.head_shapes(HEAD8), 341, DEV)
+    sd = {k: v.cpu() for k, v in sd_dev.items()}
+    B, br, C, P = 1, 2, 32, 64
+    g = torch.Generator().manual_seed(342)
+    z = torch.randn(br * B, P, 1024, generator=g)
+    x = torch.randn(B, P, C, generator=g)
+    M = br * B * P
+    got = {}
+    for seq in (0, 1):
+        comms = _sp_comms(tp, 1024, 0)
+        streams = _streams(tp)
+        engs = [E.Engine(E.HeadWeights.from_state_dict(sd_dev, DEV, tp_rank=r, tp_size=tp), None, None, num_images=B, branches=br, device=DEV,
+                         max_tokens=P, parallel_num=P, comm=comms[r], extra_ints={"tp.seq": seq}) for r in range(tp)]
+        torch.cuda.synchronize()
+        for r in range(tp):
+            with torch.cuda.stream(streams[r]):
+                _head_run(engs[r], z, x)
+        torch.cuda.synchronize()
+        for c in comms:
+            c.check()
+        xs = [e.view("head.xhat", torch.float32, (e.Mpad, C))[:M].clone() for e in engs]
+        if seq:
+            full = torch.full_like(xs[0], float("nan"))
+            for r in range(tp):
+                for bp in range(P):
+                    if (bp // 8) % tp == r:
+                        full[bp] = xs[r][bp]
+                        full[P + bp] = xs[r][P + bp]
+            got[seq] = full
+        else:
+            got[seq] = xs[0]
+        t_i = float(engs[0]._sc[1, 0])
+        del engs, comms
+    assert torch.isfinite(got[1]).all()
+    assert torch.equal(got[1], got[0])
+    ref = diff_head.net_forward(sd, torch.cat([x] * br), torch.full((br * B,), t_i), z, Policy("autocast")).float().view(M, C)
+    err = (got[1].cpu() - ref).abs()
+    assert err.max() <= 5e-2 and err.mean() <= 6e-3, (err.max(), err.mean())
+
+
+@pytest.mark.parametrize("tp,seq", [(8, 1), (8, 0), (4, 1)])
+def test_loopback_rank_runs_the_shard_alone(tp, seq):
+    """bd_comm_set_loopback: ONE rank of a tp-rank group alone on the GPU -- its weight slices, its launches, pushes into scratch copies
+    of the peers' buffers, every flag a peer would write written locally -- as eager launches and as a replayed graph, without a
+    timed-out wait (the peers contribute zeros, so only finiteness is checked).  tools/head_sweep.py --tp-shard times exactly this."""
+    from bitdance_amd import engine as E
+    from bitdance_amd.tp import TPComm, ada_gather_bytes, seq_hbuf_bytes
+    sd_dev = device_seeded_state(tm.head_shapes(HEAD8), 351, DEV)
+    B, br, C, P, n = 1, 2, 32, 64, 4
+    nada = (HEAD8["depth_adanln"] * 6 + 2) * 1024
+    comm = TPComm.loopback_rank(tp - 1, tp, 128 * 1024, DEV, gather_bytes=ada_gather_bytes(128, nada), hbuf_bytes=seq_hbuf_bytes(128, 1024))
+    comm.set_timeout(5.0)
+    eng = E.Engine(E.HeadWeights.from_state_dict(sd_dev, DEV, tp_rank=tp - 1, tp_size=tp), None, None, num_images=B, branches=br, device=DEV,
+                   max_tokens=P, parallel_num=P, comm=comm, extra_ints={"tp.seq": seq})
+    assert eng.seq_parallel == bool(seq)
+    g = torch.Generator().manual_seed(352)
+    z = torch.randn(br * B, P, 1024, generator=g)
+    noise = torch.randn(1, n + 1, B, P, C, generator=g)
+    for mode in ("eager", "graph", "graph"):
+        eng.set_schedule(n, 1.5, 1)
+        eng.load_noise(noise)
+        eng.reset([0] * (br * B))
+        eng.set_cond(z.to(DEV))
+        if mode == "graph":
+            eng.capture(0)
+            eng.launch(0)
+        else:
+            eng.head_sample()
+        torch.cuda.synchronize()
+        comm.check()
+        assert torch.isfinite(eng.pred()).all()
+    assert comm.exchanges() > 0 and comm.prepushed() == comm.exchanges()
 
 
 @pytest.mark.parametrize("weights", ["bf16", "fp8a"])

@@ -6,7 +6,13 @@
 (the run-ahead weight prefetch this tool also swept in round 3 -- profiles/r03_head_sweep1.log -- measured negative and is gone)
 
 Every configuration is timed as a hipGraph replay and its sampled latent is compared bit for bit with the first one's.
-python tools/head_sweep.py [reps] [n_steps] ["k=v,k=v;k=v,..." extra configs] [bf16|fp8|fp8a]"""
+python tools/head_sweep.py [reps] [n_steps] ["k=v,k=v;k=v,..." extra configs] [bf16|fp8|fp8a]
+
+  --tp-shard r/N [--loopback]   ONE rank's critical path at the tensor-parallel shard shapes on ONE GPU: rank r of N packs its weight
+      slices, the communicator runs in loop-back (bd_comm_set_loopback: the peers' buffers are scratch copies, every flag a peer would
+      write is written locally), so the captured graph holds exactly the launches, pushes and waits of that rank on a node -- minus the
+      links.  Configs may carry tp.seq=0/1 (all-reduce form / sequence-parallel row kernels), tp.ada_split=0/1, tune.* keys.  The
+      sampled latent is meaningless there (the peers contribute zeros) and is not compared."""
 import os
 import sys
 import time
@@ -35,16 +41,30 @@ def main():
 
 
 def run():
+    shard = None
+    if "--tp-shard" in sys.argv:
+        i = sys.argv.index("--tp-shard")
+        shard = tuple(int(v) for v in sys.argv[i + 1].split("/"))
+        del sys.argv[i:i + 2]
+    if "--loopback" in sys.argv:
+        sys.argv.remove("--loopback")
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 50
     cfgs = list(DEFAULT)
     if len(sys.argv) > 3:
         cfgs = [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in c.split(",") if kv) for c in sys.argv[3].split(";")]
+    elif shard:
+        cfgs = [{"tp.seq": 0}, {"tp.seq": 1}, {"tp.seq": 1, "sp_wait": 0}, {"tp.seq": 0}]
     dev = "cuda"
     B = 1
     cfgd = dict(ch_target=32, ch_cond=5120, ch_latent=5120, depth_latent=6, depth_adanln=2)
     sd = device_seeded_state(tm.head_shapes(cfgd), 101, dev)
-    hw = E.HeadWeights.from_state_dict(sd, dev, weights=sys.argv[4] if len(sys.argv) > 4 else "bf16")
+    wmode = sys.argv[4] if len(sys.argv) > 4 else "bf16"
+    if shard:
+        hw = E.HeadWeights.from_state_dict(sd, dev, weights=wmode, tp_rank=shard[0], tp_size=shard[1])
+        print(f"# rank {shard[0]} of {shard[1]} in loop-back: weight slices of this rank, peers' buffers are scratch, flags written locally", flush=True)
+    else:
+        hw = E.HeadWeights.from_state_dict(sd, dev, weights=wmode)
     del sd
     g = torch.Generator(device=dev).manual_seed(7)
     cond = torch.randn(2 * B, 64, 5120, device=dev, generator=g)
@@ -56,8 +76,18 @@ def run():
         opts = {k: tune.pop(k) for k in list(tune) if k.startswith("wide.") or k == "tile"}      # process-wide GEMM options
         for k, v in opts.items():
             check(lib().bd_set_gemm_option(k.encode(), v))
-        tune_shown = dict(tune, **opts)
-        eng = E.Engine(hw, None, None, num_images=B, branches=2, device=dev, max_tokens=64, parallel_num=64, tune=tune)
+        extra = {k: tune.pop(k) for k in list(tune) if k.startswith("tp.")}                         # context keys outside tune.*
+        tune_shown = dict(tune, **opts, **extra)
+        comm = None
+        if shard:
+            from bitdance_amd.tp import TPComm, ada_gather_bytes, seq_hbuf_bytes
+            comm = TPComm.loopback_rank(shard[0], shard[1], 128 * 5120, dev, gather_bytes=ada_gather_bytes(128, 14 * 5120),
+                                        hbuf_bytes=seq_hbuf_bytes(128, 5120))
+            comm.set_timeout(5.0)
+        eng = E.Engine(hw, None, None, num_images=B, branches=2, device=dev, max_tokens=64, parallel_num=64, tune=tune, comm=comm,
+                       extra_ints=extra or None)
+        if shard:
+            tune_shown = dict(tune_shown, seq=int(eng.seq_parallel), ada_split=int(eng.ada_split))
         eng.set_schedule(n, 7.5, 1)
         eng.load_noise(noise)
         eng.reset([0] * (2 * B))
@@ -67,12 +97,14 @@ def run():
         pred = eng.pred().clone()
         if ref is None:
             ref = pred
-        same = bool(torch.equal(pred, ref))
+        same = bool(torch.equal(pred, ref)) if not shard else None
         eng.capture(0)
         eng.reset([0] * (2 * B))
         eng.launch(0)
         torch.cuda.synchronize()
-        same = same and bool(torch.equal(eng.pred(), ref))
+        same = (same and bool(torch.equal(eng.pred(), ref))) if not shard else None
+        if comm is not None:
+            comm.check()
         ts = []
         for _ in range(reps):
             eng.reset([0] * (2 * B))
@@ -84,7 +116,9 @@ def run():
         dt = min(ts)
         print(f"{str(tune_shown):60s} graph {dt * 1e3:8.2f} ms/AR step  {dt / (n + 1) * 1e6:8.1f} us/eval  (median {sorted(ts)[len(ts) // 2] * 1e3:.2f})  "
               f"bit-identical to first: {same}", flush=True)
-        del eng
+        if comm is not None:
+            comm.check()
+        del eng, comm
         for k in opts:
             check(lib().bd_set_gemm_option(k.encode(), {"wide.ring": 2, "tile": 1}.get(k, -1)))
         torch.cuda.empty_cache()

@@ -36,6 +36,19 @@ SHAPES = [("head.ada", 71680, 5120, 1, 9, 1, 2), ("head.qkv", 15360, 5120, 2, 4,
           ("head.ada[x16]", 71680, 5120, 1, 8, 1, 2, 2048)]
 
 
+# num_images = 4 (the eval scripts' batch, eval/eval_dpg.py:44): 512 rows per pass, the engine's launch configurations at that row
+# count (bench.py b4.roofline.per_gemm): the 256-row kernel, K slices left to the consumer; the grouped adaLN projection of two
+# evaluations = 1024 rows on the LDS-tiled kernel.  Selected with BD_PMC_ROWS=512 -> profiles/r05_pmc_gemm_traffic_rows512.json
+SHAPES_512 = [("head.qkv", 15360, 5120, 2, 8, 1, 2, 512), ("head.wo", 5120, 5120, 5, 8, 1, 2, 512), ("head.w1", 15360, 5120, 2, 8, 1, 2, 512),
+              ("head.w2", 5120, 7680, 5, 8, 1, 2, 512), ("llm.qkv", 7168, 5120, 3, 8, 1, 2, 512), ("llm.o", 5120, 5120, 5, 8, 1, 2, 512),
+              ("llm.gu", 34816, 5120, 1, 8, 1, 2, 512), ("llm.down", 5120, 17408, 5, 8, 1, 2, 512),
+              ("head.ada[x2]", 71680, 5120, 1, 8, 1, 2, 1024)]
+if os.environ.get("BD_PMC_ROWS") == "512":
+    SHAPES, M = SHAPES_512, 512
+if os.environ.get("BD_PMC_SHAPES"):                      # "name:N:K:S:nw:kw:ring[:rows];..." -- ad-hoc sets (A/B of a launch configuration)
+    SHAPES = [tuple([f.split(":")[0]] + [int(v) for v in f.split(":")[1:]]) for f in os.environ["BD_PMC_SHAPES"].split(";") if f]
+
+
 def _shape(sh):
     """(name, N, K, S, nw, kw, ring, rows): rows defaults to M."""
     return tuple(sh) + ((M,) if len(sh) == 7 else ())
@@ -65,7 +78,7 @@ def run():
         cnt = torch.zeros(16384, dtype=torch.int32, device="cuda")
         code = nw + 16 * ring + 256 * (kw - 1)
         for _ in range(REPS):
-            if (S > 2 and name not in ("head.cond", "proj.fc2")) or name == "llm.gu":      # > 2 slices: slabs for the consumer
+            if (S > 2 and name not in ("head.cond", "proj.fc2")) or name == "llm.gu" or (M >= 256 and S > 1):      # > 2 slices (256-row passes: > 1): slabs for the consumer
                 check(lib().bd_gemm_partial(xf.data_ptr(), M // 32, wp.data_ptr(), N, K, S, code, out.data_ptr(), st))
             else:
                 check(lib().bd_gemm_bf16(xf.data_ptr(), M // 32, wp.data_ptr(), None, N, K, S, code, out.data_ptr(), cnt.data_ptr(),
@@ -128,6 +141,10 @@ def parse(out_path, fetch_db, write_db=None, sq_db=None):
             e["mfma_busy_cycles"], e["gui_active_cycles"] = round(mf), round(gui)
             e["mfma_util"] = round(mf / (gui * 1024.0), 4)    # matrix-pipe busy cycles / (kernel cycles x 256 CUs x 4 SIMDs)
             e["mfma_util_from_flops"] = round(2.0 * rows * N * K / (e["avg_ns"] * 1e-9) / 2.5e15, 4)   # same thing from 2*M*N*K / time / 2.5 PFLOP/s
+            # effective shader clock of THIS dispatch = busy cycles / wall time: the nominal 2.5 PFLOP/s assumes 2.4 GHz; a dense GEMM under
+            # profiling runs lower (DVFS), so a fraction of the nominal peak understates how busy the matrix pipe was
+            e["eff_clock_ghz"] = round(gui / e["avg_ns"], 3)
+            e["mfma_frac_at_eff_clock"] = round(e["mfma_util_from_flops"] * 2.4 / max(e["eff_clock_ghz"], 1e-6), 4)
             if "SQ_BUSY_CYCLES" in gs:
                 e["sq_busy_cycles"] = round(avg(gs["SQ_BUSY_CYCLES"]))
         res[name] = e
