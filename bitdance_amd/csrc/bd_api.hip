@@ -170,6 +170,24 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
         if (S > 3) S = 3;
         if (S < 1) S = 1;
     }
+    // Tensor-parallel shards of the 128-row passes, measured on ONE rank in loop-back (tools/head_sweep.py --tp-shard,
+    // profiles/r05_tp_shard_sweep.log): what bounds a small GEMM is a CU's vector-memory path (~47 GB/s) over the weights PLUS
+    // the 128 activation rows every workgroup re-reads -- so the work has to sit on ~240 CUs in SHORT K slices, and what a slice costs in
+    // fp32 slabs is paid to a row-parallel consumer (finalize_rows in front of the attention, swiglu_rows behind w1), not to an in-launch
+    // reduction by the last arriver.  At the tp = 8 shard (per evaluation): the tp = 1 rules 1221 us -> these 705 us.
+    if (c->tp > 1 && !two_images && c->Mpad == 128 && c->geti("tune.tp_shapes", 1) != 0) {
+        if (reduce3 && K <= 1024 && !c->wfp8) {
+            // row-split with a short local K (wo / w2 at tp = 8: 640 / 960): ONE slice -- no ticket, no slab round trip before the push
+            // epilogue -- on 32-column tiles x 2 K parts (160 workgroups), or 64-column tiles when K is not a multiple of 128
+            g.nw = 2; g.kw = (K % 128 == 0) ? 2 : 1;
+            S = 1;
+        } else if (!reduce3 && N < 7680 && K % 128 == 0 && N % 64 == 0) {
+            // column-split with few columns per rank (qkv / w1 from tp = 4 up): 64-column tiles x up to 8 K slices
+            const int t64 = N / 64;
+            g.nw = 4; g.kw = 2;
+            S = std::max(1, std::min(8, (int)std::lround(240.0 / t64)));
+        }
+    }
     // Small weights under a few thousand rows (the ImageNet 1x / 4x batches: 768 / 3072 rows, 1.2 - 3.5 MB per Linear): 256 x 256
     // tiles leave most CUs idle at one K slice (B-4x qkv: 108 workgroups; B-1x w1: 27) and splitting K to fill the chip parks
     // 12 - 18 fp32 slabs (B-1x w1: 85 MB of slabs for 3.5 MB of weights, then a separate swiglu_rows pass).  Smaller tiles
@@ -205,7 +223,7 @@ static const char* const kIntKeys[] = {
     "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid", "head.y_evals", "head.variant",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "proj.rows_all", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
     "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "rt.in_first", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ragged", "tune.ragged52", "tune.slab_cap", "tune.slab3",
-    "tune.ada_group", "tune.ada_group_nw", "tune.tp_fuse", "tune.ln_rows", "tune.small_tiles_rows", "tp.ada_split", "tp.seq", "tune.sp_wait", "tune.sp_inv"};
+    "tune.ada_group", "tune.ada_group_nw", "tune.tp_fuse", "tune.ln_rows", "tune.small_tiles_rows", "tp.ada_split", "tp.seq", "tune.sp_wait", "tune.sp_inv", "tune.finalize_s", "tune.sp_gsig", "tune.tp_shapes"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
                                          "llm.qkv", "llm.o", "llm.gu", "llm.down"};
 static bool known_int_key(const std::string& k) {
@@ -657,6 +675,17 @@ static Partial done(const bd_ctx* c, const std::string& ws, int N, int Mpad) {  
     return Partial{(const float*)c->ptr(ws), nullptr, 0, N, Mpad};
 }
 
+// Many K slices in front of a consumer with FEW workgroups (the attention of a tensor-parallel rank: 2 x heads / tp workgroups, each
+// reading its q / k / v through every slab): one row-parallel pass (a workgroup per row, every slab load in flight) sums them into the
+// finished bf16 tensor first.  "tune.finalize_s": slab counts from which this runs under tensor parallelism (default 3).
+static int finalize_if_many(bd_ctx* c, Partial* q, const char* out_ws, int M, hipStream_t st) {
+    if (c->tp <= 1 || q->S < (int)c->geti("tune.finalize_s", 3)) return 0;
+    FinalizeRowsArgs fr{*q, c->wptr(out_ws), M, q->N};
+    BD_TRY(bdk_finalize_rows(fr, st));
+    *q = Partial{(const float*)c->ptr(out_ws), nullptr, 0, q->N, q->Mpad};
+    return 0;
+}
+
 // A Linear whose output the consumer reads as bf16(sum + bias).  Few K-slices: the GEMM reduces them in the launch
 // (last-arriver epilogue) and the consumer reads one bf16 tensor.  Many K-slices: the serial tail of a single reducing
 // workgroup (S x 64-128 KiB through one CU) costs more than it saves, so the slabs stay and the consumer sums them.
@@ -701,14 +730,19 @@ static int linear_rowsplit(bd_ctx* c, const char* name, const void* A, int RB, W
 static int linear_rowsplit_sp(bd_ctx* c, const char* name, const void* A, int RB, WRef W, int N, int Klocal, const GemmCfg& g,
                               const char* scratch_ws, const char* tp_ws, int rows, int* seq, hipStream_t st) {
     if (g.S > 3) return fail(std::string(name) + ": a tensor-parallel partial needs at most 3 grid slices");
+    *seq = bdk_sp_next_seq(c->comm);
+    if (*seq < 0) return fail("sequence-parallel exchange: more than 4095 hand-offs since the last bd_head_cond / bd_head_sample");
     BdTpPush push;
-    if (!bdk_tp_push_target_sp(c->comm, rows, N, &push)) return fail(std::string(name) + ": no sequence-parallel push target for this shape");
+    // "tune.sp_gsig" = 1: the GEMM's last workgroup signals the owners; 0 (default): the owner's row kernel's first block does -- the
+    // arrival counter + barrier at the end of every GEMM workgroup cost more than the flag's head start returns (loop-back, per
+    // evaluation: tp 8 728.6 vs 702.1 us, tp 4 761.0 vs 743.4, tp 2 918.4 vs 909.5; profiles/r05_tp_rank_critical_path.log)
+    if (!bdk_tp_push_target_sp(c->comm, rows, N, c->geti("tune.sp_gsig", 0) ? *seq : 0, &push))
+        return fail(std::string(name) + ": no sequence-parallel push target for this shape");
+    if (push.done_cnt) push.done_cnt = (int*)c->wptr("gemm.cnt") + 16383;   // arrival counter in ordinary (L2-served) memory: the last counter word, never a tile's
     bdk_gemm_set_push(&push);
     BD_TRY(gemm(c, name, A, RB, W, N, Klocal, g.S, g.code(), BD_EPI_F32, (float*)c->wptr(scratch_ws), c->wptr(tp_ws), nullptr, st));
     if (!bdk_gemm_push_used()) return fail(std::string(name) + ": the GEMM did not take the push target");
     bdk_comm_count_exchange(c->comm);
-    *seq = bdk_sp_next_seq(c->comm);
-    if (*seq < 0) return fail("sequence-parallel exchange: more than 4095 hand-offs since the last bd_head_cond / bd_head_sample");
     return 0;
 }
 // the consumer GEMM of the operand rows pushed with sequence number `seq`: waits in its prologue ("tune.sp_wait" = 0: a one-workgroup
@@ -841,6 +875,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0
             l1.ln.ln_w = (const float*)c->ptr(pre + "ln1_w"); l1.ln.ln_b = (const float*)c->ptr(pre + "ln1_b");
             l1.L = L; l1.rows_local = rows_local;
             l1.part = seq_p ? (const float*)c->ptr("head.tp_part") : nullptr; l1.bias = pend_bias; l1.seq_p = seq_p;
+            l1.signal_p = c->geti("tune.sp_gsig", 0) ? 0 : 1;
             l1.seq_h = bdk_sp_next_seq(c->comm);
             if (l1.seq_h < 0) return fail("sequence-parallel exchange: more than 4095 hand-offs since the last bd_head_cond / bd_head_sample");
             BD_TRY(bdk_ln_mod_sp(l1, st));
@@ -848,6 +883,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0
             BD_TRY(sp_arm_wait(c, l1.seq_h, st));
             BD_TRY(linear(c, "head.qkv", bdk_sp_hbuf(c->comm), RB, wref(c, pre + "wqkv"), 3 * Dl, D, gq, "head.qkv_part", "head.qkv_bf",
                           c->ptr(pre + "bqkv"), Mp, &at.qkv, st));
+            BD_TRY(finalize_if_many(c, &at.qkv, "head.qkv_bf", M, st));
             at.o_frag = c->wptr("head.attn_frag"); at.nseq = M / c->Pn; at.dh = (int)c->geti("head.dh", 128); at.nhead = Dl / at.dh; at.D = Dl; at.RB = RB; at.P = c->Pn;
             BD_TRY(bdk_head_attn(at, st));
             BD_TRY(linear_rowsplit_sp(c, "head.wo", c->ptr("head.attn_frag"), RB, wref(c, pre + "wo"), D, Dl, go, "head.br_part", "head.tp_part", M, &seq_p, st));
@@ -859,9 +895,17 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0
             if (l2.seq_h < 0) return fail("sequence-parallel exchange: more than 4095 hand-offs since the last bd_head_cond / bd_head_sample");
             BD_TRY(bdk_ln_mod_sp(l2, st));
             BD_TRY(sp_arm_wait(c, l2.seq_h, st));
-            if (!(g1.S == 1 || c->geti("tune.w1_fused", 1))) return fail("tp.seq: the fused SwiGLU epilogue only");
-            BD_TRY(gemm(c, "head.w1", bdk_sp_hbuf(c->comm), RB, wref(c, pre + "w1"), 2 * Hl, D, g1.S, g1.code(), BD_EPI_SWIGLU,
-                        (float*)c->wptr("head.w1_part"), c->wptr("head.act_frag"), c->ptr(pre + "b1"), st));
+            if (g1.S == 1 || c->geti("tune.w1_fused", g1.S > 2 ? 0 : 1)) {
+                BD_TRY(gemm(c, "head.w1", bdk_sp_hbuf(c->comm), RB, wref(c, pre + "w1"), 2 * Hl, D, g1.S, g1.code(), BD_EPI_SWIGLU,
+                            (float*)c->wptr("head.w1_part"), c->wptr("head.act_frag"), c->ptr(pre + "b1"), st));
+            } else {                                           // many short K slices + a row-parallel SwiGLU pass over the slabs
+                BD_TRY(gemm(c, "head.w1", bdk_sp_hbuf(c->comm), RB, wref(c, pre + "w1"), 2 * Hl, D, g1.S, g1.code(), BD_EPI_PARTIAL,
+                            (float*)c->wptr("head.w1_part"), nullptr, nullptr, st));
+                SwigluArgs sw_;
+                sw_.up = part(c, "head.w1_part", c->ptr(pre + "b1"), g1.S, 2 * Hl, Mp);
+                sw_.act_frag = c->wptr("head.act_frag"); sw_.M = M; sw_.F = Hl; sw_.RB = RB; sw_.interleaved = 1;
+                BD_TRY(bdk_swiglu_rows(sw_, st));
+            }
             BD_TRY(linear_rowsplit_sp(c, "head.w2", c->ptr("head.act_frag"), RB, wref(c, pre + "w2"), D, Hl, g2, "head.br_part", "head.tp_part", M, &seq_p, st));
             pend_bias = c->ptr(pre + "b2");
         }
@@ -886,7 +930,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0
         fa.tok_branches = 1;
         if (chain_next) { fa.X_next = c->wptr("head.X"); fa.in_w = c->ptr("head.in_w"); fa.in_b = c->ptr("head.in_b"); }
         fs.L = L; fs.part = (const float*)c->ptr("head.tp_part"); fs.bias = pend_bias; fs.seq_p = seq_p; fs.bp_local = c->BP / c->tp;
-        fs.seq_f = 0;
+        fs.seq_f = 0; fs.signal_p = c->geti("tune.sp_gsig", 0) ? 0 : 1;
         if (fa.sc.is_final) {
             fs.seq_f = bdk_sp_next_seq(c->comm);
             if (fs.seq_f < 0) return fail("sequence-parallel exchange: more than 4095 hand-offs since the last bd_head_cond / bd_head_sample");
@@ -923,6 +967,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0
             HeadAttnArgs at;
             BD_TRY(linear(c, "head.qkv", c->ptr("head.h_frag"), RB, wref(c, pre + "wqkv", "head.h_scale"), 3 * Dl, D, gq, "head.qkv_part", "head.qkv_bf",
                           c->ptr(pre + "bqkv"), Mp, &at.qkv, st));
+            BD_TRY(finalize_if_many(c, &at.qkv, "head.qkv_bf", M, st));
             at.o_frag = c->wptr("head.attn_frag"); at.nseq = M / c->Pn; at.dh = (int)c->geti("head.dh", 128); at.nhead = Dl / at.dh; at.D = Dl; at.RB = RB; at.P = c->Pn;
             BD_TRY(bdk_head_attn(at, st));
             BD_TRY(linear_rowsplit(c, "head.wo", c->ptr("head.attn_frag"), RB, wref(c, pre + "wo"), D, Dl, go, "head.br_part", "head.br_bf",
@@ -936,7 +981,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0
         // Linear -> chunk(2) -> silu(h1)*h2.  Fused epilogue (on the last-arriving K-slice when split) writes the next
         // operand: 46.9 + 22.9 us (w1 + w2) against 40.8 + 9.5 + 26.0 us for slabs + swiglu_rows on the same MI355X
         // (tune.w1_fused = 0 selects the latter).
-        if (g1.S == 1 || c->geti("tune.w1_fused", (c->Mpad % 256 == 0) ? 0 : 1)) {
+        if (g1.S == 1 || c->geti("tune.w1_fused", (c->Mpad % 256 == 0 || g1.S > 2) ? 0 : 1)) {
             BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, wref(c, pre + "w1", "head.h_scale"), 2 * Hl, D, g1.S, g1.code(), BD_EPI_SWIGLU,
                         (float*)c->wptr("head.w1_part"), c->wptr("head.act_frag"), c->ptr(pre + "b1"), st));
         } else {

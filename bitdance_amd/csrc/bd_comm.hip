@@ -335,9 +335,17 @@ bool bdk_tp_push_target(bd_comm* c, int rows, int N, BdTpPush* out) {
 }
 void bdk_tp_mark_prepushed(bd_comm* c) { if (c) c->prepushed_next = 1; }
 // the same push target with the sequence-parallel row ownership (8-row groups dealt round-robin to the ranks, BdTpPush::il)
-bool bdk_tp_push_target_sp(bd_comm* c, int rows, int N, BdTpPush* out) {
+bool bdk_tp_push_target_sp(bd_comm* c, int rows, int N, int seq, BdTpPush* out) {
     if (!bdk_tp_push_target(c, rows, N, out) || (rows / 8) % c->size) return false;
     out->il = 1;
+    if (seq > 0) {
+        int* const spf = c->flags + BD_TP_FLAG_INTS;
+        out->done_cnt = spf + BD_SP_DONE;
+        out->rc = spf + BD_SP_RC;
+        out->seq = seq;
+        for (int q = 0; q < c->size; ++q)
+            out->sig[q] = c->loopback ? spf + BD_SP_P + q : c->peer_flags[q] + BD_TP_FLAG_INTS + BD_SP_P + c->rank;
+    }
     return true;
 }
 

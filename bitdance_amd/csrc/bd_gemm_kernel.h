@@ -507,6 +507,23 @@ BD_DEV void gemm_body(const GemmP& p) {
 template <int NP, int KW, int MB, int EPI, int R, bool RED, int MODE = 0, int WT = 0>
 __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
     gemm_body<NP, KW, MB, EPI, R, RED, MODE, WT>(p);
+    if constexpr (EPI == BD_EPI_F32) {
+        // sequence-parallel tensor parallelism: every wave has drained its pushes (vmcnt(0) at the end of the body); the workgroup that
+        // arrives LAST in the whole launch writes the hand-off's epoch into every owner's flag word -- the owners' row kernels start
+        // behind a flag that is already on its way instead of behind a signal their own first block would send
+        if (p.push.done_cnt) {                                  // block-uniform
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int total = (int)(gridDim.x * gridDim.y);
+                if (__hip_atomic_fetch_add(p.push.done_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
+                    __hip_atomic_store(p.push.done_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm for the next launch
+                    const int e = __hip_atomic_load(p.push.rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) * 4096 + p.push.seq;
+                    for (int q = 0; q < p.push.size; ++q)
+                        if (q != p.push.rank) __hip_atomic_store(p.push.sig[q], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
+    }
 }
 
 template <int NP, int KW, int MB, int EPI, int R, bool RED, int MODE = 0, int WT = 0>
@@ -518,7 +535,7 @@ static int launch_one(const GemmP& p, hipStream_t st) {
         // past the S * Mpad * N * 4 scratch (out-of-range buffer accesses are dropped silently -> wrong sums), and the tickets
         // live in a fixed block of 16384 counters
         if ((p.N / 32) % NP != 0) return -9;
-        if ((long long)(p.RB / MB) * ntiles > 16384) return -9;
+        if ((long long)(p.RB / MB) * ntiles > 16383) return -9;      // (the last word is the tensor-parallel arrival counter, bd_api.hip)
     }
     // two A-stage buffers; with KW > 1 the same LDS is re-used for the accumulators of K parts 1..KW-1
     constexpr size_t lds_a = (size_t)2 * MB * 256 * KW * 16, lds_r = (size_t)(KW - 1) * NP * MB * 4096;

@@ -280,6 +280,12 @@ struct BdTpPush {
     char* stage[8] = {};        // every rank's staging area (peer_data[q]); [rank] unused
     long long Us = 0;           // 32 B units per rank slice = rows_per_rank * N / 8
     int rank = 0, size = 0, rows_per_rank = 0;
+    // sequence-parallel form: the LAST workgroup of the launch (device-wide arrival counter) tells every owner "this rank's partial
+    // rows have landed" -- the owner's row kernel then finds the flag set instead of waiting for a signal its own first block sends
+    int* done_cnt = nullptr;    // arrival counter (zero between launches); null: the consumer kernel signals (all-reduce form)
+    int* sig[8] = {};           // where to write the epoch for owner q (q's BD_SP_P word of this rank; loop-back: the local word of q)
+    const int* rc = nullptr;    // local replay counter
+    int seq = 0;                // epoch = *rc * 4096 + seq
     int il = 0;                 // 1: sequence-parallel row ownership -- 8-row group g of the tensor belongs to rank g % size (its local
                                 //    row (g / size) * 8 + row % 8), so that a rank owns the cond row AND the uncond row of the same patch
                                 //    position (rows bp and BP + bp) and the final layer / sampler step need no exchange; 0: contiguous slices
@@ -293,6 +299,7 @@ struct BdTpPush {
 #define BD_SP_RC 0            /* replay counter: epoch = RC * 4096 + sequence number of the hand-off inside the replayed graph */
 #define BD_SP_P 8             /* [8]  "the partials of rank p are pushed" epochs */
 #define BD_SP_G 16            /* [8]  "the adaLN columns of rank p are pushed" epochs (split all-gather: push early, wait late) */
+#define BD_SP_DONE 24         /* arrival counter of the pushing GEMM's workgroups (BdTpPush::done_cnt) */
 #define BD_SP_H 32            /* [BD_SP_MAXROWS] "operand row m is pushed" epochs (also: final latent row bp) */
 #define BD_SP_FLAG_INTS (32 + BD_SP_MAXROWS)
 struct BdSpLink {
@@ -333,6 +340,7 @@ struct LnModSpArgs {           // ln_mod for this rank's rows only, fed by the p
     const void* bias = nullptr;    // its bias [D] bf16 (added once, by the reducing rank) or null
     int seq_p = 0, seq_h = 0;      // sequence numbers of the partial hand-off (0: none) and of this kernel's operand rows
     int rows_local = 0;
+    int signal_p = 1;              // 0: the pushing GEMM's last workgroup already told the owners (BdTpPush::done_cnt)
 };
 int bdk_ln_mod_sp(const LnModSpArgs& a, hipStream_t st);
 struct HeadFinalSpArgs {
@@ -342,6 +350,7 @@ struct HeadFinalSpArgs {
     const void* bias = nullptr;
     int seq_p = 0, seq_f = 0;  // seq_f: the final evaluation's latent rows (pushed to every rank's aux area); 0 otherwise
     int bp_local = 0;          // patch positions this rank owns (BP / size)
+    int signal_p = 1;
 };
 int bdk_head_final_sp(const HeadFinalSpArgs& a, hipStream_t st);
 struct TokFinishArgs {         // after the final evaluation: every rank assembles pred / tokens of ALL patch positions from the gathered latent rows
@@ -354,7 +363,7 @@ struct TokFinishArgs {         // after the final evaluation: every rank assembl
 int bdk_tok_finish(const TokFinishArgs& a, hipStream_t st);
 
 bool bdk_tp_push_target(bd_comm* c, int rows, int N, BdTpPush* out);
-bool bdk_tp_push_target_sp(bd_comm* c, int rows, int N, BdTpPush* out);
+bool bdk_tp_push_target_sp(bd_comm* c, int rows, int N, int seq, BdTpPush* out);   // seq > 0: the GEMM's last workgroup signals the owners
 void bdk_tp_mark_prepushed(bd_comm* c);
 void bdk_gemm_set_push(const BdTpPush* t);      // bd_gemm.hip
 bool bdk_gemm_push_used();

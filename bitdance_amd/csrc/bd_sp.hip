@@ -135,7 +135,7 @@ __global__ __launch_bounds__(MAX_ROW_THREADS) void ln_mod_sp_kernel(LnModSpArgs 
     }
     if (a.part) {
         const int e = sp_epoch(L, a.seq_p);
-        if (blockIdx.x == 0) sp_signal_p(L, e);
+        if (blockIdx.x == 0 && a.signal_p) sp_signal_p(L, e);
         if (!sp_wait_p(L, e, &alive_sh)) return;               // a dead exchange pushes nothing further; the host check raises on every rank
     }
     if (active) {
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(640) void head_final_sp_kernel(HeadFinalSpArgs s) {
         for (int c = 0; c < PRE; ++c) wpre[c] = ld_raw8((const bf16_t*)a.lin_w + (size_t)min(c, a.C - 1) * a.D + d0);
     }
     const int e = sp_epoch(L, s.seq_p);
-    if (blockIdx.x == 0) sp_signal_p(L, e);
+    if (blockIdx.x == 0 && s.signal_p) sp_signal_p(L, e);
     if (!sp_wait_p(L, e, &alive_sh)) return;
     if (active) {
         const __amdgpu_buffer_rsrc_t stage = sp_rsrc(L.stage[L.rank], L.stage_bytes);

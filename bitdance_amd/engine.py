@@ -413,7 +413,10 @@ class Engine:
         if self.comm is not None and head is not None and not head.mlp and self.comm.backend in ("ipc", "none") and self.comm.hbuf_bytes > 0:
             ok = (self.M == 128 and self.branches == 2 and (self.BP // 8) % self.comm.size == 0 and self.wdtype in (0, 1)
                   and self.comm.hbuf_bytes >= 128 * head.D * 2)
-            self.seq_parallel = bool(ints.get("tp.seq", 1)) and ok
+            # measured on one rank in loop-back (profiles/r05_tp_rank_critical_path.log, us per evaluation, all-reduce form vs this):
+            # tp 2 976 vs 910, tp 4 755 vs 743, tp 8 670 vs 702 -- on by default up to 4 ranks; at 8 the rank's 16 rows make every row
+            # kernel a 16-workgroup latency chain either way and the two extra destinations per push cost more than the saved launch
+            self.seq_parallel = bool(ints.get("tp.seq", 1 if self.comm.size <= 4 else 0)) and ok
             if ints.get("tp.seq", 0) and not ok:
                 raise BitDanceHipError("tp.seq: sequence-parallel row kernels need 128 rows (one image with CFG, parallel_num 64), whole 8-row "
                                        "groups of patch positions per rank, bf16 activations and a communicator with an operand landing buffer")

@@ -207,7 +207,7 @@ def test_head_eval_tensor_parallel(tp, P, weights, ada_split):
     x1 = e1.view("head.xhat", torch.float32, (e1.Mpad, C))[:M].clone()
     # tp ranks, one stream each
     nada = (HEAD8["depth_adanln"] * 6 + 2) * 1024                  # stacked adaLN width: 8192 -> 4096 / 2048 columns per rank
-    comms = _comms(tp, e1.Mpad * 1024, gather_bytes=0 if ada_split == 0 else 512 * nada * 2)
+    comms = _comms(tp, e1.Mpad * 1024, gather_bytes=0 if ada_split == 0 else 2 * 512 * nada * 2)   # two slots: double-buffered by group parity
     streams = _streams(tp)
     engs = []
     for r in range(tp):
@@ -271,7 +271,7 @@ def test_head_sample_tensor_parallel_column_split_adaln(tp, weights, split):
     nada = (HEAD8["depth_adanln"] * 6 + 2) * 1024
     outs = {}
     for sp in sorted({split, 0}):
-        comms = _comms(tp, e1.Mpad * 1024, gather_bytes=512 * nada * 2 if sp else 0)
+        comms = _comms(tp, e1.Mpad * 1024, gather_bytes=2 * 512 * nada * 2 if sp else 0)
         streams = _streams(tp)
         engs = [E.Engine(E.HeadWeights.from_state_dict(sd_dev, DEV, tp_rank=r, tp_size=tp, weights=weights), None, None, num_images=B,
                          branches=br, device=DEV, max_tokens=P, parallel_num=P, comm=comms[r], extra_ints={"tp.ada_split": sp})
@@ -485,19 +485,20 @@ def test_loopback_rank_runs_the_shard_alone(tp, seq):
     g = torch.Generator().manual_seed(352)
     z = torch.randn(br * B, P, 1024, generator=g)
     noise = torch.randn(1, n + 1, B, P, C, generator=g)
-    for mode in ("eager", "graph", "graph"):
-        eng.set_schedule(n, 1.5, 1)
-        eng.load_noise(noise)
-        eng.reset([0] * (br * B))
-        eng.set_cond(z.to(DEV))
-        if mode == "graph":
-            eng.capture(0)
-            eng.launch(0)
-        else:
-            eng.head_sample()
-        torch.cuda.synchronize()
-        comm.check()
-        assert torch.isfinite(eng.pred()).all()
+    with torch.cuda.stream(_streams(1)[0]):                         # (graph capture needs a non-default stream)
+        for mode in ("eager", "graph", "graph"):
+            eng.set_schedule(n, 1.5, 1)
+            eng.load_noise(noise)
+            eng.reset([0] * (br * B))
+            eng.set_cond(z.to(DEV))
+            if mode == "graph":
+                eng.capture(0)
+                eng.launch(0)
+            else:
+                eng.head_sample()
+            torch.cuda.synchronize()
+            comm.check()
+            assert torch.isfinite(eng.pred()).all()
     assert comm.exchanges() > 0 and comm.prepushed() == comm.exchanges()
 
 

@@ -88,6 +88,10 @@ def run():
                        extra_ints=extra or None)
         if shard:
             tune_shown = dict(tune_shown, seq=int(eng.seq_parallel), ada_split=int(eng.ada_split))
+            if ref is None:
+                print("# launch configurations at this shard (split-K, waves + 16 ring + 256 (kparts - 1)): "
+                      + ", ".join(f"{n} {eng.gemm_config('head.' + n)}" for n in ("qkv", "wo", "w1", "w2", "ada")), flush=True)
+                ref = 0
         eng.set_schedule(n, 7.5, 1)
         eng.load_noise(noise)
         eng.reset([0] * (2 * B))
