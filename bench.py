@@ -89,6 +89,9 @@ def parse():
     ap.add_argument("--no-decode", action="store_true", help="imagenet: skip the conv decoder in the timed pass")
     ap.add_argument("--tp-ada-split", default="auto", choices=["auto", "0", "1"],
                     help="tensor parallel: column-split the adaLN projection and all-gather its output (auto: from 4 ranks up)")
+    ap.add_argument("--tp-seq", default="auto", choices=["auto", "0", "1"],
+                    help="tensor parallel: sequence-parallel row kernels (csrc/bd_sp.hip: a rank owns rows / N rows of the head's residual stream, "
+                         "no stand-alone exchange kernel in an evaluation) instead of all-reduce + replicated row kernels (auto: up to 4 ranks)")
     ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8", "fp8a"],
                     help="fp8: streamed Linear weights as e4m3 + per-channel scales (BASELINE config 5; a separate precision mode); "
                          "fp8a: also e4m3 activations (per-row scales) on the fp8 matrix pipe for the GEMMs fed by a row kernel")
@@ -448,17 +451,23 @@ def main():
         from bitdance_amd.tp import TPComm
         rows_max = 2 * num_images * 64
         # (+ the gather region of the column-split adaLN projection: 14 x 5120 output columns per evaluation row, one group of evaluations)
-        from bitdance_amd.tp import ada_gather_bytes
+        from bitdance_amd.tp import ada_gather_bytes, seq_hbuf_bytes
         comm = TPComm.from_process_group(max(rows_max, 128) * 5120, device=dev, backend=args.tp_comm,
-                                         gather_bytes=ada_gather_bytes(max(rows_max, 128), 14 * 5120))
+                                         gather_bytes=ada_gather_bytes(max(rows_max, 128), 14 * 5120),
+                                         hbuf_bytes=seq_hbuf_bytes(max(rows_max, 128), 5120))   # operand landing buffer of the sequence-parallel row kernels
     pipe = syn.build_pipeline(size, dev, with_ae=True, tp=comm, weights=args.weights)
     if args.weights == "fp8":
         metric += " (fp8-e4m3 weights)"
     elif args.weights == "fp8a":
         metric += " (fp8-e4m3 weights + activations, fp8 MFMA)"
     pipe.tune = tune or None
-    if tp_mode and args.tp_ada_split != "auto":
-        pipe.extra_ints = {"tp.ada_split": int(args.tp_ada_split)}
+    if tp_mode:
+        ei = {}
+        if args.tp_ada_split != "auto":
+            ei["tp.ada_split"] = int(args.tp_ada_split)
+        if args.tp_seq != "auto":
+            ei["tp.seq"] = int(args.tp_seq)
+        pipe.extra_ints = ei or None
     if args.attn_splits:
         pipe.attn_splits = args.attn_splits
     pipe.use_graph = not args.no_graph
@@ -544,8 +553,9 @@ def main():
                 eng0 = next(iter(pipe._engines.values()))
                 fused_sum, was_split = token_checksum(eng0.tok_all).clone(), bool(getattr(eng0, "ada_split", False))
                 keep = (pipe.tune, getattr(pipe, "extra_ints", None))
+                was_seq = bool(getattr(eng0, "seq_parallel", False))
                 pipe.tune = dict(tune, tp_fuse=0)
-                pipe.extra_ints = {"tp.ada_split": 0}
+                pipe.extra_ints = {"tp.ada_split": 0, "tp.seq": 0}
                 pipe._engines.clear()
                 same = tp_pass_ok(i) and bool(torch.equal(token_checksum(next(iter(pipe._engines.values())).tok_all), fused_sum))
                 flag = torch.tensor([1 if same else 0], device="cpu" if dist.get_backend() == "gloo" else dev)
@@ -556,8 +566,9 @@ def main():
                     pipe._engines.clear()
                     one_pass(i)                                # engines and graphs of the timed configuration are built untimed
                 elif rank == 0:
-                    print("[bench] fused reduce-scatter push / column-split adaLN disagree with the unfused exchange on this node "
-                          f"(adaLN split was {'on' if was_split else 'off'}): timing the unfused forms", file=sys.stderr, flush=True)
+                    print("[bench] fused reduce-scatter push / column-split adaLN / sequence-parallel row kernels disagree with the unfused "
+                          f"all-reduce exchange on this node (adaLN split was {'on' if was_split else 'off'}, sequence-parallel "
+                          f"{'on' if was_seq else 'off'}): timing the conservative forms", file=sys.stderr, flush=True)
         else:
             one_pass(i)
     barrier()
@@ -609,6 +620,8 @@ def main():
                          "images_checked_bit_identical": args.steps + 1,
                          "weight_bytes_per_rank": int(wbytes),
                          "adaln_projection": "column-split + push all-gather" if getattr(eng, "ada_split", False) else "replicated",
+                         "head_row_kernels": ("sequence-parallel (csrc/bd_sp.hip: rows / tp rows per rank, no exchange kernel in an evaluation)"
+                                              if getattr(eng, "seq_parallel", False) else "replicated behind an all-reduce kernel per row-split Linear"),
                          "exchanges_per_image": n_x, "exchange_payload_bytes_per_rank": int(eng.M * 5120 * 6 * (n - 1) / n),
                          "ranks_bit_identical": True}
         if not args.no_roofline:

@@ -120,7 +120,12 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
     } else {
         mt = blockIdx.x % RT; rest = blockIdx.x / RT;
     }
-    const int s = rest % S, nt = rest / S;
+    // K slice of this workgroup.  Under the XCD placement `rest` % 8 is the XCD: with S = 2 / 4 / 8 the plain rest % S would pin every
+    // XCD to ONE K slice (its L2 then holds one half of the activations and the weight stream of a tile's slices never meets in one
+    // L2); rotating the slice by the group index (rest / 8: the same for all slices of a tile when S divides 8, so the map stays a
+    // bijection) lets every XCD walk through all slices
+    const int nt = rest / S;
+    const int s = (XCD && (8 % S) == 0) ? (rest % S + rest / 8) % S : rest % S;
     const int nb = (nt * 4 + wave) * NPW;
     const int nst_total = p.K >> 6;
     const int q = (nst_total + S - 1) / S;
@@ -343,7 +348,9 @@ static int launch_gemm_wide(const GemmP& p0, int epi, hipStream_t st) {
     // Measured at 512 rows (profiles/r02_gemm_sweep3.log): adaLN 311 vs 352 us, gate/up 196 vs 207, wo / w2 (5 slices) 34.5 / 40.9
     // vs 36.0 / 43.5 -- but the 2-slice qkv / w1 shapes LOSE (73 vs 68.5 us: with an even slice count every XCD then works on
     // one K half only, and the two readers of a slice contend for the same L2 channels in lockstep), so: odd slice counts only.
-    const bool xcd = (p.RB > 8) && (g_wide_xcd < 0 ? (p.N > p.RB * 32 && (p.S & 1)) : g_wide_xcd == 1);
+    // round 5: the 2-slice shapes join -- with the slice rotated by the group index (gemm_wide_kernel) every XCD walks both slices
+    // and the placement wins there as well (num_images = 4, in situ: 2347.5 vs 2387.8 us per evaluation, profiles/r05_head_sweep_b4.log)
+    const bool xcd = (p.RB > 8) && (g_wide_xcd < 0 ? (p.N > p.RB * 32 && ((p.S & 1) || p.S == 2)) : g_wide_xcd == 1);
     if (g_wide_ring == 3) return xcd ? launch_gemm_wide_v<3, true>(p, epi, st) : launch_gemm_wide_v<3, false>(p, epi, st);
     return xcd ? launch_gemm_wide_v<2, true>(p, epi, st) : launch_gemm_wide_v<2, false>(p, epi, st);
 }

@@ -66,8 +66,9 @@ def gen_tokens(llm_w: dict, llm_cfg: dict, head_w: dict, proj_w: dict, embed: to
     force_tokens: teacher forcing for tolerance tests -- [num_images, h*w, C] tokens fed back to the
                  LLM instead of the loop's own sign(pred) (the returned tokens are still the loop's own)
     """
-    tail = F.embedding(torch.tensor(list(start_ids) + list(query_ids)), embed)
-    ctx = [torch.cat([F.embedding(torch.tensor(list(ids)), embed), tail], dim=0) if ids is not None else None
+    dev = embed.device
+    tail = F.embedding(torch.tensor(list(start_ids) + list(query_ids), device=dev), embed)
+    ctx = [torch.cat([F.embedding(torch.tensor(list(ids), device=dev), embed), tail], dim=0) if ids is not None else None
            for ids in (cond_ids, uncond_ids if guidance_scale > 1.0 else None)]
     return gen_tokens_from_context(llm_w, llm_cfg, head_w, proj_w, ctx[0], ctx[1], h=h, w=w, parallel_num=parallel_num,
                                    guidance_scale=guidance_scale, num_sampling_steps=num_sampling_steps, num_images=num_images,
@@ -86,13 +87,14 @@ def gen_tokens_from_context(llm_w: dict, llm_cfg: dict, head_w: dict, proj_w: di
     D = cond_ctx.shape[1]
     cfg_on = guidance_scale > 1.0
     noise = iter(noise)
-    pos = pos_embed_2d(sincos_1d(D // 2, max_patch), h, w, ps).unsqueeze(0)          # fp32
+    dev = cond_ctx.device
+    pos = pos_embed_2d(sincos_1d(D // 2, max_patch), h, w, ps).unsqueeze(0).to(dev)  # fp32
 
     def prefill(x):
         x = x.unsqueeze(0).repeat(num_images, 1, 1)
         _, cache = qwen3.model_forward(llm_w, llm_cfg, x[:, :-P], None, None, pol)
         past = cache[0][0].shape[2]
-        ones = torch.ones(num_images, 1, P, P + past, dtype=torch.bool)
+        ones = torch.ones(num_images, 1, P, P + past, dtype=torch.bool, device=dev)
         hid, cache = qwen3.model_forward(llm_w, llm_cfg, x[:, -P:], cache, ones, pol)
         return hid[:, -P:], cache
 
@@ -111,9 +113,9 @@ def gen_tokens_from_context(llm_w: dict, llm_cfg: dict, head_w: dict, proj_w: di
             trace.setdefault("cond", []).append(hf.clone())
         out.append(tok[:num_images])
         if force_tokens is not None:
-            tok = torch.cat([force_tokens[:, sl]] * (2 if cfg_on else 1), dim=0)
+            tok = torch.cat([force_tokens[:, sl].to(dev)] * (2 if cfg_on else 1), dim=0)
         x = projector(proj_w, tok, pol) + pos[:, sl]
-        ones = torch.ones(x.shape[0], 1, P, P + cache_c[0][0].shape[2], dtype=torch.bool)
+        ones = torch.ones(x.shape[0], 1, P, P + cache_c[0][0].shape[2], dtype=torch.bool, device=dev)
         hid_c, cache_c = qwen3.model_forward(llm_w, llm_cfg, x[:num_images], cache_c, ones[:num_images], pol)
         hid_c = hid_c[:, -P:]
         if cfg_on:

@@ -92,16 +92,16 @@ def euler_maruyama(
     the initial latent ``[B,P,C]`` then one ``[B,P,C]`` tensor per SDE step."""
     noise = iter(noise)
     cfg_mult = 2 if cfg > 1.0 else 1
-    x = next(noise).to(F32)
+    x = next(noise).to(device=c.device, dtype=F32)
     assert x.shape[0] == c.shape[0] // cfg_mult and x.shape[-1] == input_dim
     ts, dts = step_table(num_sampling_steps, last_step_size, time_shift)
-    t_rows = torch.zeros(c.shape[0], dtype=F32)
+    t_rows = torch.zeros(c.shape[0], dtype=F32, device=c.device)     # (device-aware: tests/test_gpu_autocast.py runs this loop under the device's autocast)
     for i in range(num_sampling_steps):
         t_rows[:] = ts[i]
         combined = torch.cat([x] * cfg_mult, dim=0)
         xhat = forward_fn(combined, t_rows, c)
         v = velocity_from_xhat(xhat, combined, t_rows)
-        x = sde_step(x, v, ts[i], dts[i], cfg, cfg_mult, next(noise).to(F32))
+        x = sde_step(x, v, ts[i], dts[i], cfg, cfg_mult, next(noise).to(device=c.device, dtype=F32))
         if trace is not None:
             trace.append(x.clone())
     combined = torch.cat([x] * cfg_mult, dim=0)

@@ -226,3 +226,85 @@ def llm_case(device="cuda", *, layers=1, P=64, past=(1000, 1017), cfg: dict | No
     return {"max_err": err.max().item(), "mean_err": err.mean().item(), "ref_abs_mean": ref.abs().mean().item(),
             "finite": bool(torch.isfinite(got).all()), **_tstats(ts), "rows": nseq * P, "layers": layers,
             "gemm_cfg": {k: {"splitk": s, "nwaves": c_ & 15} for k, (s, c_) in cfgs.items()}}
+
+
+def ar_step_case(device="cuda", *, D=5120, C=32, P=64, depth=6, nada=2, n_steps=8, cfg=1.25, past=(1000, 1017), seed=151) -> dict:
+    """ONE autoregressive step across the head -> LLM -> head seam at true width (t2i_pipeline.py:241-270): the condition of a patch
+    -> ``DiffHead.sample`` (n_steps + 1 chained evaluations of the ``depth``-block head, guidance ``cfg``) -> ``sign`` -> the
+    2-layer projector (+ 2-D position embedding) -> ONE Qwen3-14B decoder layer + final norm over the 64 new tokens of the cond and
+    the uncond sequence against ragged caches -> the NEXT patch's condition (hidden + position embedding), device (engine: head
+    sample graph phase, projector, LLM step -- the two phases of an AR step) vs oracle on identical noise.  Reported: the sampled
+    latent's error and token agreement; the next condition's error with the oracle fed the DEVICE's tokens (numerics of projector +
+    layer alone: a flipped token is a legitimate +-2 in one projector input, not an arithmetic error) and fed its own tokens."""
+    from bitdance_amd import engine as E
+    from . import pipeline as opipe
+    B, branches = 1, 2
+    cfgd = dict(ch_target=C, ch_cond=D, ch_latent=D, depth_latent=depth, depth_adanln=nada)
+    sd_h = device_seeded_state(tm.head_shapes(cfgd), seed, device)
+    hw = E.HeadWeights.from_state_dict(sd_h, device)
+    head_w = {k: v.cpu() for k, v in sd_h.items()}
+    del sd_h
+    sd_p = device_seeded_state(tm.proj_shapes(C, D), seed + 1, device)
+    pw = E.ProjWeights.from_state_dict(sd_p, device)
+    proj_w = {k: v.cpu() for k, v in sd_p.items()}
+    del sd_p
+    c = dict(QWEN3_14B, num_hidden_layers=1)
+    nkv, hd = c["num_key_value_heads"], c["head_dim"]
+    sd_l = {k: v.to(torch.bfloat16) for k, v in device_seeded_state(tm.llm_shapes(c), seed + 2, device).items()}
+    lw = E.LlmWeights.from_state_dict(sd_l, c, device, keep_for_prefill=False)
+    llm_w = {k: v.cpu() for k, v in sd_l.items()}
+    del sd_l
+    eng = E.Engine(hw, pw, lw, num_images=B, branches=branches, device=device, max_tokens=2 * P, max_kv=max(past) + 2 * P, parallel_num=P)
+    g = torch.Generator().manual_seed(seed + 3)
+    ps = int(P ** 0.5)
+    pos = opipe.pos_embed_2d(opipe.sincos_1d(D // 2, 256), 2 * ps, 2 * ps, ps)[: 3 * P]       # patches 0 .. 2 of a 4-patch image
+    eng.pos.copy_(pos.to(device))
+    hid0 = torch.randn(branches * B, P, D, generator=g)                                        # the LLM's hidden state of the previous step
+    cond = hid0 + pos[None, :P]
+    noise = torch.randn(n_steps + 1, B, P, C, generator=g)
+    kc = eng.ws["llm.k_cache"].view(torch.bfloat16).view(1, branches * B, nkv, eng.Lmax, hd)
+    vc = eng.ws["llm.vt_cache"].view(torch.bfloat16).view(1, branches * B, nkv, hd, eng.Lmax)
+    caches = []
+    for b, L in enumerate(past):
+        k = torch.randn(1, nkv, L, hd, generator=g).to(torch.bfloat16)
+        v = torch.randn(1, nkv, L, hd, generator=g).to(torch.bfloat16)
+        kc[0, b, :, :L] = k[0].to(device)
+        vc[0, b, :, :, :L] = v[0].transpose(1, 2).to(device)
+        caches.append([[k, v]])
+    eng.set_schedule(n_steps, cfg, 1)
+    eng.load_noise(noise.view(1, n_steps + 1, B, P, C))
+    eng.reset(list(past))
+    eng.set_cond(cond.to(device))
+    eng.head_sample()
+    eng.projector()
+    eng.llm_step()
+    torch.cuda.synchronize()
+    pred = eng.pred().cpu()
+    tok = eng.tok_cur().cpu()
+    hidden = eng.hidden().cpu().view(branches * B, P, D)
+    next_cond = hidden + pos[None, P:2 * P]
+    pol = Policy("autocast")
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref_pred = diff_head.sample(head_w, cond, cfg, n_steps, list(noise), pol)[:B]
+        ref_tok = torch.sign(ref_pred)
+
+        def after(tokens):                                   # projector + position embedding + one decoder layer + final norm, per sequence
+            x = opipe.projector(proj_w, torch.cat([tokens] * branches), pol) + pos[None, :P]
+            outs = []
+            for b, L in enumerate(past):
+                ones = torch.ones(1, 1, P, L + P, dtype=torch.bool)
+                o, _ = qwen3.model_forward(llm_w, c, x[b:b + 1], list(caches[b]), ones, pol)
+                outs.append(o.float())
+            return torch.cat(outs) + pos[None, P:2 * P]
+        ref_next_forced = after(tok)
+        ref_next_free = after(ref_tok)
+    t_cpu = time.perf_counter() - t0
+    e_pred = (pred - ref_pred).abs()
+    e_f = (next_cond - ref_next_forced).abs()
+    e_free = (next_cond - ref_next_free).abs()
+    return {"pred_max_err": e_pred.max().item(), "pred_mean_err": e_pred.mean().item(),
+            "token_agreement": (tok == ref_tok).float().mean().item(), "tokens_are_sign_of_pred": bool(torch.equal(tok, torch.sign(pred))),
+            "next_cond_max_err": e_f.max().item(), "next_cond_mean_err": e_f.mean().item(), "next_cond_ref_abs_mean": ref_next_forced.abs().mean().item(),
+            "next_cond_free_max_err": e_free.max().item(), "next_cond_free_mean_err": e_free.mean().item(),
+            "finite": bool(torch.isfinite(next_cond).all()), "evaluations": n_steps + 1, "t_cpu_s": t_cpu}

@@ -75,3 +75,32 @@ def test_llm_under_device_bf16_matches_the_emulated_reference(golden_dir):
         assert e.max() <= 0.12 and e.mean() <= 1e-2, (e.max(), e.mean())
         eo = (got.float().cpu() - orc.float()).abs()
         assert eo.max() <= 0.12 and eo.mean() <= 1e-2, (eo.max(), eo.mean())
+
+
+def test_generation_loop_under_device_autocast_matches_the_emulated_reference(golden_dir):
+    """LOOP level: the whole next-patch-diffusion loop (oracle/pipeline.gen_tokens with Policy("fp32"): plain torch ops -- prefill,
+    4 AR steps x [5 chained head evaluations with CFG, sign, projector, cond / uncond LLM forwards against the growing cache]) on the
+    device under the device's own torch.autocast("cuda", bf16), teacher-forced with the reference's tokens, against ``gen_amp.npz``
+    (the unmodified reference under the CPU emulation of autocast).  The loop-level goldens (gen_amp, imagenet_amp, interleaved_amp)
+    were validated only by transitivity so far (single forwards above); this checks the emulation where they depend on it -- same
+    bounds as the CPU pin of the explicit-cast oracle (tests/test_oracle_golden.py test_gen_tokens_amp_teacher_forced)."""
+    from oracle import pipeline
+    g = load(golden_dir, "gen_amp")
+    lw = {k: v.to(torch.bfloat16).to(DEV) for k, v in tm.seeded_state(tm.llm_shapes(tm.TINY_LLM), seed=22).items()}
+    hw = {k: v.to(DEV) for k, v in tm.seeded_state(tm.head_shapes(tm.TINY_HEAD), seed=11).items()}
+    pw = {k: v.to(DEV) for k, v in tm.seeded_state(tm.proj_shapes(32, 256), seed=33).items()}
+    tok = tm.FakeTokenizer()
+    tr = {}
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        out = pipeline.gen_tokens(lw, tm.TINY_LLM, hw, pw, lw["model.embed_tokens.weight"], tok.encode("a red fox"), tok.encode("<|"),
+                                  [tm.VISION_START, tm.RES_BASE + 16, tm.RES_BASE + 16], [tm.QUERY_BASE + i for i in range(1, 64)],
+                                  h=16, w=16, parallel_num=64, guidance_scale=float(g["cfg"]), num_sampling_steps=int(g["n_steps"]),
+                                  num_images=1, noise=[n.to(DEV) for n in g["noise"]], pol=Policy("fp32"), force_tokens=g["tokens"], trace=tr)
+    pred, ref = torch.stack(tr["pred"]).float().cpu(), g["preds"][:, :1]
+    err = (pred - ref).abs()
+    firm = ref.abs() > 0.5
+    agree_firm = (torch.sign(pred)[firm] == torch.sign(ref)[firm]).float().mean().item()
+    agree = (out.float().cpu() == g["tokens"]).float().mean().item()
+    print(f"[loop under device autocast vs gen_amp] latent mean err {err.mean().item():.4f} max {err.max().item():.3f}; tokens (firm) {agree_firm:.4f}, all {agree:.4f}")
+    assert err.mean() <= 0.2, err.mean()
+    assert agree_firm >= 0.97 and agree >= 0.85, (agree_firm, agree)

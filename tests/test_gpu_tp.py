@@ -575,8 +575,10 @@ def _proc(rank, world, port, q):
         from bitdance_amd.autoencoder import VQModel
         from bitdance_amd.t2i_pipeline import BitDanceT2IPipeline
         from bitdance_amd.tp import TPComm
-        from bitdance_amd.tp import ada_gather_bytes
-        comm = TPComm.from_process_group(256 * 256, device="cuda:0", backend="ipc", gather_bytes=ada_gather_bytes(128, 14 * 256))
+        from bitdance_amd.tp import ada_gather_bytes, seq_hbuf_bytes
+        # (+ the operand landing buffer of the sequence-parallel row kernels: a second, cacheable allocation exported through its own handle)
+        comm = TPComm.from_process_group(256 * 256, device="cuda:0", backend="ipc", gather_bytes=ada_gather_bytes(128, 14 * 256),
+                                         hbuf_bytes=seq_hbuf_bytes(128, 256))
         comm.set_timeout(15.0)
         llm_sd = {k: v.to(torch.bfloat16) for k, v in tm.seeded_state(tm.llm_shapes(tm.TINY_LLM), seed=22).items()}
         ae_shapes = {k: tuple(v.shape) for k, v in VQModel(**tm.TINY_AE).state_dict().items()}
@@ -605,6 +607,13 @@ def _proc(rank, world, port, q):
             single = BitDanceT2IPipeline.from_components(**kw).gen_image("a red fox", "<|", return_tokens=True, **args).cpu()
         dist.barrier()
         assert next(iter(pipe._engines.values())).ada_split
+        assert next(iter(pipe._engines.values())).seq_parallel        # the row kernels ran in their sequence-parallel form, peers mapped through IPC
+        # the all-reduce form on the same communicator gives the same tokens bit for bit
+        pipe.extra_ints = {"tp.ada_split": 1, "tp.seq": 0}
+        pipe._engines.clear()
+        tok3 = pipe.gen_image("a red fox", "<|", return_tokens=True, **args).cpu()
+        assert not next(iter(pipe._engines.values())).seq_parallel
+        assert torch.equal(tok, tok3), "sequence-parallel and all-reduce forms differ across two processes"
         q.put((rank, tok.numpy(), bool(torch.equal(tok, tok2)), tuple(img.shape), bool(torch.isfinite(img).all()),
                None if single is None else single.numpy(), comm.exchanges()))
         dist.barrier()

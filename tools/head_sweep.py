@@ -56,7 +56,7 @@ def run():
     elif shard:
         cfgs = [{"tp.seq": 0}, {"tp.seq": 1}, {"tp.seq": 1, "sp_wait": 0}, {"tp.seq": 0}]
     dev = "cuda"
-    B = 1
+    B = int(os.environ.get("BD_SWEEP_B", "1"))             # images per pass (rows = 128 B): 4 = the eval scripts' batch
     cfgd = dict(ch_target=32, ch_cond=5120, ch_latent=5120, depth_latent=6, depth_adanln=2)
     sd = device_seeded_state(tm.head_shapes(cfgd), 101, dev)
     wmode = sys.argv[4] if len(sys.argv) > 4 else "bf16"

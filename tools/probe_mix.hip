@@ -83,6 +83,32 @@ __global__ __launch_bounds__(512) void mix_kernel(Args a) {
     if (r == 0x12345678u) a.sink[0] = r;
 }
 
+// Round 5: the L2-only leg with more requests in flight.  Every one of the workgroup's 8 waves re-reads its eighth (2 x 64 units) of
+// each 16 KiB stage of the shared buffer with INF 16 B loads outstanding per lane (INF / 2 stages at once): 8 waves x 12 loads x 1 KiB
+// = 96 KiB in flight per workgroup; launched with 1 or 2 workgroups per CU.  Is the 11.7 - 15.3 TB/s of the 4-wave x 8-load leg above
+// a limit of the L2 -> CU path, or of the concurrency that leg offered?
+template <int INF>
+__global__ __launch_bounds__(512) void l2deep_kernel(Args a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32x4 acc = {0, 0, 0, 0};
+    const int rot = a.rotate ? (int)(((blockIdx.x >> 3) * 11) % a.nst) : 0;
+    const u32x4* base = a.l2 + wave * 128 + lane;
+    constexpr int SPI = INF / 2;                               // stages per iteration
+    for (int s0 = 0; s0 + SPI <= a.l2_stages; s0 += SPI) {
+        u32x4 v[INF];
+#pragma unroll
+        for (int q = 0; q < SPI; ++q) {
+            const int st = (s0 + q + rot) % a.nst;
+            v[2 * q] = base[(size_t)st * 1024];
+            v[2 * q + 1] = base[(size_t)st * 1024 + 64];
+        }
+#pragma unroll
+        for (int j = 0; j < INF; ++j) acc ^= v[j];
+    }
+    const unsigned r = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
+    if (r == 0x12345678u) a.sink[0] = r;
+}
+
 int main() {
     const size_t HB = (size_t)3 << 30;                         // streamed pool, rotated so the Infinity Cache never helps
     char *hbm, *l2;
@@ -133,5 +159,34 @@ int main() {
     run("same wave, HBM only", 8, per_block, 0, 0, 1);
     run("same wave, HBM + L2 lockstep", 8, per_block, LS, 0, 1);
     run("same wave, HBM + L2 rotated", 8, per_block, LS, 1, 1);
+    // ---- round 5: deep L2-only legs
+    auto run_deep = [&](const char* tag, int inf, int nblocks, int l2_stages, int rotate) {
+        Args a{nullptr, 0, (const u32x4*)l2, nst, l2_stages, 0, rotate, 0, sink};
+        const int reps = 12;
+        float best = 1e9f, sum = 0.f;
+        for (int r = 0; r < reps + 2; ++r) {
+            CK(hipEventRecord(e0, 0));
+            if (inf == 8) hipLaunchKernelGGL(l2deep_kernel<8>, dim3(nblocks), dim3(512), 0, 0, a);
+            else if (inf == 12) hipLaunchKernelGGL(l2deep_kernel<12>, dim3(nblocks), dim3(512), 0, 0, a);
+            else hipLaunchKernelGGL(l2deep_kernel<16>, dim3(nblocks), dim3(512), 0, 0, a);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r >= 2) { sum += ms; if (ms < best) best = ms; }
+        }
+        const double us = sum / reps * 1e3, lb = (double)nblocks * l2_stages * 16384.0;
+        printf("%-58s %7.1f us (best %6.1f)  L2 %6.0f GB/s (best %6.0f)  per CU %5.1f GB/s\n", tag, us, best * 1e3, lb / us / 1e3, lb / (best * 1e3) / 1e3,
+               lb / us / 1e3 / 256);
+        fflush(stdout);
+    };
+    const int DS = 480;                                        // 480 stages x 16 KiB = 7.9 MB of re-reads per workgroup: long enough to leave the launch ramp behind
+    run_deep("L2 only, 8 waves x  8 loads, 1 WG/CU, lockstep", 8, 256, DS, 0);
+    run_deep("L2 only, 8 waves x 12 loads, 1 WG/CU, lockstep", 12, 256, DS, 0);
+    run_deep("L2 only, 8 waves x 12 loads, 1 WG/CU, rotated", 12, 256, DS, 1);
+    run_deep("L2 only, 8 waves x 16 loads, 1 WG/CU, rotated", 16, 256, DS, 1);
+    run_deep("L2 only, 8 waves x 12 loads, 2 WG/CU, lockstep", 12, 512, DS, 0);
+    run_deep("L2 only, 8 waves x 12 loads, 2 WG/CU, rotated", 12, 512, DS, 1);
+    run_deep("L2 only, 8 waves x 16 loads, 2 WG/CU, rotated", 16, 512, DS, 1);
+    run_deep("L2 only, 8 waves x 12 loads, 2 WG/CU, rotated, short (40 st)", 12, 512, 40 / 6 * 6, 1);
     return 0;
 }
