@@ -225,17 +225,34 @@ class TPComm:
         check(self.l.bd_comm_info(self.h, out), "bd_comm_info")
         return {"data_uncached": bool(out[0]), "flags_uncached": bool(out[1]), "mode": int(out[2]), "capacity": int(out[3])}
 
-    def _self_test(self, rows: int = 32, N: int = 256) -> bool:
-        """One exchange of a known pattern: part_r[i] = (r + 1) * v[i] with v exactly representable, so the reduced bf16
-        result must equal v * size (size + 1) / 2 bit for bit on every rank.  False on a timeout or any wrong element."""
+    def _self_test(self, shapes=((32, 256), (128, 1024), (64, 5120), (32, 256), (128, 5120), (8, 64))) -> bool:
+        """Exchanges of known patterns over the sizes the step uses, back to back on re-used buffers (an ordering race is statistical: one
+        small exchange would not show it): part_r[i] = (r + 1) * v[i] with v exactly representable, so the reduced bf16 result
+        must equal v * size (size + 1) / 2 bit for bit on every rank -- and, where the communicator has a gather region, the push
+        all-gather of per-rank column slices.  False on a timeout or any wrong element.  (The forms this cannot reach -- the push fused
+        into the GEMM epilogues, the sequence-parallel row kernels -- are compared with the conservative form on the first warm-up
+        image by bench.py, tokens bit for bit on every rank.)"""
+        ok = True
         with torch.cuda.device(self.device):
-            v = ((torch.arange(rows * N, device=self.device) % 61) - 30).float().view(rows, N) / 4.0
-            part = (v * (self.rank + 1)).contiguous()
             try:
                 self.set_timeout(5.0)
-                got = self.allreduce(part)
-                torch.cuda.current_stream().synchronize()
-                ok = self.l.bd_comm_error(self.h) == 0 and torch.equal(got.float(), v * (self.size * (self.size + 1) / 2))
+                for rep, (rows, N) in enumerate(shapes):
+                    if rows * N > int(self.info()["capacity"]) - 128 * 8:
+                        continue
+                    v = ((torch.arange(rows * N, device=self.device) % 61) - 30 + rep).float().view(rows, N) / 4.0
+                    part = (v * (self.rank + 1)).contiguous()
+                    got = self.allreduce(part)
+                    torch.cuda.current_stream().synchronize()
+                    ok = ok and self.l.bd_comm_error(self.h) == 0 and torch.equal(got.float(), v * (self.size * (self.size + 1) / 2))
+                if ok and self.gather_bytes > 0:
+                    for rep, (rows, nl) in enumerate(((64, 256), (128, 1024), (64, 256))):
+                        if rows * nl * self.size * 2 > self.gather_bytes:
+                            continue
+                        cols = [(((torch.arange(rows * nl, device=self.device) % 53) - 26 + 3 * r + rep).float() / 8.0).view(rows, nl).to(torch.bfloat16)
+                                for r in range(self.size)]
+                        got = self.allgather(cols[self.rank].contiguous())
+                        torch.cuda.current_stream().synchronize()
+                        ok = ok and self.l.bd_comm_error(self.h) == 0 and torch.equal(got, torch.cat(cols, dim=1))
             except BitDanceHipError:
                 ok = False
             finally:
