@@ -107,7 +107,7 @@ def parse():
 def pmc_entries(rows: int) -> dict:
     """The committed PMC passes for GEMM launches at ``rows`` rows (tools/pmc_gemm_traffic.py; newest round first)."""
     tag = "" if rows == 128 else f"_rows{rows}"
-    for r in ("r05", "r04", "r03", "r02", "r01"):
+    for r in ("r05", "archive/r04"):
         pj = os.path.join(ROOT, "profiles", f"{r}_pmc_gemm_traffic{tag}.json")
         if os.path.exists(pj):
             d = json.load(open(pj))
@@ -250,7 +250,7 @@ def gemm_roofline(eng, run, rows: int) -> dict:
     # wide-read correction: tools/pmc_gemm_traffic.py -> profiles/r0*_pmc_gemm_traffic.json), weighted by this step's
     # launch mix; only valid for the shapes / launch configs that pass measured, else null
     traffic, traffic_src = None, None
-    for fn in ("r05_pmc_gemm_traffic.json", "r04_pmc_gemm_traffic.json", "r03_pmc_gemm_traffic.json", "r02_pmc_gemm_traffic.json", "r01_pmc_gemm_traffic.json"):
+    for fn in ("r05_pmc_gemm_traffic.json", "archive/r04_pmc_gemm_traffic.json"):
         pj = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(pj) or rows != 128:
             continue
