@@ -244,6 +244,42 @@ def test_context_planning_tensor_parallel(tp):
     l3.bd_ctx_destroy(c3)
 
 
+def test_tensor_parallel_shard_launch_rules():
+    """choose_cfg's rules for the tensor-parallel shards of the 128-row passes (round 5; measured on one rank in loop-back,
+    profiles/r05_tp_rank_critical_path.log): a column-split Linear with few columns per rank runs 64-column tiles (2 panels x 2 K
+    parts) over up to 8 short K slices whose slabs a row-parallel pass sums; a row-split Linear with a short local K runs ONE slice
+    (no in-launch reduction in front of the push epilogue); "tune.tp_shapes" = 0 restores the tp = 1 rules; "tp.seq" needs a
+    communicator with an operand landing buffer."""
+    want = {8: {"head.qkv": (8, 4, 2), "head.w1": (8, 4, 2), "head.wo": (1, 2, 2), "head.w2": (1, 2, 1)},
+            4: {"head.qkv": (4, 4, 2), "head.w1": (4, 4, 2)},
+            2: {}}
+    for tp, cfgs in want.items():
+        l, c = _ctx(DIMS_14B)
+        assert l.bd_ctx_set_tp(c, 0, tp) == 0 and l.bd_ctx_finalize(c) == 0, l.bd_last_error()
+        for name, cfg in cfgs.items():
+            assert _cfg(l, c, name) == cfg, (tp, name, _cfg(l, c, name))
+        for name in ("head.wo", "head.w2", "llm.o", "llm.down"):
+            assert _cfg(l, c, name)[0] <= 3
+        l.bd_ctx_destroy(c)
+    l, c = _ctx({**DIMS_14B, "tune.tp_shapes": 0})
+    assert l.bd_ctx_set_tp(c, 0, 8) == 0 and l.bd_ctx_finalize(c) == 0
+    assert _cfg(l, c, "head.qkv")[0] > 8 and _cfg(l, c, "head.wo")[0] == 3          # the tp = 1 rules: 14 slices of 128-column tiles; 3 reduced slices
+    l.bd_ctx_destroy(c)
+    l, c = _ctx({**DIMS_14B, "tp.seq": 1})
+    assert l.bd_ctx_set_tp(c, 0, 2) == 0 and l.bd_ctx_finalize(c) != 0 and b"tp.seq" in l.bd_last_error()
+    l.bd_ctx_destroy(c)
+
+
+def test_tensor_parallel_buffer_sizes():
+    """tp.ada_gather_bytes: TWO slots of one group's modulation tensor (double-buffered by group parity: a peer may push group
+    g + 1 while this rank still reads g); tp.seq_hbuf_bytes: the bf16 operand rows of a 128-row pass, nothing for other row counts."""
+    from bitdance_amd.tp import ada_gather_bytes, seq_hbuf_bytes
+    assert ada_gather_bytes(128, 14 * 5120) == 2 * 4 * 128 * 14 * 5120 * 2
+    assert ada_gather_bytes(32, 14 * 5120) == 2 * 16 * 32 * 14 * 5120 * 2
+    assert ada_gather_bytes(512, 14 * 5120) == 2 * 2 * 512 * 14 * 5120 * 2 and ada_gather_bytes(2048, 1024) == 0
+    assert seq_hbuf_bytes(128, 5120) == 128 * 5120 * 2 and seq_hbuf_bytes(512, 5120) == 0 and seq_hbuf_bytes(32, 5120) == 0
+
+
 def test_small_weight_tile_rule_for_the_imagenet_batches():
     """choose_cfg (bd_api.hip): small weights under a few thousand rows run 256 x 128 (4 waves) or 128 x 64 (2 waves) tiles at one K
     slice with the fused epilogues instead of 256 x 256 tiles split 12-18 ways (B-1x: 768 rows; B-4x: 3072 rows); the 12 288-row
