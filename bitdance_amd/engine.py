@@ -406,9 +406,9 @@ class Engine:
         # sequence-parallel row kernels (csrc/bd_sp.hip): every rank owns rows / tp rows of the head's residual stream and no stand-alone
         # exchange kernel is left in an evaluation.  Default wherever the form applies: the hand-written exchange with an operand landing
         # buffer, 128 rows (one image, 64-token patches), the cond / uncond rows of a patch position on one rank, bf16 activations.
-        # "tp.seq" = 0 in ``extra_ints`` keeps the all-reduce form.  Ranks that share ONE GPU (in-process tests) wait in a tiny kernel in
-        # front of the consuming GEMM ("tune.sp_wait" = 0) from 3 ranks up: a chip full of polling GEMM workgroups of two ranks could
-        # starve the third rank's row kernel they are waiting for.
+        # "tp.seq" = 0 in ``extra_ints`` keeps the all-reduce form.  Ranks that share ONE physical GPU (in-process tests, several processes
+        # on a single-GPU box) wait in a one-workgroup kernel in front of the consuming GEMM ("tune.sp_wait" = 0): a chip full of polling
+        # GEMM workgroups would starve the peer rank's row kernel they are waiting for (observed: two 14B ranks on one GPU time out).
         self.seq_parallel = False
         if self.comm is not None and head is not None and not head.mlp and self.comm.backend in ("ipc", "none") and self.comm.hbuf_bytes > 0:
             ok = (self.M == 128 and self.branches == 2 and (self.BP // 8) % self.comm.size == 0 and self.wdtype in (0, 1)
@@ -421,7 +421,7 @@ class Engine:
                 raise BitDanceHipError("tp.seq: sequence-parallel row kernels need 128 rows (one image with CFG, parallel_num 64), whole 8-row "
                                        "groups of patch positions per rank, bf16 activations and a communicator with an operand landing buffer")
         ints["tp.seq"] = int(self.seq_parallel)
-        if self.seq_parallel and "tune.sp_wait" not in ints and getattr(self.comm, "in_process_peers", False) and self.comm.size > 2:
+        if self.seq_parallel and "tune.sp_wait" not in ints and getattr(self.comm, "shares_gpu", False):
             ints["tune.sp_wait"] = 0
         for k, v in ints.items():
             check(self.l.bd_ctx_set_int(self.ctx, k.encode(), int(v)))

@@ -126,6 +126,7 @@ class TPComm:
         self.rank, self.size = rank, size
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.in_process_peers = False
+        self.shares_gpu = False                          # some ranks of the group sit on the same physical GPU (set by the constructors)
         self.loopback = False
         with torch.cuda.device(self.device):
             self.h = self.l.bd_comm_create3(rank, size, int(max_elems), int(gather_bytes), int(hbuf_bytes))
@@ -190,6 +191,10 @@ class TPComm:
             infos = [None] * size
             dist.all_gather_object(infos, (self.info(), _device_uuid(self.device)), group=group)
             cross_device = len({i[1] for i in infos}) > 1
+            # several ranks on ONE physical GPU (functional runs on a single-GPU box): a kernel that polls in every workgroup (the
+            # sequence-parallel form's GEMM-side wait) could fill the chip and starve the very rank it waits for -- Engine then
+            # puts the wait into a one-workgroup kernel in front of the GEMM ("tune.sp_wait" = 0)
+            self.shares_gpu = len({i[1] for i in infos}) < size
             if backend == "ipc" and cross_device and not all(i[0]["data_uncached"] and i[0]["flags_uncached"] for i in infos):
                 self.fallback_reason = "exchange buffers are not uncached (fine-grained) on every rank"
                 backend = "rccl"
@@ -281,6 +286,7 @@ class TPComm:
         comms = [cls(r, size, max_elems, device, gather_bytes, hbuf_bytes) for r in range(size)]
         for a in comms:
             a.in_process_peers = True
+            a.shares_gpu = True
             for b in comms:
                 if a is not b:
                     check(a.l.bd_comm_set_peer_ptrs3(a.h, b.rank, a.l.bd_comm_local_data(b.h), a.l.bd_comm_local_flags(b.h),

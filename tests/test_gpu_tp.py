@@ -356,14 +356,17 @@ def _sp_comms(tp, D, nada, split=False):
     return comms
 
 
-@pytest.mark.parametrize("tp,tune,split", [(2, {}, 0), (2, {"sp_wait": 0}, 0), (2, {"sp_inv": 1}, 1), (4, {}, 0), (4, {}, 1)])
+@pytest.mark.parametrize("tp,tune,split", [(2, {"sp_wait": 1}, 0), (2, {}, 0), (2, {"sp_wait": 1, "sp_inv": 1}, 1), (2, {"sp_wait": 1, "sp_gsig": 1}, 0),
+                                           (4, {}, 0), (4, {}, 1)])
 def test_head_sample_sequence_parallel_equals_allreduce_form(tp, tune, split):
     """The sequence-parallel form of the tensor-parallel head (csrc/bd_sp.hip: a rank owns rows / tp rows of the residual stream; the
     row-split GEMM's epilogue pushes each owner its rows of the fp32 partial, the owner's row kernel reduces in rank order, normalises,
     modulates and pushes bf16 operand rows to every rank, the consuming GEMM polls per-row flags; final layer / sampler step on the
     owner, latent rows gathered after the last evaluation) against the all-reduce form (tp.seq = 0): every element is computed by
     exactly one rank from the same partials in the same order, so the sampled latents and tokens are BIT-identical -- between the
-    forms and between the ranks -- eagerly and as replayed hipGraphs (epochs = replay counter x 4096 + sequence number)."""
+    forms and between the ranks -- eagerly and as replayed hipGraphs (epochs = replay counter x 4096 + sequence number).  Ranks that
+    share one GPU default to the wait kernel in front of the consuming GEMM; "sp_wait" = 1 runs the product's GEMM-prologue wait
+    (safe here: the tiny model's GEMMs do not fill the chip), "sp_gsig" the GEMM-side signal, "sp_inv" the every-wave invalidate."""
     from bitdance_amd import engine as E
     sd_dev = device_seeded_state(tm.head_shapes(HEAD8), 331, DEV)
     B, br, C, P, n = 1, 2, 32, 64, 5
