@@ -677,9 +677,12 @@ static Partial done(const bd_ctx* c, const std::string& ws, int N, int Mpad) {  
 
 // Many K slices in front of a consumer with FEW workgroups (the attention of a tensor-parallel rank: 2 x heads / tp workgroups, each
 // reading its q / k / v through every slab): one row-parallel pass (a workgroup per row, every slab load in flight) sums them into the
-// finished bf16 tensor first.  "tune.finalize_s": slab counts from which this runs under tensor parallelism (default 3).
+// finished bf16 tensor first.  "tune.finalize_s": slab count from which this runs (default: 3 under tensor parallelism, off on one GPU).
 static int finalize_if_many(bd_ctx* c, Partial* q, const char* out_ws, int M, hipStream_t st) {
-    if (c->tp <= 1 || q->S < (int)c->geti("tune.finalize_s", 3)) return 0;
+    // default: from 3 slabs under tensor parallelism; from 2 at 512 rows and more on one GPU (num_images = 4: 320 attention workgroups each
+    // walking two 31 MB fp32 slabs -- 2286 vs 2318 us per evaluation with the pass in front, profiles/r05_head_sweep_b4.log); off otherwise
+    const int from_s = (int)c->geti("tune.finalize_s", c->tp > 1 ? 3 : (c->Mpad >= 512 ? 2 : 0));
+    if (from_s <= 0 || q->S < from_s) return 0;
     FinalizeRowsArgs fr{*q, c->wptr(out_ws), M, q->N};
     BD_TRY(bdk_finalize_rows(fr, st));
     *q = Partial{(const float*)c->ptr(out_ws), nullptr, 0, q->N, q->Mpad};
