@@ -497,7 +497,10 @@ int bd_ctx_finalize(bd_ctx* c) {
                 // each for 4 on the 256-row kernel; in situ on one box (profiles/r04_head_sweep_ada_group.log) 987.9 us per evaluation at
                 // G = 16 against 1003.7 / 1007.0 at G = 4, 998.3 at 8, 990.8 at 26.  293 MB of modulation tensor instead of 73.
                 // Tensor-parallel contexts keep 512 rows (the gather region and the all-gather payload scale with G).
-                if (c->geti("tune.ada_group", -1) < 0 && can && Mp == 128 && tp <= 1 && !c->wfp8 && c->hNada >= 4096 && c->hD >= 2048) g = 16;
+                // (round 5: the same 2048 rows per GEMM at 256 / 512 rows per evaluation -- num_images = 4: 2318.6 vs 2336-2339 us per
+                // evaluation at 4 evaluations per GEMM against 2, profiles/r05_head_sweep_b4.log)
+                if (c->geti("tune.ada_group", -1) < 0 && can && (Mp == 128 || Mp == 256 || Mp == 512) && tp <= 1 && !c->wfp8 && c->hNada >= 4096 && c->hD >= 2048)
+                    g = 2048 / Mp;
                 if (g < 1 || g > 64 || (g > 1 && ((c->RB * g) % 8 != 0 || !can)))
                     return fail("tune.ada_group: 1..64 evaluations, rows a multiple of 256, adaLN width a multiple of 256, bf16 weights or fp8 weights + activations");
                 c->adaG = (int)g;
