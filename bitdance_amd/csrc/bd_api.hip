@@ -699,7 +699,10 @@ static int linear(bd_ctx* c, const char* name, const void* A, int RB, WRef W, in
                   const char* scratch_ws, const char* out_ws, const void* bias, int Mpad, Partial* res, hipStream_t st,
                   bool force_reduce = false) {
     // 256-row passes run the 4-wave x 2-panel kernel, which has no in-launch reduction: slabs for the consumer there
-    const int max_s = (int)c->geti("tune.reduce_max_s", (c->Mpad % 256 == 0) ? 0 : 2);
+    // (round 5: at 512 rows and more the 256-row kernel reduces TWO slices in the launch too -- the consumers stop reading fp32 slabs)
+    // -- for the wide weights of the 14B models on the 8-wave 256-row kernel, the forms measured; the ImageNet batches keep their rules)
+    const bool wide_red = c->Mpad >= 512 && (double)N * K * 2 > 12e6 && (g.nw & 15) == 8 && g.kw == 1 && !c->wfp8;
+    const int max_s = (int)c->geti("tune.reduce_max_s", (c->Mpad % 256 == 0) ? (wide_red ? 2 : 0) : 2);
     if (g.S <= max_s || g.S == 1 || force_reduce) {            // a single slice needs no reduction: bias + rounding in the epilogue
         BD_TRY(gemm(c, name, A, RB, W, N, K, g.S, g.code(), BD_EPI_BF16, (float*)c->wptr(scratch_ws), c->wptr(out_ws), bias, st));
         *res = Partial{(const float*)c->ptr(out_ws), nullptr, 0, N, Mpad};
@@ -987,6 +990,9 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0
         // Linear -> chunk(2) -> silu(h1)*h2.  Fused epilogue (on the last-arriving K-slice when split) writes the next
         // operand: 46.9 + 22.9 us (w1 + w2) against 40.8 + 9.5 + 26.0 us for slabs + swiglu_rows on the same MI355X
         // (tune.w1_fused = 0 selects the latter).
+        // (256-row passes: slabs + swiglu_rows.  The fused epilogue behind the 256-row kernel's in-launch reduction -- "tune.w1_fused" = 1 at
+        // 512 rows -- measured 25 us SLOWER per launch: the last arriver of a tile writes the whole SwiGLU tile with 2-byte stores; 2390 vs 2250 us
+        // per evaluation, profiles/r05_head_sweep_b4.log)
         if (g1.S == 1 || c->geti("tune.w1_fused", (c->Mpad % 256 == 0 || g1.S > 2) ? 0 : 1)) {
             BD_TRY(gemm(c, "head.w1", c->ptr("head.h_frag"), RB, wref(c, pre + "w1", "head.h_scale"), 2 * Hl, D, g1.S, g1.code(), BD_EPI_SWIGLU,
                         (float*)c->wptr("head.w1_part"), c->wptr("head.act_frag"), c->ptr(pre + "b1"), st));

@@ -91,7 +91,12 @@ __global__ void rows_to_afrag_kernel(bf16_t* __restrict__ dst, const float* __re
 //     so WR = 2 hides only ~0.85 us of HBM latency behind the MFMAs; WR = 3 doubles that for 32 more VGPRs.
 //   * XCD = 1: the row tiles that stream the same weight slice are placed on the SAME XCD (blocks b and b + 8): the second
 //     reader hits that XCD's L2 instead of making the fabric deliver the slice to two L2s.
-template <int EPI, int WR, bool XCD>
+//   * RED (round 5): two K slices reduced INSIDE the launch -- each slice parks its accumulators (accumulator order, 16 B `sc1`
+//     write-through stores), takes a ticket on the tile's counter, and the slice that arrives second adds the other's slab to its own
+//     registers (own + other == other + own: the result does not depend on the arrival order) and runs the bf16 / SwiGLU epilogue.
+//     At num_images = 4 the consumers of the 2-slice GEMMs were reading 63 MB of fp32 slabs per launch (finalize_rows + head_attn
+//     behind qkv, swiglu_rows behind w1); with RED they read 16 / 8 MB of bf16 written once.
+template <int EPI, int WR, bool XCD, bool RED = false>
 __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
     constexpr int MB = 8, NPW = 2, NT = 256, UNITS = MB * 256, XL = UNITS / NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -255,6 +260,44 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
         if (j + 1 < nst) phase(std::integral_constant<int, 1>{}, j + 1);
     }
 
+    if constexpr (RED) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+        static_assert(!RED, "the relaxed sc1 slab hand-off is validated for gfx950 only");
+#endif
+        // S == 2 (the launcher guarantees it).  Region (tile, wave, slice) = [accumulator][r4][lane] x 16 B.
+        const __amdgpu_buffer_rsrc_t sl = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((size_t)2 * p.Mpad * p.N * 4), 0x00020000);
+        const int tile = mt * (p.N >> 8) + nt;
+        const size_t region0 = ((size_t)tile * 4 + wave) * 2;
+        auto slab_off = [&](int s_, int a, int r4) -> unsigned {
+            return (unsigned)((((region0 + s_) * (MB * NPW) + a) * 4 + r4) * 1024 + lane * 16);
+        };
+        constexpr int SC1 = 16;
+#pragma unroll
+        for (int a = 0; a < MB * NPW; ++a)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(acc[a][4 * r4]), __float_as_uint(acc[a][4 * r4 + 1]),
+                                                               __float_as_uint(acc[a][4 * r4 + 2]), __float_as_uint(acc[a][4 * r4 + 3])},
+                                                       sl, slab_off(s, a, r4), 0, SC1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* const flag = reinterpret_cast<int*>(smem);
+        int* const ticket = p.cnt + tile;
+        if (tid == 0) flag[0] = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (flag[0] != 1) return;                                          // the other slice finishes this tile
+#pragma unroll
+        for (int a = 0; a < MB * NPW; ++a) {
+            u32x4 v[4];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) v[r4] = __builtin_amdgcn_raw_buffer_load_b128(sl, slab_off(1 - s, a, r4), 0, SC1);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[a][4 * r4 + j] += __uint_as_float(v[r4][j]);
+        }
+        if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+    }
     // ---- epilogue (same forms as gemm_kernel)
     const int col = nb * 32 + (lane & 31);
     float bias_pn[NPW];
@@ -327,6 +370,17 @@ template <int WR, bool XCD>
 static int launch_gemm_wide_v(const GemmP& p, int epi, hipStream_t st) {
     const int ntiles = p.N / 256;
     dim3 grid(ntiles * p.S * (p.RB / 8));
+    if (p.S > 1 && epi != BD_EPI_PARTIAL) {                       // two slices reduced in the launch (RED)
+        if (p.S != 2 || !p.cnt || !p.out || (long long)ntiles * (p.RB / 8) > 16383) return -4;
+        static unsigned long long optin_r[2] = {0, 0};
+        const int nr = 3 * 8 * 256 * 16;
+        if (!bd_lds_optin((const void*)gemm_wide_kernel<BD_EPI_BF16, WR, XCD, true>, nr, &optin_r[0]) ||
+            !bd_lds_optin((const void*)gemm_wide_kernel<BD_EPI_SWIGLU, WR, XCD, true>, nr, &optin_r[1])) return -8;
+        if (epi == BD_EPI_BF16) BD_LAUNCH((gemm_wide_kernel<BD_EPI_BF16, WR, XCD, true>), grid, dim3(256), (size_t)nr, st, p);
+        else if (epi == BD_EPI_SWIGLU) BD_LAUNCH((gemm_wide_kernel<BD_EPI_SWIGLU, WR, XCD, true>), grid, dim3(256), (size_t)nr, st, p);
+        else return -4;
+        return bd_launch_status();
+    }
     const size_t lds = (size_t)3 * 8 * 256 * 16;
     static unsigned long long optin[3] = {0, 0, 0};
     const int n = 3 * 8 * 256 * 16;                                // 96 KiB of dynamic LDS needs the opt-in, per device
@@ -386,11 +440,12 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
     // 256-row passes over 256-column tiles: 4 waves x 2 panels (MFMA-friendly) instead of 8 waves x 1 panel;
     // same grid.  BD_GEMM_WIDE=0 keeps the 8-wave form (A/B switch for measurements).
     static const bool wide = [] { const char* e = getenv("BD_GEMM_WIDE"); return !(e && e[0] == '0'); }();
-    if (wide && MB == 8 && nw == 8 && N % 256 == 0 && epi != BD_EPI_F32 && !(S > 1 && epi != BD_EPI_PARTIAL)) {
+    // (a reduced epilogue -- S > 1 with bf16 / SwiGLU output -- exists for exactly two slices, round 5; more slices: the generic kernel)
+    if (wide && MB == 8 && nw == 8 && N % 256 == 0 && epi != BD_EPI_F32 && !(S > 1 && epi != BD_EPI_PARTIAL && (S != 2 || RB < 16))) {
         // >= 512 rows: the matrix pipe is the roofline -> both operands through LDS, 256 x 256 tiles (bd_gemm_tile.hip)
         // (measured, profiles/r03_gemm_tile_v4.log: ahead of the 256-row kernel from 1024 rows on wide N -- adaLN x8 693 vs 786 us,
         // ImageNet w1 89 vs 114 us -- behind it at 512 rows and on narrow N, where it has too few tiles per CU)
-        if (g_tile && RB >= 32 && N >= 4096 && g_w_layout == 0) return bdk_gemm_tile(p, epi, st);
+        if (g_tile && RB >= 32 && N >= 4096 && g_w_layout == 0 && !(S > 1 && epi != BD_EPI_PARTIAL)) return bdk_gemm_tile(p, epi, st);
         return launch_gemm_wide(p, epi, st);
     }
 #define BD_CASE(NPV, KWV, MBV, RV) if (np == NPV && kw == KWV && MB == MBV && ring == RV) return launch_gemm<NPV, KWV, MBV, RV>(p, epi, st);
