@@ -298,7 +298,8 @@ struct BdTpPush {
 #define BD_SP_MAXROWS 512
 #define BD_SP_RC 0            /* replay counter: epoch = RC * 4096 + sequence number of the hand-off inside the replayed graph */
 #define BD_SP_P 8             /* [8]  "the partials of rank p are pushed" epochs */
-#define BD_SP_G 16            /* [8]  "the adaLN columns of rank p are pushed" epochs (split all-gather: push early, wait late) */
+#define BD_SP_G 16            /* [8]  reserved: "the adaLN columns of rank p are pushed" epochs for an all-gather pushed a group ahead and waited for
+                                        by its first consumer (not built: needs links to measure) */
 #define BD_SP_DONE 24         /* arrival counter of the pushing GEMM's workgroups (BdTpPush::done_cnt) */
 #define BD_SP_H 32            /* [BD_SP_MAXROWS] "operand row m is pushed" epochs (also: final latent row bp) */
 #define BD_SP_FLAG_INTS (32 + BD_SP_MAXROWS)
