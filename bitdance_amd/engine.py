@@ -411,8 +411,10 @@ class Engine:
         # GEMM workgroups would starve the peer rank's row kernel they are waiting for (observed: two 14B ranks on one GPU time out).
         self.seq_parallel = False
         if self.comm is not None and head is not None and not head.mlp and self.comm.backend in ("ipc", "none") and self.comm.hbuf_bytes > 0:
+            # (a node whose self-test only passed WITH system-scope fences around the flags keeps the all-reduce form: the sequence-parallel
+            # kernels implement the fence-less hand-off only)
             ok = (self.M == 128 and self.branches == 2 and (self.BP // 8) % self.comm.size == 0 and self.wdtype in (0, 1)
-                  and self.comm.hbuf_bytes >= 128 * head.D * 2)
+                  and self.comm.hbuf_bytes >= 128 * head.D * 2 and not getattr(self.comm, "fences", 0))
             # measured on one rank in loop-back (profiles/r05_tp_rank_critical_path.log, us per evaluation, all-reduce form vs this):
             # tp 2 976 vs 910, tp 4 755 vs 743, tp 8 670 vs 702 -- on by default up to 4 ranks; at 8 the rank's 16 rows make every row
             # kernel a 16-workgroup latency chain either way and the two extra destinations per push cost more than the saved launch
