@@ -436,3 +436,22 @@ def test_bench_roofline_accounting():
     assert grouped["evaluations_per_launch"] == 4 and grouped["rows_per_pass"] == 512
     assert abs(grouped["TFLOPs"] - 2.0 * 512 * 71680 * 5120 / 0.400e-3 / 1e12) < 1.0
     assert abs(grouped["algorithmic_GBs"] - 4 * wa / 0.400 / 1e6) < 0.5 and abs(grouped["GBs"] - wa / 0.400 / 1e6) < 0.5
+
+
+def test_bench_pmc_annotation_reads_the_committed_passes():
+    """bench.py attaches `mfma_busy` / `eff_clock_ghz` of the committed PMC passes (profiles/r05_pmc_gemm_traffic*.json) to a per-GEMM
+    row only when that pass measured the SAME launch configuration; the 512-row pass feeds the `b4` object."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    per = [{"name": "head.qkv", "splitk": 2, "nwaves": 4, "kparts": 1}, {"name": "head.qkv", "splitk": 4, "nwaves": 4, "kparts": 1},
+           {"name": "head.nope", "splitk": 1, "nwaves": 4, "kparts": 1}]
+    src = b.annotate_pmc(per, 128)
+    assert src and src.endswith("r05_pmc_gemm_traffic.json")
+    assert 0.1 < per[0]["mfma_busy"] < 0.5 and 1.0 < per[0]["eff_clock_ghz"] < 4.0
+    assert "mfma_busy" not in per[1] and "mfma_busy" not in per[2]          # another split-K / an unknown GEMM: no numbers invented
+    per4 = [{"name": "head.wo", "splitk": 5, "nwaves": 8, "kparts": 1}]
+    assert b.annotate_pmc(per4, 512).endswith("r05_pmc_gemm_traffic_rows512.json") and "mfma_busy" in per4[0]
+    assert b.pmc_entries(256) == {}
