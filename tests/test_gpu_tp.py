@@ -424,6 +424,52 @@ def test_head_sample_sequence_parallel_equals_allreduce_form(tp, tune, split):
         assert torch.equal(a, b), (a - b).abs().max()                               # sequence-parallel == all-reduce form, bit for bit
 
 
+def test_head_sample_sequence_parallel_true_dims_equals_allreduce_form():
+    """The same bit-for-bit statement at the TRUE head dimensions (D = 5120, 6 blocks, 40 heads, the 14B launch configurations of the
+    tp = 2 shard: 240-workgroup GEMMs, 640-thread row kernels), two ranks as streams of this GPU, 7 chained evaluations, twice (epochs
+    advance).  Ranks sharing a GPU wait in the one-workgroup kernel in front of the consuming GEMM (Engine's default there): with the
+    GEMM-prologue wait a chip full of polling workgroups starves the peer rank's row kernel on ONE GPU (observed: time-out) -- that
+    form is value-checked at the tiny dimensions above and timed in loop-back (tools/head_sweep.py --tp-shard)."""
+    from bitdance_amd import engine as E
+    from bitdance_amd.tp import TPComm, seq_hbuf_bytes
+    tp = 2
+    cfgd = dict(ch_target=32, ch_cond=5120, ch_latent=5120, depth_latent=6, depth_adanln=2)
+    sd = device_seeded_state(tm.head_shapes(cfgd), 101, DEV)
+    hws = [E.HeadWeights.from_state_dict(sd, DEV, tp_rank=r, tp_size=tp) for r in range(tp)]
+    del sd
+    B, br, P, C, n = 1, 2, 64, 32, 6
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(br * B, P, 5120, generator=g)
+    noise = torch.randn(1, n + 1, B, P, C, generator=g)
+    streams = _streams(tp)
+    outs = {}
+    for seq in (0, 1):
+        comms = TPComm.in_process(tp, 128 * 5120, DEV, hbuf_bytes=seq_hbuf_bytes(128, 5120))
+        for c in comms:
+            c.set_timeout(8.0)
+        engs = [E.Engine(hws[r], None, None, num_images=B, branches=br, device=DEV, max_tokens=P, parallel_num=P, comm=comms[r],
+                         extra_ints={"tp.seq": seq, "tp.ada_split": 0}) for r in range(tp)]
+        assert all(e.seq_parallel == bool(seq) for e in engs)
+        torch.cuda.synchronize()
+        for rep in range(2):
+            for r in range(tp):
+                with torch.cuda.stream(streams[r]):
+                    engs[r].set_schedule(n, 1.5, 1)
+                    engs[r].load_noise(noise)
+                    engs[r].reset([0] * (br * B))
+                    engs[r].set_cond(z.to(DEV))
+                    engs[r].head_sample()
+            torch.cuda.synchronize()
+            for c in comms:
+                c.check()
+        ps = [e.pred().clone() for e in engs]
+        assert torch.equal(ps[1], ps[0]) and torch.isfinite(ps[0]).all()
+        assert comms[0].prepushed() == comms[0].exchanges() > 0
+        outs[seq] = ps[0]
+        del engs, comms
+    assert torch.equal(outs[1], outs[0])
+
+
 @pytest.mark.parametrize("tp", [2, 4])
 def test_head_eval_sequence_parallel_rows_vs_oracle(tp):
     """One evaluation in the sequence-parallel form: every rank produces x_hat for the patch positions it owns (8-row groups dealt
