@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbitdance_hip.so")
+# BD_HIP_LIB: a measurement build of the SAME sources (tools/launch_anatomy.py loads libbitdance_hip_stamp.so); never a fallback
+LIB_PATH = os.environ.get("BD_HIP_LIB") or os.path.join(HERE, "libbitdance_hip.so")
 
 _lib = None
 
@@ -91,6 +92,7 @@ _PROTOS = {
     "bd_comm_set_peer_ptrs3": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bd_comm_local_hbuf": (C.c_void_p, [C.c_void_p]),
     "bd_comm_hbuf_bytes": (C.c_longlong, [C.c_void_p]),
+    "bd_comm_sp_selftest": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bd_comm_set_loopback": (C.c_int, [C.c_void_p]),
     "bd_comm_prepushed": (C.c_longlong, [C.c_void_p]),
     "bd_comm_gather_ptr": (C.c_void_p, [C.c_void_p]),

@@ -32,19 +32,23 @@ def _newer(target: str, deps: list[str]) -> bool:
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, stamp: bool = False) -> str:
     """Compile what is out of date and link.  Safe to call from every rank of a multi-process launch: one process builds
-    under an exclusive file lock, the others wait and then find everything up to date; the library is replaced atomically."""
-    os.makedirs(OBJ, exist_ok=True)
-    with open(os.path.join(OBJ, ".lock"), "w") as lock:
+    under an exclusive file lock, the others wait and then find everything up to date; the library is replaced atomically.
+    ``stamp``: the MEASUREMENT build libbitdance_hip_stamp.so (-DBD_GEMM_STAMP: in-kernel phase stamps, csrc/bd_common.h) that
+    tools/launch_anatomy.py loads instead of the product library; the product build compiles none of that code."""
+    obj = OBJ + ("_stamp" if stamp else "")
+    os.makedirs(obj, exist_ok=True)
+    with open(os.path.join(obj, ".lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            return _build_locked(force, verbose)
+            return _build_locked(force, verbose, obj, LIB.replace(".so", "_stamp.so") if stamp else LIB,
+                                 FLAGS + (["-DBD_GEMM_STAMP"] if stamp else []))
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def _build_locked(force: bool, verbose: bool) -> str:
+def _build_locked(force: bool, verbose: bool, OBJ: str = OBJ, LIB: str = LIB, FLAGS: list = FLAGS) -> str:
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "bitdance_hip.h"))
     jobs = []
@@ -76,4 +80,4 @@ def _build_locked(force: bool, verbose: bool) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, stamp="--stamp" in sys.argv))

@@ -16,6 +16,37 @@
 
 static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return -1; }
+
+#ifdef BD_GEMM_STAMP
+// ---- launch anatomy (measurement build only, tools/launch_anatomy.py): every stamped launch gets 8 words per workgroup of the
+// caller's device buffer; the host keeps (name, offset, workgroups) per launch.  Not part of the C ABI of the product library.
+namespace {
+struct StampRec { std::string name; long long off; int nwg; };
+unsigned long long* g_stamp_buf = nullptr;
+long long g_stamp_cap = 0, g_stamp_used = 0;                // in 8-byte words
+std::vector<StampRec> g_stamp_recs;
+thread_local std::string g_stamp_label = "gemm";
+}
+unsigned long long* bdk_stamp_next(const char* name, int nwg) {
+    if (!g_stamp_buf || g_stamp_used + (long long)nwg * 8 > g_stamp_cap) return nullptr;
+    unsigned long long* r = g_stamp_buf + g_stamp_used;
+    g_stamp_recs.push_back({name, g_stamp_used, nwg});
+    g_stamp_used += (long long)nwg * 8;
+    return r;
+}
+void bdk_stamp_label(const char* name) { g_stamp_label = name; }
+const char* bdk_stamp_current_label() { return g_stamp_label.c_str(); }
+extern "C" {
+int anatomy_begin(void* dev_buf, long long bytes) { g_stamp_buf = (unsigned long long*)dev_buf; g_stamp_cap = bytes / 8; g_stamp_used = 0; g_stamp_recs.clear(); return 0; }
+int anatomy_count(void) { return (int)g_stamp_recs.size(); }
+int anatomy_get(int i, char* name64, long long* off_words, int* nwg) {
+    if (i < 0 || i >= (int)g_stamp_recs.size()) return -1;
+    std::strncpy(name64, g_stamp_recs[i].name.c_str(), 63); name64[63] = 0;
+    *off_words = g_stamp_recs[i].off; *nwg = g_stamp_recs[i].nwg;
+    return 0;
+}
+}
+#endif
 void bdk_set_error(const std::string& m) { g_err = m; }      // bd_comm.hip reports through the same bd_last_error()
 
 #define BD_TRY(expr)                                                                     \
@@ -622,6 +653,10 @@ int bd_ctx_bind(bd_ctx* c) {
 }
 
 int bd_head_set_schedule(bd_ctx* c, int n_steps, const float* s, float cfg) {
+    // sequence-parallel form: one sampling run issues 4 hand-offs per block and evaluation (+ the final latent rows); the sequence
+    // numbers of a run must fit the epoch's low bits (bd_common.h) -- refuse here, before anything is launched or captured
+    if (c->sp && ((long long)(n_steps + 1) * 4 * c->hNB + 1 > BD_SP_SEQ_MAX))
+        return fail("bd_head_set_schedule: too many sampling steps for the sequence-parallel hand-off (tp.seq = 0 keeps the all-reduce form)");
     c->sched.clear();
     for (int i = 0; i <= n_steps; ++i) {
         SamplerScalars q;
@@ -664,6 +699,9 @@ static int gemm(bd_ctx* c, const char* name, const void* A, int RB, WRef W, int 
         hipEventRecord(r.e0, st);
     }
     int* cnt = (epi != BD_EPI_PARTIAL && S > 1) ? (int*)c->wptr("gemm.cnt") : nullptr;   // in-launch reduction tickets
+#ifdef BD_GEMM_STAMP
+    bdk_stamp_label(name);
+#endif
     const int rc = W.a ? bdk_gemm8a(A, W.a, RB, W.w, W.s, N, K, S, nw, epi, out, act, bias, cnt, st)
                        : bdk_gemm(A, RB, W.w, N, K, S, nw, epi, out, act, bias, cnt, st, W.s);
     if (c->prof_on) { hipEventRecord(r.e1, st); c->prof.push_back(r); }
@@ -740,7 +778,7 @@ static int linear_rowsplit_sp(bd_ctx* c, const char* name, const void* A, int RB
                               const char* scratch_ws, const char* tp_ws, int rows, int* seq, hipStream_t st) {
     if (g.S > 3) return fail(std::string(name) + ": a tensor-parallel partial needs at most 3 grid slices");
     *seq = bdk_sp_next_seq(c->comm);
-    if (*seq < 0) return fail("sequence-parallel exchange: more than 4095 hand-offs since the last bd_head_cond / bd_head_sample");
+    if (*seq < 0) return fail("sequence-parallel exchange: more than 65535 hand-offs since the last bd_head_cond / bd_head_sample");
     BdTpPush push;
     // "tune.sp_gsig" = 1: the GEMM's last workgroup signals the owners; 0 (default): the owner's row kernel's first block does -- the
     // arrival counter + barrier at the end of every GEMM workgroup cost more than the flag's head start returns (loop-back, per
@@ -886,7 +924,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0
             l1.part = seq_p ? (const float*)c->ptr("head.tp_part") : nullptr; l1.bias = pend_bias; l1.seq_p = seq_p;
             l1.signal_p = c->geti("tune.sp_gsig", 0) ? 0 : 1;
             l1.seq_h = bdk_sp_next_seq(c->comm);
-            if (l1.seq_h < 0) return fail("sequence-parallel exchange: more than 4095 hand-offs since the last bd_head_cond / bd_head_sample");
+            if (l1.seq_h < 0) return fail("sequence-parallel exchange: more than 65535 hand-offs since the last bd_head_cond / bd_head_sample");
             BD_TRY(bdk_ln_mod_sp(l1, st));
             HeadAttnArgs at;
             BD_TRY(sp_arm_wait(c, l1.seq_h, st));
@@ -901,7 +939,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0
             l2.ln.ln_w = (const float*)c->ptr(pre + "ln2_w"); l2.ln.ln_b = (const float*)c->ptr(pre + "ln2_b");
             l2.part = (const float*)c->ptr("head.tp_part"); l2.bias = c->ptr(pre + "bo"); l2.seq_p = seq_p;
             l2.seq_h = bdk_sp_next_seq(c->comm);
-            if (l2.seq_h < 0) return fail("sequence-parallel exchange: more than 4095 hand-offs since the last bd_head_cond / bd_head_sample");
+            if (l2.seq_h < 0) return fail("sequence-parallel exchange: more than 65535 hand-offs since the last bd_head_cond / bd_head_sample");
             BD_TRY(bdk_ln_mod_sp(l2, st));
             BD_TRY(sp_arm_wait(c, l2.seq_h, st));
             if (g1.S == 1 || c->geti("tune.w1_fused", g1.S > 2 ? 0 : 1)) {
@@ -942,7 +980,7 @@ static int head_eval(bd_ctx* c, int i, hipStream_t st, int ada_buf = -1, bool x0
         fs.seq_f = 0; fs.signal_p = c->geti("tune.sp_gsig", 0) ? 0 : 1;
         if (fa.sc.is_final) {
             fs.seq_f = bdk_sp_next_seq(c->comm);
-            if (fs.seq_f < 0) return fail("sequence-parallel exchange: more than 4095 hand-offs since the last bd_head_cond / bd_head_sample");
+            if (fs.seq_f < 0) return fail("sequence-parallel exchange: more than 65535 hand-offs since the last bd_head_cond / bd_head_sample");
         }
         BD_TRY(bdk_head_final_sp(fs, st));
         if (fa.sc.is_final) {

@@ -56,6 +56,7 @@ BD_DEV void p_to_afrags(const float* p, int lane, u32x4& a_lo, u32x4& a_hi) {
 __global__ __launch_bounds__(256) void head_attn_kernel(HeadAttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * KSTR];
     __shared__ __attribute__((aligned(16))) bf16_t Vs[128 * VSTR];
+    BD_KSTAMP(a.stamp, 0);
     const int seq = blockIdx.x / a.nhead, h = blockIdx.x % a.nhead;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = a.D;
@@ -192,6 +193,7 @@ __global__ __launch_bounds__(256) void head_attn_kernel(HeadAttnArgs a) {
                            pack2(oacc[nb][4 * qd + 2] / lsum, oacc[nb][4 * qd + 3] / lsum));
         }
     (void)inv;
+    BD_KSTAMP_END(a.stamp);
 }
 
 // seq <= 32 branch of the reference (flow_head:203-208), here P = 16 (the 16x models): explicit softmax with the
@@ -347,7 +349,8 @@ __global__ __launch_bounds__(256) void head_attn16_mfma_kernel(HeadAttnArgs a) {
 
 int bdk_head_attn(const HeadAttnArgs& a, hipStream_t st) {
     if (a.dh != 128 && !(a.dh == 64 && a.P <= 16)) return -2;
-    if (a.P == 64) BD_LAUNCH(head_attn_kernel, dim3(a.nseq * a.nhead), dim3(256), 0, st, a);
+    BD_STAMPED(HeadAttnArgs, a, "head_attn", a.nseq * a.nhead);
+    if (a.P == 64) BD_LAUNCH(head_attn_kernel, dim3(a.nseq * a.nhead), dim3(256), 0, st, a_l);
     else if (a.P == 16 && a.qkv.S == 0 && a.qkv.N % 8 == 0) {       // finished bf16 qkv: matrix-pipe scores, 4 heads per workgroup
         const int blocks = (a.nseq * a.nhead + 3) / 4;
         if (a.dh == 64) BD_LAUNCH(head_attn16_mfma_kernel<64>, dim3(blocks), dim3(256), 0, st, a);

@@ -91,6 +91,7 @@ struct ArArgs {
     int fences = 0;
     int prepushed = 0;          // 1: the producing GEMM's epilogue already pushed every peer's slice into its staging row (bdk_tp_push_target)
     int loopback = 0;           // 1: no peers (bd_comm_set_loopback): the flag a peer t would write here is written by this rank itself
+    BD_STAMP_FIELD
 };
 
 // The fence-less hand-off (payload: sc0 sc1 write-through stores drained by vmcnt(0); flag: relaxed system-scope store; reader: sc0 sc1
@@ -123,7 +124,7 @@ BD_DEV bool tp_wait(const ArArgs& a, int base, int b, int e, int err_index) {
         const int* f = a.flags + base + t * BD_TP_GMAX + b;
         const long long t0 = wall_clock64();
         bool dead = __hip_atomic_load(a.flags + err_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
-        while (!dead && (int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+        while (!dead && bd_epoch_before(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), e)) {
             __builtin_amdgcn_s_sleep(2);
             if (wall_clock64() - t0 > a.timeout_ticks) {
                 __hip_atomic_fetch_or(a.flags + err_index, 1 << t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -151,9 +152,10 @@ BD_DEV __amdgpu_buffer_rsrc_t sys_rsrc(void* base, long long bytes) {
 }
 
 __global__ __launch_bounds__(256) void tp_allreduce_kernel(ArArgs a) {
+    BD_KSTAMP(a.stamp, 0);
     const int b = blockIdx.x, tid = threadIdx.x;
     const int FA = 0, FB = BD_TP_MAX * BD_TP_GMAX, ERR = 2 * BD_TP_MAX * BD_TP_GMAX, EP = ERR + 1;
-    const int e = a.flags[EP + b] + 1;                       // only this block ever writes its epoch word
+    const int e = (int)((unsigned)a.flags[EP + b] + 1u);     // only this block ever writes its epoch word (unsigned: wraps, bd_common.h)
     const int Ub = (a.Us + a.G - 1) / a.G;
     const int c0 = b * Ub, c1 = min(a.Us, c0 + Ub);
     // ---- phase 1: push my partial of every peer's slice into that peer's staging row [rank]
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(256) void tp_allreduce_kernel(ArArgs a) {
     tp_signal(a, FB, b, e);
     (void)tp_wait(a, FB, b, e, ERR);
     if (tid == 0) a.flags[EP + b] = e;
+    BD_KSTAMP_END(a.stamp);
 }
 
 // after an RCCL all-reduce the fp32 sums sit in the staging area: the consumer adds bias and rounds (Partial with S = 1)
@@ -253,6 +256,9 @@ int bdk_tp_allreduce(bd_comm* c, const float* part, const void* bias, int rows, 
     a.G = (a.Us + 255) / 256;
     if (a.G > BD_TP_GMAX) a.G = BD_TP_GMAX;
     if (a.G < 1) a.G = 1;
+#ifdef BD_GEMM_STAMP
+    a.stamp = bdk_stamp_next("tp_allreduce", a.G);
+#endif
     BD_LAUNCH(tp_allreduce_kernel, dim3(a.G), dim3(256), 0, st, a);
     if (bd_launch_status() != 0) return -1;
     Partial r{reinterpret_cast<const float*>(c->data + a.stage_bytes), nullptr, 0, N, Mpad};
@@ -277,7 +283,7 @@ struct AgArgs {
 __global__ __launch_bounds__(256) void tp_allgather_kernel(AgArgs g) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const int FC = 2 * BD_TP_MAX * BD_TP_GMAX + 1 + BD_TP_GMAX, ERR = 2 * BD_TP_MAX * BD_TP_GMAX, EPC = FC + BD_TP_MAX * BD_TP_GMAX;
-    const int e = g.flags[EPC + b] + 1;
+    const int e = (int)((unsigned)g.flags[EPC + b] + 1u);
     const long long U = (long long)g.rows * g.Nl8, Ub = (U + g.G - 1) / g.G;
     const long long u0 = b * Ub, u1 = min(U, u0 + Ub);
     __amdgpu_buffer_rsrc_t dst[BD_TP_MAX];
@@ -379,7 +385,7 @@ bool bdk_sp_link(bd_comm* c, BdSpLink* out) {
 }
 long long bdk_sp_hbuf_bytes(const bd_comm* c) { return c ? c->hbuf_bytes : 0; }
 void* bdk_sp_hbuf(const bd_comm* c) { return c ? c->hbuf : nullptr; }
-int bdk_sp_next_seq(bd_comm* c) { return (c && c->sp_seq < 4095) ? ++c->sp_seq : -1; }
+int bdk_sp_next_seq(bd_comm* c) { return (c && c->sp_seq < BD_SP_SEQ_MAX) ? ++c->sp_seq : -1; }
 void bdk_comm_count_exchange(bd_comm* c) { if (c) { c->n_exchanges++; c->n_prepushed++; } }
 bool bdk_sp_hwait(bd_comm* c, int seq, int rows, BdHWait* out) {
     if (!c || !c->hbuf || rows > BD_SP_MAXROWS) return false;
@@ -393,7 +399,7 @@ bool bdk_sp_hwait(bd_comm* c, int seq, int rows, BdHWait* out) {
     return true;
 }
 __global__ void sp_begin_kernel(int* spf) {
-    if (threadIdx.x == 0) __hip_atomic_store(spf + BD_SP_RC, __hip_atomic_load(spf + BD_SP_RC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1,
+    if (threadIdx.x == 0) __hip_atomic_store(spf + BD_SP_RC, (int)((unsigned)__hip_atomic_load(spf + BD_SP_RC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u),
                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 int bdk_sp_begin(bd_comm* c, hipStream_t st) {
@@ -406,10 +412,10 @@ int bdk_sp_begin(bd_comm* c, hipStream_t st) {
 // invalidates the caches) instead of polling in 240 workgroups -- the form for several ranks sharing ONE GPU, where a chip full of
 // polling GEMM workgroups would starve the peer rank's row kernel they are waiting for (tests), and an A/B for the in-GEMM wait
 __global__ void sp_wait_rows_kernel(BdHWait w) {
-    const int e = __hip_atomic_load(w.rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) * 4096 + w.seq;
+    const int e = bd_sp_epoch_of(__hip_atomic_load(w.rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), w.seq);
     const long long t0 = wall_clock64();
     for (int i = threadIdx.x; i < w.n; i += blockDim.x) {
-        while ((int)(__hip_atomic_load(w.flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+        while (bd_epoch_before(__hip_atomic_load(w.flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), e)) {
             if (__hip_atomic_load(w.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
             if (wall_clock64() - t0 > w.timeout_ticks) { __hip_atomic_fetch_or(w.err, 1 << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
             __builtin_amdgcn_s_sleep(2);
@@ -627,6 +633,13 @@ int bd_comm_set_peer_ptrs3(bd_comm* c, int peer, void* data, void* flags, void* 
 }
 void* bd_comm_local_hbuf(bd_comm* c) { return c->hbuf; }
 long long bd_comm_hbuf_bytes(bd_comm* c) { return c->hbuf_bytes; }
+
+/* one round of the sequence-parallel hand-off's self-test (bd_sp.hip): this rank pushes its rows of pattern `round` into every rank's operand
+ * landing buffer, then checks every row of its own buffer behind the GEMM prologue's wait; *bad_dev (device int) += mismatching 16 B units */
+int bd_comm_sp_selftest(bd_comm* c, int round, int rows, int D, int wait_in_check, int* bad_dev, void* stream) {
+    const int rc = bdk_sp_selftest(c, round, rows, D, wait_in_check, bad_dev, (hipStream_t)stream);
+    return rc == 0 ? 0 : cfail("bd_comm_sp_selftest failed with " + std::to_string(rc));
+}
 
 /* ONE rank of a `size`-rank group alone on this GPU: every peer's buffers become scratch allocations of this process, every flag a
  * peer would write is written locally by the block that plays the same role.  The rank's kernels then launch, stream, push and wait

@@ -110,6 +110,46 @@ BD_DEV float row_quant_scale(const float* v, bool active, float* red, float* sca
     return am > 0.f ? __fdiv_rn(448.0f, am) : 0.f;
 }
 
+// Epochs of the flag hand-offs (bd_comm.hip, bd_sp.hip, the GEMM prologue wait): values only grow, MODULO 2^32 -- all epoch arithmetic is
+// unsigned (a signed `flag - e < 0` is undefined behaviour at the wrap and clang folds it into `flag < e`, which passes stale flags after
+// 2^31: ADVICE r05).  Sequence-parallel epochs = replay counter * 2^16 + the hand-off's sequence number inside the replayed graph
+// (1 .. BD_SP_SEQ_MAX: 65535 hand-offs per sampling run = ~2700 sampling steps at 6 blocks; the replay counter wraps harmlessly).
+#define BD_SP_SEQ_BITS 16
+#define BD_SP_SEQ_MAX ((1 << BD_SP_SEQ_BITS) - 1)
+BD_DEV int bd_sp_epoch_of(int rc, int seq) { return (int)(((unsigned)rc << BD_SP_SEQ_BITS) + (unsigned)seq); }
+BD_DEV bool bd_epoch_before(int flag, int e) { return (int)((unsigned)flag - (unsigned)e) < 0; }     // flag has not reached e yet
+
+// Launch anatomy (measurement builds only: -DBD_GEMM_STAMP, tools/launch_anatomy.py builds libbitdance_hip_stamp.so): thread 0 of every
+// workgroup writes s_memrealtime (the chip-wide 100 MHz clock: comparable across CUs and kernels) into 8 words per workgroup of the
+// launch's stamp region.  GEMM: 0 workgroup start, 1 first A stage in LDS, 2 first W stage landed, 3 K loop done, 4 K parts reduced in
+// LDS, 5 slabs drained + ticket taken, 6 last store drained, 7 (slice << 8) | last-arriver bit.  Row kernels: 0 start, 6 end.
+// The product build compiles none of it.
+#ifdef BD_GEMM_STAMP
+#define BD_STAMP_FIELD unsigned long long* stamp = nullptr;
+BD_DEV unsigned long long bd_realtime() {          // inline asm: stays where it is written, between the waits around it
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+BD_DEV void bd_kstamp(unsigned long long* s, int k) {
+    if (s && threadIdx.x == 0) s[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = bd_realtime();
+}
+BD_DEV void bd_kstamp_val(unsigned long long* s, int k, unsigned long long v) {
+    if (s && threadIdx.x == 0) s[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = v;
+}
+#define BD_KSTAMP(s, k) bd_kstamp(s, k)
+#define BD_KSTAMP_END(s) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); bd_kstamp(s, 6); } while (0)
+unsigned long long* bdk_stamp_next(const char* name, int nwg);      // bd_api.hip: the next launch's region (null: stamping off)
+void bdk_stamp_label(const char* name);                             // names the GEMM launches that follow
+const char* bdk_stamp_current_label();
+#define BD_STAMPED(ARGS_T, a, name, nwg) ARGS_T a##_st = a; a##_st.stamp = bdk_stamp_next(name, nwg); const ARGS_T& a##_l = a##_st
+#else
+#define BD_STAMP_FIELD
+#define BD_KSTAMP(s, k) do {} while (0)
+#define BD_KSTAMP_END(s) do {} while (0)
+#define BD_STAMPED(ARGS_T, a, name, nwg) const ARGS_T& a##_l = a
+#endif
+
 // Device-resident state of the autoregressive loop, read by every step-dependent kernel so that
 // one captured hipGraph can be replayed for every AR step.
 #define BD_MAX_SEQ 64  // per-sequence KV-length slots: num_images <= 32 with CFG on the Qwen3 path (imagenet sequences share slot 0)

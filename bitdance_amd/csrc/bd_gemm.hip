@@ -415,6 +415,10 @@ static int launch_gemm_wide(const GemmP& p0, int epi, hipStream_t st) {
 int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_ring, int epi,
              float* out_partial, void* out_act, const void* bias, int* cnt, hipStream_t st, const float* wscale) {
     if (wscale) return bdk_gemm8(A, RB, W, wscale, N, K, S, nw_ring, epi, out_partial, out_act, bias, cnt, st);   // fp8 weights: bd_gemm8.hip
+    // the armed push target / operand wait belong to THIS call whatever happens to it: taken (and cleared) before any early return, so a
+    // rejected shape cannot leave them attached to the next, unrelated GEMM of the thread
+    BdTpPush pend_push; const bool have_push = bdk_gemm_claim_push(epi, RB, N, &pend_push);
+    BdHWait pend_hw; const bool have_hw = bdk_gemm_take_hwait(&pend_hw);
     const int nw = nw_ring & 15;
     int ring = (nw_ring >> 4) & 15;
     const int kw = ((nw_ring >> 8) & 3) + 1;
@@ -430,8 +434,8 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
     size_t PS, SS;
     bdk_w_strides(N / 32, K, &PS, &SS);
     GemmP p{(const u32x4*)A, (const u32x4*)W, out_partial, (bf16_t*)out_act, (const bf16_t*)bias, cnt, nullptr, RB, N, K, S, RB * 32, PS, SS};
-    (void)bdk_gemm_claim_push(epi, RB, N, &p.push);    // the 128-row kernel's epilogue pushes the peers' slices itself (bd_gemm_kernel.h)
-    if (bdk_gemm_take_hwait(&p.hw) && (RB % 8 == 0 || ((nw_ring >> 11) & 1))) return -10;     // (the 128-row plain-loop kernel only)
+    if (have_push) p.push = pend_push;                 // the 128-row kernel's epilogue pushes the peers' slices itself (bd_gemm_kernel.h)
+    if (have_hw) { if (RB % 8 == 0 || pipe) return -10; p.hw = pend_hw; }     // (the 128-row plain-loop kernel only)
     // rows per pass over the weights: 256 (two images with CFG: W streamed once for both) when the row count allows,
     // else 128 / 64 / 32
     const int MB = (RB % 8 == 0 && nw >= 4 && kw == 1) ? 8 : ((RB % 4 == 0) ? 4 : RB);

@@ -68,6 +68,9 @@ int bdk_pack_w8k(void* dst, const void* src, const void* src2, int panels, int K
 // fp8 weights AND fp8 activations (A: the A8 layout + `ascale` [rows] fp32): the launch forms of the 128-row kernel
 int bdk_gemm8a(const void* A8, const float* ascale, int RB, const void* W8k, const float* wscale, int N, int K, int S, int nw_ring, int epi,
                float* out_partial, void* out_act, const void* bias, int* cnt, hipStream_t st) {
+    // (armed push target / operand wait: taken before any early return, bdk_gemm.  The sequence-parallel hand-off carries bf16 rows only)
+    { BdTpPush none_p; (void)bdk_gemm_claim_push(-1, RB, N, &none_p); }
+    { BdHWait none; if (bdk_gemm_take_hwait(&none)) return -10; }
     const int nw = nw_ring & 15;
     const int kw = ((nw_ring >> 8) & 3) + 1;
     if (kw > 2 || nw % kw || !ascale || !wscale) return -7;
@@ -79,7 +82,6 @@ int bdk_gemm8a(const void* A8, const float* ascale, int RB, const void* W8k, con
     const size_t PS = (size_t)(K >> 6) * 128, SS = 128;
     GemmP p{(const u32x4*)A8, (const u32x4*)W8k, out_partial, (bf16_t*)out_act, (const bf16_t*)bias, cnt, wscale, RB, N, K, S, RB * 32, PS, SS};
     p.ascale = ascale;
-    { BdHWait none; if (bdk_gemm_take_hwait(&none)) return -10; }   // (the sequence-parallel hand-off carries bf16 operand rows only)
     // 256-row passes (the adaLN projection of a group of evaluations, bd_api.hip head_ada_group): one pass over the weights per 256
     // rows, same MFMA and K order per row as the 128-row form -> bit-identical rows.  Only that call shape (one slice, bf16 epilogue):
     // everything else keeps the 128-row forms the parity tests cover
@@ -98,6 +100,9 @@ int bdk_gemm8a(const void* A8, const float* ascale, int RB, const void* W8k, con
 
 int bdk_gemm8(const void* A, int RB, const void* W8, const float* wscale, int N, int K, int S, int nw_ring, int epi,
               float* out_partial, void* out_act, const void* bias, int* cnt, hipStream_t st) {
+    // the armed push target / operand wait belong to THIS call: taken (and cleared) before any early return (bdk_gemm)
+    BdTpPush pend_push; const bool have_push = bdk_gemm_claim_push(epi, RB, N, &pend_push);   // tensor parallelism: the fp32-partial epilogue pushes the peers' rows
+    BdHWait pend_hw; const bool have_hw = bdk_gemm_take_hwait(&pend_hw);                      // sequence-parallel: the operand comes from the peers' row kernels
     const int nw = nw_ring & 15;
     const int kw = ((nw_ring >> 8) & 3) + 1;
     if (kw > 2 || nw % kw) return -7;
@@ -110,8 +115,8 @@ int bdk_gemm8(const void* A, int RB, const void* W8, const float* wscale, int N,
     GemmP p{(const u32x4*)A, (const u32x4*)W8, out_partial, (bf16_t*)out_act, (const bf16_t*)bias, cnt, wscale, RB, N, K, S, RB * 32, PS, SS};
     const int MB = (RB % 4 == 0) ? 4 : RB;                     // 128-row passes (row blocks beyond 4: grid.y)
     if (MB != 4 && MB != 2 && MB != 1) return -5;
-    (void)bdk_gemm_claim_push(epi, RB, N, &p.push);            // tensor parallelism: the fp32-partial epilogue pushes the peers' rows (as in bdk_gemm)
-    (void)bdk_gemm_take_hwait(&p.hw);                          // sequence-parallel: the operand comes from the peers' row kernels
+    if (have_push) p.push = pend_push;
+    if (have_hw) p.hw = pend_hw;
     // ring 2 (two 2 KiB stages per wave in flight).  Ring 4 was measured SLOWER (adaLN 125 vs 97 us, profiles/r02_bench_fp8_v2.json):
     // at 128 rows and half the bytes per weight the workgroup is bound by its LDS-read + MFMA work per stage (256 FLOP per weight
     // byte, at the ridge), not by bytes in flight.

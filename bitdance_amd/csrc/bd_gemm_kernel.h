@@ -5,6 +5,7 @@
 #include <type_traits>
 #include "bd_common.h"
 #include "bd_kernels.h"
+#include "bd_hwait.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 
@@ -49,26 +50,8 @@ struct GemmP {
     BdTpPush push;                   // BD_EPI_F32 under tensor parallelism: the epilogue pushes the peers' slices (size > 1)
     BdHWait hw;                      // sequence-parallel tensor parallelism: the A operand is pushed by the peers' row kernels -- poll its row flags
                                      // after the first weight stages are in flight, then invalidate and load it (flags == nullptr: no wait)
+    BD_STAMP_FIELD                   // measurement builds (-DBD_GEMM_STAMP): the launch's stamp region (bd_common.h)
 };
-
-// The consumer side of the sequence-parallel hand-off (bd_sp.hip): the weights do not depend on the peers, so the first R stages are
-// requested BEFORE this; the operand rows were written into cacheable local memory by sc0 sc1 write-through stores from other GPUs
-// (or, in the one-GPU tests, other XCDs), so after the flags this CU's L1 and this XCD's L2 may still hold lines of the PREVIOUS
-// operand: one `buffer_inv sc0 sc1` (system-scope invalidate of non-coherent lines) ahead of the barrier, then plain loads.
-BD_DEV void gemm_hwait(const BdHWait& w, int tid, int nthreads) {
-    const int e = __hip_atomic_load(w.rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) * 4096 + w.seq;
-    const long long t0 = wall_clock64();
-    for (int i = tid; i < w.n; i += nthreads) {
-        while ((int)(__hip_atomic_load(w.flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
-            if (__hip_atomic_load(w.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;      // a dead exchange: run on (garbage in, the host raises)
-            if (wall_clock64() - t0 > w.timeout_ticks) { __hip_atomic_fetch_or(w.err, 1 << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    if (w.inv == 0 && tid < 64) asm volatile("buffer_inv sc0 sc1" ::: "memory");
-    __syncthreads();
-    if (w.inv == 1) asm volatile("buffer_inv sc0 sc1" ::: "memory");
-}
 
 // MFMA-bound form for >= 512 rows: both operands through LDS, 256 x 256 workgroup tiles (bd_gemm_tile.hip)
 int bdk_gemm_tile(const GemmP& p, int epi, hipStream_t st);
@@ -110,6 +93,7 @@ BD_DEV void gemm_body(const GemmP& p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u32x4* const lds = reinterpret_cast<u32x4*>(smem);    // two A-stage buffers of UNITS each
 
+    BD_KSTAMP(p.stamp, 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pw = wave % NP, kg = wave / NP;              // panel / K-part of this wave
     const int S = p.S;
@@ -270,6 +254,7 @@ BD_DEV void gemm_body(const GemmP& p) {
         for (int r = 1; r < R; ++r)
             if (r < nst) load_w(w[r], r);                      // the weight stream starts before the wait ...
         gemm_hwait(p.hw, tid, NT);                             // ... which ends when every operand row has landed
+        BD_KSTAMP(p.stamp, 1);
         load_x(xr[0], 0);
         store_x(lds, xr[0]);
 #pragma unroll
@@ -279,11 +264,20 @@ BD_DEV void gemm_body(const GemmP& p) {
         load_x(xr[0], 0);
         load_w(w[0], 0);
         store_x(lds, xr[0]);
+#ifdef BD_GEMM_STAMP
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WL) : "memory");            // the A stage has landed (W stage 0 still in flight)
+        BD_KSTAMP(p.stamp, 1);
+#endif
 #pragma unroll
         for (int r = 1; r < R; ++r)
             if (r < nst) { load_x(xr[r % XR], r); load_w(w[r], r); }
     }
     __syncthreads();
+#ifdef BD_GEMM_STAMP
+    if (nst >= R) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((R - 1) * (XL + WL)) : "memory");   // W stage 0 has landed, the younger stages fly on
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BD_KSTAMP(p.stamp, 2);
+#endif
 
     int i = 0;
     // steady state: stage j = i + ph; every ring / buffer index below is a compile-time constant
@@ -314,6 +308,7 @@ BD_DEV void gemm_body(const GemmP& p) {
     }
   }
 
+    BD_KSTAMP(p.stamp, 3);
     // ---- K parts of one panel meet in LDS: parts 1..KW-1 park their accumulators, part 0 adds them in order
     if constexpr (KW > 1) {
         __syncthreads();                                                  // every wave is done with the A tiles
@@ -340,6 +335,7 @@ BD_DEV void gemm_body(const GemmP& p) {
                     }
         }
     }
+    BD_KSTAMP(p.stamp, 4);
     const bool owner = (kg == 0) && pvalid;                                // the wave that holds the tile's sums
     if constexpr (WT != 0) {                                               // dequantisation scale of this lane's output column
         const float sc = p.wscale[nbl * 32 + (lane & 31)];
@@ -456,6 +452,11 @@ BD_DEV void gemm_body(const GemmP& p) {
         int* const ticket = p.cnt + (mt * ntl + nt);
         if (tid == 0) flag[0] = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
+#ifdef BD_GEMM_STAMP
+        BD_KSTAMP(p.stamp, 5);
+        bd_kstamp_val(p.stamp, 7, ((unsigned long long)s << 8) | (flag[0] == S - 1 ? 1u : 0u));
+        if (flag[0] != S - 1) BD_KSTAMP(p.stamp, 6);
+#endif
         if (flag[0] != S - 1 || !owner) return;                           // not the last slice of this tile / nothing to store
         if (S == 2) {
             // two slices: own + other == other + own bit for bit, so the last arriver keeps its accumulators and
@@ -474,6 +475,7 @@ BD_DEV void gemm_body(const GemmP& p) {
             for (int m = 0; m < MB; ++m) finalize(m);
             if (EPI == BD_EPI_F32 && p.push.size > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            BD_KSTAMP_END(p.stamp);
             return;
         }
 #pragma unroll
@@ -494,6 +496,7 @@ BD_DEV void gemm_body(const GemmP& p) {
         }
         if (EPI == BD_EPI_F32 && p.push.size > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+        BD_KSTAMP_END(p.stamp);
         return;
     }
     if (EPI == BD_EPI_F32 && p.push.size > 1) __syncthreads();           // every wave is done with the A tiles (the patches overlay them)
@@ -502,6 +505,11 @@ BD_DEV void gemm_body(const GemmP& p) {
         for (int m = 0; m < MB; ++m) finalize(m);
     }
     if (EPI == BD_EPI_F32 && p.push.size > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the pushes are at their destinations before the kernel ends
+#ifdef BD_GEMM_STAMP
+    bd_kstamp_val(p.stamp, 5, 0);
+    bd_kstamp_val(p.stamp, 7, (unsigned long long)s << 8);
+    BD_KSTAMP_END(p.stamp);
+#endif
 }
 
 template <int NP, int KW, int MB, int EPI, int R, bool RED, int MODE = 0, int WT = 0>
@@ -517,7 +525,7 @@ __global__ __launch_bounds__(NP * KW * 64) void gemm_kernel(GemmP p) {
                 const int total = (int)(gridDim.x * gridDim.y);
                 if (__hip_atomic_fetch_add(p.push.done_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
                     __hip_atomic_store(p.push.done_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm for the next launch
-                    const int e = __hip_atomic_load(p.push.rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) * 4096 + p.push.seq;
+                    const int e = bd_sp_epoch_of(__hip_atomic_load(p.push.rc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), p.push.seq);
                     for (int q = 0; q < p.push.size; ++q)
                         if (q != p.push.rank) __hip_atomic_store(p.push.sig[q], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
@@ -546,7 +554,13 @@ static int launch_one(const GemmP& p, hipStream_t st) {
         static unsigned long long optin = 0;                      // per device (bd_kernels.h)
         if (!bd_lds_optin((const void*)gemm_kernel<NP, KW, MB, EPI, R, RED, MODE, WT>, (int)lds, &optin)) return -8;
     }
+#ifdef BD_GEMM_STAMP
+    GemmP q = p;
+    q.stamp = bdk_stamp_next(bdk_stamp_current_label(), (int)(grid.x * grid.y));
+    BD_LAUNCH((gemm_kernel<NP, KW, MB, EPI, R, RED, MODE, WT>), grid, dim3(NP * KW * 64), lds, st, q);
+#else
     BD_LAUNCH((gemm_kernel<NP, KW, MB, EPI, R, RED, MODE, WT>), grid, dim3(NP * KW * 64), lds, st, p);
+#endif
     return bd_launch_status();
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "bd_common.h"          // (BD_STAMP_FIELD: every translation unit must see the same struct layouts)
 
 // hipGetLastError() is sticky per thread: another library's benign failure (torch probing peers, querying an
 // unfinished event ...) would otherwise be blamed on our launch.  Clear before, check after.
@@ -84,6 +85,7 @@ struct LnModArgs {          // x (+= pending branch * gate) ; h = LN(x)*(1+scale
     float eps;
     float* a8_scale = nullptr;   // not null: h goes out as fp8-e4m3 in the A8 layout + one fp32 scale per row (fp8 x fp8 GEMMs)
     int wave_rows = 0;           // 1: one wave per row, eight rows per workgroup (many rows of a narrow model; D <= 1024, bf16 output)
+    BD_STAMP_FIELD
 };
 int bdk_ln_mod(const LnModArgs& a, hipStream_t st);
 
@@ -119,6 +121,7 @@ struct HeadFinalArgs {      // pending update, final LN-mod, Linear(D->C), 2*sig
     void* X_next = nullptr; // not null (and not the final step): x0 = input_proj(x_t) of the NEXT evaluation, written over X's rows of this
     const void* in_w = nullptr;   // workgroup (flow_head:326) -- saves the next evaluation's prologue launch
     const void* in_b = nullptr;
+    BD_STAMP_FIELD
 };
 int bdk_head_final(const HeadFinalArgs& a, hipStream_t st);
 
@@ -136,7 +139,7 @@ struct HeadYAllArgs {       // y_i = silu(time_embed(t_i) + cond_embed(c)) for E
 };
 int bdk_head_y_all(const HeadYAllArgs& a, hipStream_t st);
 
-struct FinalizeRowsArgs { Partial in; void* out; int M, N; };   // bf16 row-major out = bf16(sum of slabs + bias)
+struct FinalizeRowsArgs { Partial in; void* out; int M, N; BD_STAMP_FIELD };   // bf16 row-major out = bf16(sum of slabs + bias)
 int bdk_finalize_rows(const FinalizeRowsArgs& a, hipStream_t st);
 
 struct InitLatentArgs { float* xt; const float* noise; long long noise_step_stride; const BdStepState* state; int n; };
@@ -146,6 +149,7 @@ struct SwigluArgs {         // split-K fallback of the fused epilogue: act = sil
     Partial up;             // [.,Mpad,2F]; column order: interleaved ? packed pairs (16 gate | 16 up per 32) : [gate F | up F]
     void* act_frag;
     int M, F, RB, interleaved;
+    BD_STAMP_FIELD
 };
 int bdk_swiglu_rows(const SwigluArgs& a, hipStream_t st);
 
@@ -285,7 +289,7 @@ struct BdTpPush {
     int* done_cnt = nullptr;    // arrival counter (zero between launches); null: the consumer kernel signals (all-reduce form)
     int* sig[8] = {};           // where to write the epoch for owner q (q's BD_SP_P word of this rank; loop-back: the local word of q)
     const int* rc = nullptr;    // local replay counter
-    int seq = 0;                // epoch = *rc * 4096 + seq
+    int seq = 0;                // epoch = bd_sp_epoch_of(*rc, seq)
     int il = 0;                 // 1: sequence-parallel row ownership -- 8-row group g of the tensor belongs to rank g % size (its local
                                 //    row (g / size) * 8 + row % 8), so that a rank owns the cond row AND the uncond row of the same patch
                                 //    position (rows bp and BP + bp) and the final layer / sampler step need no exchange; 0: contiguous slices
@@ -296,7 +300,7 @@ struct BdTpPush {
 // the row kernel of the owner sums them, applies gate / residual / LayerNorm / modulation for ITS rows only and pushes the bf16
 // operand rows to every rank's landing buffer; the consuming GEMM polls the per-row flags before its first activation load.
 #define BD_SP_MAXROWS 512
-#define BD_SP_RC 0            /* replay counter: epoch = RC * 4096 + sequence number of the hand-off inside the replayed graph */
+#define BD_SP_RC 0            /* replay counter: epoch = RC * 2^16 + sequence number of the hand-off inside the replayed graph (bd_common.h) */
 #define BD_SP_P 8             /* [8]  "the partials of rank p are pushed" epochs */
 #define BD_SP_G 16            /* [8]  reserved: "the adaLN columns of rank p are pushed" epochs for an all-gather pushed a group ahead and waited for
                                         by its first consumer (not built: needs links to measure) */
@@ -320,14 +324,15 @@ struct BdHWait {               // the consumer GEMM's wait for the pushed operan
     const int* rc = nullptr;      // local replay counter
     int* err = nullptr;
     long long timeout_ticks = 0;
-    int seq = 0, n = 0;           // epoch = *rc * 4096 + seq; rows to wait for
+    int seq = 0, n = 0;           // epoch = bd_sp_epoch_of(*rc, seq); rows to wait for
     int inv = 0;                  // 0: wave 0 invalidates (buffer_inv sc0 sc1) before the barrier; 1: every wave after it
 };
 int bdk_sp_begin(bd_comm* c, hipStream_t st);          // once per replayed graph / eager sequence: RC += 1, sequence numbers restart
-int bdk_sp_next_seq(bd_comm* c);                        // the next hand-off's sequence number (1 .. 4095); -1: exhausted
+int bdk_sp_next_seq(bd_comm* c);                        // the next hand-off's sequence number (1 .. BD_SP_SEQ_MAX); -1: exhausted
 bool bdk_sp_link(bd_comm* c, BdSpLink* out);            // false: no sequence-parallel exchange on this communicator
 bool bdk_sp_hwait(bd_comm* c, int seq, int rows, BdHWait* out);
 int bdk_sp_wait_rows(bd_comm* c, int seq, int rows, hipStream_t st);   // the wait as its own tiny kernel ("tune.sp_wait" = 0)
+int bdk_sp_selftest(bd_comm* c, int round, int rows, int D, int wait_in_check, int* bad_dev, hipStream_t st);   // bd_sp.hip
 long long bdk_sp_hbuf_bytes(const bd_comm* c);
 void* bdk_sp_hbuf(const bd_comm* c);
 void bdk_gemm_set_hwait(const BdHWait* w);              // bd_gemm.hip: the NEXT bdk_gemm / bdk_gemm8 call waits in its prologue
@@ -376,6 +381,7 @@ struct HeadAttnArgs {       // DiT attention over one patch (seq = P = 64 or 16)
     void* o_frag;           // out fragment-major bf16 [Mpad][D]
     int nseq, nhead, D, RB, P;
     int dh;                 // head dim: 128, or 64 with P = 16 (imagenet head)
+    BD_STAMP_FIELD
 };
 int bdk_head_attn(const HeadAttnArgs& a, hipStream_t st);
 

@@ -22,16 +22,19 @@ BD_DEV float slab_bf(const Partial& q, int row, int col) { return bfr(slab_sum(q
 // bf16 row-major finalisation of a split-K Linear output (cond_embed, once per AR step)
 // ------------------------------------------------------------------------------------------------
 __global__ void finalize_rows_kernel(FinalizeRowsArgs a) {
+    BD_KSTAMP(a.stamp, 0);
     const int m = blockIdx.x;
     for (int c = threadIdx.x; c < a.N / 8; c += blockDim.x) {
         float v[8];
         slab8(a.in, m, c * 8, v);
         *reinterpret_cast<u32x4*>((bf16_t*)a.out + (size_t)m * a.N + c * 8) = pack8(v);
     }
+    BD_KSTAMP_END(a.stamp);
 }
 int bdk_finalize_rows(const FinalizeRowsArgs& a, hipStream_t st) {
     if (a.N % 8) return -2;
-    BD_LAUNCH(finalize_rows_kernel, dim3(a.M), dim3(256), 0, st, a);
+    BD_STAMPED(FinalizeRowsArgs, a, "finalize_rows", a.M);
+    BD_LAUNCH(finalize_rows_kernel, dim3(a.M), dim3(256), 0, st, a_l);
     return bd_launch_status();
 }
 
@@ -139,6 +142,7 @@ BD_DEV void modulate8(const float* x, float mean, float rstd, const float* lw, c
 
 __global__ void ln_mod_kernel(LnModArgs a) {
     __shared__ float red[32];
+    BD_KSTAMP(a.stamp, 0);
     const int m = blockIdx.x, d0 = threadIdx.x * 8;
     const bool active = d0 < a.D;
     const bf16_t* ada = (const bf16_t*)a.ada + (size_t)m * a.ada_ld;
@@ -183,9 +187,11 @@ __global__ void ln_mod_kernel(LnModArgs a) {
     if (a.a8_scale) {                                              // fp8 x fp8 GEMMs behind this row kernel: per-row e4m3 of the fp32 h
         const float inv = row_quant_scale(h, active, red, a.a8_scale, m);
         if (active) quant8_store((unsigned char*)a.h_frag, m, d0, a.RB, h, inv);
+        BD_KSTAMP_END(a.stamp);
         return;
     }
     *reinterpret_cast<u32x4*>((bf16_t*)a.h_frag + afrag_off(m, d0, a.RB)) = pack8(h);   // cast by the next Linear
+    BD_KSTAMP_END(a.stamp);
 }
 // Many rows of a narrow model (the ImageNet batch: 12 288 rows of D = 768): one workgroup per row is 12 288 two-wave workgroups with
 // two LDS block reductions each, and the eight rows that share every 128 B line of the fragment-major output are written from
@@ -258,7 +264,8 @@ int bdk_ln_mod(const LnModArgs& a, hipStream_t st) {
         else BD_LAUNCH(ln_mod_rows_kernel<2>, grid, dim3(512), 0, st, a);
         return bd_launch_status();
     }
-    BD_LAUNCH(ln_mod_kernel, dim3(a.M), dim3(t), 0, st, a);
+    BD_STAMPED(LnModArgs, a, "ln_mod", a.M);
+    BD_LAUNCH(ln_mod_kernel, dim3(a.M), dim3(t), 0, st, a_l);
     return bd_launch_status();
 }
 
@@ -313,6 +320,7 @@ __global__ __launch_bounds__(640) void head_final_kernel(HeadFinalArgs a) {
     __shared__ float wsum[16][64];
     __shared__ float xh[64];
     __shared__ float xnext[32];
+    BD_KSTAMP(a.stamp, 0);
     const int bp = blockIdx.x, d0 = threadIdx.x * 8, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwav = blockDim.x >> 6;
     const bool active = d0 < a.D;
@@ -460,11 +468,13 @@ __global__ __launch_bounds__(640) void head_final_kernel(HeadFinalArgs a) {
             if (two) *reinterpret_cast<u32x4*>((bf16_t*)a.X_next + (size_t)m1 * a.D + d0) = q;
         }
     }
+    BD_KSTAMP_END(a.stamp);
 }
 int bdk_head_final(const HeadFinalArgs& a, hipStream_t st) {
     const int t = row_threads(a.D);
     if (t < 0 || t > 640 || a.D % 8 || a.C > 32) return -2;      // 64 accumulators/thread: register budget of 10 waves
-    BD_LAUNCH(head_final_kernel, dim3(a.BP), dim3(t), 0, st, a);
+    BD_STAMPED(HeadFinalArgs, a, "head_final", a.BP);
+    BD_LAUNCH(head_final_kernel, dim3(a.BP), dim3(t), 0, st, a_l);
     return bd_launch_status();
 }
 
@@ -481,6 +491,7 @@ int bdk_init_latent(const InitLatentArgs& a, hipStream_t st) {
 // SwiGLU from split-K slabs (when the fused GEMM epilogue would leave the chip under-filled): act = silu(h1)*h2
 // ------------------------------------------------------------------------------------------------
 __global__ void swiglu_rows_kernel(SwigluArgs a) {
+    BD_KSTAMP(a.stamp, 0);
     const int m = blockIdx.x;
     for (int c = threadIdx.x; c < a.F / 8; c += blockDim.x) {
         const int f0 = c * 8;
@@ -493,12 +504,14 @@ __global__ void swiglu_rows_kernel(SwigluArgs a) {
         for (int j = 0; j < 8; ++j) o[j] = silu_bf(g[j]) * u[j];
         *reinterpret_cast<u32x4*>((bf16_t*)a.act_frag + afrag_off(m, f0, a.RB)) = pack8(o);
     }
+    BD_KSTAMP_END(a.stamp);
 }
 int bdk_swiglu_rows(const SwigluArgs& a, hipStream_t st) {
     if (a.F % 8) return -2;
     int t = ((a.F / 8 + 63) / 64) * 64;
     if (t > MAX_ROW_THREADS) t = MAX_ROW_THREADS;
-    BD_LAUNCH(swiglu_rows_kernel, dim3(a.M), dim3(t), 0, st, a);
+    BD_STAMPED(SwigluArgs, a, "swiglu_rows", a.M);
+    BD_LAUNCH(swiglu_rows_kernel, dim3(a.M), dim3(t), 0, st, a_l);
     return bd_launch_status();
 }
 

@@ -18,11 +18,12 @@
 // No stand-alone exchange kernel is left in the evaluation: 12 row kernels with one flag round each, instead of 12 exchanges with two
 // flag rounds plus 12 replicated row kernels.
 //
-// Flags: epoch = replay counter * 4096 + the hand-off's sequence number inside the replayed graph (BD_SP_*, bd_kernels.h): values only
-// grow, so a captured graph replays without resets.  Payload and flags follow bd_comm.hip's hand-off: sc0 sc1 write-through 16 B stores,
+// Flags: epoch = replay counter * 2^16 + the hand-off's sequence number inside the replayed graph (BD_SP_*, bd_kernels.h; bd_common.h
+// bd_sp_epoch_of): values only grow modulo 2^32 and are compared in unsigned arithmetic, so a captured graph replays without resets.  Payload and flags follow bd_comm.hip's hand-off: sc0 sc1 write-through 16 B stores,
 // s_waitcnt vmcnt(0), relaxed system-scope flag store; readers of remotely written staging rows use sc0 sc1 loads.  Every wait is
 // bounded by a wall-clock budget and reports through the communicator's error word (bd_comm_error).
 #include "bd_rowhelp.h"
+#include "bd_hwait.h"
 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "bd_sp.hip: the sc0 sc1 / vmcnt(0) flag hand-off is validated for gfx950 only"
@@ -33,7 +34,7 @@ BD_DEV __amdgpu_buffer_rsrc_t sp_rsrc(void* base, long long bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
 }
 BD_DEV int sp_epoch(const BdSpLink& L, int seq) {
-    return __hip_atomic_load(L.spf_local + BD_SP_RC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) * 4096 + seq;
+    return bd_sp_epoch_of(__hip_atomic_load(L.spf_local + BD_SP_RC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), seq);
 }
 // global row of this rank's local row lr: 8-row group (lr >> 3) * size + rank
 BD_DEV int sp_row(int rank, int size, int lr) { return (((lr >> 3) * size + rank) << 3) + (lr & 7); }
@@ -56,7 +57,7 @@ BD_DEV bool sp_wait_p(const BdSpLink& L, int e, int* alive_sh) {
         const int* f = L.spf_local + BD_SP_P + t;
         const long long t0 = wall_clock64();
         bool dead = __hip_atomic_load(L.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
-        while (!dead && (int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+        while (!dead && bd_epoch_before(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), e)) {
             __builtin_amdgcn_s_sleep(1);
             if (wall_clock64() - t0 > L.timeout_ticks) {
                 __hip_atomic_fetch_or(L.err, 1 << t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -115,6 +116,7 @@ BD_DEV void sp_reduce8(const BdSpLink& L, const __amdgpu_buffer_rsrc_t stage, in
 __global__ __launch_bounds__(MAX_ROW_THREADS) void ln_mod_sp_kernel(LnModSpArgs a) {
     __shared__ float red[32];
     __shared__ int alive_sh;
+    BD_KSTAMP(a.ln.stamp, 0);
     const BdSpLink& L = a.L;
     const int lr = blockIdx.x, d0 = threadIdx.x * 8, D = a.ln.D;
     const int m = sp_row(L.rank, L.size, lr);
@@ -175,10 +177,16 @@ __global__ __launch_bounds__(MAX_ROW_THREADS) void ln_mod_sp_kernel(LnModSpArgs 
         int* const dst = L.loopback ? L.spf_local + BD_SP_H + sp_row(t, L.size, lr) : L.spf[t] + BD_SP_H + m;
         __hip_atomic_store(dst, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    BD_KSTAMP_END(a.ln.stamp);
 }
 int bdk_ln_mod_sp(const LnModSpArgs& a, hipStream_t st) {
     const int t = row_threads(a.ln.D);
     if (t < 0 || a.ln.D % 8 || a.ln.a8_scale || a.rows_local < 1 || a.rows_local % 8 || a.ln.M > BD_SP_MAXROWS) return -2;
+#ifdef BD_GEMM_STAMP
+    LnModSpArgs a2 = a; a2.ln.stamp = bdk_stamp_next("ln_mod_sp", a.rows_local);
+    BD_LAUNCH(ln_mod_sp_kernel, dim3(a.rows_local), dim3(t), 0, st, a2);
+    return bd_launch_status();
+#endif
     BD_LAUNCH(ln_mod_sp_kernel, dim3(a.rows_local), dim3(t), 0, st, a);
     return bd_launch_status();
 }
@@ -395,7 +403,7 @@ __global__ void tok_finish_kernel(TokFinishArgs a) {
         const int* f = L.spf_local + BD_SP_H + bp;
         const long long t0 = wall_clock64();
         int good = 1;
-        while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+        while (bd_epoch_before(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), e)) {
             if (__hip_atomic_load(L.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) { good = 0; break; }
             if (wall_clock64() - t0 > L.timeout_ticks) { __hip_atomic_fetch_or(L.err, 1 << 17, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); good = 0; break; }
             __builtin_amdgcn_s_sleep(1);
@@ -420,5 +428,68 @@ __global__ void tok_finish_kernel(TokFinishArgs a) {
 int bdk_tok_finish(const TokFinishArgs& a, hipStream_t st) {
     if (a.C > 32 || a.BP > BD_SP_MAXROWS) return -2;
     BD_LAUNCH(tok_finish_kernel, dim3(a.BP), dim3(64), 0, st, a);
+    return bd_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Construction-time self-test of THIS hand-off (the all-reduce self-test does not reach it).  What is specific to the
+// sequence-parallel form is the operand landing buffer: ordinary CACHEABLE device memory that other GPUs write with sc0 sc1 stores and
+// that this GPU re-reads through its L2 after one `buffer_inv sc0 sc1` (bd_hwait.h) -- one-GPU tests cannot show a stale line there.
+// Round r: every rank pushes its OWN rows (the product's row ownership and fragment-major addresses) of a pattern that depends on
+// (row, 16 B unit, r) into every rank's buffer and raises the row flags; 64 workgroups per rank then run the GEMM prologue's wait
+// (the same device function) and compare every unit of every row.  The host runs several rounds back to back, each behind a barrier
+// of the ranks (so that round r + 1 finds round r's lines warm in the consumers' caches -- the stale-line case), and keeps the
+// all-reduce form if any rank counts a mismatch (tp.py TPComm._sp_self_test; Engine: "tp.seq" needs comm.sp_ok).
+// ------------------------------------------------------------------------------------------------
+struct SpTestArgs { BdSpLink L; BdHWait w; int seq, rows, D, RB, round; int* bad; };
+BD_DEV u32x4 sp_test_pattern(int m, int u, int round) {
+    const unsigned h = (unsigned)round * 0x9E3779B1u ^ (unsigned)m * 0x85EBCA6Bu ^ (unsigned)u * 0xC2B2AE35u;
+    return (u32x4){h, h ^ 0x11111111u, h ^ 0x22222222u, h ^ 0x33333333u};
+}
+__global__ __launch_bounds__(256) void sp_test_push_kernel(SpTestArgs a) {
+    const BdSpLink& L = a.L;
+    const int lr = blockIdx.x, m = sp_row(L.rank, L.size, lr);
+    for (int u = threadIdx.x; u < a.D / 8; u += 256) {
+        const u32x4 v = sp_test_pattern(m, u, a.round);
+        const unsigned off = (unsigned)(afrag_off(m, u * 8, a.RB) * 2);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q < L.size) __builtin_amdgcn_raw_buffer_store_b128(v, sp_rsrc(L.hbuf[q], L.hbuf_bytes), off, 0, BD_SYS_AUX);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < L.size) {
+        const int e = sp_epoch(L, a.seq);
+        int* const dst = L.loopback ? L.spf_local + BD_SP_H + sp_row(t, L.size, lr) : L.spf[t] + BD_SP_H + m;
+        __hip_atomic_store(dst, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+__global__ __launch_bounds__(256) void sp_test_check_kernel(SpTestArgs a) {
+    if (a.w.flags) gemm_hwait(a.w, threadIdx.x, 256);           // (null: a one-workgroup wait kernel ran in front, "tune.sp_wait" = 0)
+    const u32x4* h = reinterpret_cast<const u32x4*>(a.L.hbuf[a.L.rank]);
+    const int upr = a.D / 8;
+    int bad = 0;
+    for (int i = threadIdx.x; i < a.rows * upr; i += 256) {      // EVERY workgroup reads every unit: each CU / XCD sees the whole operand
+        const int m = i / upr, u = i % upr;
+        const u32x4 got = h[afrag_off(m, u * 8, a.RB) / 8], want = sp_test_pattern(m, u, a.round);
+        bad += (got[0] != want[0]) | (got[1] != want[1]) | (got[2] != want[2]) | (got[3] != want[3]);
+    }
+    if (bad) atomicAdd(a.bad, bad);
+}
+int bdk_sp_selftest(bd_comm* c, int round, int rows, int D, int wait_in_check, int* bad_dev, hipStream_t st) {
+    SpTestArgs a;
+    if (!bdk_sp_link(c, &a.L) || rows % 32 || rows > BD_SP_MAXROWS || (rows / 8) % a.L.size || D % 8 || (long long)rows * D * 2 > a.L.hbuf_bytes) return -2;
+    if (bdk_sp_begin(c, st) != 0) return -1;
+    a.seq = bdk_sp_next_seq(c);
+    if (!bdk_sp_hwait(c, a.seq, rows, &a.w)) return -2;
+    a.rows = rows; a.D = D; a.RB = rows / 32; a.round = round; a.bad = bad_dev;
+    BD_LAUNCH(sp_test_push_kernel, dim3(rows / a.L.size), dim3(256), 0, st, a);
+    if (bd_launch_status() != 0) return -1;
+    if (!wait_in_check) {
+        if (bdk_sp_wait_rows(c, a.seq, rows, st) != 0) return -1;
+        a.w.flags = nullptr;
+    }
+    BD_LAUNCH(sp_test_check_kernel, dim3(64), dim3(256), 0, st, a);
     return bd_launch_status();
 }

@@ -418,7 +418,14 @@ class Engine:
             # measured on one rank in loop-back (profiles/r05_tp_rank_critical_path.log, us per evaluation, all-reduce form vs this):
             # tp 2 976 vs 910, tp 4 755 vs 743, tp 8 670 vs 702 -- on by default up to 4 ranks; at 8 the rank's 16 rows make every row
             # kernel a 16-workgroup latency chain either way and the two extra destinations per push cost more than the saved launch
-            self.seq_parallel = bool(ints.get("tp.seq", 1 if self.comm.size <= 4 else 0)) and ok
+            # ... and only behind the hand-off's own self-test when the ranks sit on DIFFERENT devices (TPComm.from_process_group sets
+            # comm.sp_ok; ranks inside one process / loop-back share one L2 domain and leave it None): the landing buffer is cacheable
+            # memory written by the peers, which one-GPU tests cannot vouch for.  An explicit "tp.seq" = 1 still needs
+            # sp_ok not to be False.
+            sp_ok = getattr(self.comm, "sp_ok", None)
+            trusted = sp_ok is True or (sp_ok is None and (getattr(self.comm, "in_process_peers", False) or getattr(self.comm, "loopback", False)))
+            ok = ok and sp_ok is not False
+            self.seq_parallel = bool(ints.get("tp.seq", 1 if (self.comm.size <= 4 and trusted) else 0)) and ok
             if ints.get("tp.seq", 0) and not ok:
                 raise BitDanceHipError("tp.seq: sequence-parallel row kernels need 128 rows (one image with CFG, parallel_num 64), whole 8-row "
                                        "groups of patch positions per rank, bf16 activations and a communicator with an operand landing buffer")

@@ -128,6 +128,10 @@ class TPComm:
         self.in_process_peers = False
         self.shares_gpu = False                          # some ranks of the group sit on the same physical GPU (set by the constructors)
         self.loopback = False
+        # the sequence-parallel hand-off's own self-test (cacheable landing buffer written by the peers): None = not run (ranks inside
+        # one process / loop-back: one L2 domain, covered by the GPU tests), True / False = from_process_group's verdict.  Engine turns
+        # the sequence-parallel row kernels on by default only when this is not False -- and, across devices, only when it is True.
+        self.sp_ok = None
         with torch.cuda.device(self.device):
             self.h = self.l.bd_comm_create3(rank, size, int(max_elems), int(gather_bytes), int(hbuf_bytes))
         if not self.h:
@@ -216,6 +220,21 @@ class TPComm:
                 if not all(oks):
                     self.fallback_reason = f"exchange self-test failed on ranks {[r for r, o in enumerate(oks) if not o]}"
                     backend = "rccl"
+            if backend == "ipc" and self.hbuf_bytes > 0:
+                # ... and of the sequence-parallel hand-off (its landing buffer is ordinary cacheable memory the peers write): six rounds of
+                # changing patterns, every rank checks every 16 B unit behind the GEMM prologue's wait.  A failure keeps the all-reduce
+                # form (Engine reads sp_ok); it does not touch the exchange backend
+                ok = not self.fences and self._sp_self_test(lambda: dist.barrier(group=group))
+                oks = [None] * size
+                dist.all_gather_object(oks, bool(ok), group=group)
+                self.sp_ok = all(oks)
+                if not self.sp_ok:
+                    dist.barrier(group=group)
+                    check(self.l.bd_comm_reset(self.h), "bd_comm_reset")
+                    dist.barrier(group=group)
+                    if rank == 0:
+                        print("[bitdance_amd.tp] the sequence-parallel hand-off's self-test failed on ranks "
+                              f"{[r for r, o in enumerate(oks) if not o]}: the head keeps the all-reduce form", flush=True)
             if self.fallback_reason and rank == 0:
                 print(f"[bitdance_amd.tp] {self.fallback_reason}: exchanges go through RCCL (ncclAllReduce)", flush=True)
             if backend == "rccl":
@@ -258,6 +277,36 @@ class TPComm:
                         got = self.allgather(cols[self.rank].contiguous())
                         torch.cuda.current_stream().synchronize()
                         ok = ok and self.l.bd_comm_error(self.h) == 0 and torch.equal(got, torch.cat(cols, dim=1))
+            except BitDanceHipError:
+                ok = False
+            finally:
+                self.set_timeout(20.0)
+        return bool(ok)
+
+    def sp_selftest_round(self, rnd: int, rows: int = 128, D: int | None = None, bad: torch.Tensor | None = None) -> torch.Tensor:
+        """One round of the sequence-parallel hand-off's self-test on the current stream (bd_comm_sp_selftest): returns the device int
+        that accumulates mismatching 16 B units.  Every rank runs the same rounds, a barrier of the ranks between two rounds."""
+        if D is None:
+            D = min(5120, (self.hbuf_bytes // (rows * 2)) // 8 * 8)
+        if bad is None:
+            bad = torch.zeros(1, dtype=torch.int32, device=self.device)
+        check(self.l.bd_comm_sp_selftest(self.h, int(rnd), int(rows), int(D), 0 if self.shares_gpu else 1, bad.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream), "bd_comm_sp_selftest")
+        return bad
+
+    def _sp_self_test(self, barrier, rounds: int = 6) -> bool:
+        """False on a timeout or any wrong unit in any round.  ``barrier``: all ranks have finished the round (the next round's pushes
+        overwrite the buffers the slowest rank may still be checking)."""
+        ok = True
+        with torch.cuda.device(self.device):
+            try:
+                self.set_timeout(5.0)
+                bad = torch.zeros(1, dtype=torch.int32, device=self.device)
+                for rnd in range(rounds):
+                    self.sp_selftest_round(rnd, bad=bad)
+                    torch.cuda.current_stream().synchronize()
+                    ok = ok and self.l.bd_comm_error(self.h) == 0 and int(bad.item()) == 0
+                    barrier()
             except BitDanceHipError:
                 ok = False
             finally:

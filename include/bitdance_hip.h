@@ -146,6 +146,13 @@ int bd_comm_open_peer3(bd_comm* c, int peer, const void* handles192);
 int bd_comm_set_peer_ptrs3(bd_comm* c, int peer, void* data, void* flags, void* hbuf);   /* peers inside this process */
 void* bd_comm_local_hbuf(bd_comm* c);
 long long bd_comm_hbuf_bytes(bd_comm* c);
+/* Self-test of the sequence-parallel hand-off itself (cacheable landing buffer written by the peers' sc0 sc1 stores, read back after the
+ * GEMM prologue's flag wait + invalidate): one round = this rank pushes its own rows of a (row, unit, round)-dependent pattern into every
+ * rank's buffer and raises the row flags, then 64 workgroups wait like the consuming GEMM and compare every 16 B unit of every row;
+ * *bad_dev (a device int the caller zeroes) += mismatches.  Every rank calls it with the same arguments, rounds separated by a barrier
+ * of the ranks; wait_in_check = 0 puts the wait into a one-workgroup kernel (ranks sharing one GPU).  No reference counterpart
+ * (the reference has no tensor parallelism: eval/eval_dpg.py:25-29 runs replicas). */
+int bd_comm_sp_selftest(bd_comm* c, int round, int rows, int D, int wait_in_check, int* bad_dev, void* stream);
 /* ONE rank of a `size`-rank group alone on this GPU: the peers' buffers become scratch copies, every flag a peer would write is written
  * locally -- the rank's launches, weight shards, pushes and waits minus the links, for timing its critical path on one GPU
  * (tools/head_sweep.py --tp-shard).  The results are meaningless (the peers contribute zeros). */

@@ -846,3 +846,93 @@ def test_planned_tensor_parallel_gemms_launch_and_match(tp, P):
         assert int(cnt.abs().sum()) == 0, tag
         del w, x, xf, scratch
     l.bd_ctx_destroy(c)
+
+
+@pytest.mark.parametrize("tp,shares", [(2, True), (4, True), (2, False)])
+def test_sequence_parallel_handoff_selftest_in_process(tp, shares):
+    """The construction-time self-test of the sequence-parallel hand-off (bd_comm_sp_selftest; TPComm.from_process_group runs it before
+    Engine may default to the sequence-parallel form across devices): every rank pushes ITS rows of a round-dependent pattern into
+    every rank's cacheable landing buffer, every rank checks all 128 x 5120 values behind the GEMM prologue's wait (``shares`` False)
+    or behind the one-workgroup wait kernel (ranks sharing a GPU).  Six rounds on re-used buffers: zero mismatches, no time-out.
+    Then the ranks are given DIFFERENT round numbers: every rank must count exactly the peers' rows as wrong (the check can fail)."""
+    from bitdance_amd.tp import TPComm, seq_hbuf_bytes
+    comms = TPComm.in_process(tp, 128 * 5120, DEV, hbuf_bytes=seq_hbuf_bytes(128, 5120))
+    streams = _streams(tp)
+    bads = [torch.zeros(1, dtype=torch.int32, device=DEV) for _ in range(tp)]
+    for c in comms:
+        c.set_timeout(8.0)
+        c.shares_gpu = shares
+    torch.cuda.synchronize()
+    for rnd in range(6):
+        for r in range(tp):
+            with torch.cuda.stream(streams[r]):
+                comms[r].sp_selftest_round(rnd, bad=bads[r])
+        torch.cuda.synchronize()
+        for c in comms:
+            c.check()
+    assert [int(b.item()) for b in bads] == [0] * tp
+    # negative control: the ranks disagree about the round -> every rank must COUNT the peers' rows (64 workgroups x rows x 640 units)
+    for r in range(tp):
+        with torch.cuda.stream(streams[r]):
+            comms[r].sp_selftest_round(6 + r, bad=bads[r])
+    torch.cuda.synchronize()
+    want = 64 * (128 - 128 // tp) * 640
+    assert [int(b.item()) for b in bads] == [want] * tp
+
+
+@pytest.mark.parametrize("rc0", [(1 << 15) - 2, (1 << 16) - 2])
+def test_sequence_parallel_epochs_across_the_wrap(rc0):
+    """epochs = replay counter * 2^16 + sequence number are compared in UNSIGNED arithmetic (bd_common.h bd_epoch_before).
+    The replay counter of every rank is preset two runs short of the point where the epoch changes sign (RC = 2^15) / wraps to zero
+    (RC = 2^16), with every flag word at that counter's epoch 0 (what a long-running server would hold); four sampling runs then cross
+    the boundary.  The sequence-parallel form must stay bit-identical to the all-reduce form on every run and between the ranks -- a
+    signed comparison folded into `flag < e` passes stale flags right after the wrap and the ranks diverge (or a wait times out)."""
+    import ctypes as C
+    from bitdance_amd import engine as E
+    tp = 2
+    hip = C.CDLL("libamdhip64.so")
+    sd_dev = device_seeded_state(tm.head_shapes(HEAD8), 331, DEV)
+    B, br, Cc, P, n = 1, 2, 32, 64, 3
+    g = torch.Generator().manual_seed(77)
+    z = torch.randn(br * B, P, 1024, generator=g)
+    noise = torch.randn(1, n + 1, B, P, Cc, generator=g)
+    nada = (HEAD8["depth_adanln"] * 6 + 2) * 1024
+    hws = [E.HeadWeights.from_state_dict(sd_dev, DEV, tp_rank=r, tp_size=tp) for r in range(tp)]
+    outs = {}
+    for seq in (0, 1):
+        comms = _sp_comms(tp, 1024, nada, 0)
+        streams = _streams(tp)
+        if seq:
+            FLAG_INTS, SP_INTS = 3 * 8 * 64 + 1 + 2 * 64, 32 + 512            # BD_TP_FLAG_INTS, BD_SP_FLAG_INTS (bd_comm.hip, bd_kernels.h)
+            blk = (C.c_int32 * SP_INTS)()
+            e0 = (rc0 << 16) & 0xFFFFFFFF
+            e0 = e0 - (1 << 32) if e0 >= (1 << 31) else e0
+            for i in range(SP_INTS):
+                blk[i] = e0
+            blk[0] = rc0                                                      # BD_SP_RC
+            blk[24] = 0                                                       # BD_SP_DONE: an arrival counter, zero between launches
+            for c in comms:
+                fl = c.l.bd_comm_local_flags(c.h)
+                assert hip.hipMemcpy(C.c_void_p(fl + 4 * FLAG_INTS), blk, 4 * SP_INTS, 1) == 0
+            torch.cuda.synchronize()
+        engs = [E.Engine(hws[r], None, None, num_images=B, branches=br, device=DEV, max_tokens=P, parallel_num=P, comm=comms[r],
+                         extra_ints={"tp.seq": seq, "tp.ada_split": 0}) for r in range(tp)]
+        res = []
+        for run in range(4):
+            for r in range(tp):
+                with torch.cuda.stream(streams[r]):
+                    engs[r].set_schedule(n, 1.5, 1)
+                    engs[r].load_noise(noise)
+                    engs[r].reset([0] * (br * B))
+                    engs[r].set_cond(z.to(DEV))
+                    engs[r].head_sample()
+            torch.cuda.synchronize()
+            for c in comms:
+                c.check()
+            ps = [e.pred().clone() for e in engs]
+            assert torch.equal(ps[0], ps[1]), f"ranks diverged on run {run} (seq {seq}, RC0 {rc0})"
+            res.append(ps[0])
+        outs[seq] = res
+        del engs, comms
+    for run, (a, b) in enumerate(zip(outs[0], outs[1])):
+        assert torch.equal(a, b), f"run {run}: sequence-parallel differs from the all-reduce form across the epoch boundary"
