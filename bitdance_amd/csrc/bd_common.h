@@ -39,6 +39,24 @@ BD_DEV float fdiv(float a, float b) { return __fdiv_rn(a, b); }
 BD_DEV float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x)); }
 BD_DEV float silu_bf(float x_bf) { return bfr(silu_f(x_bf)); }       // bf16 tensor in -> bf16 out
 
+// Fused SwiGLU on a 32 x 32 accumulator whose columns are a packed (16 gate | 16 up) panel: lanes (l & 16) == 0 hold gate feature
+// l & 15, lane l ^ 16 the matching up feature, 16 rows each (register r -> row (r&3) + 8 (r>>2) + 4 (l>>5)).
+//     out = bf16( bf16(silu(bf16(h1 + b1))) * bf16(h2 + b2) )                                       flow_head_parallel_x.py:250-251
+// One cross-lane exchange per PAIR of rows, no branch: the gate lane keeps row 2j and receives up[2j], the up lane takes row 2j + 1
+// and receives gate[2j + 1] -- every lane evaluates 8 SiLUs instead of the gate lanes 16 behind a per-element exec mask (round 6: the
+// per-element form was a 200-cycle serial chain per value on a one-wave-per-SIMD workgroup: 3 us of a 128-row launch's tail, 25 us of a
+// 256-row one's).  out[j] belongs to register r = 2j + ((lane >> 4) & 1), feature lane & 15; the bits are those of the per-element form.
+BD_DEV void swiglu_pairs(const f32x16& a, float bias_col, int lane, bf16_t (&out)[8]) {
+    const bool up = (lane & 16) != 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v0 = bfr(a[2 * j] + bias_col), v1 = bfr(a[2 * j + 1] + bias_col);      // Linear outputs rounded to bf16
+        const float got = __shfl_xor(up ? v0 : v1, 16);
+        const float g = up ? got : v0, u = up ? v1 : got;
+        out[j] = f2bf(silu_bf(g) * u);                                                    // silu -> bf16, product -> bf16
+    }
+}
+
 // MFMA-operand ("fragment-major") activation layout.
 // A [rows][K] bf16 matrix is stored as 1 KiB chunks, one per (k-step of 16, row-block of 32):
 //   chunk(ks, rb) holds, for lane l (0..63), the 8 bf16  A[rb*32 + (l&31)][ks*16 + (l>>5)*8 + 0..7]

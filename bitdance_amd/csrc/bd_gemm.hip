@@ -200,8 +200,23 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
     for (int m = 0; m < MB; ++m) xf[0][m] = cur[m * 64 + lane];
 
     // one phase = one 64-deep K stage j: 4 k-steps x 16 MFMAs.  PAR = j % WR selects the W register slot.
+#ifdef BD_GEMM_STAMP
+    // measurement build: shader-clock cycles wave 0 spends (1) waiting for this phase's W stage, (2) waiting for the A stage it writes to
+    // LDS, (3) at the per-phase barrier -- explicit waits in front of the compiler's own, bracketed by s_memtime (bd_common.h stamps:
+    // word 1 = W wait, 2 = A wait, 4 = barrier, 5 = whole loop, all in shader cycles; 0 / 3 / 6 = realtime start / loop end / drained)
+    unsigned long long st_w = 0, st_a = 0, st_b = 0;
+    const unsigned long long st_loop0 = __builtin_readcyclecounter();
+    BD_KSTAMP(p.stamp, 0);
+#endif
     auto phase = [&](auto PAR, int j) {
         constexpr int P = decltype(PAR)::value;
+#ifdef BD_GEMM_STAMP
+        {
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 + 8 * (WR - 1)) : "memory");
+            st_w += __builtin_readcyclecounter() - t0;
+        }
+#endif
         // k-step 0 (xf[0]) | read k-step 1 -> xf[1]
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
@@ -211,6 +226,13 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         // k-step 1 (xf[1]) | read k-step 2 -> xf[0] | write A stage j+2 (loaded during phase j-1)
+#ifdef BD_GEMM_STAMP
+        {
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * (WR - 1)) : "memory");
+            st_a += __builtin_readcyclecounter() - t0;
+        }
+#endif
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             xf[0][m] = cur[(2 * MB + m) * 64 + lane];
@@ -238,7 +260,13 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         load_w(w[P], j + WR);                 // this slot's MFMAs have all issued
+#ifdef BD_GEMM_STAMP
+        const unsigned long long tb0 = __builtin_readcyclecounter();
         __syncthreads();
+        st_b += __builtin_readcyclecounter() - tb0;
+#else
+        __syncthreads();
+#endif
         u32x4* t = cur; cur = nxt; nxt = wr3; wr3 = t;
         if (j == last) BD_MFMA_DRAIN();       // the last phase is followed, across a branch, by the accumulator reads (bd_common.h)
     };
@@ -260,6 +288,12 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
         if (j + 1 < nst) phase(std::integral_constant<int, 1>{}, j + 1);
     }
 
+#ifdef BD_GEMM_STAMP
+    BD_KSTAMP(p.stamp, 3);
+    bd_kstamp_val(p.stamp, 1, st_w); bd_kstamp_val(p.stamp, 2, st_a); bd_kstamp_val(p.stamp, 4, st_b);
+    bd_kstamp_val(p.stamp, 5, __builtin_readcyclecounter() - st_loop0);
+    bd_kstamp_val(p.stamp, 7, (unsigned long long)nst);
+#endif
     if constexpr (RED) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
         static_assert(!RED, "the relaxed sc1 slab hand-off is validated for gfx950 only");
@@ -272,64 +306,140 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
             return (unsigned)((((region0 + s_) * (MB * NPW) + a) * 4 + r4) * 1024 + lane * 16);
         };
         constexpr int SC1 = 16;
-#pragma unroll
-        for (int a = 0; a < MB * NPW; ++a)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4)
-                __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(acc[a][4 * r4]), __float_as_uint(acc[a][4 * r4 + 1]),
-                                                               __float_as_uint(acc[a][4 * r4 + 2]), __float_as_uint(acc[a][4 * r4 + 3])},
-                                                       sl, slab_off(s, a, r4), 0, SC1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // TICKET FIRST (round 6): only the slice that arrives first parks its accumulators; the second keeps its own in registers, waits
+        // for the first one's "slab drained" mark and adds that slab (own + other == other + own bit for bit).  Before, both slices parked
+        // and drained 256 KiB per workgroup ahead of the ticket: twice the slab traffic, and ~5 us of store drain on the critical path of
+        // the workgroup that finishes the tile (profiles/r06_launch_anatomy_b4.log: loop end -> last store 14.6 us median with the
+        // reduction against 6 us with plain slabs).  Counter: +1 per arrival, +2 when the first slice's stores have drained; the second
+        // arriver re-arms it.  The first arriver is running by construction when the second waits for it -- no residency assumption.
         int* const flag = reinterpret_cast<int*>(smem);
         int* const ticket = p.cnt + tile;
+        if (!p.red_first) {                                                // ("red.first" = 0, the round-5 form: both slices park, then the ticket)
+#pragma unroll
+            for (int a = 0; a < MB * NPW; ++a)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+                    __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(acc[a][4 * r4]), __float_as_uint(acc[a][4 * r4 + 1]),
+                                                                   __float_as_uint(acc[a][4 * r4 + 2]), __float_as_uint(acc[a][4 * r4 + 3])},
+                                                           sl, slab_off(s, a, r4), 0, SC1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
         if (tid == 0) flag[0] = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        if (flag[0] != 1) return;                                          // the other slice finishes this tile
+        if (!p.red_first && flag[0] == 0) { BD_KSTAMP_END(p.stamp); return; }
+        if (p.red_first && flag[0] == 0) {                                 // first slice of the tile: park, drain, mark, leave
 #pragma unroll
-        for (int a = 0; a < MB * NPW; ++a) {
-            u32x4 v[4];
+            for (int a = 0; a < MB * NPW; ++a)
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) v[r4] = __builtin_amdgcn_raw_buffer_load_b128(sl, slab_off(1 - s, a, r4), 0, SC1);
+                for (int r4 = 0; r4 < 4; ++r4)
+                    __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(acc[a][4 * r4]), __float_as_uint(acc[a][4 * r4 + 1]),
+                                                                   __float_as_uint(acc[a][4 * r4 + 2]), __float_as_uint(acc[a][4 * r4 + 3])},
+                                                           sl, slab_off(s, a, r4), 0, SC1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(ticket, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            BD_KSTAMP_END(p.stamp);
+            return;
+        }
+        if (p.red_first && tid == 0) {                                     // second slice: the other slab must have drained (bounded: ~2 s)
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 3 && wall_clock64() - t0 < 200000000LL) __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+        // the other slice's slab in batches of 8 accumulators (32 loads of 16 B in flight per lane: the operand registers of the K loop are dead
+        // here); one accumulator at a time was 16 dependent round trips to write-through lines of another XCD
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4)
+        for (int a0 = 0; a0 < MB * NPW; a0 += 8) {
+            u32x4 v[8][4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[a][4 * r4 + j] += __uint_as_float(v[r4][j]);
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) v[a][r4] = __builtin_amdgcn_raw_buffer_load_b128(sl, slab_off(1 - s, a0 + a, r4), 0, SC1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[a0 + a][4 * r4 + j] += __uint_as_float(v[a][r4][j]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
     }
-    // ---- epilogue (same forms as gemm_kernel)
+    // ---- epilogue (the values of gemm_kernel's forms).  bf16 / SwiGLU outputs leave through a per-wave LDS patch as 16 B per lane
+    // (round 6): straight from the accumulators a store instruction writes 2 bytes per lane -- 256 partial-line store instructions per
+    // wave, which is what made the fused SwiGLU behind the in-launch reduction 25 us slower per launch than slabs + swiglu_rows at
+    // num_images = 4 (profiles/r05_head_sweep_b4.log).  The A tiles are dead here (every wave passed the loop's last barrier after its
+    // last fragment read); the first 1 KiB stays the reduction's flag word.
     const int col = nb * 32 + (lane & 31);
     float bias_pn[NPW];
 #pragma unroll
     for (int pn = 0; pn < NPW; ++pn) bias_pn[pn] = (EPI != BD_EPI_PARTIAL && p.bias) ? bf2f(p.bias[col + pn * 32]) : 0.f;
+    if constexpr (EPI == BD_EPI_BF16) {
+        // row-major bf16: two alternating patches of [32 rows][64 columns (+ 8 pad)] per wave; read back as 8 rows x 128 contiguous bytes
+        constexpr int PITCH = 72;
+        bf16_t* const patch = reinterpret_cast<bf16_t*>(smem + 1024) + wave * (2 * 32 * PITCH);
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            bf16_t* const pt = patch + (m & 1) * (32 * PITCH);
+#pragma unroll
+            for (int pn = 0; pn < NPW; ++pn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    pt[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * PITCH + pn * 32 + (lane & 31)] = f2bf(acc[m * NPW + pn][r] + bias_pn[pn]);
+            __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): this wave's own writes (no other wave touches the patch)
+            bf16_t* const o = p.act + (size_t)(mt * MB + m) * 32 * p.N + (size_t)nb * 32;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + (lane >> 3), seg = lane & 7;
+                *reinterpret_cast<u32x4*>(o + (size_t)row * p.N + seg * 8) = *reinterpret_cast<const u32x4*>(pt + row * PITCH + seg * 8);
+            }
+        }
+        BD_KSTAMP_END(p.stamp);
+        return;
+    }
+    if constexpr (EPI == BD_EPI_SWIGLU) {
+        // one accumulator (32 rows x 32 packed columns = 16 gate + 16 up features) = exactly ONE 1 KiB chunk of the fragment-major
+        // operand: (row block, k-step = packed panel).  Every lane ends up with feature l & 15 of 8 rows (swiglu_pairs): 8 two-byte LDS
+        // writes into the chunk's layout, then the chunk goes out as one coalesced 16 B-per-lane store.
+        bf16_t* const patch = reinterpret_cast<bf16_t*>(smem + 1024) + wave * (MB * NPW * 512);     // 16 chunks of 1 KiB per wave
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int pn = 0; pn < NPW; ++pn) {
+                bf16_t* const ch = patch + (m * NPW + pn) * 512;
+                const int f = lane & 15;
+                bf16_t o8[8];
+                swiglu_pairs(acc[m * NPW + pn], bias_pn[pn], lane, o8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int r = 2 * j + ((lane >> 4) & 1);
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    ch[(row + 32 * (f >> 3)) * 8 + (f & 7)] = o8[j];
+                }
+            }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int pn = 0; pn < NPW; ++pn) {
+                const u32x4 v = reinterpret_cast<const u32x4*>(patch + (m * NPW + pn) * 512)[lane];
+                reinterpret_cast<u32x4*>(p.act)[((size_t)(nb + pn) * p.RB + (mt * MB + m)) * 64 + lane] = v;
+            }
+        BD_KSTAMP_END(p.stamp);
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int pn = 0; pn < NPW; ++pn) {
             const f32x16& a = acc[m * NPW + pn];
-            const int colp = col + pn * 32;
-            if (EPI == BD_EPI_PARTIAL) {
-                float* o = p.out + ((size_t)s * p.Mpad + (size_t)(mt * MB + m) * 32) * p.N + colp;
+            float* o = p.out + ((size_t)s * p.Mpad + (size_t)(mt * MB + m) * 32) * p.N + col + pn * 32;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = a[r];
-            } else if (EPI == BD_EPI_BF16) {
-                bf16_t* o = p.act + (size_t)(mt * MB + m) * 32 * p.N + colp;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = f2bf(a[r] + bias_pn[pn]);
-            } else {
-                const int f = (nb + pn) * 16 + (lane & 15);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = bfr(a[r] + bias_pn[pn]);
-                    const float other = __shfl_xor(v, 16);
-                    if ((lane & 16) == 0) {
-                        const int row = (mt * MB + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        p.act[afrag_off(row, f, p.RB)] = f2bf(silu_bf(v) * other);
-                    }
-                }
-            }
+            for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = a[r];
         }
+    BD_KSTAMP_END(p.stamp);
 }
 
 // measurement switches of the 256-row kernel (process-wide; bd_set_gemm_option): W register ring depth and XCD placement
@@ -354,6 +464,8 @@ bool bdk_gemm_claim_push(int epi, int RB, int N, BdTpPush* out) {
     return ok;
 }
 bool bdk_gemm_push_used() { const bool u = g_push_used; g_push_used = false; g_push_set = false; return u; }
+static int g_red_first = 1;
+int bdk_red_first() { return g_red_first; }
 static int g_tile = 1;                                   // >= 512 rows: the LDS-tiled MFMA-bound kernel (bd_gemm_tile.hip); 0 = 256-row kernel
 int bdk_set_gemm_option(const char* name, int v) {
     const std::string n(name);
@@ -363,6 +475,8 @@ int bdk_set_gemm_option(const char* name, int v) {
     if (n == "wide.ring" && (v == 2 || v == 3)) { g_wide_ring = v; return 0; }
     if (n == "wide.xcd" && v >= -1 && v <= 1) { g_wide_xcd = v; return 0; }
     if (n == "wide.keep" && v >= -1 && v <= 1) { g_wide_keep = v; return 0; }
+    if (n == "red.first" && v >= 0 && v <= 1) { g_red_first = v; return 0; }
+    if (n.rfind("rows.", 0) == 0) return bdk_set_rows_option(name, v);
     return -1;
 }
 
@@ -396,6 +510,10 @@ static int launch_gemm_wide_v(const GemmP& p, int epi, hipStream_t st) {
 
 static int launch_gemm_wide(const GemmP& p0, int epi, hipStream_t st) {
     GemmP p = p0;
+    p.red_first = g_red_first;
+#ifdef BD_GEMM_STAMP
+    p.stamp = bdk_stamp_next((std::string("wide:") + bdk_stamp_current_label()).c_str(), (p.N / 256) * p.S * (p.RB / 8));
+#endif
     p.w_keep = g_wide_keep < 0 ? (p.RB > 8) : g_wide_keep;
     // several row tiles per weight slice: keep them on one XCD when the slice is what dominates the traffic (N columns of
     // weights against RB * 32 rows of activations per K); a large batch (ImageNet: 12 288 rows) is the other way round.

@@ -50,8 +50,10 @@ struct GemmP {
     BdTpPush push;                   // BD_EPI_F32 under tensor parallelism: the epilogue pushes the peers' slices (size > 1)
     BdHWait hw;                      // sequence-parallel tensor parallelism: the A operand is pushed by the peers' row kernels -- poll its row flags
                                      // after the first weight stages are in flight, then invalidate and load it (flags == nullptr: no wait)
+    int red_first = 1;               // two-slice in-launch reduction: 1 = ticket first, only the first arriver parks its slab (round 6); 0 = both park
     BD_STAMP_FIELD                   // measurement builds (-DBD_GEMM_STAMP): the launch's stamp region (bd_common.h)
 };
+int bdk_red_first();                 // process-wide A/B switch (bd_set_gemm_option "red.first")
 
 // MFMA-bound form for >= 512 rows: both operands through LDS, 256 x 256 workgroup tiles (bd_gemm_tile.hip)
 int bdk_gemm_tile(const GemmP& p, int epi, hipStream_t st);
@@ -400,14 +402,13 @@ BD_DEV void gemm_body(const GemmP& p) {
             for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = f2bf(a[r] + bias_col);
         } else {  // BD_EPI_SWIGLU: lanes (l&16)==0 hold gate feature f, lanes (l&16)!=0 the matching up feature
             const int f = nbl * 16 + (lane & 15);
+            bf16_t o8[8];
+            swiglu_pairs(a, bias_col, lane, o8);                              // (bd_common.h: one exchange per pair of rows, no branch)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = bfr(a[r] + bias_col);                     // Linear output rounded to bf16
-                const float other = __shfl_xor(v, 16);
-                if ((lane & 16) == 0) {
-                    const int row = (mt * MB + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    p.act[afrag_off(row, f, p.RB)] = f2bf(silu_bf(v) * other);   // silu -> bf16, product -> bf16
-                }
+            for (int j = 0; j < 8; ++j) {
+                const int r = 2 * j + ((lane >> 4) & 1);
+                const int row = (mt * MB + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                p.act[afrag_off(row, f, p.RB)] = o8[j];
             }
         }
     };
@@ -437,6 +438,63 @@ BD_DEV void gemm_body(const GemmP& p) {
             return (unsigned)((((region0 + s_) * MB + m) * 4 + r4) * 1024 + lane * 16);
         };
         constexpr int SC1 = 16;                                                  // buffer cache-policy bit: sc1 (agent scope)
+        if (S == 2 && p.red_first) {
+            // TWO slices, ticket first (round 6): only the slice that arrives FIRST parks its accumulators (and marks the tile's counter
+            // +2 once its stores have drained); the second keeps its own in registers, waits for that mark and adds the parked slab --
+            // own + other == other + own bit for bit, so the result does not depend on the arrival order.  Before, both slices parked and
+            // drained ahead of the ticket (profiles/r06_launch_anatomy.log: "slabs drained + ticket" 1.7 us on every workgroup of qkv / w1,
+            // then 2-5 us for the last arriver): half the slab traffic, and the finishing workgroup skips its own store drain.  The first
+            // arriver is running by construction when the second waits for it; the wait is bounded all the same.
+            int* const flag = reinterpret_cast<int*>(smem);
+            int* const ticket = p.cnt + (mt * ntl + nt);
+            __syncthreads();                                              // all waves are done with the LDS tiles / the K-part sums
+            if (tid == 0) flag[0] = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const bool first = flag[0] == 0;
+#ifdef BD_GEMM_STAMP
+            BD_KSTAMP(p.stamp, 5);
+            bd_kstamp_val(p.stamp, 7, ((unsigned long long)s << 8) | (first ? 0u : 1u));
+#endif
+            if (first) {
+                if (owner) {
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4)
+                            __builtin_amdgcn_raw_buffer_store_b128(
+                                (u32x4){__float_as_uint(acc[m][4 * r4]), __float_as_uint(acc[m][4 * r4 + 1]), __float_as_uint(acc[m][4 * r4 + 2]),
+                                        __float_as_uint(acc[m][4 * r4 + 3])}, sl, slab_off(s, m, r4), 0, SC1);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-throughs
+                __syncthreads();
+                if (tid == 0) __hip_atomic_fetch_add(ticket, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                BD_KSTAMP(p.stamp, 6);
+                return;
+            }
+            if (tid == 0) {
+                const long long t0 = wall_clock64();
+                while (__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 3 && wall_clock64() - t0 < 200000000LL) __builtin_amdgcn_s_sleep(1);
+            }
+            __syncthreads();
+            if (!owner) return;
+            u32x4 v[MB][4];
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) v[m][r4] = __builtin_amdgcn_raw_buffer_load_b128(sl, slab_off(1 - s, m, r4), 0, SC1);
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[m][4 * r4 + j] += __uint_as_float(v[m][r4][j]);
+#pragma unroll
+            for (int m = 0; m < MB; ++m) finalize(m);
+            if (EPI == BD_EPI_F32 && p.push.size > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+            BD_KSTAMP_END(p.stamp);
+            return;
+        }
         if (owner) {
 #pragma unroll
             for (int m = 0; m < MB; ++m)
@@ -458,19 +516,18 @@ BD_DEV void gemm_body(const GemmP& p) {
         if (flag[0] != S - 1) BD_KSTAMP(p.stamp, 6);
 #endif
         if (flag[0] != S - 1 || !owner) return;                           // not the last slice of this tile / nothing to store
-        if (S == 2) {
-            // two slices: own + other == other + own bit for bit, so the last arriver keeps its accumulators and
-            // fetches only the other slab
+        if (S == 2) {                                                     // ("red.first" = 0: both slices parked; the last arriver adds the other slab)
+            u32x4 v[MB][4];
 #pragma unroll
-            for (int m = 0; m < MB; ++m) {
-                u32x4 v[4];
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) v[r4] = __builtin_amdgcn_raw_buffer_load_b128(sl, slab_off(1 - s, m, r4), 0, SC1);
+                for (int r4 = 0; r4 < 4; ++r4) v[m][r4] = __builtin_amdgcn_raw_buffer_load_b128(sl, slab_off(1 - s, m, r4), 0, SC1);
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[m][4 * r4 + j] += __uint_as_float(v[r4][j]);
-            }
+                    for (int j = 0; j < 4; ++j) acc[m][4 * r4 + j] += __uint_as_float(v[m][r4][j]);
 #pragma unroll
             for (int m = 0; m < MB; ++m) finalize(m);
             if (EPI == BD_EPI_F32 && p.push.size > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -556,10 +613,13 @@ static int launch_one(const GemmP& p, hipStream_t st) {
     }
 #ifdef BD_GEMM_STAMP
     GemmP q = p;
+    q.red_first = bdk_red_first();
     q.stamp = bdk_stamp_next(bdk_stamp_current_label(), (int)(grid.x * grid.y));
     BD_LAUNCH((gemm_kernel<NP, KW, MB, EPI, R, RED, MODE, WT>), grid, dim3(NP * KW * 64), lds, st, q);
 #else
-    BD_LAUNCH((gemm_kernel<NP, KW, MB, EPI, R, RED, MODE, WT>), grid, dim3(NP * KW * 64), lds, st, p);
+    GemmP q = p;
+    q.red_first = bdk_red_first();
+    BD_LAUNCH((gemm_kernel<NP, KW, MB, EPI, R, RED, MODE, WT>), grid, dim3(NP * KW * 64), lds, st, q);
 #endif
     return bd_launch_status();
 }

@@ -323,14 +323,13 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(GemmP p, int dbg) {
                 for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = a[r];
             } else {                                             // BD_EPI_SWIGLU: lanes (l & 16) == 0 hold gate f, the others the matching up
                 const int f = panel * 16 + (lane & 15);
+                bf16_t o8[8];
+                swiglu_pairs(a, bias_col, lane, o8);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = bfr(a[r] + bias_col);
-                    const float other = __shfl_xor(v, 16);
-                    if ((lane & 16) == 0) {
-                        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        p.act[afrag_off(row, f, p.RB)] = f2bf(silu_bf(v) * other);
-                    }
+                for (int j = 0; j < 8; ++j) {
+                    const int r = 2 * j + ((lane >> 4) & 1);
+                    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    p.act[afrag_off(row, f, p.RB)] = o8[j];
                 }
             }
         }

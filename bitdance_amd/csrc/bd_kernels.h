@@ -141,6 +141,7 @@ int bdk_head_y_all(const HeadYAllArgs& a, hipStream_t st);
 
 struct FinalizeRowsArgs { Partial in; void* out; int M, N; BD_STAMP_FIELD };   // bf16 row-major out = bf16(sum of slabs + bias)
 int bdk_finalize_rows(const FinalizeRowsArgs& a, hipStream_t st);
+int bdk_set_rows_option(const char* name, int v);    // bd_rows.hip: "rows.ln_occ" 4|5, "rows.swiglu_t" 512|1024 (A/B switches)
 
 struct InitLatentArgs { float* xt; const float* noise; long long noise_step_stride; const BdStepState* state; int n; };
 int bdk_init_latent(const InitLatentArgs& a, hipStream_t st);    // x_0 = first draw of this AR step (sampling_x.py:60)

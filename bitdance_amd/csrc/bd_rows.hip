@@ -6,6 +6,17 @@
 // rounding points of the reference's autocast flow, so between two weight-streaming GEMMs there is one small
 // launch and no standalone elementwise pass.
 #include "bd_rowhelp.h"
+#include <string>
+
+// A/B switches (bd_set_gemm_option "rows.*"): registers-per-thread bound of ln_mod (waves per SIMD: 4 = one 640-thread workgroup per CU,
+// 5 = two), thread cap of swiglu_rows (512 = three workgroups per CU, 1024 = one 960-thread workgroup)
+static int g_ln_occ = 4, g_swiglu_t = 512;   // measured on one box at 512 rows (profiles/r06_head_sweep_b4.log): ln_occ 5 +0.9 % SLOWER (4 spilled registers; the dispatch skew of 512 ten-wave workgroups is the dispatcher, not residency), swiglu_t 512 -0.2 %
+int bdk_set_rows_option(const char* name, int v) {
+    const std::string n(name);
+    if (n == "rows.ln_occ" && (v == 4 || v == 5)) { g_ln_occ = v; return 0; }
+    if (n == "rows.swiglu_t" && (v == 512 || v == 1024)) { g_swiglu_t = v; return 0; }
+    return -1;
+}
 
 // scalar helpers (small kernels)
 BD_DEV float slab_sum(const Partial& q, int row, int col) {
@@ -140,7 +151,11 @@ BD_DEV void modulate8(const float* x, float mean, float rstd, const float* lw, c
     }
 }
 
-__global__ void ln_mod_kernel(LnModArgs a) {
+// OCC = waves per SIMD the register allocation must admit (launch bound): 4 = the compiler's own 98 registers, one 640-thread workgroup per
+// CU; 5 = 96 registers (4 spilled), two per CU.  Round 6 measured 5 slower at 512 rows (+0.9 % per evaluation) and equal at 128: kept as an
+// A/B switch ("rows.ln_occ"), default 4.
+template <int OCC>
+__global__ __launch_bounds__(MAX_ROW_THREADS, OCC) void ln_mod_kernel(LnModArgs a) {
     __shared__ float red[32];
     BD_KSTAMP(a.stamp, 0);
     const int m = blockIdx.x, d0 = threadIdx.x * 8;
@@ -265,7 +280,8 @@ int bdk_ln_mod(const LnModArgs& a, hipStream_t st) {
         return bd_launch_status();
     }
     BD_STAMPED(LnModArgs, a, "ln_mod", a.M);
-    BD_LAUNCH(ln_mod_kernel, dim3(a.M), dim3(t), 0, st, a_l);
+    if (g_ln_occ == 5) BD_LAUNCH(ln_mod_kernel<5>, dim3(a.M), dim3(t), 0, st, a_l);
+    else BD_LAUNCH(ln_mod_kernel<4>, dim3(a.M), dim3(t), 0, st, a_l);
     return bd_launch_status();
 }
 
@@ -508,8 +524,10 @@ __global__ void swiglu_rows_kernel(SwigluArgs a) {
 }
 int bdk_swiglu_rows(const SwigluArgs& a, hipStream_t st) {
     if (a.F % 8) return -2;
+    // at most 512 threads: three 8-wave workgroups fit a CU at this kernel's 80 registers (960 threads = 15 waves was one per CU: the 512
+    // workgroups of num_images = 4 ran as two waves of workgroups, profiles/r06_launch_anatomy_b4.log); the row loop covers the rest
     int t = ((a.F / 8 + 63) / 64) * 64;
-    if (t > MAX_ROW_THREADS) t = MAX_ROW_THREADS;
+    if (t > g_swiglu_t) t = g_swiglu_t;
     BD_STAMPED(SwigluArgs, a, "swiglu_rows", a.M);
     BD_LAUNCH(swiglu_rows_kernel, dim3(a.M), dim3(t), 0, st, a_l);
     return bd_launch_status();

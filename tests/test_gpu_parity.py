@@ -619,6 +619,74 @@ def test_gemm_in_launch_splitk_reduction(eng_mod, M, N, K, S, nw):
         assert torch.equal(out[:M], first[:M])               # fixed summation order: bit-identical run to run
 
 
+@pytest.mark.parametrize("M,N,K,S", [(512, 15360, 5120, 2), (512, 15360, 5120, 1), (256, 512, 256, 1), (512, 2304, 384, 2), (1024, 5120, 7680, 2)])
+def test_gemm_256_row_kernel_wide_epilogues(eng_mod, M, N, K, S):
+    """The 256-row kernel (gemm_wide_kernel) with its 16 B-per-lane epilogues (round 6: bf16 rows and SwiGLU operand chunks leave through a
+    per-wave LDS patch), one K slice and two slices reduced inside the launch: the bf16(+bias) output equals the correctly rounded fp64
+    reference up to accumulation-order flips and is bit-identical run to run; the fused SwiGLU equals silu(bf16(h1)) * bf16(h2) at the
+    reference's rounding points (flow_head_parallel_x.py:250-251) -- the same bounds as test_gemm_swiglu -- and, at one slice, the
+    128-row kernel's bits."""
+    from bitdance_amd._lib import check, lib
+    tile_was = 1
+    check(lib().bd_set_gemm_option(b"tile", 0))                 # the 256-row kernel also where the tiled kernel would take over
+    try:
+        g = torch.Generator(device=DEV).manual_seed(M + N + K + S)
+        x = torch.randn(M, K, device=DEV, generator=g)
+        w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)
+        b = (torch.randn(N, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+        xf, rb = frag(eng_mod, x)
+        st = torch.cuda.current_stream().cuda_stream
+        scratch = torch.empty(max(S, 2) * rb * 32 * N, device=DEV)
+        cnt = torch.zeros(16384, dtype=torch.int32, device=DEV)
+        # ---- bf16 + bias
+        wp = eng_mod.pack_linear([w], DEV)
+        ref = (x.to(torch.bfloat16).double() @ w.double().t() + b.double())[:M]
+        want = ref.to(torch.bfloat16)
+        first = None
+        for it in range(3):
+            out = torch.full((rb * 32, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            check(lib().bd_gemm_bf16(xf.data_ptr(), rb, wp.data_ptr(), b.data_ptr(), N, K, S, 8, scratch.data_ptr(), cnt.data_ptr(), out.data_ptr(), st))
+            torch.cuda.synchronize()
+            assert int(cnt.abs().sum()) == 0
+            d = (out[:M].double() - want.double()).abs()
+            assert bool((d <= 2.0 ** -7 * ref.abs().clamp_min(2.0 ** -6)).all()), (it, float(d.max()))
+            assert float((out[:M] != want).double().mean()) <= 0.02
+            first = out.clone() if first is None else first
+            assert torch.equal(out, first)
+        # ---- fused SwiGLU (N = 2 F packed gate / up)
+        F_ = N // 2
+        wsp = eng_mod.pack_swiglu(w[:F_], w[F_:], DEV)
+        bsp = eng_mod.pack_swiglu_bias(b[:F_], b[F_:], DEV)
+        h = (x.to(torch.bfloat16).float() @ w.float().t() + b.float()).to(torch.bfloat16)
+        sref = torch.nn.functional.silu(h[:, :F_]) * h[:, F_:]
+        acts = []
+        for it in range(2):
+            act = torch.full((rb * 32 * F_,), float("nan"), dtype=torch.bfloat16, device=DEV)
+            if S == 1:
+                check(lib().bd_gemm_swiglu(xf.data_ptr(), rb, wsp.data_ptr(), bsp.data_ptr(), N, K, 8, act.data_ptr(), st))
+            else:
+                check(lib().bd_gemm_swiglu_splitk(xf.data_ptr(), rb, wsp.data_ptr(), bsp.data_ptr(), N, K, S, 8, scratch.data_ptr(), cnt.data_ptr(),
+                                                  act.data_ptr(), st))
+            torch.cuda.synchronize()
+            a = act.view(F_ // 16, rb, 2, 32, 8).permute(1, 3, 0, 2, 4).reshape(rb * 32, F_)[:M]
+            d = (a.float() - sref.float()).abs()
+            assert torch.isfinite(a).all() and (d > 0).float().mean() <= 0.02 and d.max() <= 0.07, ((d > 0).float().mean(), d.max())
+            acts.append(act)
+        assert torch.equal(acts[0], acts[1])
+        if S == 1 and M % 128 == 0:                              # one slice: every K sum in the 128-row kernel's order -> its bits
+            act4 = torch.zeros(rb * 32 * F_, dtype=torch.bfloat16, device=DEV)
+            for r0 in range(0, M, 128):
+                xs, rbs = frag(eng_mod, x[r0:r0 + 128])
+                a4 = torch.zeros(rbs * 32 * F_, dtype=torch.bfloat16, device=DEV)
+                check(lib().bd_gemm_swiglu(xs.data_ptr(), rbs, wsp.data_ptr(), bsp.data_ptr(), N, K, 4, a4.data_ptr(), st))
+                torch.cuda.synchronize()
+                got = acts[0].view(F_ // 16, rb, 2, 32, 8).permute(1, 3, 0, 2, 4).reshape(rb * 32, F_)[r0:r0 + 128]
+                assert torch.equal(got, a4.view(F_ // 16, rbs, 2, 32, 8).permute(1, 3, 0, 2, 4).reshape(rbs * 32, F_)[:128])
+            del act4
+    finally:
+        check(lib().bd_set_gemm_option(b"tile", tile_was))
+
+
 # ----------------------------------------------------------------------------------------------- imagenet (I1-I3)
 def test_imagenet_head_eval_dh64_vs_oracle(eng_mod):
     """diff_head_parallel.TransEncoder (head_dim 64, explicit-softmax attention, no final sigmoid) on the HIP head:

@@ -76,14 +76,15 @@ def main():
         del sd
         tune = {k[5:]: v for k, v in extra.items() if k.startswith("tune.")}
         ei = {k: v for k, v in extra.items() if k.startswith("tp.")}
-        eng = E.Engine(hw, None, None, num_images=1, branches=2, device=dev, max_tokens=64, parallel_num=64, tune=tune or None, comm=comm,
+        B = int(os.environ.get("BD_ANATOMY_B", "1"))        # images per pass (4: the 256-row kernel's wait-cycle stamps, "wide:<gemm>")
+        eng = E.Engine(hw, None, None, num_images=B, branches=2, device=dev, max_tokens=64, parallel_num=64, tune=tune or None, comm=comm,
                        extra_ints=ei or None)
         g = torch.Generator(device=dev).manual_seed(7)
-        cond = torch.randn(2, 64, 5120, device=dev, generator=g)
-        noise = torch.randn(1, n + 1, 1, 64, 32, device=dev, generator=g)
+        cond = torch.randn(2 * B, 64, 5120, device=dev, generator=g)
+        noise = torch.randn(1, n + 1, B, 64, 32, device=dev, generator=g)
         eng.set_schedule(n, 7.5, 1)
         eng.load_noise(noise)
-        eng.reset([0, 0])
+        eng.reset([0] * (2 * B))
         eng.set_cond(cond)
         eng.head_sample()                                   # eager warm-up, unstamped (no buffer yet)
         torch.cuda.synchronize()
@@ -91,7 +92,7 @@ def main():
         check(l.anatomy_begin(buf.data_ptr(), buf.numel()))
         eng.capture(0)                                      # the stamp regions are baked into the captured kernel arguments
         for _ in range(3):
-            eng.reset([0, 0])
+            eng.reset([0] * (2 * B))
             eng.launch(0)
         torch.cuda.synchronize()
         if comm is not None:
@@ -103,10 +104,31 @@ def main():
             check(l.anatomy_get(i, nm, C.byref(off), C.byref(nwg)))
             w = words[off.value: off.value + nwg.value * 8].reshape(nwg.value, 8).astype(np.int64)
             recs.append((nm.value.decode(), w))
+    if os.environ.get("BD_ANATOMY_DUMP"):                    # raw stamps of the last three evaluations' launches, for offline analysis
+        keep = recs[-3 * 43:]
+        np.savez_compressed(os.environ["BD_ANATOMY_DUMP"], names=np.array([n_ for n_, _ in keep]), **{f"w{i}": w for i, (_, w) in enumerate(keep)})
     print(f"# launch anatomy: {wmode} weights, {'rank %d of %d in loop-back' % shard if shard else 'one GPU (tp = 1)'}, {n + 1} evaluations, "
           f"{len(recs)} stamped launches; seq {int(getattr(eng, 'seq_parallel', False))}; times in us (10 ns clock)")
     cfgs = ", ".join(f"{k} S={eng.gemm_config('head.' + k)[0]} code={eng.gemm_config('head.' + k)[1]}" for k in ("qkv", "wo", "w1", "w2"))
     print(f"# launch configurations: {cfgs}")
+    # ---- the 256-row kernel (num_images >= 2): shader cycles wave 0 of every workgroup spent waiting, against its whole K loop
+    wide = defaultdict(list)
+    for name, w in recs:
+        if name.startswith("wide:") and w[:, 0].min() > 0:
+            wide[name].append(w)
+    for name, ws in wide.items():
+        loop = np.concatenate([w[:, 5] for w in ws[1:] or ws]).astype(np.float64)
+        ww, wa, wb = (np.concatenate([w[:, k] for w in ws[1:] or ws]).astype(np.float64) for k in (1, 2, 4))
+        nst = ws[0][:, 7].max()
+        span = np.mean([(w[:, 6].max() - w[:, 0].min()) * TICK_US for w in ws[1:] or ws])
+        lp = np.mean([np.median(w[:, 3] - w[:, 0]) * TICK_US for w in ws[1:] or ws])
+        tail = np.mean([np.median(w[:, 6] - w[:, 3]) * TICK_US for w in ws[1:] or ws])
+        tailmax = np.mean([(w[:, 6] - w[:, 3]).max() * TICK_US for w in ws[1:] or ws])
+        print(f"\n== {name}: {len(ws)} launches x {ws[0].shape[0]} workgroups, {nst} stages of 64 MFMAs per wave (2048 cycles of matrix pipe each)")
+        print(f"   K loop: median {np.median(loop):9.0f} cycles = {np.median(loop) / nst:6.0f} per stage; of which waiting for W {np.median(ww / loop):.3f}, "
+              f"for A {np.median(wa / loop):.3f}, at the barrier {np.median(wb / loop):.3f} (medians over workgroups; max W {np.max(ww / loop):.3f} A {np.max(wa / loop):.3f} barrier {np.max(wb / loop):.3f})")
+        print(f"   realtime: K loop {lp:7.2f} us, loop end -> last store drained median {tail:6.2f} / max {tailmax:6.2f} us, kernel span {span:7.2f} us")
+    recs = [(n_, w) for n_, w in recs if not n_.startswith("wide:")]
     # ---- per kernel name: phases reduced over the grid, then averaged over the launches
     phases = OrderedDict([("dispatch skew (start - first start)", (None, 0)), ("start -> first A in LDS", (0, 1)), ("start -> first W landed", (0, 2)),
                           ("first W -> K loop done", (2, 3)), ("K parts through LDS", (3, 4)), ("slabs drained + ticket", (4, 5)),
