@@ -85,6 +85,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-b4", action="store_true", help="headline workload on one GPU: skip the extra num_images=4 point (SURVEY 8(d): the eval scripts' batch)")
+    ap.add_argument("--no-throughput", action="store_true", help="headline workload on one GPU: skip the extra saturated-batch point")
+    ap.add_argument("--throughput-images", type=int, default=8, help="num_images of the `throughput` point (default 8; 16 gives ~5 %% more and takes twice as long)")
+    ap.add_argument("--no-replicas", action="store_true", help="N > 1, tensor parallel: skip the independent-replicas point timed after the tensor-parallel pass")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="imagenet: skip the conv decoder in the timed pass")
     ap.add_argument("--tp-ada-split", default="auto", choices=["auto", "0", "1"],
@@ -467,6 +470,7 @@ def main():
             ei["tp.ada_split"] = int(args.tp_ada_split)
         if args.tp_seq != "auto":
             ei["tp.seq"] = int(args.tp_seq)
+            ei["tp.llm_seq"] = int(args.tp_seq)
         pipe.extra_ints = ei or None
     if args.attn_splits:
         pipe.attn_splits = args.attn_splits
@@ -555,7 +559,7 @@ def main():
                 keep = (pipe.tune, getattr(pipe, "extra_ints", None))
                 was_seq = bool(getattr(eng0, "seq_parallel", False))
                 pipe.tune = dict(tune, tp_fuse=0)
-                pipe.extra_ints = {"tp.ada_split": 0, "tp.seq": 0}
+                pipe.extra_ints = {"tp.ada_split": 0, "tp.seq": 0, "tp.llm_seq": 0}
                 pipe._engines.clear()
                 same = tp_pass_ok(i) and bool(torch.equal(token_checksum(next(iter(pipe._engines.values())).tok_all), fused_sum))
                 flag = torch.tensor([1 if same else 0], device="cpu" if dist.get_backend() == "gloo" else dev)
@@ -591,6 +595,43 @@ def main():
                   "(re-run with --tp-seq 0 / --tune tp_fuse=0 / --tp-comm rccl to localise)", file=sys.stderr, flush=True)
     dt = max_over_ranks(dt, dist, "cpu" if (dist is not None and dist.get_backend() == "gloo") else dev)
 
+    # One line carries both answers: the tensor-parallel `value` above AND what the same N GPUs deliver as independent
+    # replicas over disjoint images -- what the reference's evaluation scripts do (eval/eval_dpg.py:25-29) and, for images/s, the better use
+    # of a node.  Timed after the tensor-parallel pass on the same lease: every rank builds the unsharded model beside
+    # its shard, one untimed + one timed image.
+    replicas = None
+    if tp_mode and not args.no_replicas:
+        ok, why = 1, ""
+        try:
+            pipe_r = syn.build_pipeline(size, dev, with_ae=True, tp=None, weights=args.weights)
+            pipe_r.tune = {k: v for k, v in tune.items() if not k.startswith("tp")} or None
+            if args.attn_splits:
+                pipe_r.attn_splits = args.attn_splits
+            pipe_r.use_graph = not args.no_graph
+
+            def pass_r(i):
+                torch.manual_seed(rank_seed(1234, rank, 1000 + i))
+                with torch.amp.autocast("cuda", enabled=True, dtype=torch.bfloat16):
+                    return pipe_r.gen_image(**kw)
+            pass_r(0)
+            barrier()
+            tr = time.perf_counter()
+            img_r = pass_r(1)
+            barrier()
+            dtr = time.perf_counter() - tr
+            assert torch.isfinite(img_r).all()
+            del pipe_r, img_r
+            torch.cuda.empty_cache()
+        except Exception as e:                                 # (out of memory beside the shard, ...): the line says so
+            ok, why, dtr = 0, str(e)[:200], 0.0
+            barrier(); barrier()
+        flag = torch.tensor([ok], device="cpu" if dist.get_backend() == "gloo" else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        dtr = max_over_ranks(dtr, dist, "cpu" if dist.get_backend() == "gloo" else dev)
+        replicas = ({"value": round(world * num_images / dtr, 5), "unit": "images/s", "n_gpus": world, "steps": 1, "warmup": 1,
+                     "ms_per_step": round(dtr * 1e3, 2), "scaling": "weak", "parallelism": f"replicas x{world}"}
+                    if int(flag.item()) == 1 else {"value": None, "error": why or "a rank failed"})
+
     if rank == 0:
         n = world
         images = (1 if tp_mode else n) * num_images * args.steps
@@ -611,6 +652,8 @@ def main():
                        "hipgraph": pipe.use_graph, **({"tensor_parallel_fallback": tp_note} if tp_note else {})},
             "phases_ms_last_step": {k: round(v, 1) for k, v in pipe.timings().items()},
         }
+        if replicas is not None:
+            out["replicas"] = replicas
         if tp_mode:
             wbytes = sum(t.numel() * t.element_size() for w_ in (pipe.head_w, pipe.llm_w, pipe.proj_w) for t in w_.ptrs.values())
             nblk, L = pipe.head_w.nblocks, pipe.llm_w.cfg["num_hidden_layers"]
@@ -628,6 +671,8 @@ def main():
                          "adaln_projection": "column-split + push all-gather" if getattr(eng, "ada_split", False) else "replicated",
                          "head_row_kernels": ("sequence-parallel (csrc/bd_sp.hip: rows / tp rows per rank, no exchange kernel in an evaluation)"
                                               if getattr(eng, "seq_parallel", False) else "replicated behind an all-reduce kernel per row-split Linear"),
+                         "llm_row_kernels": ("sequence-parallel (csrc/bd_sp.hip rms_sp: rows / tp rows of the residual stream per rank, no exchange kernel in a decode step)"
+                                             if getattr(eng, "llm_seq_parallel", False) else "replicated behind an all-reduce kernel per row-split Linear"),
                          "exchanges_per_image": n_x, "exchange_payload_bytes_per_rank": int(eng.M * 5120 * 6 * (n - 1) / n),
                          "ranks_bit_identical": ranks_identical}
         if not args.no_roofline:
@@ -636,35 +681,47 @@ def main():
                 out["roofline"] = gemm_roofline(eng, lambda: (eng.head_sample(), eng.projector(), eng.llm_step()), eng.M)
             if tp_mode:
                 out["roofline"]["note"] = "rank 0's launches: per-rank slices of the weights"
-        if world == 1 and size == "14b-64x" and num_images == 1 and not args.no_b4 and (H, W) == (1024, 1024):
+        if world == 1 and size == "14b-64x" and num_images == 1 and (H, W) == (1024, 1024):
             # "Report B=1 ... and B=4 (num_images=4, what the eval scripts do, eval/eval_dpg.py:44)".  `value` above
-            # stays the B = 1 headline; this is ONE untimed warm-up + ONE timed gen_image of four images on the same pipeline
-            # (the B = 1 engine is dropped, a 512-row engine built), then its GEMM launches profiled in situ (MFMA-bound).
-            kw4 = dict(kw, num_images=4)
+            # stays the B = 1 headline; each extra point is ONE untimed warm-up + ONE timed gen_image of that many images on the same
+            # pipeline (the previous engine is dropped, one for the new row count built), then its GEMM launches profiled in situ
+            # (MFMA-bound).  "b4" = the eval scripts' batch; "throughput" = the batch where this code base's images/s saturate on one
+            # GPU (round 6: 0.505 / 0.529 images/s at 8 / 16 images, profiles/r06_bench_b8_first.json, _b16_first.json -- 8 keeps the
+            # default run inside a few minutes).
+            def extra_point(nimg: int, seed: int) -> dict:
+                kwn = dict(kw, num_images=nimg)
 
-            def pass4(i):
-                torch.manual_seed(rank_seed(4321, rank, i))
-                with torch.amp.autocast("cuda", enabled=True, dtype=torch.bfloat16):
-                    return pipe.gen_image(**kw4)
-            pass4(0)
-            torch.cuda.synchronize()
-            t4 = time.perf_counter()
-            img4 = pass4(1)
-            torch.cuda.synchronize()
-            dt4 = time.perf_counter() - t4
-            assert torch.isfinite(img4).all() and img4.shape[0] == 4
-            eng4 = next(iter(pipe._engines.values()))
-            b4 = {"value": round(4 / dt4, 5), "unit": "images/s", "num_images": 4, "steps": 1, "warmup": 1, "ms_per_step": round(dt4 * 1e3, 2),
-                  "rows_per_pass": eng4.M, "phases_ms": {k: round(v, 1) for k, v in pipe.timings().items()}}
-            if not args.no_roofline:
-                with torch.cuda.stream(pipe._stream):
-                    r4 = gemm_roofline(eng4, lambda: (eng4.head_sample(), eng4.projector(), eng4.llm_step()), eng4.M)
-                b4["roofline"] = {k: r4.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "mfma_busy", "eff_clock_ghz", "pmc_source",
-                                                          "flop_per_launch", "launches", "avg_launch_us")}
-                b4["roofline"]["per_gemm"] = [{k: q[k] for k in ("name", "launches", "avg_us", "TFLOPs", "frac_of_mfma_peak", "mfma_busy", "eff_clock_ghz",
-                                                                  "splitk", "nwaves") if k in q} for q in r4["per_gemm"]]
-            out["b4"] = b4
-            del eng4, img4
+                def passn(i):
+                    torch.manual_seed(rank_seed(seed, rank, i))
+                    with torch.amp.autocast("cuda", enabled=True, dtype=torch.bfloat16):
+                        return pipe.gen_image(**kwn)
+                passn(0)
+                torch.cuda.synchronize()
+                tn = time.perf_counter()
+                imgn = passn(1)
+                torch.cuda.synchronize()
+                dtn = time.perf_counter() - tn
+                assert torch.isfinite(imgn).all() and imgn.shape[0] == nimg
+                engn = next(iter(pipe._engines.values()))
+                pt = {"value": round(nimg / dtn, 5), "unit": "images/s", "num_images": nimg, "steps": 1, "warmup": 1, "ms_per_step": round(dtn * 1e3, 2),
+                      "rows_per_pass": engn.M, "phases_ms": {k: round(v, 1) for k, v in pipe.timings().items()}}
+                if not args.no_roofline:
+                    with torch.cuda.stream(pipe._stream):
+                        rn = gemm_roofline(engn, lambda: (engn.head_sample(), engn.projector(), engn.llm_step()), engn.M)
+                    pt["roofline"] = {k: rn.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "mfma_busy", "eff_clock_ghz", "pmc_source",
+                                                              "flop_per_launch", "launches", "avg_launch_us")}
+                    pt["roofline"]["per_gemm"] = [{k: q[k] for k in ("name", "launches", "avg_us", "TFLOPs", "frac_of_mfma_peak", "mfma_busy", "eff_clock_ghz",
+                                                                      "splitk", "nwaves") if k in q} for q in rn["per_gemm"]]
+                del engn, imgn
+                pipe._engines.clear()
+                torch.cuda.empty_cache()
+                return pt
+            if not args.no_b4:
+                out["b4"] = extra_point(4, 4321)
+            if not args.no_throughput:
+                out["throughput"] = extra_point(args.throughput_images, 8765)
+                out["throughput"]["note"] = ("images/s of ONE gen_image call at the batch where one GPU saturates (MFMA-bound: every head GEMM at >= 1024 rows); "
+                                             "`value` above stays the num_images = 1 headline")
         if world == 1 and not args.no_cpu_baseline:
             del pipe
             out["cpu_baseline"] = cpu_baseline_t2i(args, P, ar_steps, n_sampling + 1, px=int((H * W) ** 0.5))

@@ -95,6 +95,7 @@ struct bd_ctx {
     // stream; no stand-alone exchange kernel inside an evaluation.  sp_fseq: sequence number of the final latent hand-off of the
     // sampling run being issued (tok_finish waits for it)
     bool sp = false;
+    bool sp_llm = false;                  // "tp.llm_seq": the Qwen3 decode step on the same hand-off (rms_sp_kernel; round 6)
     int sp_fseq = 0;
     int ada_slots = 1;                    // column-split adaLN: the gathered modulation tensor is double-buffered by group parity
 
@@ -254,7 +255,7 @@ static const char* const kIntKeys[] = {
     "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid", "head.y_evals", "head.variant",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "proj.rows_all", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
     "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "rt.in_first", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ragged", "tune.ragged52", "tune.slab_cap", "tune.slab3",
-    "tune.ada_group", "tune.ada_group_nw", "tune.tp_fuse", "tune.ln_rows", "tune.small_tiles_rows", "tp.ada_split", "tp.seq", "tune.sp_wait", "tune.sp_inv", "tune.finalize_s", "tune.sp_gsig", "tune.tp_shapes"};
+    "tune.ada_group", "tune.ada_group_nw", "tune.tp_fuse", "tune.ln_rows", "tune.small_tiles_rows", "tp.ada_split", "tp.seq", "tp.llm_seq", "tune.sp_wait", "tune.sp_inv", "tune.finalize_s", "tune.sp_gsig", "tune.tp_shapes"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
                                          "llm.qkv", "llm.o", "llm.gu", "llm.down"};
 static bool known_int_key(const std::string& k) {
@@ -630,6 +631,17 @@ int bd_ctx_finalize(bd_ctx* c) {
             add("llm.act_frag", Mp * c->lFl * 2);
             add("llm.hidden", Mp * c->lD * 4);
             if (tp > 1) add("llm.tp_part", Mp * c->lD * 4);
+            c->sp_llm = false;
+            if (c->geti("tp.llm_seq", 0)) {
+                // the decode step's row kernels sequence-parallel: 128 rows in whole 8-row groups per rank, bf16 operand rows, a landing
+                // buffer that holds the bf16 operand region AND the fp32 final-rows region (tp.seq_hbuf_bytes)
+                BdSpLink L;
+                if (tp < 2 || !c->comm || !bdk_sp_link(c->comm, &L)) return fail("tp.llm_seq: needs a tensor-parallel communicator created with an operand landing buffer (bd_comm_create3)");
+                if (c->M != 128 || Mp != 128 || c->fp8a || (c->M / 8) % tp || c->lvariant != 0)
+                    return fail("tp.llm_seq: 128 rows (one image with CFG, parallel_num 64) in whole 8-row groups per rank, bf16 activations, the Qwen3 path");
+                if (bdk_sp_hbuf_bytes(c->comm) < Mp * c->lD * 6) return fail("tp.llm_seq: the communicator's operand landing buffer is smaller than rows x llm.D x 6");
+                c->sp_llm = true;
+            }
         }
         c->finalized = true;
         return 0;
@@ -1187,8 +1199,89 @@ static int llm_step_in(bd_ctx* c, hipStream_t st) {
     return 0;
 }
 
+// The decode step with sequence-parallel row kernels (bd_sp.hip rms_sp_kernel): a rank owns rows / tp rows of the fp32 residual stream; per
+// layer  rms_sp -> qkv (waits for the operand rows) -> q/k norm + RoPE + append -> attention -> o_proj (pushes partial rows to the owners)
+// -> rms_sp -> gate/up (waits) -> down_proj (pushes) ; the final norm's rows travel as fp32 and every rank finishes hidden state and the
+// next patch's condition itself (sp_final_rows_kernel).  No stand-alone exchange kernel: 2 L + 1 hand-offs of operand rows and 2 L of
+// partial rows instead of 2 L all-reduce kernels with two flag rounds each + 2 L replicated RMSNorms.  Values: the all-reduce form's,
+// bit for bit (the partials are summed in rank order and rounded once to bf16 by the owner).
+static int llm_step_sp(bd_ctx* c, hipStream_t st) {
+    const int D = c->lD, F = c->lFl, Mp = c->Mpad, RB = c->RB, M = c->M, nh = c->lnhl, nkv = c->lnkvl;
+    const int nseq = c->branches * c->B;
+    const float eps = (float)c->getf("llm.eps", 1e-6);
+    BdStepState* state = (BdStepState*)c->wptr("state");
+    const GemmCfg &gq = c->cfg("llm.qkv"), &go = c->cfg("llm.o"), &gg = c->cfg("llm.gu"), &gd = c->cfg("llm.down");
+    const size_t layer_elems = (size_t)nseq * nkv * c->lLmax * 128;
+    BdSpLink L;
+    if (!bdk_sp_link(c->comm, &L)) return fail("sequence-parallel exchange: the communicator lost its peers");
+    BD_TRY(bdk_sp_begin(c->comm, st));                      // sequence numbers restart with every replay of the step
+    const char* const too_many = "sequence-parallel exchange: more than 65535 hand-offs in one Qwen3 step";
+    int seq_p = 0;
+    RmsSpArgs a1;
+    a1.r.R = (float*)c->wptr("llm.R");
+    a1.r.pend = Partial{nullptr, nullptr, 0, 0, 0};
+    a1.r.a_frag = nullptr; a1.r.hidden_out = nullptr; a1.r.cond_frag = nullptr; a1.r.pos = nullptr; a1.r.state = state;
+    a1.r.M = M; a1.r.D = D; a1.r.RB = RB; a1.r.P = c->Pn; a1.r.eps = eps; a1.r.bf16_stream = 0;
+    a1.L = L; a1.rows_local = M / c->tp; a1.signal_p = c->geti("tune.sp_gsig", 0) ? 0 : 1;
+    for (int l = 0; l < c->lL; ++l) {
+        const std::string pre = "llm.l" + std::to_string(l) + ".";
+        a1.r.w = c->ptr(pre + "in_norm");
+        a1.part = seq_p ? (const float*)c->ptr("llm.tp_part") : nullptr; a1.seq_p = seq_p;
+        if ((a1.seq_h = bdk_sp_next_seq(c->comm)) < 0) return fail(too_many);
+        BD_TRY(bdk_rms_sp(a1, st));
+        QkvPostArgs qa;
+        BD_TRY(sp_arm_wait(c, a1.seq_h, st));
+        BD_TRY(linear(c, "llm.qkv", bdk_sp_hbuf(c->comm), RB, wref(c, pre + "wqkv"), c->lNqkv, D, gq, "llm.qkv_part", "llm.qkv_bf", nullptr, Mp, &qa.qkv, st));
+        qa.qn_w = c->ptr(pre + "q_norm"); qa.kn_w = c->ptr(pre + "k_norm");
+        qa.cos = (const float*)c->ptr("llm.cos"); qa.sin = (const float*)c->ptr("llm.sin");
+        qa.q_out = c->wptr("llm.q");
+        qa.k_cache = (bf16_t*)c->wptr("llm.k_cache") + l * layer_elems;
+        qa.vt_cache = (bf16_t*)c->wptr("llm.vt_cache") + l * layer_elems;
+        qa.state = state; qa.M = M; qa.P = c->Pn; qa.nh = nh; qa.nkv = nkv; qa.Lmax = c->lLmax; qa.eps = eps; qa.rope_bf16 = 0;
+        BD_TRY(bdk_qkv_post(qa, st));
+        LlmAttnArgs aa;
+        aa.q = c->ptr("llm.q"); aa.k_cache = qa.k_cache; aa.vt_cache = qa.vt_cache;
+        aa.o_part = (float*)c->wptr("llm.attn_opart"); aa.ml_part = (float*)c->wptr("llm.attn_ml");
+        aa.o_frag = c->wptr("llm.attn_frag"); aa.state = state;
+        aa.nseq = nseq; aa.P = c->Pn; aa.nh = nh; aa.nkv = nkv; aa.Lmax = c->lLmax; aa.splits = c->lsplits; aa.RB = RB; aa.causal = 0;
+        BD_TRY(bdk_llm_attn(aa, st));
+        BD_TRY(linear_rowsplit_sp(c, "llm.o", c->ptr("llm.attn_frag"), RB, wref(c, pre + "wo"), D, nh * 128, go, "llm.br_part", "llm.tp_part", M, &seq_p, st));
+        RmsSpArgs a2 = a1;
+        a2.r.w = c->ptr(pre + "post_norm");
+        a2.part = (const float*)c->ptr("llm.tp_part"); a2.seq_p = seq_p;
+        if ((a2.seq_h = bdk_sp_next_seq(c->comm)) < 0) return fail(too_many);
+        BD_TRY(bdk_rms_sp(a2, st));
+        BD_TRY(sp_arm_wait(c, a2.seq_h, st));
+        BD_TRY(gemm(c, "llm.gu", bdk_sp_hbuf(c->comm), RB, wref(c, pre + "wgu"), 2 * F, D, gg.S, gg.code(), BD_EPI_SWIGLU,
+                    (float*)c->wptr("llm.gu_part"), c->wptr("llm.act_frag"), nullptr, st));
+        BD_TRY(linear_rowsplit_sp(c, "llm.down", c->ptr("llm.act_frag"), RB, wref(c, pre + "wdown"), D, F, gd, "llm.br_part", "llm.tp_part", M, &seq_p, st));
+    }
+    if (!c->geti("rt.no_advance", 0)) {
+        StepAdvanceArgs sa{state, nseq, c->Pn};
+        BD_TRY(bdk_step_advance(sa, st));
+    }
+    RmsSpArgs af = a1;
+    af.r.w = c->ptr("llm.final_norm");
+    af.part = seq_p ? (const float*)c->ptr("llm.tp_part") : nullptr; af.seq_p = seq_p;
+    if ((af.seq_h = bdk_sp_next_seq(c->comm)) < 0) return fail(too_many);
+    af.final_rows = 1; af.final_off = (long long)Mp * D * 2;
+    BD_TRY(bdk_rms_sp(af, st));
+    SpFinalRowsArgs fr;
+    if (!bdk_sp_hwait(c->comm, af.seq_h, M, &fr.w)) return fail("sequence-parallel exchange: no flag block");
+    fr.rows = (const float*)((const char*)bdk_sp_hbuf(c->comm) + af.final_off);
+    fr.hidden_out = (float*)c->wptr("llm.hidden");
+    const bool emit = c->geti("rt.emit_cond", 1) != 0 && c->has_head;
+    fr.cond_frag = emit ? c->wptr("head.cond_frag") : nullptr;
+    fr.pos = emit ? (const float*)c->ptr("pos") : nullptr;
+    fr.state = state; fr.M = M; fr.D = D; fr.RB = RB; fr.P = c->Pn;
+    BD_TRY(bdk_sp_final_rows(fr, st));
+    return 0;
+}
+
 static int llm_step(bd_ctx* c, hipStream_t st) {
     if (c->lvariant == 1) return llm_step_in(c, st);
+    // (the once-per-image prefill -- causal blocks of prompt tokens, bf16 hidden states -- keeps the all-reduce form)
+    if (c->sp_llm && !c->geti("rt.llm_causal", 0) && !c->geti("rt.llm_bf16", 0)) return llm_step_sp(c, st);
     // nh / nkv / F: this rank's q heads, kv heads and FFN features (the full counts at tp = 1)
     const int D = c->lD, F = c->lFl, Mp = c->Mpad, RB = c->RB, M = c->M, nh = c->lnhl, nkv = c->lnkvl;
     const int nseq = c->branches * c->B;

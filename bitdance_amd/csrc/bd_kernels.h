@@ -360,6 +360,28 @@ struct HeadFinalSpArgs {
     int signal_p = 1;
 };
 int bdk_head_final_sp(const HeadFinalSpArgs& a, hipStream_t st);
+// The Qwen3 decode step on the same hand-off (round 6): residual stream rows OWNED by a rank, RMSNorm on the owner, bf16 operand rows to
+// every rank (rms_sp_kernel); the step's final-norm rows travel as fp32 and every rank finishes hidden state / next condition itself.
+struct RmsSpArgs {
+    RmsArgs r;                 // R (fp32 residual, rows at their global index), w, eps, M, D, RB, P, pos, state; pend / a_frag unused;
+                               // hidden_out / cond_frag are written by sp_final_rows_kernel, not here
+    BdSpLink L;
+    const float* part = nullptr;   // this rank's own fp32 partial [Mpad][D] of the pending row-split Linear (o_proj / down_proj); null: none
+    int seq_p = 0, seq_h = 0;      // hand-off of the partials (0: none) / of this kernel's rows
+    int rows_local = 0;
+    int signal_p = 1;
+    int final_rows = 0;            // 1: the step's final norm -- fp32 rows w * normed, row-major [M][D], instead of bf16 operand fragments
+    long long final_off = 0;       //    ... at this byte offset of the landing buffers (behind the operand region)
+};
+int bdk_rms_sp(const RmsSpArgs& a, hipStream_t st);
+struct SpFinalRowsArgs {       // every rank, after the final rms_sp: hidden_out = row, cond_frag = bf16(row + pos)   (rms_kernel's tail, HF:59-64, t2i:244-245)
+    BdHWait w;                 // per-row flags of the final hand-off
+    const float* rows;         // local landing buffer, fp32 row-major [M][D]
+    float* hidden_out; void* cond_frag; const float* pos; const BdStepState* state;
+    int M, D, RB, P;
+};
+int bdk_sp_final_rows(const SpFinalRowsArgs& a, hipStream_t st);
+
 struct TokFinishArgs {         // after the final evaluation: every rank assembles pred / tokens of ALL patch positions from the gathered latent rows
     BdSpLink L;
     int seq_f = 0;

@@ -432,6 +432,115 @@ int bdk_tok_finish(const TokFinishArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Qwen3 decode step, sequence-parallel (round 6): R (+= bf16(sum of the ranks' o_proj / down_proj partials)) and
+// RMSNorm for the rows THIS RANK owns, operand rows to every rank                         HF modeling_qwen3.py:59-64, 294-323
+// The arithmetic is rms_kernel's (bd_rows.hip) on the value tp_allreduce_kernel would have produced: partials summed in rank order,
+// rounded once to bf16, added to the fp32 residual -- the two forms agree bit for bit.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MAX_ROW_THREADS) void rms_sp_kernel(RmsSpArgs a) {
+    __shared__ float red[32];
+    __shared__ int alive_sh;
+    const BdSpLink& L = a.L;
+    const int lr = blockIdx.x, d0 = threadIdx.x * 8, D = a.r.D;
+    const int m = sp_row(L.rank, L.size, lr);
+    const bool active = d0 < D;
+    float r[8];
+    u32x4 wr = {0, 0, 0, 0}, own0 = wr, own1 = wr;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = 0.f;
+    if (active) {                                              // everything local is in flight before the wait
+        wr = ld_raw8((const bf16_t*)a.r.w + d0);
+        ld_f32x8(a.r.R + (size_t)m * D + d0, r);
+        if (a.part) {
+            const u32x4* src = reinterpret_cast<const u32x4*>(a.part + (size_t)m * D + d0);
+            own0 = src[0]; own1 = src[1];
+        }
+    }
+    if (a.part) {
+        const int e = sp_epoch(L, a.seq_p);
+        if (blockIdx.x == 0 && a.signal_p) sp_signal_p(L, e);
+        if (!sp_wait_p(L, e, &alive_sh)) return;
+    }
+    float ss = 0.f;
+    if (active) {
+        if (a.part) {
+            float o[8];
+            sp_reduce8(L, sp_rsrc(L.stage[L.rank], L.stage_bytes), a.rows_local, D, lr, d0, own0, own1, nullptr, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = r[j] + o[j];            // fp32 residual + bf16 branch (decode; the prefill keeps the all-reduce form)
+            st_f32x8(a.r.R + (size_t)m * D + d0, r);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += r[j] * r[j];
+    }
+    const float rs = rsqrtf(block_sum(ss, red) / (float)D + a.r.eps);
+    if (active) {
+        float w[8], n[8];
+        unpack8(wr, w);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) n[j] = fmul(w[j], fmul(r[j], rs));
+        if (a.final_rows) {                                            // fp32 rows, row-major, into every rank's landing buffer
+            const u32x4 v0 = {__float_as_uint(n[0]), __float_as_uint(n[1]), __float_as_uint(n[2]), __float_as_uint(n[3])};
+            const u32x4 v1 = {__float_as_uint(n[4]), __float_as_uint(n[5]), __float_as_uint(n[6]), __float_as_uint(n[7])};
+            const unsigned off = (unsigned)(a.final_off + ((size_t)m * D + d0) * 4);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < L.size) {
+                    __builtin_amdgcn_raw_buffer_store_b128(v0, sp_rsrc(L.hbuf[q], L.hbuf_bytes), off, 0, BD_SYS_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(v1, sp_rsrc(L.hbuf[q], L.hbuf_bytes), off + 16, 0, BD_SYS_AUX);
+                }
+        } else {
+            const u32x4 hv = pack8(n);                                 // cast by the next Linear
+            const unsigned off = (unsigned)(afrag_off(m, d0, a.r.RB) * 2);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < L.size) __builtin_amdgcn_raw_buffer_store_b128(hv, sp_rsrc(L.hbuf[q], L.hbuf_bytes), off, 0, BD_SYS_AUX);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < L.size) {
+        const int e = sp_epoch(L, a.seq_h);
+        int* const dst = L.loopback ? L.spf_local + BD_SP_H + sp_row(t, L.size, lr) : L.spf[t] + BD_SP_H + m;
+        __hip_atomic_store(dst, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+int bdk_rms_sp(const RmsSpArgs& a, hipStream_t st) {
+    const int t = row_threads(a.r.D);
+    if (t < 0 || a.r.D % 8 || a.r.a8_scale || a.r.bf16_stream || a.rows_local < 1 || a.rows_local % 8 || a.r.M > BD_SP_MAXROWS) return -2;
+    if ((a.final_rows ? a.final_off + (long long)a.r.M * a.r.D * 4 : (long long)a.r.M * a.r.D * 2) > a.L.hbuf_bytes) return -3;
+    BD_LAUNCH(rms_sp_kernel, dim3(a.rows_local), dim3(t), 0, st, a);
+    return bd_launch_status();
+}
+
+// every rank: the final-norm rows of ALL sequences have landed (per-row flags, the GEMM prologue's wait + invalidate) -> hidden state
+// and the next patch's condition, exactly rms_kernel's tail
+__global__ __launch_bounds__(MAX_ROW_THREADS) void sp_final_rows_kernel(SpFinalRowsArgs a) {
+    const int m = blockIdx.x, d0 = threadIdx.x * 8;
+    BdHWait w = a.w;
+    w.flags = a.w.flags + m; w.n = 1;                              // this workgroup's row only
+    gemm_hwait(w, threadIdx.x, blockDim.x);
+    if (d0 >= a.D) return;
+    float n[8];
+    ld_f32x8(a.rows + (size_t)m * a.D + d0, n);
+    if (a.hidden_out) st_f32x8(a.hidden_out + (size_t)m * a.D + d0, n);
+    if (a.cond_frag) {
+        float p[8];
+        ld_f32x8(a.pos + ((size_t)a.state->step * a.P + (m % a.P)) * a.D + d0, p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[j] = fadd(n[j], p[j]);
+        *reinterpret_cast<u32x4*>((bf16_t*)a.cond_frag + afrag_off(m, d0, a.RB)) = pack8(p);
+    }
+}
+int bdk_sp_final_rows(const SpFinalRowsArgs& a, hipStream_t st) {
+    const int t = row_threads(a.D);
+    if (t < 0 || a.D % 8 || a.M > BD_SP_MAXROWS || !a.w.flags) return -2;
+    BD_LAUNCH(sp_final_rows_kernel, dim3(a.M), dim3(t), 0, st, a);
+    return bd_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Construction-time self-test of THIS hand-off (the all-reduce self-test does not reach it).  What is specific to the
 // sequence-parallel form is the operand landing buffer: ordinary CACHEABLE device memory that other GPUs write with sc0 sc1 stores and
 // that this GPU re-reads through its L2 after one `buffer_inv sc0 sc1` (bd_hwait.h) -- one-GPU tests cannot show a stale line there.

@@ -430,7 +430,20 @@ class Engine:
                 raise BitDanceHipError("tp.seq: sequence-parallel row kernels need 128 rows (one image with CFG, parallel_num 64), whole 8-row "
                                        "groups of patch positions per rank, bf16 activations and a communicator with an operand landing buffer")
         ints["tp.seq"] = int(self.seq_parallel)
-        if self.seq_parallel and "tune.sp_wait" not in ints and getattr(self.comm, "shares_gpu", False):
+        # ... and the Qwen3 decode step on the same hand-off (csrc/bd_sp.hip rms_sp_kernel; "tp.llm_seq"): the same conditions and the
+        # same default (the prefill, eager and once per image, keeps the all-reduce form inside the same context)
+        self.llm_seq_parallel = False
+        if self.comm is not None and llm is not None and self.comm.backend in ("ipc", "none") and self.comm.hbuf_bytes > 0:
+            sp_ok = getattr(self.comm, "sp_ok", None)
+            trusted = sp_ok is True or (sp_ok is None and (getattr(self.comm, "in_process_peers", False) or getattr(self.comm, "loopback", False)))
+            okl = (self.M == 128 and (self.M // 8) % self.comm.size == 0 and self.wdtype in (0, 1) and llm.cfg["head_dim"] == 128
+                   and self.comm.hbuf_bytes >= 128 * llm.cfg["hidden_size"] * 6 and not getattr(self.comm, "fences", 0) and sp_ok is not False)
+            self.llm_seq_parallel = bool(ints.get("tp.llm_seq", 1 if (self.comm.size <= 4 and trusted) else 0)) and okl
+            if ints.get("tp.llm_seq", 0) and not okl:
+                raise BitDanceHipError("tp.llm_seq: the sequence-parallel Qwen3 step needs 128 rows in whole 8-row groups per rank, bf16 activations "
+                                       "and a communicator with an operand landing buffer of rows x hidden x 6 bytes whose hand-off self-test passed")
+        ints["tp.llm_seq"] = int(self.llm_seq_parallel)
+        if (self.seq_parallel or self.llm_seq_parallel) and "tune.sp_wait" not in ints and getattr(self.comm, "shares_gpu", False):
             ints["tune.sp_wait"] = 0
         for k, v in ints.items():
             check(self.l.bd_ctx_set_int(self.ctx, k.encode(), int(v)))

@@ -105,9 +105,12 @@ def ada_gather_bytes(rows: int, ada_cols: int, group: int | None = None) -> int:
 
 def seq_hbuf_bytes(rows: int, width: int) -> int:
     """Capacity of the operand landing buffer of the sequence-parallel exchange (csrc/bd_sp.hip): the bf16 operand rows every rank
-    pushes to every rank, [padded rows][width].  rows = branches * num_images * parallel_num; 0 where that form does not apply (it is
-    built for 128-row passes: one image, 64-token patches)."""
-    return rows * width * 2 if rows == 128 else 0
+    pushes to every rank, [padded rows][width], followed by the landing area of the one fp32 hand-off of the path, the Qwen3 step's
+    final-norm rows (rms_sp_kernel -> sp_final_rows_kernel: hidden state and the next patch's condition are assembled on every rank).
+    rows = branches * num_images * parallel_num; 0 where that form does not apply (it is built for 128-row passes: one image,
+    64-token patches)."""
+    return rows * width * 6 if rows == 128 else 0        # bf16 operand region | fp32 final-rows region (never overlaid: a rank may enter the
+                                                         # next phase and push operand rows while a peer still reads the final rows)
 
 
 # ----------------------------------------------------------------------------------------------- communicator

@@ -119,7 +119,7 @@ def head_case(device="cuda", *, D=5120, Dz=None, C=32, P=64, B=1, branches=2, de
 
 
 def head_sample_case(device="cuda", *, D=5120, C=32, P=64, B=1, depth=6, nada=2, head_dim=128, n_steps=4, cfg=1.25, seed=131,
-                     tune: dict | None = None, weights: str = "bf16") -> dict:
+                     tune: dict | None = None, weights: str = "bf16", fp32_floor: bool = False) -> dict:
     """``DiffHead.sample`` at true width: n_steps + 1 CHAINED evaluations of the ``depth``-block head with classifier-free
     guidance ``cfg`` (sampling_x.py:44-97 driving flow_head_parallel_x.py:325-342), device vs oracle on the same noise.  At a
     guidance scale near 1 the chain is contractive, so the bound is a statement about the implementations, not about chaos
@@ -149,9 +149,22 @@ def head_sample_case(device="cuda", *, D=5120, C=32, P=64, B=1, depth=6, nada=2,
     t_cpu = time.perf_counter() - t0
     err = (pred - ref).abs()
     agree = (torch.sign(pred) == torch.sign(ref)).float().mean().item()
-    return {"max_err": err.max().item(), "mean_err": err.mean().item(), "ref_abs_mean": ref.abs().mean().item(),
-            "finite": bool(torch.isfinite(pred).all()), "tokens_are_sign_of_pred": bool(torch.equal(tok, torch.sign(pred))),
-            "token_agreement": agree, "evaluations": n_steps + 1, "t_cpu_s": t_cpu}
+    out = {"max_err": err.max().item(), "mean_err": err.mean().item(), "ref_abs_mean": ref.abs().mean().item(),
+           "finite": bool(torch.isfinite(pred).all()), "tokens_are_sign_of_pred": bool(torch.equal(tok, torch.sign(pred))),
+           "token_agreement": agree, "evaluations": n_steps + 1, "t_cpu_s": t_cpu}
+    if fp32_floor:
+        # the noise floor the device is judged against: how far the REFERENCE'S OWN bf16-autocast arithmetic lands from exact (fp32)
+        # arithmetic after the same chain on the same noise -- two bf16 implementations cannot be expected to agree better than that
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            ref32 = diff_head.sample(sd, z, cfg, n_steps, list(noise), Policy("fp32"))[:B]
+        e_floor, e_dev32 = (ref - ref32).abs(), (pred - ref32).abs()
+        out.update({"floor_max_err": e_floor.max().item(), "floor_mean_err": e_floor.mean().item(),
+                    "floor_token_agreement": (torch.sign(ref) == torch.sign(ref32)).float().mean().item(),
+                    "dev_vs_fp32_max_err": e_dev32.max().item(), "dev_vs_fp32_mean_err": e_dev32.mean().item(),
+                    "dev_vs_fp32_token_agreement": (torch.sign(pred) == torch.sign(ref32)).float().mean().item(),
+                    "t_cpu_fp32_s": time.perf_counter() - t0})
+    return out
 
 
 def ae_case(device="cuda", *, config: str = "AE_D16C32", px: int = 256, seed: int = 5, repeats: int = 1) -> dict:

@@ -15,10 +15,16 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
+    config.addinivalue_line("markers", "slow: minutes of CPU oracle beside the GPU run; only with BD_RUN_SLOW=1")
 
 
 def pytest_collection_modifyitems(config, items):
     import torch
+    if not os.environ.get("BD_RUN_SLOW"):
+        skip_slow = pytest.mark.skip(reason="slow characterisation run: set BD_RUN_SLOW=1")
+        for item in items:
+            if "slow" in item.keywords:
+                item.add_marker(skip_slow)
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU visible")

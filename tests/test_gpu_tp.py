@@ -936,3 +936,74 @@ def test_sequence_parallel_epochs_across_the_wrap(rc0):
         del engs, comms
     for run, (a, b) in enumerate(zip(outs[0], outs[1])):
         assert torch.equal(a, b), f"run {run}: sequence-parallel differs from the all-reduce form across the epoch boundary"
+
+
+@pytest.mark.parametrize("dims,tp,layers", [("tiny", 2, 2), ("14b", 2, 2), ("14b", 4, 1)])
+def test_llm_step_sequence_parallel_equals_allreduce_form(dims, tp, layers):
+    """The Qwen3 decode step with sequence-parallel row kernels (csrc/bd_sp.hip rms_sp_kernel + sp_final_rows_kernel, "tp.llm_seq" = 1:
+    a rank owns rows / tp rows of the fp32 residual stream; o_proj / down_proj push their partial rows to the owners, the owner sums in
+    rank order, rounds once to bf16, adds, RMS-normalises and pushes the operand rows to every rank; q/k/v and gate/up wait for them in
+    their prologue; the final norm's rows travel as fp32 and every rank writes the hidden state itself) against the all-reduce form
+    ("tp.llm_seq" = 0: tp_allreduce_kernel + replicated rms_kernel; HF modeling_qwen3.py:294-323): every element is computed once from
+    the same partials in the same order, so hidden states, appended K / V and the owners' residual rows are BIT-identical -- between the
+    forms and between the ranks -- on two consecutive steps (epochs advance, nothing is reset).  tiny: 4 q / 2 kv heads; 14b: the true
+    Qwen3-14B layer (D = 5120, 40 / 8 heads, FFN 17408) at the launch configurations of the tp shard, two sequences x 64 tokens = 128 rows."""
+    from bitdance_amd import engine as E
+    from bitdance_amd.tp import TPComm, seq_hbuf_bytes
+    from oracle.true_dims import QWEN3_14B
+    P = 64
+    c = dict(tm.TINY_LLM if dims == "tiny" else QWEN3_14B, num_hidden_layers=layers)
+    sd = {k: v.to(torch.bfloat16) for k, v in device_seeded_state(tm.llm_shapes(c), 22, DEV).items()}
+    L, nkv, hd, D = layers, c["num_key_value_heads"], c["head_dim"], c["hidden_size"]
+    pasts = [(75, 40), (139, 104)]                                # second step: the first step's tokens appended
+    g = torch.Generator(device=DEV).manual_seed(5)
+    xs = [torch.randn(2 * P, D, device=DEV, generator=g) for _ in pasts]
+    kfill = torch.randn(L, 2, nkv, 64, hd, device=DEV, generator=g).to(torch.bfloat16)        # cached keys / values of the first 64 positions
+    vfill = torch.randn(L, 2, nkv, hd, 64, device=DEV, generator=g).to(torch.bfloat16)
+    lws = [E.LlmWeights.from_state_dict(sd, c, DEV, keep_for_prefill=False, tp_rank=r, tp_size=tp) for r in range(tp)]
+    del sd
+    streams = _streams(tp)
+    outs = {}
+    for seq in (0, 1):
+        comms = TPComm.in_process(tp, 128 * D, DEV, hbuf_bytes=seq_hbuf_bytes(128, D))
+        for cm in comms:
+            cm.set_timeout(8.0)
+        engs = [E.Engine(None, None, lws[r], num_images=1, branches=2, device=DEV, max_tokens=P, max_kv=256, comm=comms[r],
+                         extra_ints={"tp.llm_seq": seq}) for r in range(tp)]
+        assert all(e.llm_seq_parallel == bool(seq) for e in engs)
+        n = nkv // tp
+        for r, e in enumerate(engs):
+            e.ws["llm.k_cache"].view(torch.bfloat16).view(L, 2, n, e.Lmax, hd)[:, :, :, :64] = kfill[:, :, r * n:(r + 1) * n]
+            e.ws["llm.vt_cache"].view(torch.bfloat16).view(L, 2, n, hd, e.Lmax)[:, :, :, :, :64] = vfill[:, :, r * n:(r + 1) * n]
+            e.set_int("rt.emit_cond", 0)
+        torch.cuda.synchronize()
+        res = []
+        for step, past in enumerate(pasts):
+            for r in range(tp):
+                with torch.cuda.stream(streams[r]):
+                    if step == 0:
+                        engs[r].reset(list(past))                  # (step 1 continues from the lengths step 0 advanced to)
+                    engs[r].residual()[:2 * P].copy_(xs[step])
+                    engs[r].llm_step()
+            torch.cuda.synchronize()
+            for cm in comms:
+                cm.check()
+            hs = [e.hidden().clone() for e in engs]
+            for r in range(1, tp):
+                assert torch.equal(hs[r], hs[0]), f"rank {r} diverged (llm_seq {seq}, step {step})"
+            assert torch.isfinite(hs[0]).all()
+            kv = [(e.ws["llm.k_cache"].clone(), e.ws["llm.vt_cache"].clone()) for e in engs]
+            # the residual rows a rank OWNS (8-row groups dealt round-robin); the all-reduce form keeps every row on every rank
+            own = [torch.cat([e.residual()[g8 * 8:(g8 + 1) * 8] for g8 in range(r, 16, tp)]).clone() for r, e in enumerate(engs)]
+            res.append((hs[0], kv, own))
+        assert comms[0].exchanges() == 2 * L * len(pasts)
+        assert comms[0].prepushed() == comms[0].exchanges()        # every partial left in a GEMM epilogue (both forms fuse the push at 128 rows)
+        outs[seq] = res
+        del engs, comms
+    for step in range(len(pasts)):
+        h0, kv0, own0 = outs[0][step]
+        h1, kv1, own1 = outs[1][step]
+        assert torch.equal(h0, h1), (step, (h0 - h1).abs().max())
+        for r in range(tp):
+            assert torch.equal(kv0[r][0], kv1[r][0]) and torch.equal(kv0[r][1], kv1[r][1]), (step, r)
+            assert torch.equal(own0[r], own1[r]), (step, r)

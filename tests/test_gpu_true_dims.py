@@ -70,6 +70,26 @@ def test_head_sample_chain_true_dims_vs_oracle():
     assert r["mean_err"] <= 0.03 and r["max_err"] <= 0.21 and r["token_agreement"] >= 0.975, r
 
 
+@pytest.mark.slow
+def test_head_sample_full_depth_true_dims_vs_oracle_and_fp32_floor():
+    """The sampler at the depth the headline runs: DiffHead.sample with N = 50 and guidance 7.5
+    (sampling_x.py:44-97, t2i_pipeline.py:110-118 defaults) = 51 chained evaluations of the 6-block head at D = 5120, device vs the
+    oracle (bf16-autocast policy) on identical noise -- and, on the same noise, the oracle under autocast vs the oracle in fp32: how far
+    a bf16 REFERENCE is from exact arithmetic after this chain, i.e. the floor below which two bf16 implementations cannot agree.
+    ~10 minutes of CPU oracle: run with BD_RUN_SLOW=1; measured numbers in DESIGN.md section 4."""
+    from oracle.true_dims import head_sample_case
+    r = head_sample_case(D=5120, depth=6, nada=2, n_steps=50, cfg=7.5, fp32_floor=True)
+    print(f"[head sample D=5120, 51 evaluations, cfg 7.5] device vs oracle(autocast): max {r['max_err']:.4f} mean {r['mean_err']:.5f} tokens {r['token_agreement']:.4f} | "
+          f"oracle(autocast) vs oracle(fp32): max {r['floor_max_err']:.4f} mean {r['floor_mean_err']:.5f} tokens {r['floor_token_agreement']:.4f} | "
+          f"device vs oracle(fp32): max {r['dev_vs_fp32_max_err']:.4f} mean {r['dev_vs_fp32_mean_err']:.5f} tokens {r['dev_vs_fp32_token_agreement']:.4f} "
+          f"(|latent| mean {r['ref_abs_mean']:.3f}; oracle {r['t_cpu_s']:.0f} + {r['t_cpu_fp32_s']:.0f} s)")
+    assert r["finite"] and r["tokens_are_sign_of_pred"], r
+    # the device must sit no further from the bf16 reference than 1.5 x the distance of that reference from exact arithmetic
+    # (both are one bf16 rounding history away from the fp32 chain), and agree with it on the tokens at least as well
+    assert r["mean_err"] <= 1.5 * r["floor_mean_err"] + 1e-3, r
+    assert r["token_agreement"] >= r["floor_token_agreement"] - 0.02, r
+
+
 def test_ar_step_across_the_seam_true_dims_vs_oracle():
     """ONE AR step across the head -> LLM -> head seam at D = 5120 (t2i_pipeline.py:241-270): DiffHead.sample (N = 8, guidance 1.25,
     the full 6-block head) -> sign -> projector + position embedding -> ONE Qwen3-14B decoder layer step of the cond / uncond

@@ -272,12 +272,13 @@ def test_tensor_parallel_shard_launch_rules():
 
 def test_tensor_parallel_buffer_sizes():
     """tp.ada_gather_bytes: TWO slots of one group's modulation tensor (double-buffered by group parity: a peer may push group
-    g + 1 while this rank still reads g); tp.seq_hbuf_bytes: the bf16 operand rows of a 128-row pass, nothing for other row counts."""
+    g + 1 while this rank still reads g); tp.seq_hbuf_bytes: the operand rows of a 128-row pass (+ the fp32 landing area of the Qwen3 step's
+    final hand-off), nothing for other row counts."""
     from bitdance_amd.tp import ada_gather_bytes, seq_hbuf_bytes
     assert ada_gather_bytes(128, 14 * 5120) == 2 * 4 * 128 * 14 * 5120 * 2
     assert ada_gather_bytes(32, 14 * 5120) == 2 * 16 * 32 * 14 * 5120 * 2
     assert ada_gather_bytes(512, 14 * 5120) == 2 * 2 * 512 * 14 * 5120 * 2 and ada_gather_bytes(2048, 1024) == 0
-    assert seq_hbuf_bytes(128, 5120) == 128 * 5120 * 2 and seq_hbuf_bytes(512, 5120) == 0 and seq_hbuf_bytes(32, 5120) == 0
+    assert seq_hbuf_bytes(128, 5120) == 128 * 5120 * 6 and seq_hbuf_bytes(512, 5120) == 0 and seq_hbuf_bytes(32, 5120) == 0
 
 
 def test_small_weight_tile_rule_for_the_imagenet_batches():
