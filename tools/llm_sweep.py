@@ -34,6 +34,11 @@ def main():
 
 
 def run():
+    shard = None
+    if "--tp-shard" in sys.argv:                             # ONE rank's critical path at the tensor-parallel shard, in loop-back (tools/head_sweep.py)
+        i = sys.argv.index("--tp-shard")
+        shard = tuple(int(v) for v in sys.argv[i + 1].split("/"))
+        del sys.argv[i:i + 2]
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     cfgs = list(DEFAULT)
     if len(sys.argv) > 2:
@@ -42,7 +47,14 @@ def run():
     cfg = dict(syn.QWEN3_14B)
     cfg["num_hidden_layers"] = LAYERS
     cfg["vocab_size"] = 1024
-    lw = E.LlmWeights.from_state_dict(syn.random_llm_state(cfg, dev), cfg, dev, keep_for_prefill=False)
+    if shard:
+        lw = E.LlmWeights.from_state_dict(syn.random_llm_state(cfg, dev), cfg, dev, keep_for_prefill=False, tp_rank=shard[0], tp_size=shard[1])
+        print(f"# rank {shard[0]} of {shard[1]} in loop-back: this rank's weight slices, peers' buffers are scratch, flags written locally "
+              f"(values are meaningless: the peers contribute zeros)", flush=True)
+        if len(sys.argv) <= 2:
+            cfgs = [{"tp.llm_seq": 0}, {"tp.llm_seq": 1}, {"tp.llm_seq": 0}, {"tp.llm_seq": 1}]
+    else:
+        lw = E.LlmWeights.from_state_dict(syn.random_llm_state(cfg, dev), cfg, dev, keep_for_prefill=False)
     g = torch.Generator(device=dev).manual_seed(3)
     x = torch.randn(128, cfg["hidden_size"], device=dev, generator=g)
     ref = None
@@ -50,9 +62,18 @@ def run():
     for tune in cfgs:
         tune = dict(tune)
         splits = tune.pop("splits", 8)
+        extra = {k: tune.pop(k) for k in list(tune) if k.startswith("tp.")}
+        comm = None
+        if shard:
+            from bitdance_amd.tp import TPComm, seq_hbuf_bytes
+            comm = TPComm.loopback_rank(shard[0], shard[1], 128 * 5120, dev, hbuf_bytes=seq_hbuf_bytes(128, 5120))
+            comm.set_timeout(5.0)
         eng = E.Engine(None, None, lw, num_images=1, branches=2, device=dev, max_tokens=64, max_kv=past + 256, attn_splits=splits,
-                       tune=tune)
+                       tune=tune, comm=comm, extra_ints=extra or None)
         tune["splits"] = splits
+        tune.update(extra)
+        if shard:
+            tune["llm_seq"] = int(eng.llm_seq_parallel)
         eng.set_int("rt.emit_cond", 0)                      # no head in this context
         st = torch.cuda.current_stream()
 
@@ -82,7 +103,9 @@ def run():
         cf = "  ".join(f"{n}:S{eng.gemm_config('llm.' + n)[0]}w{eng.gemm_config('llm.' + n)[1]}" for n in ("qkv", "o", "gu", "down"))
         print(f"{str(tune):75s} {min(ts) / LAYERS * 1e3:7.1f} us/layer (median {sorted(ts)[len(ts) // 2] / LAYERS * 1e3:7.1f})  GEMM us: {per}  "
               f"[{cf}]  max|d hidden| vs first {err:.3g}", flush=True)
-        del eng
+        if comm is not None:
+            comm.check()
+        del eng, comm
         torch.cuda.empty_cache()
 
 
