@@ -751,7 +751,11 @@ static int linear(bd_ctx* c, const char* name, const void* A, int RB, WRef W, in
     // 256-row passes run the 4-wave x 2-panel kernel, which has no in-launch reduction: slabs for the consumer there
     // (round 5: at 512 rows and more the 256-row kernel reduces TWO slices in the launch too -- the consumers stop reading fp32 slabs)
     // -- for the wide weights of the 14B models on the 8-wave 256-row kernel, the forms measured; the ImageNet batches keep their rules)
-    const bool wide_red = c->Mpad >= 512 && (double)N * K * 2 > 12e6 && (g.nw & 15) == 8 && g.kw == 1 && !c->wfp8;
+    // (round 6, same box, 512 rows: slabs + finalize_rows 2339 us per evaluation against 2374 with the two slices reduced in the launch,
+    //  even with the ticket-first form and the 16 B epilogues -- the reducing workgroup's tail (wait for the partner's drain, 256 KiB of
+    //  write-through slab back through one CU, epilogue) is 17 us median against 6 for plain slabs, profiles/r06_launch_anatomy.log;
+    //  "tune.reduce_max_s" = 2 selects the in-launch reduction there)
+    const bool wide_red = false && c->Mpad >= 512 && (double)N * K * 2 > 12e6 && (g.nw & 15) == 8 && g.kw == 1 && !c->wfp8;
     const int max_s = (int)c->geti("tune.reduce_max_s", (c->Mpad % 256 == 0) ? (wide_red ? 2 : 0) : 2);
     if (g.S <= max_s || g.S == 1 || force_reduce) {            // a single slice needs no reduction: bias + rounding in the epilogue
         BD_TRY(gemm(c, name, A, RB, W, N, K, g.S, g.code(), BD_EPI_BF16, (float*)c->wptr(scratch_ws), c->wptr(out_ws), bias, st));
