@@ -86,7 +86,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-b4", action="store_true", help="headline workload on one GPU: skip the extra num_images=4 point (SURVEY 8(d): the eval scripts' batch)")
     ap.add_argument("--no-throughput", action="store_true", help="headline workload on one GPU: skip the extra saturated-batch point")
-    ap.add_argument("--throughput-images", type=int, default=8, help="num_images of the `throughput` point (default 8; 16 gives ~5 %% more and takes twice as long)")
+    ap.add_argument("--throughput-images", type=int, default=16, help="num_images of the `throughput` point (default 16: where one GPU saturates -- 0.55 / 0.575 / 0.576 images/s at 8 / 16 / 32)")
     ap.add_argument("--no-replicas", action="store_true", help="N > 1, tensor parallel: skip the independent-replicas point timed after the tensor-parallel pass")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="imagenet: skip the conv decoder in the timed pass")
@@ -253,7 +253,7 @@ def gemm_roofline(eng, run, rows: int) -> dict:
     # wide-read correction: tools/pmc_gemm_traffic.py -> profiles/r0*_pmc_gemm_traffic.json), weighted by this step's
     # launch mix; only valid for the shapes / launch configs that pass measured, else null
     traffic, traffic_src = None, None
-    for fn in ("r05_pmc_gemm_traffic.json", "archive/r04_pmc_gemm_traffic.json"):
+    for fn in ("r06_pmc_gemm_traffic.json", "r05_pmc_gemm_traffic.json"):
         pj = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(pj) or rows != 128:
             continue

@@ -168,6 +168,20 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
         const int cap = (int)std::floor(operands / slab);
         if (S > std::max(1, cap) && c->geti("tune.slab_cap", 1) != 0) S = std::max(1, cap);
     }
+    // >= 1024 rows and FEW 256 x 256 tiles (the N = 5120 Linears of the 14B models: 80 tiles at 8 images, 160 at 16 -- 31 / 62 % of the CUs at
+    // one K slice): pick the slice count that fills whole waves of 256 workgroups, charging 3 % per extra fp32 slab.  Measured (round 6,
+    // tools/head_sweep.py, us per evaluation): 8 images wo / w2 at 3 slices 3613 vs 3819 at 2 (4: 3940, 1: 4305); 16 images 3 slices 6929 vs
+    // 7185 at 1 (2: 7332).  512 rows keep their 5 slices (6 measured slower: 13-stage loops are all ramp), small weights their cap above.
+    if (two_images && row_tiles >= 4 && !swiglu && g.nw >= 8 && (double)N * K * 2 > 12e6 && ntiles * row_tiles < 1024 &&
+        (double)((ntiles * row_tiles + 255) / 256 * 256) / (ntiles * row_tiles) > 1.2 && c->geti("tune.fill_waves", 1) != 0) {
+        const int W0 = ntiles * row_tiles;                     // (a last wave of workgroups less than ~83 % full at one slice)
+        double best = 1e30;
+        for (int s_ = 1; s_ <= 6; ++s_) {
+            const int wgs = W0 * s_;
+            const double cost = (double)((wgs + 255) / 256 * 256) / wgs * (1.0 + 0.03 * (s_ - 1));
+            if (cost < best - 1e-9) { best = cost; S = s_; }
+        }
+    }
     if (ntiles >= 260 && !swiglu && row_tiles == 1) S = 3;   // > 1 wave of workgroups: split for tail balance
     if (swiglu && ntiles >= 130) S = 1;
     const bool kw2_shape = !two_images && K % 128 == 0 && N % 64 == 0 && g.nw != 10;
@@ -254,7 +268,7 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
 static const char* const kIntKeys[] = {
     "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid", "head.y_evals", "head.variant",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "proj.rows_all", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
-    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "rt.in_first", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.ragged", "tune.ragged52", "tune.slab_cap", "tune.slab3",
+    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "rt.in_first", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.fill_waves", "tune.ragged", "tune.ragged52", "tune.slab_cap", "tune.slab3",
     "tune.ada_group", "tune.ada_group_nw", "tune.tp_fuse", "tune.ln_rows", "tune.small_tiles_rows", "tp.ada_split", "tp.seq", "tp.llm_seq", "tune.sp_wait", "tune.sp_inv", "tune.finalize_s", "tune.sp_gsig", "tune.tp_shapes"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
                                          "llm.qkv", "llm.o", "llm.gu", "llm.down"};

@@ -104,8 +104,8 @@ struct ArArgs {
 BD_DEV void tp_signal(const ArArgs& a, int base, int b, int e) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int t = threadIdx.x;
-    if (t < a.size && t != a.rank) {
+    const int t = bd_spread_lane(a.size);                     // one flag per wave: parallel fabric writes (bd_common.h)
+    if (t >= 0 && t != a.rank) {
         if (a.fences) __threadfence_system();
         int* const dst = a.loopback ? a.flags + base + t * BD_TP_GMAX + b : a.peer_flags[t] + base + a.rank * BD_TP_GMAX + b;
         __hip_atomic_store(dst, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -117,10 +117,10 @@ BD_DEV void tp_signal(const ArArgs& a, int base, int b, int e) {
 // others return a silently corrupted image)
 BD_DEV bool tp_wait(const ArArgs& a, int base, int b, int e, int err_index) {
     __shared__ int alive_sh;
-    const int t = threadIdx.x;
-    if (t == 0) alive_sh = 1;
+    if (threadIdx.x == 0) alive_sh = 1;
     __syncthreads();
-    if (t < a.size && t != a.rank) {
+    const int t = bd_spread_lane(a.size);
+    if (t >= 0 && t != a.rank) {
         const int* f = a.flags + base + t * BD_TP_GMAX + b;
         const long long t0 = wall_clock64();
         bool dead = __hip_atomic_load(a.flags + err_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;

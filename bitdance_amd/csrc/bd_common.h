@@ -168,6 +168,16 @@ const char* bdk_stamp_current_label();
 #define BD_STAMPED(ARGS_T, a, name, nwg) const ARGS_T& a##_l = a
 #endif
 
+// n one-lane system-scope flag accesses (one per destination rank) spread over the workgroup's WAVES: lanes 0..n-1 of ONE wave storing to n
+// uncached words leave as n serialized fabric writes (~0.5 us each: ln_mod_sp's "flags raised" phase was 4.1 us at 8 ranks against 1.5 at
+// 2, profiles/r06_launch_anatomy.log) -- lane 0 of wave q stores flag q instead (more destinations than waves: lanes 0, 1, ... of each).
+// Returns the destination this thread handles, or -1.
+BD_DEV int bd_spread_lane(int n) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+    const int q = wave + lane * nw;
+    return (q < n && lane < (n + nw - 1) / nw) ? q : -1;
+}
+
 // Device-resident state of the autoregressive loop, read by every step-dependent kernel so that
 // one captured hipGraph can be replayed for every AR step.
 #define BD_MAX_SEQ 64  // per-sequence KV-length slots: num_images <= 32 with CFG on the Qwen3 path (imagenet sequences share slot 0)

@@ -466,12 +466,14 @@ bool bdk_gemm_claim_push(int epi, int RB, int N, BdTpPush* out) {
 bool bdk_gemm_push_used() { const bool u = g_push_used; g_push_used = false; g_push_set = false; return u; }
 static int g_red_first = 1;
 int bdk_red_first() { return g_red_first; }
+static int g_tile_minrb = 32;                            // row blocks from which the tiled kernel takes over ("tile.minrb": 16 = from 512 rows)
 static int g_tile = 1;                                   // >= 512 rows: the LDS-tiled MFMA-bound kernel (bd_gemm_tile.hip); 0 = 256-row kernel
 int bdk_set_gemm_option(const char* name, int v) {
     const std::string n(name);
     // 0: 256-row kernel; 1: tiled kernel, operand fetch by shape; 2 / 3: tiled kernel, register-staged / LDS-DMA fetch forced
     if (n == "tile" && v >= 0 && v <= 3) { g_tile = v ? 1 : 0; bdk_gemm_tile_stg(v == 2 ? 1 : (v == 3 ? 0 : -1)); return 0; }
     if (n == "tile.debug" && v >= 0 && v <= 3) { bdk_gemm_tile_debug(v); return 0; }
+    if (n == "tile.minrb" && v >= 8 && v % 8 == 0) { g_tile_minrb = v; return 0; }
     if (n == "wide.ring" && (v == 2 || v == 3)) { g_wide_ring = v; return 0; }
     if (n == "wide.xcd" && v >= -1 && v <= 1) { g_wide_xcd = v; return 0; }
     if (n == "wide.keep" && v >= -1 && v <= 1) { g_wide_keep = v; return 0; }
@@ -567,7 +569,7 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
         // >= 512 rows: the matrix pipe is the roofline -> both operands through LDS, 256 x 256 tiles (bd_gemm_tile.hip)
         // (measured, profiles/r03_gemm_tile_v4.log: ahead of the 256-row kernel from 1024 rows on wide N -- adaLN x8 693 vs 786 us,
         // ImageNet w1 89 vs 114 us -- behind it at 512 rows and on narrow N, where it has too few tiles per CU)
-        if (g_tile && RB >= 32 && N >= 4096 && g_w_layout == 0 && !(S > 1 && epi != BD_EPI_PARTIAL)) return bdk_gemm_tile(p, epi, st);
+        if (g_tile && RB >= g_tile_minrb && N >= 4096 && g_w_layout == 0 && !(S > 1 && epi != BD_EPI_PARTIAL)) return bdk_gemm_tile(p, epi, st);
         return launch_gemm_wide(p, epi, st);
     }
 #define BD_CASE(NPV, KWV, MBV, RV) if (np == NPV && kw == KWV && MB == MBV && ring == RV) return launch_gemm<NPV, KWV, MBV, RV>(p, epi, st);

@@ -42,18 +42,18 @@ BD_DEV int sp_row(int rank, int size, int lr) { return (((lr >> 3) * size + rank
 // "every push of my row-split GEMM is at its destination" (the GEMM drained its stores before it ended; this kernel starts behind the
 // kernel boundary): one block tells every peer
 BD_DEV void sp_signal_p(const BdSpLink& L, int e) {
-    const int t = threadIdx.x;
-    if (t < L.size && t != L.rank) {
+    const int t = bd_spread_lane(L.size);                     // one flag per wave: parallel fabric writes (bd_common.h)
+    if (t >= 0 && t != L.rank) {
         int* const dst = L.loopback ? L.spf_local + BD_SP_P + t : L.spf[t] + BD_SP_P + L.rank;
         __hip_atomic_store(dst, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 // all threads call; false (block-uniform): the exchange is dead (a wait ran out of its budget here or on a peer)
 BD_DEV bool sp_wait_p(const BdSpLink& L, int e, int* alive_sh) {
-    const int t = threadIdx.x;
-    if (t == 0) *alive_sh = 1;
+    if (threadIdx.x == 0) *alive_sh = 1;
     __syncthreads();
-    if (t < L.size && t != L.rank) {
+    const int t = bd_spread_lane(L.size);
+    if (t >= 0 && t != L.rank) {
         const int* f = L.spf_local + BD_SP_P + t;
         const long long t0 = wall_clock64();
         bool dead = __hip_atomic_load(L.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
@@ -135,11 +135,16 @@ __global__ __launch_bounds__(MAX_ROW_THREADS) void ln_mod_sp_kernel(LnModSpArgs 
             own0 = src[0]; own1 = src[1];
         }
     }
+#ifdef BD_GEMM_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BD_KSTAMP(a.ln.stamp, 1);
+#endif
     if (a.part) {
         const int e = sp_epoch(L, a.seq_p);
         if (blockIdx.x == 0 && a.signal_p) sp_signal_p(L, e);
         if (!sp_wait_p(L, e, &alive_sh)) return;               // a dead exchange pushes nothing further; the host check raises on every rank
     }
+    BD_KSTAMP(a.ln.stamp, 2);
     if (active) {
         unpack8(xr, x);
         if (a.part) {
@@ -151,8 +156,13 @@ __global__ __launch_bounds__(MAX_ROW_THREADS) void ln_mod_sp_kernel(LnModSpArgs 
             *reinterpret_cast<u32x4*>((bf16_t*)a.ln.X + (size_t)m * D + d0) = pack8(x);
         }
     }
+#ifdef BD_GEMM_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BD_KSTAMP(a.ln.stamp, 3);
+#endif
     float mean, rstd;
     ln_stats(x, active, D, a.ln.eps, red, mean, rstd);
+    BD_KSTAMP(a.ln.stamp, 4);
     if (active) {
         float h[8], sc[8], sf[8];
         unpack8(scr, sc);
@@ -170,9 +180,10 @@ __global__ __launch_bounds__(MAX_ROW_THREADS) void ln_mod_sp_kernel(LnModSpArgs 
             if (q < L.size) __builtin_amdgcn_raw_buffer_store_b128(hv, sp_rsrc(L.hbuf[q], L.hbuf_bytes), off, 0, BD_SYS_AUX);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this row is at every destination ...
+    BD_KSTAMP(a.ln.stamp, 5);
     __syncthreads();
-    const int t = threadIdx.x;
-    if (t < L.size) {                                          // ... then its flag, on every rank (this one included)
+    const int t = bd_spread_lane(L.size);
+    if (t >= 0) {                                              // ... then its flag, on every rank (this one included), one store per wave
         const int e = sp_epoch(L, a.seq_h);
         int* const dst = L.loopback ? L.spf_local + BD_SP_H + sp_row(t, L.size, lr) : L.spf[t] + BD_SP_H + m;
         __hip_atomic_store(dst, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -376,9 +387,10 @@ __global__ __launch_bounds__(640) void head_final_sp_kernel(HeadFinalSpArgs s) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t < L.size) {
+        const int tq = bd_spread_lane(L.size);
+        if (tq >= 0) {
             const int ef = sp_epoch(L, s.seq_f);
-            int* const dst = L.loopback ? L.spf_local + BD_SP_H + sp_row(t, L.size, lb) : L.spf[t] + BD_SP_H + bp;
+            int* const dst = L.loopback ? L.spf_local + BD_SP_H + sp_row(tq, L.size, lb) : L.spf[tq] + BD_SP_H + bp;
             __hip_atomic_store(dst, ef, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -499,8 +511,8 @@ __global__ __launch_bounds__(MAX_ROW_THREADS) void rms_sp_kernel(RmsSpArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int t = threadIdx.x;
-    if (t < L.size) {
+    const int t = bd_spread_lane(L.size);
+    if (t >= 0) {
         const int e = sp_epoch(L, a.seq_h);
         int* const dst = L.loopback ? L.spf_local + BD_SP_H + sp_row(t, L.size, lr) : L.spf[t] + BD_SP_H + m;
         __hip_atomic_store(dst, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -567,8 +579,8 @@ __global__ __launch_bounds__(256) void sp_test_push_kernel(SpTestArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int t = threadIdx.x;
-    if (t < L.size) {
+    const int t = bd_spread_lane(L.size);
+    if (t >= 0) {
         const int e = sp_epoch(L, a.seq);
         int* const dst = L.loopback ? L.spf_local + BD_SP_H + sp_row(t, L.size, lr) : L.spf[t] + BD_SP_H + m;
         __hip_atomic_store(dst, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

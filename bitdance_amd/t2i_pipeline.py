@@ -367,6 +367,12 @@ class BitDanceT2IPipeline:
                 if mine.shape[0]:
                     full[lo:lo + mine.shape[0]] = part
                 return self.tp.all_reduce_(full)                              # disjoint shares + zeros: exact
+            # large batches in chunks (per-image results are independent: convolutions and per-sample GroupNorm): the native decoder's
+            # padded NHWC work buffers at 1024 px are ~0.5 GB per image and layer -- 32 images at once exceeded the 288 GB beside the
+            # model, its KV caches and workspaces.  A GAN decoder draws noise per call, so its batch stays whole.
+            chunk = int(getattr(self, "decode_chunk", 8))
+            if b > chunk and not gan:
+                return torch.cat([self.ae.decode(x[i:i + chunk]) for i in range(0, b, chunk)])
             return self.ae.decode(x)
         finally:
             torch.backends.cudnn.benchmark = prev

@@ -129,6 +129,14 @@ def main():
               f"for A {np.median(wa / loop):.3f}, at the barrier {np.median(wb / loop):.3f} (medians over workgroups; max W {np.max(ww / loop):.3f} A {np.max(wa / loop):.3f} barrier {np.max(wb / loop):.3f})")
         print(f"   realtime: K loop {lp:7.2f} us, loop end -> last store drained median {tail:6.2f} / max {tailmax:6.2f} us, kernel span {span:7.2f} us")
     recs = [(n_, w) for n_, w in recs if not n_.startswith("wide:")]
+    sp = [w for n_, w in recs if n_ == "ln_mod_sp" and w[:, 0].min() > 0 and w[:, 5].min() > 0]
+    if sp:
+        lab = ["start -> local loads landed", "-> partial flags of every peer seen", "-> staged partials summed, residual written", "-> LayerNorm statistics",
+               "-> operand rows pushed and drained", "-> flags raised, end"]
+        print(f"\n== ln_mod_sp, phase by phase ({len(sp)} launches x {sp[0].shape[0]} workgroups; median over workgroups, mean over launches)")
+        for k, name in enumerate(lab):
+            a_, b_ = (0, 1) if k == 0 else ((k, k + 1) if k < 5 else (5, 6))
+            print(f"   {name:48s} {np.mean([np.median(w[:, b_] - w[:, a_]) for w in sp[2:] or sp]) * TICK_US:6.2f}")
     # ---- per kernel name: phases reduced over the grid, then averaged over the launches
     phases = OrderedDict([("dispatch skew (start - first start)", (None, 0)), ("start -> first A in LDS", (0, 1)), ("start -> first W landed", (0, 2)),
                           ("first W -> K loop done", (2, 3)), ("K parts through LDS", (3, 4)), ("slabs drained + ticket", (4, 5)),
