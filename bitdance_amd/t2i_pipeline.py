@@ -358,21 +358,24 @@ class BitDanceT2IPipeline:
             # would leave the group with diverged generator offsets, and the next image's sampling noise -- engine.draw_noise, same
             # generator -- would differ across ranks.  Every rank decodes the whole batch there: the replicated state stays replicated.)
             gan = bool(getattr(getattr(self.ae, "decoder", None), "gan", False))
-            if self.tp is not None and b > 1 and getattr(self, "tp_split_decode", True) and not gan:
-                per = (b + self.tp.size - 1) // self.tp.size
-                lo = self.tp.rank * per
-                mine = x[lo:lo + per]
-                part = self.ae.decode(mine if mine.shape[0] else x[:1])      # a rank without a share still learns shape / dtype
-                full = torch.zeros((b,) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
-                if mine.shape[0]:
-                    full[lo:lo + mine.shape[0]] = part
-                return self.tp.all_reduce_(full)                              # disjoint shares + zeros: exact
             # large batches in chunks (per-image results are independent: convolutions and per-sample GroupNorm): the native decoder's
             # padded NHWC work buffers at 1024 px are ~0.5 GB per image and layer -- 32 images at once exceeded the 288 GB beside the
             # model, its KV caches and workspaces.  A GAN decoder draws noise per call, so its batch stays whole.
             chunk = int(getattr(self, "decode_chunk", 8))
-            if b > chunk and not gan:
-                return torch.cat([self.ae.decode(x[i:i + chunk]) for i in range(0, b, chunk)])
-            return self.ae.decode(x)
+
+            def dec(t):
+                if t.shape[0] > chunk and not gan:
+                    return torch.cat([self.ae.decode(t[i:i + chunk]) for i in range(0, t.shape[0], chunk)])
+                return self.ae.decode(t)
+            if self.tp is not None and b > 1 and getattr(self, "tp_split_decode", True) and not gan:
+                per = (b + self.tp.size - 1) // self.tp.size
+                lo = self.tp.rank * per
+                mine = x[lo:lo + per]
+                part = dec(mine if mine.shape[0] else x[:1])                 # a rank without a share still learns shape / dtype
+                full = torch.zeros((b,) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
+                if mine.shape[0]:
+                    full[lo:lo + mine.shape[0]] = part
+                return self.tp.all_reduce_(full)                              # disjoint shares + zeros: exact
+            return dec(x)
         finally:
             torch.backends.cudnn.benchmark = prev

@@ -147,6 +147,8 @@ def test_native_decoder_tiny_vs_torch(gh, gw):
     print(f"[ae tiny] max {d.max().item():.4f} mean {d.mean().item():.5f} (ref mean |x| {scale:.3f})")
     assert d.mean().item() <= 0.02 * scale + 2e-3 and d.max().item() <= 0.25 * max(1.0, ref.abs().max().item())
     assert torch.equal(nat.decode(z), nat.decode(z))                       # deterministic (no atomics anywhere)
+    # an image's result does not depend on what else is in the batch (decode_image decodes large batches in chunks, round 6)
+    assert torch.equal(torch.cat([nat.decode(z[:1]), nat.decode(z[1:])]), nat.decode(z))
     with torch.no_grad(), torch.autocast("cuda", dtype=BF16):              # the module's own decode() takes the native path on a GPU
         via = ae.decode(z)
     assert torch.equal(via, nat.decode(z))
