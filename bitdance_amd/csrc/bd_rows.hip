@@ -10,7 +10,7 @@
 
 // A/B switches (bd_set_gemm_option "rows.*"): registers-per-thread bound of ln_mod (waves per SIMD: 4 = one 640-thread workgroup per CU,
 // 5 = two), thread cap of swiglu_rows (512 = three workgroups per CU, 1024 = one 960-thread workgroup)
-static int g_ln_occ = 4, g_swiglu_t = 512;   // measured on one box at 512 rows (profiles/r06_head_sweep_b4.log): ln_occ 5 +0.9 % SLOWER (4 spilled registers; the dispatch skew of 512 ten-wave workgroups is the dispatcher, not residency), swiglu_t 512 -0.2 %
+static int g_ln_occ = 5, g_swiglu_t = 512;   // measured (profiles/r06_head_sweep_b4.log, same box): ln_occ 5 (83 registers, the affine fetched after the reductions) -0.6 % per evaluation at 128 and 2048 rows, +-0 at 512; swiglu_t 512 -0.2 % at 512 rows
 int bdk_set_rows_option(const char* name, int v) {
     const std::string n(name);
     if (n == "rows.ln_occ" && (v == 4 || v == 5)) { g_ln_occ = v; return 0; }
@@ -151,9 +151,10 @@ BD_DEV void modulate8(const float* x, float mean, float rstd, const float* lw, c
     }
 }
 
-// OCC = waves per SIMD the register allocation must admit (launch bound): 4 = the compiler's own 98 registers, one 640-thread workgroup per
-// CU; 5 = 96 registers (4 spilled), two per CU.  Round 6 measured 5 slower at 512 rows (+0.9 % per evaluation) and equal at 128: kept as an
-// A/B switch ("rows.ln_occ"), default 4.
+// OCC = waves per SIMD the register allocation must admit (launch bound): 4 = the up-front loads of everything (98 registers, ONE 640-thread
+// workgroup per CU); 5 = the LayerNorm affine fetched after the reductions (83 registers, two workgroups per CU; round 6).  Same-box A/B
+// ("rows.ln_occ"): 5 is 0.6 % faster per evaluation at 128 and at 2048 rows and equal at 512 (the 512-row kernel runs two waves of
+// workgroups either way: its rows are bound by the slab reads, not by residency) -- default 5.
 template <int OCC>
 __global__ __launch_bounds__(MAX_ROW_THREADS, OCC) void ln_mod_kernel(LnModArgs a) {
     __shared__ float red[32];
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(MAX_ROW_THREADS, OCC) void ln_mod_kernel(LnModArgs 
         xr = ld_raw8((const bf16_t*)a.X + (size_t)m * a.D + d0);
         scr = ld_raw8(ada + a.scale_off + d0);
         sfr = ld_raw8(ada + a.shift_off + d0);
-        if (a.ln_w) { ld_f32x8(a.ln_w + d0, w); ld_f32x8(a.ln_b + d0, b); }
+        if (OCC == 4 && a.ln_w) { ld_f32x8(a.ln_w + d0, w); ld_f32x8(a.ln_b + d0, b); }
         if (a.pend.p) {
             gr = ld_raw8(ada + a.gate_off + d0);
             float o[8], g[8];
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(MAX_ROW_THREADS, OCC) void ln_mod_kernel(LnModArgs 
 #pragma unroll
     for (int j = 0; j < 8; ++j) h[j] = 0.f;
     if (active) {
+        if (OCC != 4 && a.ln_w) { ld_f32x8(a.ln_w + d0, w); ld_f32x8(a.ln_b + d0, b); }   // (the two-per-CU form fetches the affine late: 16 registers fewer across the reductions; L2-hot)
         unpack8(scr, sc);
         unpack8(sfr, sf);
 #pragma unroll

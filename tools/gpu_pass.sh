@@ -13,8 +13,8 @@ cd $R
 for step in "$@"; do
   case $step in
     bench) timeout 400 python bench.py --steps 3 --warmup 1 > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err; tail -c 1500 $O/${TAG}_bench_default.json ;;
-    b4prof|b1prof)
-      NI=4; [ $step = b1prof ] && NI=1
+    b4prof|b1prof|b8prof|b16prof)
+      NI=${step#b}; NI=${NI%prof}
       (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_$step && timeout 300 rocprofv3 --kernel-trace --output-format rocpd -d /tmp/prof_$step -o p -- python $R/bench.py --num-images $NI --steps 1 --warmup 1 --no-roofline --no-cpu-baseline --no-b4 --no-throughput > $O/${TAG}_rocprof_$step.log 2>&1)
       DB=$(ls /tmp/prof_$step/*.db /tmp/prof_$step/*/*.db 2>/dev/null | head -1)
       [ -n "$DB" ] && python tools/rocpd_stats.py $DB $O/${TAG}_kernel_stats_$step.md > /dev/null 2>&1; head -30 $O/${TAG}_kernel_stats_$step.md ;;

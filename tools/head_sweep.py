@@ -124,7 +124,7 @@ def run():
             comm.check()
         del eng, comm
         for k in opts:
-            check(lib().bd_set_gemm_option(k.encode(), {"wide.ring": 2, "tile": 1, "red.first": 1, "rows.ln_occ": 4, "rows.swiglu_t": 512, "tile.minrb": 32}.get(k, -1)))
+            check(lib().bd_set_gemm_option(k.encode(), {"wide.ring": 2, "tile": 1, "red.first": 1, "rows.ln_occ": 5, "rows.swiglu_t": 512, "tile.minrb": 32}.get(k, -1)))
         torch.cuda.empty_cache()
 
 
