@@ -35,7 +35,11 @@ int bd_set_weight_layout(int stage_major);
  * values.  "wide.ring" 2|3 = weight stages a wave of the 256-row kernel keeps in flight; "wide.xcd" -1|0|1 = row tiles of one
  * weight slice on one XCD (by shape / off / on); "wide.keep" -1|0|1 = default-policy instead of non-temporal weight loads when
  * several row tiles read a slice; "tile" 0|1|2|3 = from 1024 rows on N >= 4096: the 256-row kernel / the LDS-tiled 256 x 256
- * kernel with its operand fetch chosen by shape / register-staged fetch forced / LDS-DMA fetch forced (bd_gemm_tile.hip). */
+ * kernel with its operand fetch chosen by shape / register-staged fetch forced / LDS-DMA fetch forced (bd_gemm_tile.hip);
+ * "tile.minrb" 8, 16, ... = row blocks from which the tiled kernel takes over (default 32 = 1024 rows);
+ * "red.first" 0|1 = two-slice in-launch reduction with the ticket taken first (1, default: only the first arriver parks its
+ * accumulators) or both slices parking (0); "rows.ln_occ" 4|5 = ln_mod's register bound (one / two 640-thread workgroups per CU,
+ * default 5); "rows.swiglu_t" 512|1024 = thread cap of swiglu_rows (default 512). */
 int bd_set_gemm_option(const char* name, int value);
 int bd_pack_weight_swiglu(void* dst_packed, const void* gate_bf16, const void* up_bf16, int F, int K, void* stream);
 int bd_rows_to_frag(void* dst_frag, const void* src, int src_is_fp32, int M, int K, int row_blocks, void* stream);
