@@ -36,6 +36,17 @@ def test_head_eval_14b_two_images_true_dims():
     assert r["finite"] and r["max_err"] <= HEAD_MAX and r["mean_err"] <= HEAD_MEAN, r
 
 
+@pytest.mark.parametrize("B", [8, 16])
+def test_head_eval_14b_eight_images_true_dims(B):
+    """num_images = 8 / 16 (M = 1024 / 2048 rows: bench.py's `throughput` regime): qkv / w1 / adaLN on the LDS-tiled kernel with fused epilogues, wo / w2 as
+    THREE K slices of 256 x 256 tiles (choose_cfg's wave-filling rule, round 6) whose fp32 slabs ln_mod / head_final sum, 16 sequences of
+    attention -- one block at true width against the oracle, the per-evaluation bounds of this file."""
+    from oracle.true_dims import head_case
+    r = head_case(D=5120, P=64, B=B, branches=2, depth=1, nada=1, seed=127)
+    assert r["gemm_cfg"]["wo"]["splitk"] == 3 and r["gemm_cfg"]["w2"]["splitk"] == 3, r["gemm_cfg"]
+    assert r["finite"] and r["max_err"] <= HEAD_MAX and r["mean_err"] <= HEAD_MEAN, r
+
+
 def test_head_eval_bitdance_b_dims_vs_oracle():
     """ImageNet BitDance-B head at its real dimensions (model_parallel.py:456-465: width 768, 12 heads of 64, 6 blocks,
     2 adaLN, 32 latent channels, P = 16, no final sigmoid) for a batch of 8 classes with CFG: vs the ORACLE."""
