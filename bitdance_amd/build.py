@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libbitdance_hip.so")
-SOURCES = ["bd_gemm.hip", "bd_gemm_tile.hip", "bd_gemm8.hip", "bd_rows.hip", "bd_conv.hip", "bd_attn.hip", "bd_comm.hip", "bd_sp.hip", "bd_api.hip"]
+SOURCES = ["bd_gemm.hip", "bd_gemm_tile.hip", "bd_gemm_half.hip", "bd_gemm8.hip", "bd_rows.hip", "bd_conv.hip", "bd_attn.hip", "bd_comm.hip", "bd_sp.hip", "bd_api.hip"]
 # -ffp-contract=off: the row kernels restate separately-rounded torch ops (bit-exact sampler update); HIP's
 # __fadd_rn/__fmul_rn are plain operators, so contraction must be disabled at the compiler level.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]

@@ -57,7 +57,7 @@ void bdk_set_error(const std::string& m) { g_err = m; }      // bd_comm.hip repo
 
 // nw = waves per workgroup, kw = waves sharing one 32-column panel (split-K inside the workgroup, bd_gemm.hip), ring = K
 // stages in flight per wave, S = split-K over the grid
-struct GemmCfg { int S = 1, nw = 4, ring = 2, kw = 1; int code() const { return nw + 16 * ring + 256 * (kw - 1); } };
+struct GemmCfg { int S = 1, nw = 4, ring = 2, kw = 1, half = 0; int code() const { return nw + 16 * ring + 256 * (kw - 1) + 4096 * half; } };   // half: the 256 x 128-tile kernel (bd_gemm_half.hip)
 
 struct bd_ctx {
     std::map<std::string, long long> I;
@@ -247,6 +247,16 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
         g.nw = nw; g.kw = 1;
         S = swiglu ? 1 : std::max(1, std::min(4, (int)std::lround(240.0 / wgs)));
     }
+    // 512 rows on the big weights of the 14B models (bd_gemm_half.hip: 256 x 128 tiles, split-K inside the workgroup; "tune.half" bit mask):
+    //   1: N = 15360 (qkv, gate / up of the head): 240 tiles at ONE slice -- rounded / SwiGLU output, no slabs (was 120 tiles x 2 slices)
+    //   2: N = 5120 .. 7168 (wo, w2, o, down, llm.qkv): 80 .. 112 tiles x 3 / 2 slices = 3 / 2 slabs (was 40 x 5 / 56 x 3 on 256 x 256 tiles)
+    //   4: N > 16384 (gate / up of the LLM: 544 tiles, three waves of workgroups instead of two at twice the length)
+    if (two_images && row_tiles == 2 && g.nw >= 8 && g.kw == 1 && N % 128 == 0 && K % 64 == 0 && (double)N * K * 2 > 12e6 && !c->wfp8 && c->tp <= 1 && !reduce3) {
+        const int hm = (int)c->geti("tune.half", 7), t128 = (N / 128) * row_tiles;
+        if (N >= 8192 && N <= 16384 && (hm & 1)) { S = 1; g.half = 1; }
+        else if (N > 16384 && (hm & 4)) { S = 1; g.half = 1; }
+        else if (N < 8192 && (hm & 2) && !swiglu) { S = std::max(1, std::min(4, (int)std::lround(240.0 / t128))); g.half = 1; }
+    }
     g.S = S;
     // K stages in flight per wave: 2; 3 for the 4-wave tiles of the 128-row passes (qkv / w1: only 32 KiB per CU in flight at ring 2;
     // in situ on one box, profiles/r03_bench_b1_ring*.json: qkv 39.4 vs 41.6 us, w1 42.5 vs 44.8, image 0.2597 vs 0.2552 /s; ring 4 and
@@ -268,7 +278,7 @@ static GemmCfg choose_cfg(const bd_ctx* c, const std::string& name, int N, int K
 static const char* const kIntKeys[] = {
     "B", "branches", "P", "wdtype", "head.D", "head.C", "head.Dz", "head.H", "head.nblocks", "head.nada", "head.T", "head.dh", "head.sigmoid", "head.y_evals", "head.variant",
     "proj.D", "proj.C", "proj.hid", "proj.variant", "proj.rows_all", "llm.D", "llm.L", "llm.nh", "llm.nkv", "llm.F", "llm.Lmax", "llm.splits",
-    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "rt.in_first", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.fill_waves", "tune.ragged", "tune.ragged52", "tune.slab_cap", "tune.slab3",
+    "llm.head_dim", "llm.variant", "rt.dump_xhat", "rt.emit_cond", "rt.chain", "rt.llm_causal", "rt.llm_bf16", "rt.no_advance", "rt.in_first", "tune.reduce_max_s", "tune.w1_fused", "tune.kw2", "tune.kparts8", "tune.fill_waves", "tune.half", "tune.ragged", "tune.ragged52", "tune.slab_cap", "tune.slab3",
     "tune.ada_group", "tune.ada_group_nw", "tune.tp_fuse", "tune.ln_rows", "tune.small_tiles_rows", "tp.ada_split", "tp.seq", "tp.llm_seq", "tune.sp_wait", "tune.sp_inv", "tune.finalize_s", "tune.sp_gsig", "tune.tp_shapes"};
 static const char* const kGemmNames[] = {"head.cond", "head.ada", "head.qkv", "head.wo", "head.w1", "head.w2", "proj.fc2",
                                          "llm.qkv", "llm.o", "llm.gu", "llm.down"};

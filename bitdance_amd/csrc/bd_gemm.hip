@@ -349,16 +349,17 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
         __syncthreads();
         // the other slice's slab in batches of 8 accumulators (32 loads of 16 B in flight per lane: the operand registers of the K loop are dead
         // here); one accumulator at a time was 16 dependent round trips to write-through lines of another XCD
+constexpr int RB_ = 4;
 #pragma unroll
-        for (int a0 = 0; a0 < MB * NPW; a0 += 8) {
-            u32x4 v[8][4];
+        for (int a0 = 0; a0 < MB * NPW; a0 += RB_) {
+            u32x4 v[RB_][4];
 #pragma unroll
-            for (int a = 0; a < 8; ++a)
+            for (int a = 0; a < RB_; ++a)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) v[a][r4] = __builtin_amdgcn_raw_buffer_load_b128(sl, slab_off(1 - s, a0 + a, r4), 0, SC1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int a = 0; a < 8; ++a)
+            for (int a = 0; a < RB_; ++a)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4)
 #pragma unroll
@@ -446,6 +447,7 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(GemmP p) {
 static int g_wide_keep = -1;                              // weight loads of the 256-row kernel: -1 = default policy when > 1 row tile, 0 = always nt, 1 = never nt
 static int g_wide_ring = 2, g_wide_xcd = -1;            // xcd: -1 = by shape (on when the weights outweigh the rows), 0 / 1 forced
 void bdk_gemm_tile_debug(int v);
+void bdk_gemm_half_form(int v);
 // tensor parallelism: the push target of the NEXT bdk_gemm call with the fp32-partial epilogue on the 128-row bf16 kernel (set by
 // bd_api.hip linear_rowsplit through bd_comm.hip bdk_tp_push_target; consumed and reported by bdk_gemm_push_used)
 static thread_local BdTpPush g_push;
@@ -467,6 +469,7 @@ bool bdk_gemm_push_used() { const bool u = g_push_used; g_push_used = false; g_p
 static int g_red_first = 1;
 int bdk_red_first() { return g_red_first; }
 static int g_tile_minrb = 32;                            // row blocks from which the tiled kernel takes over ("tile.minrb": 16 = from 512 rows)
+static int g_half = 1;                                   // 512-768 rows, one K slice, bf16 / SwiGLU output: the 256 x 128-tile kernel (bd_gemm_half.hip); 0 = off, 2 = any N
 static int g_tile = 1;                                   // >= 512 rows: the LDS-tiled MFMA-bound kernel (bd_gemm_tile.hip); 0 = 256-row kernel
 int bdk_set_gemm_option(const char* name, int v) {
     const std::string n(name);
@@ -478,6 +481,8 @@ int bdk_set_gemm_option(const char* name, int v) {
     if (n == "wide.xcd" && v >= -1 && v <= 1) { g_wide_xcd = v; return 0; }
     if (n == "wide.keep" && v >= -1 && v <= 1) { g_wide_keep = v; return 0; }
     if (n == "red.first" && v >= 0 && v <= 1) { g_red_first = v; return 0; }
+    if (n == "half" && v >= 0 && v <= 2) { g_half = v; return 0; }
+    if (n == "half.form" && (v == 0 || v == 4 || v == 12)) { bdk_gemm_half_form(v); return 0; }
     if (n.rfind("rows.", 0) == 0) return bdk_set_rows_option(name, v);
     return -1;
 }
@@ -565,6 +570,12 @@ int bdk_gemm(const void* A, int RB, const void* W, int N, int K, int S, int nw_r
     // same grid.  BD_GEMM_WIDE=0 keeps the 8-wave form (A/B switch for measurements).
     static const bool wide = [] { const char* e = getenv("BD_GEMM_WIDE"); return !(e && e[0] == '0'); }();
     // (a reduced epilogue -- S > 1 with bf16 / SwiGLU output -- exists for exactly two slices, round 5; more slices: the generic kernel)
+    // 512 / 768 rows at ONE K slice with a rounded output (bd_api.hip choose_cfg "tune.half"): 256 x 128 tiles, split-K inside the workgroup
+    // (nw + 16: the caller asks for this kernel -- bd_api.hip GemmCfg::half; "half" = 2 routes every fitting shape, tests)
+    if (g_half && MB == 8 && nw == 8 && RB >= 16 && RB < g_tile_minrb && g_w_layout == 0 && N % 128 == 0 && K % 64 == 0 && !have_hw &&
+        ((S == 1 && (epi == BD_EPI_BF16 || epi == BD_EPI_SWIGLU)) || epi == BD_EPI_PARTIAL) && (K / 64) / S >= 2 &&
+        (g_half == 2 || ((nw_ring >> 12) & 1)))
+        return bdk_gemm_half(p, epi, st);
     if (wide && MB == 8 && nw == 8 && N % 256 == 0 && epi != BD_EPI_F32 && !(S > 1 && epi != BD_EPI_PARTIAL && (S != 2 || RB < 16))) {
         // >= 512 rows: the matrix pipe is the roofline -> both operands through LDS, 256 x 256 tiles (bd_gemm_tile.hip)
         // (measured, profiles/r03_gemm_tile_v4.log: ahead of the 256-row kernel from 1024 rows on wide N -- adaLN x8 693 vs 786 us,

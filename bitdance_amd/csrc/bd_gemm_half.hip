@@ -1,0 +1,311 @@
+// 512-row form of the MFMA-bound GEMM (round 6): 256 x 128 workgroup tiles, ONE K slice, split-K INSIDE the workgroup.
+//
+// Why: at num_images = 4 (512 rows, eval/eval_dpg.py:44) the N = 15360 Linears of the 14B head (qkv, gate / up) are 2 x 60 tiles of
+// 256 x 256 -- 120 workgroups for 256 CUs -- so the 256-row kernel (bd_gemm.hip gemm_wide_kernel) runs them as two K slices that park
+// fp32 slabs (63 MB per launch) for head_attn / swiglu_rows to re-read; reducing the two slices inside the launch costs more than it
+// saves (bd_api.hip linear()).  Halving the tile width gives 240 tiles at one slice: no slabs, no tickets, bias + rounding / SwiGLU in
+// the epilogue, and the consumers read one bf16 tensor.
+//
+// Shape of the workgroup: 8 waves = 2 GROUPS x (2 row halves x 2 column halves); wave tile 128 x 64 (8 accumulators of 32 x 32, the
+// tiled kernel's LDS diet: 6 ds_read_b128 per 8 MFMAs).  The two groups split K by 32-deep SUB-STAGE parity (group 0 the even ones, group
+// 1 the odd ones) and are otherwise independent: each fetches, parks and reads only its own sub-stages (16 A chunks + 8 W chunks =
+// 24 KiB in its own LDS slot), so nothing is read twice and one slot per group is enough -- the fragments of sub-stage i are in
+// registers before sub-stage i + 1 is written over them.  Waves w and w + 4 share a SIMD and run half a step apart (ping-pong, as in
+// bd_gemm_tile.hip): while one group issues its 16 MFMAs from registers the other reads its next 12 fragments from LDS.
+//   half-step 2i    :  group 0  LOAD(i)   |  group 1  MFMA(i - 1)
+//   half-step 2i + 1:  group 0  MFMA(i)   |  group 1  LOAD(i)
+// MFMA(i) also issues the wave's 6 global loads (4 A chunks, 2 W chunks, 16 B per lane) of sub-stage i + 2 between its first MFMAs and
+// writes sub-stage i + 1 (loaded during MFMA(i - 1)) to the slot between its last ones: ~3.5 half-steps of L2 / HBM latency covered by
+// two register sets, all waits counted by the compiler (straight-line pairs of sub-stages: the vmcnt state at the back edge equals the
+// one at entry).  After the loop the groups swap half of their accumulators through LDS (group 0 finishes row blocks 0-1 of the wave
+// tile, group 1 row blocks 2-3: a + b == b + a bit for bit) and every wave runs the epilogue of its 64 x 64 quarter through an LDS patch
+// (16 B per lane stores).  Every output element is (sum over even sub-stages, ascending) + (sum over odd sub-stages, ascending) in fp32.
+#include "bd_gemm_kernel.h"
+#include <string>
+
+// FORM 0: the product kernel.  FORM 4 / 12 (measurement builds only, wrong results): no global loads / neither loads nor LDS stores in the loop --
+// the price list behind the header's numbers (profiles/r06_half_kernel_anatomy.log).  Pipelinings measured and dropped (same box, per
+// evaluation at 512 rows): loads + parking in the LOAD segment with two slots per group 2242 vs 2191 us (the LOAD segment grows from 244 to
+// 925 cycles: the LDS store path is the cost wherever it sits), three register sets (18 KiB in flight per wave) 2098 vs 2092, every store in
+// its own MFMA gap with the waves that share a store-path half on alternating gaps 2060 vs 2064.
+template <int EPI, int FORM>
+__global__ __launch_bounds__(512) void gemm_half_kernel(GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4* const lds = reinterpret_cast<u32x4*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 2, wg = wave & 3, wr = wg >> 1, wc = wg & 1;
+
+    // tile of this workgroup: the RT row tiles that stream the same 128 weight columns run on ONE XCD (blocks b and b + 8 -- block b
+    // is dispatched to XCD b % 8), so a weight line comes from HBM once
+    const int RT = p.RB >> 3, NTS = (p.N >> 7) * p.S;             // row tiles; (column tile, K slice) pairs
+    int mt, rest;
+    {
+        const int full = (NTS / 8) * 8;
+        if ((int)blockIdx.x < full * RT) {
+            const int grp = blockIdx.x / (8 * RT), j = blockIdx.x % (8 * RT);
+            mt = j / 8; rest = grp * 8 + (j % 8);
+        } else {
+            const int left = NTS - full, jj = blockIdx.x - full * RT;
+            mt = jj / left; rest = full + jj % left;
+        }
+    }
+    // K slices (fp32 slabs, BD_EPI_PARTIAL only): slice s takes the 64-deep sub-stage PAIRS [p0, p0 + n); each group one sub-stage of a pair
+    const int nt = rest / p.S, s = rest % p.S;
+    const int pairs = p.K >> 6, q = (pairs + p.S - 1) / p.S, p0 = s * q;
+    const int n = min(q, pairs - p0);                             // sub-stages per group (K % 64 == 0: both groups the same count)
+
+    // this wave's 6 chunks of a sub-stage of its group: A chunks (k-step wg >> 1, row blocks (wg & 1) * 4 ..+3: 4 KiB contiguous), W chunks
+    // (panel wg of the tile, k-steps 0 and 1: 2 KiB contiguous).  Sub-stage i of group g is the 32-deep slice t = 2 i + g of K.
+    const size_t a_step = (size_t)4 * p.RB * 64, w_step = 256;     // per sub-stage of the group (= two sub-stages of K)
+    const u32x4* const a_src = p.A + ((size_t)(g * 2 + (wg >> 1)) * p.RB + mt * 8 + (wg & 1) * 4) * 64 + lane + (size_t)p0 * a_step;
+    const u32x4* const w_src = p.W + (size_t)(nt * 4 + wg) * p.PS + (size_t)g * 128 + lane + (size_t)p0 * w_step;
+    u32x4* const slot = lds + g * (24 * 64);
+    u32x4* const park_a = slot + (wg * 4) * 64 + lane;
+    u32x4* const park_w = slot + (16 + wg * 2) * 64 + lane;
+
+    u32x4 stg[2][6];
+    auto fetch = [&](auto SET, int i) {
+        constexpr int Q = decltype(SET)::value;
+        const int ic = min(i, n - 1);                            // past the end: the last sub-stage again (same loads in every segment)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) stg[Q][c] = a_src[(size_t)ic * a_step + c * 64];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) stg[Q][4 + c] = w_src[(size_t)ic * w_step + c * 64];
+    };
+    auto park = [&](auto SET) {
+        constexpr int Q = decltype(SET)::value;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) park_a[c * 64] = stg[Q][c];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) park_w[c * 64] = stg[Q][4 + c];
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
+
+#ifdef BD_GEMM_STAMP
+    // measurement build: shader cycles wave 0 spends waiting for the loads it parks (word 1), at the barriers (word 4), in its LOAD segments
+    // (word 2), the whole loop (word 5); words 0 / 3 / 6 realtime start / loop end / drained; 7 = sub-stages per group
+    unsigned long long st_w = 0, st_b = 0, st_l = 0;
+    const unsigned long long st_loop0 = __builtin_readcyclecounter();
+    BD_KSTAMP(p.stamp, 0);
+#define HALF_SYNC() do { const unsigned long long t0_ = __builtin_readcyclecounter(); __syncthreads(); st_b += __builtin_readcyclecounter() - t0_; } while (0)
+#define HALF_LOAD() do { const unsigned long long t0_ = __builtin_readcyclecounter(); load_seg(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_l += __builtin_readcyclecounter() - t0_; } while (0)
+#else
+#define HALF_SYNC() __syncthreads()
+#define HALF_LOAD() load_seg()
+#endif
+    u32x4 af[2][4], wf[2][2];
+    auto load_seg = [&]() {
+        const u32x4* const a = slot + lane;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) af[ks][m] = a[(ks * 8 + wr * 4 + m) * 64];
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn) wf[ks][nn] = a[(16 + (wc * 2 + nn) * 2 + ks) * 64];
+        }
+    };
+    // MFMA(i), i % 2 == Q: the loads of sub-stage i + 2 into set Q (free: sub-stage i was parked during MFMA(i - 1)) behind the first six
+    // MFMA pairs, the parking of sub-stage i + 1 (set Q ^ 1) behind the last two
+    auto mfma_seg = [&](auto SET, int i) {
+        constexpr int Q = decltype(SET)::value;
+        const int ic = min(i + 2, n - 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int pr = ks * 4 + m;
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn) acc[m][nn] = mfma32(af[ks][m], wf[ks][nn], acc[m][nn]);
+                constexpr bool FETCH = !(FORM & 4), PARK = !(FORM & 8);     // (FORM 4 / 12: measurement only -- wrong results)
+                if (pr < 4) { if (FETCH) stg[Q][pr] = a_src[(size_t)ic * a_step + pr * 64]; }
+                else if (pr < 6) { if (FETCH) stg[Q][pr] = w_src[(size_t)ic * w_step + (pr - 4) * 64]; }
+                else if (pr == 6) {
+#ifdef BD_GEMM_STAMP
+                    { const unsigned long long t0 = __builtin_readcyclecounter(); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); st_w += __builtin_readcyclecounter() - t0; }
+#endif
+                    if (PARK) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) park_a[c * 64] = stg[Q ^ 1][c];
+                    }
+                } else if (PARK) {
+                    park_a[3 * 64] = stg[Q ^ 1][3];
+                    park_w[0] = stg[Q ^ 1][4];
+                    park_w[64] = stg[Q ^ 1][5];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    {
+        fetch(I0{}, 0);
+        fetch(I1{}, 1);
+        park(I0{});
+        if (g == 1) __syncthreads();                              // group 1 runs half a step behind
+        int i = 0;
+        for (; i + 1 < n; i += 2) {
+            HALF_SYNC(); HALF_LOAD(); HALF_SYNC(); mfma_seg(I0{}, i);
+            HALF_SYNC(); HALF_LOAD(); HALF_SYNC(); mfma_seg(I1{}, i + 1);
+        }
+        if (i < n) { HALF_SYNC(); HALF_LOAD(); HALF_SYNC(); mfma_seg(I0{}, i); }
+        if (g == 0) __syncthreads();
+    }
+    BD_MFMA_DRAIN();
+#ifdef BD_GEMM_STAMP
+    BD_KSTAMP(p.stamp, 3);
+    bd_kstamp_val(p.stamp, 1, st_w); bd_kstamp_val(p.stamp, 2, st_l); bd_kstamp_val(p.stamp, 4, st_b);
+    bd_kstamp_val(p.stamp, 5, __builtin_readcyclecounter() - st_loop0);
+    bd_kstamp_val(p.stamp, 7, (unsigned long long)n);
+#endif
+    __syncthreads();                                              // every wave is out of the loop: the slots are free
+
+    // ---- the groups swap halves: wave (g, wg) keeps row blocks 2 g, 2 g + 1 of its wave tile and hands the other two to wave (g ^ 1, wg)
+    // through that wave's own 16 KiB region [accumulator (ml, nn)][r4][lane] x 16 B; after the barrier it adds what it received and owns
+    // the region (its epilogue patch).  One instance per group: the accumulator halves are compile-time register ranges.
+    auto finish = [&](auto GRP) {
+        constexpr int G = decltype(GRP)::value;
+        {
+            u32x4* const theirs = lds + (size_t)(wave ^ 4) * 1024 + lane;
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn) {
+                    const f32x16& a = acc[(1 - G) * 2 + ml][nn];
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4)
+                        theirs[((ml * 2 + nn) * 4 + r4) * 64] = (u32x4){__float_as_uint(a[4 * r4]), __float_as_uint(a[4 * r4 + 1]),
+                                                                        __float_as_uint(a[4 * r4 + 2]), __float_as_uint(a[4 * r4 + 3])};
+                }
+        }
+        __syncthreads();
+        f32x16 fin[2][2];
+        {
+            const u32x4* const mine = lds + (size_t)wave * 1024 + lane;
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn) {
+                    const f32x16& a = acc[G * 2 + ml][nn];
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const u32x4 v = mine[((ml * 2 + nn) * 4 + r4) * 64];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) fin[ml][nn][4 * r4 + j] = a[4 * r4 + j] + __uint_as_float(v[j]);
+                    }
+                }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0): the region is this wave's alone from here on
+
+        // epilogue of the wave's 64 rows x 64 columns (D layout of the 32 x 32 MFMA: lane -> column lane & 31, register r -> row
+        // (r & 3) + 8 (r >> 2) + 4 (lane >> 5)); the forms of gemm_wide_kernel
+        const int pn0 = nt * 4 + wc * 2;                          // first of the wave's two 32-column panels
+        const int rb0 = mt * 8 + wr * 4 + G * 2;                  // first of its two row blocks
+        if constexpr (EPI == BD_EPI_PARTIAL) {                    // fp32 slab of this K slice (the consumer sums the slabs in slice order)
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn) {
+                    float* const o = p.out + ((size_t)s * p.Mpad + (size_t)(rb0 + ml) * 32) * p.N + (pn0 + nn) * 32 + (lane & 31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * p.N] = fin[ml][nn][r];
+                }
+            BD_KSTAMP_END(p.stamp);
+            return;
+        }
+        float bias_pn[2];
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) bias_pn[nn] = p.bias ? bf2f(p.bias[(pn0 + nn) * 32 + (lane & 31)]) : 0.f;
+        bf16_t* const patch = reinterpret_cast<bf16_t*>(smem + (size_t)wave * 16384);
+        if constexpr (EPI == BD_EPI_BF16) {
+            constexpr int PITCH = 72;
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml) {
+                bf16_t* const pt = patch + ml * (32 * PITCH);
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        pt[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * PITCH + nn * 32 + (lane & 31)] = f2bf(fin[ml][nn][r] + bias_pn[nn]);
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                bf16_t* const o = p.act + (size_t)(rb0 + ml) * 32 * p.N + (size_t)pn0 * 32;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = it * 8 + (lane >> 3), seg = lane & 7;
+                    *reinterpret_cast<u32x4*>(o + (size_t)row * p.N + seg * 8) = *reinterpret_cast<const u32x4*>(pt + row * PITCH + seg * 8);
+                }
+            }
+        } else {
+            // SwiGLU: one accumulator = one 1 KiB chunk of the fragment-major operand of the next Linear: (row block, k-step = packed panel)
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn) {
+                    bf16_t* const ch = patch + (ml * 2 + nn) * 512;
+                    const int f = lane & 15;
+                    bf16_t o8[8];
+                    swiglu_pairs(fin[ml][nn], bias_pn[nn], lane, o8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = 2 * j + ((lane >> 4) & 1);
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        ch[(row + 32 * (f >> 3)) * 8 + (f & 7)] = o8[j];
+                    }
+                }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+            for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn) {
+                    const u32x4 v = reinterpret_cast<const u32x4*>(patch + (ml * 2 + nn) * 512)[lane];
+                    reinterpret_cast<u32x4*>(p.act)[((size_t)(pn0 + nn) * p.RB + (rb0 + ml)) * 64 + lane] = v;
+                }
+        }
+    };
+    if (g == 0) finish(I0{}); else finish(I1{});
+    BD_KSTAMP_END(p.stamp);
+}
+
+static int g_half_form = 0;
+void bdk_gemm_half_form(int v) { g_half_form = v; }
+template <int EPI, int FORM>
+static int launch_half_f(const GemmP& p, hipStream_t st) {
+    constexpr int lds = 8 * 16384;                                 // 128 KiB: the accumulator swap (the K loop uses the first 48 / 96 KiB)
+    static unsigned long long optin = 0;
+    if (!bd_lds_optin((const void*)gemm_half_kernel<EPI, FORM>, lds, &optin)) return -8;
+    BD_LAUNCH((gemm_half_kernel<EPI, FORM>), dim3((p.N / 128) * p.S * (p.RB / 8)), dim3(512), lds, st, p);
+    return bd_launch_status();
+}
+template <int EPI>
+static int launch_half(const GemmP& p, hipStream_t st) {
+    switch (g_half_form) {
+#ifdef BD_GEMM_STAMP
+        case 4: return launch_half_f<EPI, 4>(p, st);
+        case 12: return launch_half_f<EPI, 12>(p, st);
+#endif
+        default: return launch_half_f<EPI, 0>(p, st);
+    }
+}
+// RB % 8 == 0 (256-row tiles), N % 128 == 0, K % 64 == 0, every K slice >= 128 deep; one K slice with bf16(+bias) or SwiGLU output, or S
+// slices as fp32 slabs (BD_EPI_PARTIAL); panel-major bf16 weights
+int bdk_gemm_half(const GemmP& p0, int epi, hipStream_t st) {
+    GemmP p = p0;
+#ifdef BD_GEMM_STAMP
+    p.stamp = bdk_stamp_next((std::string("wide:half:") + bdk_stamp_current_label()).c_str(), (p.N / 128) * p.S * (p.RB / 8));
+#endif
+    if (p.RB % 8 || p.N % 128 || p.K % 64 || p.S < 1 || (p.S > 1 && epi != BD_EPI_PARTIAL) || epi == BD_EPI_F32) return -2;
+    const int pairs = p.K / 64, q = (pairs + p.S - 1) / p.S;
+    if ((p.S - 1) * q >= pairs || pairs - (p.S - 1) * q < 2 || q < 2) return -3;
+    if (epi == BD_EPI_PARTIAL) return launch_half<BD_EPI_PARTIAL>(p, st);
+    if (epi == BD_EPI_BF16) return launch_half<BD_EPI_BF16>(p, st);
+    return launch_half<BD_EPI_SWIGLU>(p, st);
+}

@@ -58,6 +58,8 @@ int bdk_red_first();                 // process-wide A/B switch (bd_set_gemm_opt
 // MFMA-bound form for >= 512 rows: both operands through LDS, 256 x 256 workgroup tiles (bd_gemm_tile.hip)
 int bdk_gemm_tile(const GemmP& p, int epi, hipStream_t st);
 void bdk_gemm_tile_stg(int v);
+// 512-row form: 256 x 128 tiles at one K slice, split-K inside the workgroup, bf16 / SwiGLU epilogues (bd_gemm_half.hip)
+int bdk_gemm_half(const GemmP& p, int epi, hipStream_t st);
 
 // R = depth of the per-wave W register ring = number of K stages a wave keeps in flight.  The A stage is
 // prefetched equally far ahead (R-1 register slots, then one ds_write into the double-buffered LDS tile): vmcnt retires

@@ -629,6 +629,7 @@ def test_gemm_256_row_kernel_wide_epilogues(eng_mod, M, N, K, S):
     from bitdance_amd._lib import check, lib
     tile_was = 1
     check(lib().bd_set_gemm_option(b"tile", 0))                 # the 256-row kernel also where the tiled kernel would take over
+    check(lib().bd_set_gemm_option(b"half", 0))                 # ... and where the 256 x 128-tile kernel would
     try:
         g = torch.Generator(device=DEV).manual_seed(M + N + K + S)
         x = torch.randn(M, K, device=DEV, generator=g)
@@ -685,6 +686,87 @@ def test_gemm_256_row_kernel_wide_epilogues(eng_mod, M, N, K, S):
             del act4
     finally:
         check(lib().bd_set_gemm_option(b"tile", tile_was))
+        check(lib().bd_set_gemm_option(b"half", 1))
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 15360, 5120), (512, 256, 128), (768, 384, 192), (500, 1152, 704), (512, 5120, 7680)])
+def test_gemm_512_row_kernel_half_tiles(eng_mod, M, N, K):
+    """The 512-row kernel (bd_gemm_half.hip: 256 x 128 tiles, ONE K slice, the two wave groups of a workgroup take the even / odd 32-deep
+    K sub-stages and add their accumulators through LDS).  bf16(+bias): equals the correctly rounded fp64 reference up to accumulation-order
+    flips, bit-identical run to run, and bit-identical to the 256-row kernel's TWO-slab sum order where that is the same sum -- it is not
+    (even / odd sub-stages against first / second half of K), so the comparison with that kernel is by the rounding bound only.  Fused
+    SwiGLU: silu(bf16(h1)) * bf16(h2) at the reference's rounding points (flow_head_parallel_x.py:250-251), test_gemm_swiglu's bounds."""
+    from bitdance_amd._lib import check, lib
+    check(lib().bd_set_gemm_option(b"half", 2))                 # any N (the default routes 8192 <= N <= 16384 only)
+    try:
+        g = torch.Generator(device=DEV).manual_seed(M + N + K)
+        x = torch.randn(M, K, device=DEV, generator=g)
+        w = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)
+        b = (torch.randn(N, device=DEV, generator=g) * 0.1).to(torch.bfloat16)
+        xf, rb = frag(eng_mod, x)
+        assert rb % 8 == 0 and rb >= 16
+        st = torch.cuda.current_stream().cuda_stream
+        scratch = torch.empty(2 * rb * 32 * N, device=DEV)
+        cnt = torch.zeros(16384, dtype=torch.int32, device=DEV)
+        wp = eng_mod.pack_linear([w], DEV)
+        ref = (x.to(torch.bfloat16).double() @ w.double().t() + b.double())[:M]
+        want = ref.to(torch.bfloat16)
+        first = None
+        for it in range(3):
+            out = torch.full((rb * 32, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            check(lib().bd_gemm_bf16(xf.data_ptr(), rb, wp.data_ptr(), b.data_ptr(), N, K, 1, 8, scratch.data_ptr(), cnt.data_ptr(), out.data_ptr(), st))
+            torch.cuda.synchronize()
+            assert torch.isfinite(out.float()).all()            # every element of the padded tile rows written
+            d = (out[:M].double() - want.double()).abs()
+            assert bool((d <= 2.0 ** -7 * ref.abs().clamp_min(2.0 ** -6)).all()), (it, float(d.max()))
+            assert float((out[:M] != want).double().mean()) <= 0.02
+            first = out.clone() if first is None else first
+            assert torch.equal(out, first)
+        # the 256-row kernel on the same operands (one slice): same values up to the order of the fp32 sums
+        check(lib().bd_set_gemm_option(b"half", 0))
+        check(lib().bd_set_gemm_option(b"tile", 0))
+        out_w = torch.full((rb * 32, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        if N % 256 == 0:
+            check(lib().bd_gemm_bf16(xf.data_ptr(), rb, wp.data_ptr(), b.data_ptr(), N, K, 1, 8, scratch.data_ptr(), cnt.data_ptr(), out_w.data_ptr(), st))
+            torch.cuda.synchronize()
+            assert float((out_w[:M] != first[:M]).double().mean()) <= 0.02
+        check(lib().bd_set_gemm_option(b"tile", 1))
+        check(lib().bd_set_gemm_option(b"half", 2))
+        # ---- K slices as fp32 slabs (the N = 5120 Linears at 512 rows: 3 slabs): the slab sum equals the fp64 product of the bf16 operands
+        for S in (2, 3):
+            if (K // 64) // S < 2:
+                continue
+            slabs = torch.full((S, rb * 32, N), float("nan"), device=DEV)
+            check(lib().bd_gemm_partial(xf.data_ptr(), rb, wp.data_ptr(), N, K, S, 8, slabs.data_ptr(), st))
+            torch.cuda.synchronize()
+            assert torch.isfinite(slabs).all()
+            tot = slabs.double().sum(0)[:M]
+            refp = x.to(torch.bfloat16).double() @ w.double().t()
+            assert float((tot - refp).abs().max()) <= 1e-4 * max(1.0, float(refp.abs().max())), (S, float((tot - refp).abs().max()))
+            slabs2 = torch.empty_like(slabs)
+            check(lib().bd_gemm_partial(xf.data_ptr(), rb, wp.data_ptr(), N, K, S, 8, slabs2.data_ptr(), st))
+            torch.cuda.synchronize()
+            assert torch.equal(slabs, slabs2)
+        # ---- fused SwiGLU (N = 2 F packed gate / up)
+        F_ = N // 2
+        wsp = eng_mod.pack_swiglu(w[:F_], w[F_:], DEV)
+        bsp = eng_mod.pack_swiglu_bias(b[:F_], b[F_:], DEV)
+        h = (x.to(torch.bfloat16).float() @ w.float().t() + b.float()).to(torch.bfloat16)
+        sref = torch.nn.functional.silu(h[:, :F_]) * h[:, F_:]
+        acts = []
+        for it in range(2):
+            act = torch.full((rb * 32 * F_,), float("nan"), dtype=torch.bfloat16, device=DEV)
+            check(lib().bd_gemm_swiglu(xf.data_ptr(), rb, wsp.data_ptr(), bsp.data_ptr(), N, K, 8, act.data_ptr(), st))
+            torch.cuda.synchronize()
+            assert torch.isfinite(act.float()).all()
+            a = act.view(F_ // 16, rb, 2, 32, 8).permute(1, 3, 0, 2, 4).reshape(rb * 32, F_)[:M]
+            d = (a.float() - sref.float()).abs()
+            assert (d > 0).float().mean() <= 0.02 and d.max() <= 0.07, ((d > 0).float().mean(), d.max())
+            acts.append(act)
+        assert torch.equal(acts[0], acts[1])
+    finally:
+        check(lib().bd_set_gemm_option(b"half", 1))
+        check(lib().bd_set_gemm_option(b"tile", 1))
 
 
 # ----------------------------------------------------------------------------------------------- imagenet (I1-I3)

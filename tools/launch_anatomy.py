@@ -49,7 +49,7 @@ def main():
         del args[i:i + 2]
     extra = {}
     for a in list(args):
-        if a.startswith("tp.") or a.startswith("tune."):
+        if a.startswith(("tp.", "tune.", "opt.")):
             k, v = a.split("=")
             extra[k] = int(v)
             args.remove(a)
@@ -74,6 +74,9 @@ def main():
         else:
             hw = E.HeadWeights.from_state_dict(sd, dev, weights=wmode)
         del sd
+        for k, v in extra.items():                          # process-wide GEMM options ("opt.half.form=4": measurement forms of bd_gemm_half.hip)
+            if k.startswith("opt."):
+                check(l.bd_set_gemm_option(k[4:].encode(), v))
         tune = {k[5:]: v for k, v in extra.items() if k.startswith("tune.")}
         ei = {k: v for k, v in extra.items() if k.startswith("tp.")}
         B = int(os.environ.get("BD_ANATOMY_B", "1"))        # images per pass (4: the 256-row kernel's wait-cycle stamps, "wide:<gemm>")
@@ -124,6 +127,12 @@ def main():
         lp = np.mean([np.median(w[:, 3] - w[:, 0]) * TICK_US for w in ws[1:] or ws])
         tail = np.mean([np.median(w[:, 6] - w[:, 3]) * TICK_US for w in ws[1:] or ws])
         tailmax = np.mean([(w[:, 6] - w[:, 3]).max() * TICK_US for w in ws[1:] or ws])
+        if name.startswith("wide:half:"):                   # bd_gemm_half.hip: words 1 / 2 / 4 = waiting for the loads it parks / LOAD segments / barriers
+            print(f"\n== {name}: {len(ws)} launches x {ws[0].shape[0]} workgroups, {nst} sub-stages per wave group (16 MFMAs = 512 cycles of matrix pipe per group and sub-stage, two groups per SIMD)")
+            print(f"   K loop: median {np.median(loop):9.0f} cycles = {np.median(loop) / nst:6.0f} per sub-stage pair (1024 of matrix pipe); of which waiting for its loads {np.median(ww / loop):.3f}, "
+                  f"in LOAD segments {np.median(wa / loop):.3f}, at the barriers {np.median(wb / loop):.3f} (medians over workgroups; max loads {np.max(ww / loop):.3f} barrier {np.max(wb / loop):.3f})")
+            print(f"   realtime: K loop {lp:7.2f} us, loop end -> last store drained median {tail:6.2f} / max {tailmax:6.2f} us, kernel span {span:7.2f} us")
+            continue
         print(f"\n== {name}: {len(ws)} launches x {ws[0].shape[0]} workgroups, {nst} stages of 64 MFMAs per wave (2048 cycles of matrix pipe each)")
         print(f"   K loop: median {np.median(loop):9.0f} cycles = {np.median(loop) / nst:6.0f} per stage; of which waiting for W {np.median(ww / loop):.3f}, "
               f"for A {np.median(wa / loop):.3f}, at the barrier {np.median(wb / loop):.3f} (medians over workgroups; max W {np.max(ww / loop):.3f} A {np.max(wa / loop):.3f} barrier {np.max(wb / loop):.3f})")
