@@ -110,7 +110,7 @@ def parse():
 def pmc_entries(rows: int) -> dict:
     """The committed PMC passes for GEMM launches at ``rows`` rows (tools/pmc_gemm_traffic.py; newest round first)."""
     tag = "" if rows == 128 else f"_rows{rows}"
-    for r in ("r05", "archive/r04"):
+    for r in ("r06", "r05", "archive/r04"):
         pj = os.path.join(ROOT, "profiles", f"{r}_pmc_gemm_traffic{tag}.json")
         if os.path.exists(pj):
             d = json.load(open(pj))

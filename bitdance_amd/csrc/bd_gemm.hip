@@ -482,7 +482,7 @@ int bdk_set_gemm_option(const char* name, int v) {
     if (n == "wide.keep" && v >= -1 && v <= 1) { g_wide_keep = v; return 0; }
     if (n == "red.first" && v >= 0 && v <= 1) { g_red_first = v; return 0; }
     if (n == "half" && v >= 0 && v <= 2) { g_half = v; return 0; }
-    if (n == "half.form" && (v == 0 || v == 4 || v == 12)) { bdk_gemm_half_form(v); return 0; }
+    if (n == "half.form" && (v == 0 || v == 1 || v == 4 || v == 12)) { bdk_gemm_half_form(v); return 0; }
     if (n.rfind("rows.", 0) == 0) return bdk_set_rows_option(name, v);
     return -1;
 }

@@ -14,20 +14,27 @@
 // bd_gemm_tile.hip): while one group issues its 16 MFMAs from registers the other reads its next 12 fragments from LDS.
 //   half-step 2i    :  group 0  LOAD(i)   |  group 1  MFMA(i - 1)
 //   half-step 2i + 1:  group 0  MFMA(i)   |  group 1  LOAD(i)
-// MFMA(i) also issues the wave's 6 global loads (4 A chunks, 2 W chunks, 16 B per lane) of sub-stage i + 2 between its first MFMAs and
-// writes sub-stage i + 1 (loaded during MFMA(i - 1)) to the slot between its last ones: ~3.5 half-steps of L2 / HBM latency covered by
-// two register sets, all waits counted by the compiler (straight-line pairs of sub-stages: the vmcnt state at the back edge equals the
-// one at entry).  After the loop the groups swap half of their accumulators through LDS (group 0 finishes row blocks 0-1 of the wave
-// tile, group 1 row blocks 2-3: a + b == b + a bit for bit) and every wave runs the epilogue of its 64 x 64 quarter through an LDS patch
-// (16 B per lane stores).  Every output element is (sum over even sub-stages, ascending) + (sum over odd sub-stages, ascending) in fp32.
+// MFMA(i) also issues the wave's global loads (16 B per lane) of sub-stage i + 2 between its first MFMAs and writes sub-stage i + 1
+// (loaded during MFMA(i - 1)) to the slot between its last ones: ~3.5 half-steps of L2 / HBM latency covered by two register sets, all
+// waits counted by the compiler (straight-line runs of sub-stages: the vmcnt state at the back edge equals the one at entry).  After the
+// loop the groups swap half of their accumulators through LDS (group 0 finishes row blocks 0-1 of the wave tile, group 1 row blocks 2-3:
+// a + b == b + a bit for bit) and every wave runs the epilogue of its 64 x 64 quarter through an LDS patch (16 B per lane stores).
+// Every output element is (sum over even sub-stages, ascending) + (sum over odd sub-stages, ascending) in fp32, in both forms below.
+//
+// What a sub-stage pair costs (wave 0, shader cycles, qkv 512 x 15360 x 5120; 1024 = the matrix pipe's own time; measurement forms 4 / 12,
+// profiles/r06_half_kernel_anatomy.log): 1263 with neither loads nor LDS stores in the loop (LOAD segments 244, barrier skew), + 512 for
+// the 12 ds_write_b128 of the pair (24 KiB per half-step into an LDS store path of ~79 B/clk: a store holds its wave while its data
+// moves, and the MFMAs behind it in program order wait), + 130 for the 12 global loads = 1905.  Hence FORM 1 (default): W does not go
+// through LDS at all -- 1713 cycles, at a clock the power governor lowers from 2.02 to 1.86 GHz (75.5 -> 73.8 us of loop).
 #include "bd_gemm_kernel.h"
 #include <string>
 
-// FORM 0: the product kernel.  FORM 4 / 12 (measurement builds only, wrong results): no global loads / neither loads nor LDS stores in the loop --
-// the price list behind the header's numbers (profiles/r06_half_kernel_anatomy.log).  Pipelinings measured and dropped (same box, per
-// evaluation at 512 rows): loads + parking in the LOAD segment with two slots per group 2242 vs 2191 us (the LOAD segment grows from 244 to
-// 925 cycles: the LDS store path is the cost wherever it sits), three register sets (18 KiB in flight per wave) 2098 vs 2092, every store in
-// its own MFMA gap with the waves that share a store-path half on alternating gaps 2060 vs 2064.
+// FORM 1 (default): W fragments straight from HBM / L2 into registers, A through LDS.  FORM 0: both operands through LDS ("half.form" = 0;
+// the same sums bit for bit).  FORM 4 / 12 (measurement builds only, wrong results): FORM 0 without the global loads / with neither loads
+// nor LDS stores in the loop.  Pipelinings of FORM 0 measured and dropped (same box, us per evaluation at 512 rows): loads + parking in the
+// LOAD segment with two slots per group 2242 vs 2191 (the LOAD segment grows from 244 to 925 cycles: the store path costs the same wherever
+// it sits), three register sets (18 KiB in flight per wave) 2098 vs 2092, every store in its own MFMA gap with the two waves that share a
+// store-path half on alternating gaps 2060 vs 2064.
 template <int EPI, int FORM>
 __global__ __launch_bounds__(512) void gemm_half_kernel(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -147,7 +154,82 @@ __global__ __launch_bounds__(512) void gemm_half_kernel(GemmP p) {
 
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    {
+    if constexpr (FORM == 1) {
+        // W STRAIGHT INTO REGISTERS: a wave's two W fragments of a k-step are one 1 KiB chunk each in HBM already (MFMA operand order), and only
+        // the two waves with the same column half use them -- so every wave loads its own (the partner's copy is an L1 / L2 hit) and only A
+        // goes through LDS: 4 instead of 6 LDS stores and 8 instead of 12 fragment reads per wave and sub-stage, for 8 instead of 6 global
+        // loads.  W of sub-stage i + 2 is loaded during MFMA(i) into the third register set (four half-steps of cover).
+        using I2 = std::integral_constant<int, 2>;
+        u32x4 wfr[3][2][2];
+        const u32x4* const wd = p.W + (size_t)(nt * 4 + wc * 2) * p.PS + (size_t)g * 128 + lane + (size_t)p0 * w_step;
+        u32x4* const slotA = lds + g * (16 * 64);
+        u32x4* const pkA = slotA + (wg * 4) * 64 + lane;
+        auto fetch_w = [&](auto WS, int j) {
+            constexpr int Wq = decltype(WS)::value;
+            const int jc = min(j, n - 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn) wfr[Wq][ks][nn] = wd[(size_t)nn * p.PS + ks * 64 + (size_t)jc * w_step];
+        };
+        auto fetch_a = [&](auto AS, int j) {
+            constexpr int Aq = decltype(AS)::value;
+            const int jc = min(j, n - 1);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) stg[Aq][c] = a_src[(size_t)jc * a_step + c * 64];
+        };
+        auto load_a = [&]() {
+            const u32x4* const a = slotA + lane;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) af[ks][m] = a[(ks * 8 + wr * 4 + m) * 64];
+        };
+        auto seg = [&](auto AS, auto WS, int i) {
+            constexpr int Aq = decltype(AS)::value, Wq = decltype(WS)::value, Wn = (Wq + 2) % 3;
+            const int jc = min(i + 2, n - 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int pr = ks * 4 + m;
+#pragma unroll
+                    for (int nn = 0; nn < 2; ++nn) acc[m][nn] = mfma32(af[ks][m], wfr[Wq][ks][nn], acc[m][nn]);
+                    if (pr < 4) {
+                        stg[Aq][pr] = a_src[(size_t)jc * a_step + pr * 64];
+                        wfr[Wn][pr >> 1][pr & 1] = wd[(size_t)(pr & 1) * p.PS + (pr >> 1) * 64 + (size_t)jc * w_step];
+                    } else {
+                        pkA[(pr - 4) * 64] = stg[Aq ^ 1][pr - 4];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        };
+#ifdef BD_GEMM_STAMP
+#define HALF_LOADA() do { const unsigned long long t0_ = __builtin_readcyclecounter(); load_a(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_l += __builtin_readcyclecounter() - t0_; } while (0)
+#else
+#define HALF_LOADA() load_a()
+#endif
+#define HALF_STEP(AS, WS, i) do { HALF_SYNC(); HALF_LOADA(); HALF_SYNC(); seg(AS{}, WS{}, i); } while (0)
+        fetch_a(I0{}, 0);
+        fetch_w(I0{}, 0);
+        fetch_a(I1{}, 1);
+        fetch_w(I1{}, 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pkA[c * 64] = stg[0][c];
+        if (g == 1) __syncthreads();
+        int i = 0;
+        for (; i + 5 < n; i += 6) {
+            HALF_STEP(I0, I0, i); HALF_STEP(I1, I1, i + 1); HALF_STEP(I0, I2, i + 2);
+            HALF_STEP(I1, I0, i + 3); HALF_STEP(I0, I1, i + 4); HALF_STEP(I1, I2, i + 5);
+        }
+        if (i < n) HALF_STEP(I0, I0, i);
+        if (i + 1 < n) HALF_STEP(I1, I1, i + 1);
+        if (i + 2 < n) HALF_STEP(I0, I2, i + 2);
+        if (i + 3 < n) HALF_STEP(I1, I0, i + 3);
+        if (i + 4 < n) HALF_STEP(I0, I1, i + 4);
+        if (g == 0) __syncthreads();
+    } else {
         fetch(I0{}, 0);
         fetch(I1{}, 1);
         park(I0{});
@@ -275,7 +357,7 @@ __global__ __launch_bounds__(512) void gemm_half_kernel(GemmP p) {
     BD_KSTAMP_END(p.stamp);
 }
 
-static int g_half_form = 0;
+static int g_half_form = 1;     // 1: W straight into registers (default, round 6: -0.6 .. -1.1 % per evaluation at 512 rows, same box); 0: both operands through LDS
 void bdk_gemm_half_form(int v) { g_half_form = v; }
 template <int EPI, int FORM>
 static int launch_half_f(const GemmP& p, hipStream_t st) {
@@ -288,11 +370,12 @@ static int launch_half_f(const GemmP& p, hipStream_t st) {
 template <int EPI>
 static int launch_half(const GemmP& p, hipStream_t st) {
     switch (g_half_form) {
+        case 0: return launch_half_f<EPI, 0>(p, st);
 #ifdef BD_GEMM_STAMP
         case 4: return launch_half_f<EPI, 4>(p, st);
         case 12: return launch_half_f<EPI, 12>(p, st);
 #endif
-        default: return launch_half_f<EPI, 0>(p, st);
+        default: return launch_half_f<EPI, 1>(p, st);
     }
 }
 // RB % 8 == 0 (256-row tiles), N % 128 == 0, K % 64 == 0, every K slice >= 128 deep; one K slice with bf16(+bias) or SwiGLU output, or S

@@ -39,14 +39,17 @@ int bd_set_weight_layout(int stage_major);
  * "tile.minrb" 8, 16, ... = row blocks from which the tiled kernel takes over (default 32 = 1024 rows);
  * "red.first" 0|1 = two-slice in-launch reduction with the ticket taken first (1, default: only the first arriver parks its
  * accumulators) or both slices parking (0); "rows.ln_occ" 4|5 = ln_mod's register bound (one / two 640-thread workgroups per CU,
- * default 5); "rows.swiglu_t" 512|1024 = thread cap of swiglu_rows (default 512). */
+ * default 5); "rows.swiglu_t" 512|1024 = thread cap of swiglu_rows (default 512); "half" 0|1|2 = the 256 x 128-tile kernel of the
+ * 512-row passes (bd_gemm_half.hip): off / where the launch code asks for it (nwaves + 4096; default) / for every shape it can run;
+ * "half.form" 1|0 = its weight fragments straight into registers (default) / both operands through LDS. */
 int bd_set_gemm_option(const char* name, int value);
 int bd_pack_weight_swiglu(void* dst_packed, const void* gate_bf16, const void* up_bf16, int F, int K, void* stream);
 int bd_rows_to_frag(void* dst_frag, const void* src, int src_is_fp32, int M, int K, int row_blocks, void* stream);
 
 /* ---- F.linear under bf16 autocast (flow_head_parallel_x.py:326-339, HF modeling_qwen3.py:81-83,252-279).
  *      out_partial: [splitk][row_blocks*32][N] fp32 slabs, summed (+bias, bf16 rounding) by the consumer.
- *      nwaves = waves per workgroup (2, 4, 8) [+ 16 * ring, ring in {2,3,4} = K stages a wave keeps in flight]. */
+ *      nwaves = waves per workgroup (2, 4, 8) [+ 16 * ring, ring in {2,3,4} = K stages a wave keeps in flight]
+ *      [+ 4096: >= 512 rows, < 1024 rows: the 256 x 128-tile kernel, one K slice with a rounded output or any number of slabs]. */
 int bd_gemm_partial(const void* a_frag, int row_blocks, const void* w_packed, int N, int K, int splitk, int nwaves,
                     float* out_partial, void* stream);
 /* The same Linear with the split-K slices reduced INSIDE the launch (the last-arriving slice of each tile sums the

@@ -689,6 +689,9 @@ def test_gemm_256_row_kernel_wide_epilogues(eng_mod, M, N, K, S):
         check(lib().bd_set_gemm_option(b"half", 1))
 
 
+HALF_FORM_DEFAULT = 1
+
+
 @pytest.mark.parametrize("M,N,K", [(512, 15360, 5120), (512, 256, 128), (768, 384, 192), (500, 1152, 704), (512, 5120, 7680)])
 def test_gemm_512_row_kernel_half_tiles(eng_mod, M, N, K):
     """The 512-row kernel (bd_gemm_half.hip: 256 x 128 tiles, ONE K slice, the two wave groups of a workgroup take the even / odd 32-deep
@@ -712,7 +715,8 @@ def test_gemm_512_row_kernel_half_tiles(eng_mod, M, N, K):
         ref = (x.to(torch.bfloat16).double() @ w.double().t() + b.double())[:M]
         want = ref.to(torch.bfloat16)
         first = None
-        for it in range(3):
+        for it in range(4):                                     # both operand paths of the K loop ("half.form" 0 / 1): the same sums, bit for bit
+            check(lib().bd_set_gemm_option(b"half.form", it & 1))
             out = torch.full((rb * 32, N), float("nan"), dtype=torch.bfloat16, device=DEV)
             check(lib().bd_gemm_bf16(xf.data_ptr(), rb, wp.data_ptr(), b.data_ptr(), N, K, 1, 8, scratch.data_ptr(), cnt.data_ptr(), out.data_ptr(), st))
             torch.cuda.synchronize()
@@ -766,6 +770,7 @@ def test_gemm_512_row_kernel_half_tiles(eng_mod, M, N, K):
         assert torch.equal(acts[0], acts[1])
     finally:
         check(lib().bd_set_gemm_option(b"half", 1))
+        check(lib().bd_set_gemm_option(b"half.form", HALF_FORM_DEFAULT))
         check(lib().bd_set_gemm_option(b"tile", 1))
 
 

@@ -73,7 +73,7 @@ def run():
     from bitdance_amd._lib import check, lib
     for tune in cfgs:
         tune = dict(tune)
-        opts = {k: tune.pop(k) for k in list(tune) if k.startswith(("wide.", "red.", "rows.", "tile.")) or k == "tile"}      # process-wide GEMM options
+        opts = {k: tune.pop(k) for k in list(tune) if k.startswith(("wide.", "red.", "rows.", "tile.", "half.")) or k == "tile"}      # process-wide GEMM options
         for k, v in opts.items():
             check(lib().bd_set_gemm_option(k.encode(), v))
         extra = {k: tune.pop(k) for k in list(tune) if k.startswith("tp.")}                         # context keys outside tune.*
@@ -124,7 +124,7 @@ def run():
             comm.check()
         del eng, comm
         for k in opts:
-            check(lib().bd_set_gemm_option(k.encode(), {"wide.ring": 2, "tile": 1, "red.first": 1, "rows.ln_occ": 5, "rows.swiglu_t": 512, "tile.minrb": 32}.get(k, -1)))
+            check(lib().bd_set_gemm_option(k.encode(), {"wide.ring": 2, "tile": 1, "red.first": 1, "rows.ln_occ": 5, "rows.swiglu_t": 512, "tile.minrb": 32, "half.form": 1}.get(k, -1)))
         torch.cuda.empty_cache()
 
 

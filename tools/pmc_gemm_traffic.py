@@ -39,9 +39,12 @@ SHAPES = [("head.ada", 71680, 5120, 1, 9, 1, 2), ("head.qkv", 15360, 5120, 2, 4,
 # num_images = 4 (the eval scripts' batch, eval/eval_dpg.py:44): 512 rows per pass, the engine's launch configurations at that row
 # count (bench.py b4.roofline.per_gemm): the 256-row kernel, K slices left to the consumer; the grouped adaLN projection of two
 # evaluations = 1024 rows on the LDS-tiled kernel.  Selected with BD_PMC_ROWS=512 -> profiles/r05_pmc_gemm_traffic_rows512.json
-SHAPES_512 = [("head.qkv", 15360, 5120, 2, 8, 1, 2, 512), ("head.wo", 5120, 5120, 5, 8, 1, 2, 512), ("head.w1", 15360, 5120, 2, 8, 1, 2, 512),
-              ("head.w2", 5120, 7680, 5, 8, 1, 2, 512), ("llm.qkv", 7168, 5120, 3, 8, 1, 2, 512), ("llm.o", 5120, 5120, 5, 8, 1, 2, 512),
-              ("llm.gu", 34816, 5120, 1, 8, 1, 2, 512), ("llm.down", 5120, 17408, 5, 8, 1, 2, 512),
+# (round 6: the 256 x 128-tile kernel, bd_gemm_half.hip -- launch code + 4096: one K slice with a rounded output for the N = 15360 shapes,
+# 3 / 2 slabs for the N = 5120 / 7168 shapes -> profiles/r06_pmc_gemm_traffic_rows512.json)
+H = 4096
+SHAPES_512 = [("head.qkv", 15360, 5120, 1, 8 + H, 1, 2, 512), ("head.wo", 5120, 5120, 3, 8 + H, 1, 2, 512), ("head.w1", 15360, 5120, 1, 8 + H, 1, 2, 512),
+              ("head.w2", 5120, 7680, 3, 8 + H, 1, 2, 512), ("llm.qkv", 7168, 5120, 2, 8 + H, 1, 2, 512), ("llm.o", 5120, 5120, 3, 8 + H, 1, 2, 512),
+              ("llm.gu", 34816, 5120, 1, 8 + H, 1, 2, 512), ("llm.down", 5120, 17408, 3, 8 + H, 1, 2, 512),
               ("head.ada[x2]", 71680, 5120, 1, 8, 1, 2, 1024)]
 if os.environ.get("BD_PMC_ROWS") == "512":
     SHAPES, M = SHAPES_512, 512
@@ -98,7 +101,7 @@ def _rows(db_path, counter):
 
 def parse(out_path, fetch_db, write_db=None, sq_db=None):
     def gemms(rows):
-        g = [r for r in rows if "gemm_kernel" in r[1] or "gemm_wide" in r[1] or "gemm_tile" in r[1]]
+        g = [r for r in rows if "gemm_kernel" in r[1] or "gemm_wide" in r[1] or "gemm_tile" in r[1] or "gemm_half" in r[1]]
         assert len(g) == REPS * len(SHAPES), (len(g), REPS * len(SHAPES))
         return g
 
@@ -129,7 +132,7 @@ def parse(out_path, fetch_db, write_db=None, sq_db=None):
         sl = slice(i * REPS + 1, (i + 1) * REPS)              # drop the first launch of each shape (cold TLB / code)
         avg = lambda g: sum(r[2] for r in g[sl]) / (REPS - 1)
         alg = N * K * 2
-        e = dict(N=N, K=K, rows=rows, splitk=S, nwaves=nw, kparts=kw, ring=ring, fetch_size_kib_raw=round(avg(gf), 1), hbm_read_bytes=round(avg(gf) * fetch_scale),
+        e = dict(N=N, K=K, rows=rows, splitk=S, nwaves=nw & 15, kernel=('gemm_half_kernel' if nw & 4096 else 'by launch code'), kparts=kw, ring=ring, fetch_size_kib_raw=round(avg(gf), 1), hbm_read_bytes=round(avg(gf) * fetch_scale),
                  algorithmic_bytes=alg)
         e["read_ratio"] = round(e["hbm_read_bytes"] / alg, 4)
         e["avg_ns"] = round(sum(r[3] for r in gf[sl]) / (REPS - 1))
