@@ -440,7 +440,7 @@ def test_bench_roofline_accounting():
 
 
 def test_bench_pmc_annotation_reads_the_committed_passes():
-    """bench.py attaches `mfma_busy` / `eff_clock_ghz` of the committed PMC passes (profiles/r05_pmc_gemm_traffic*.json) to a per-GEMM
+    """bench.py attaches `mfma_busy` / `eff_clock_ghz` of the committed PMC passes (profiles/r06_pmc_gemm_traffic*.json) to a per-GEMM
     row only when that pass measured the SAME launch configuration; the 512-row pass feeds the `b4` object."""
     import importlib.util
     import os
@@ -450,9 +450,9 @@ def test_bench_pmc_annotation_reads_the_committed_passes():
     per = [{"name": "head.qkv", "splitk": 2, "nwaves": 4, "kparts": 1}, {"name": "head.qkv", "splitk": 4, "nwaves": 4, "kparts": 1},
            {"name": "head.nope", "splitk": 1, "nwaves": 4, "kparts": 1}]
     src = b.annotate_pmc(per, 128)
-    assert src and src.endswith("r05_pmc_gemm_traffic.json")
+    assert src and src.endswith("r06_pmc_gemm_traffic.json")
     assert 0.1 < per[0]["mfma_busy"] < 0.5 and 1.0 < per[0]["eff_clock_ghz"] < 4.0
     assert "mfma_busy" not in per[1] and "mfma_busy" not in per[2]          # another split-K / an unknown GEMM: no numbers invented
-    per4 = [{"name": "head.wo", "splitk": 5, "nwaves": 8, "kparts": 1}]
-    assert b.annotate_pmc(per4, 512).endswith("r05_pmc_gemm_traffic_rows512.json") and "mfma_busy" in per4[0]
+    per4 = [{"name": "head.wo", "splitk": 3, "nwaves": 8, "kparts": 1}, {"name": "head.wo", "splitk": 5, "nwaves": 8, "kparts": 1}]   # (round 6: 3 slabs on the 256 x 128-tile kernel)
+    assert b.annotate_pmc(per4, 512).endswith("r06_pmc_gemm_traffic_rows512.json") and "mfma_busy" in per4[0] and "mfma_busy" not in per4[1]
     assert b.pmc_entries(256) == {}
