@@ -36,6 +36,27 @@ def test_head_eval_14b_two_images_true_dims():
     assert r["finite"] and r["max_err"] <= HEAD_MAX and r["mean_err"] <= HEAD_MEAN, r
 
 
+@pytest.mark.parametrize("half", [7, 0])
+def test_head_eval_14b_four_images_true_dims(half):
+    """num_images = 4 (M = 512 rows, eval/eval_dpg.py:44 -- bench.py's `b4`): the 256 x 128-tile kernel (bd_gemm_half.hip, round 6) with one K slice
+    and the rounded / SwiGLU epilogues for qkv / w1 and THREE fp32 slabs for wo / w2, against the oracle at the per-evaluation bounds of this
+    file; `tune.half` = 0: the 256-row kernel with 2 / 5 slabs (the round-5 launch rules) inside the same bounds."""
+    from oracle.true_dims import head_case
+    r = head_case(D=5120, P=64, B=4, branches=2, depth=1, nada=1, seed=131, tune={"half": half})
+    want = {"qkv": 1, "w1": 1, "wo": 3, "w2": 3} if half else {"qkv": 2, "w1": 2, "wo": 5, "w2": 5}
+    assert {k: r["gemm_cfg"][k]["splitk"] for k in want} == want, r["gemm_cfg"]
+    assert r["finite"] and r["max_err"] <= HEAD_MAX and r["mean_err"] <= HEAD_MEAN, r
+
+
+def test_llm_decode_step_qwen3_14b_512_rows():
+    """The Qwen3-14B layer at num_images = 4 with CFG (8 sequences x 64 new tokens = 512 rows, ragged caches): qkv / o / down as 2 / 3 / 3
+    slabs and gate / up at one slice on the 256 x 128-tile kernel."""
+    from oracle.true_dims import llm_case
+    r = llm_case(layers=1, past=(1000, 1017, 911, 805, 1100, 957, 1001, 640), seed=211)
+    assert {k: r["gemm_cfg"][k]["splitk"] for k in ("qkv", "o", "gu", "down")} == {"qkv": 2, "o": 3, "gu": 1, "down": 3}, r["gemm_cfg"]
+    assert r["finite"] and r["max_err"] <= LLM_MAX and r["mean_err"] <= LLM_MEAN, r
+
+
 @pytest.mark.parametrize("B", [8, 16])
 def test_head_eval_14b_eight_images_true_dims(B):
     """num_images = 8 / 16 (M = 1024 / 2048 rows: bench.py's `throughput` regime): qkv / w1 / adaLN on the LDS-tiled kernel with fused epilogues, wo / w2 as
