@@ -473,8 +473,8 @@ static int g_half = 1;                                   // 512-768 rows, one K 
 static int g_tile = 1;                                   // >= 512 rows: the LDS-tiled MFMA-bound kernel (bd_gemm_tile.hip); 0 = 256-row kernel
 int bdk_set_gemm_option(const char* name, int v) {
     const std::string n(name);
-    // 0: 256-row kernel; 1: tiled kernel, operand fetch by shape; 2 / 3: tiled kernel, register-staged / LDS-DMA fetch forced
-    if (n == "tile" && v >= 0 && v <= 3) { g_tile = v ? 1 : 0; bdk_gemm_tile_stg(v == 2 ? 1 : (v == 3 ? 0 : -1)); return 0; }
+    // 0: 256-row kernel; 1: tiled kernel, operand fetch by shape; 2 / 3 / 4: tiled kernel, register-staged / LDS-DMA / W-in-registers fetch forced
+    if (n == "tile" && v >= 0 && v <= 4) { g_tile = v ? 1 : 0; bdk_gemm_tile_stg(v == 2 ? 1 : (v == 3 ? 0 : (v == 4 ? 2 : -1))); return 0; }
     if (n == "tile.debug" && v >= 0 && v <= 3) { bdk_gemm_tile_debug(v); return 0; }
     if (n == "tile.minrb" && v >= 8 && v % 8 == 0) { g_tile_minrb = v; return 0; }
     if (n == "wide.ring" && (v == 2 || v == 3)) { g_wide_ring = v; return 0; }

@@ -42,7 +42,7 @@ BD_DEV void dma_chunk(const u32x4* gsrc, unsigned lds_byte) {
 
 }  // namespace
 
-template <int EPI, bool STG = false>
+template <int EPI, int STG = 0>
 __global__ __launch_bounds__(512) void gemm_tile_kernel(GemmP p, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const u32x4* const lds = reinterpret_cast<const u32x4*>(smem);
@@ -150,7 +150,134 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(GemmP p, int dbg) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    if constexpr (STG) {
+    if constexpr (STG == 2) {
+        // W STRAIGHT INTO REGISTERS (tile option 4, round 6; an A/B form, not the default).  A wave's two W fragments of a k-step are whole 1 KiB
+        // chunks in HBM already and only the wave of the other row half shares them, so every wave loads its own W (the partner's copy is an
+        // L1 / L2 hit) and only A goes through LDS: per wave and stage 2 LDS stores instead of 4, 8 fragment reads instead of 12, 6 global loads
+        // instead of 4.  A: every wave fetches 2 of the stage's 16 chunks three stages ahead (three register sets) and parks them one stage
+        // before they are read; W of stage j + 2 is loaded during MFMA(j) over the set it is reading, each load behind the last MFMA that reads
+        // its register.  Same MFMAs in the same order as the other two forms: bit-identical results.
+        // Why it exists and what it showed: in bd_gemm_half.hip the LDS stores are the largest single cost of the loop, and THIS loop with its
+        // stores removed runs at 0.70 of the matrix peak instead of 0.50 -- but with half of them removed it runs at 0.48 (adaLN x16 1252 vs
+        // 1224 us, qkv at 2048 / 1024 rows 266 / 134 vs 268 / 137, ImageNet w1 81 vs 83): the 0.70 was the power governor's answer to operands
+        // that stop changing (an LDS nobody writes), not a faster loop.  This kernel sits at the LDS-fed power ceiling of the chip
+        // (tools/probe_mfma.hip: 0.62 on random data), whichever way its operands arrive.
+        u32x4 sa[3][2], wr_[2][2][2];
+        u32x4* const ldsw = reinterpret_cast<u32x4*>(smem);
+        // this wave's two A chunks of a stage are adjacent (chunks 2 wave, 2 wave + 1: one k-step, consecutive row blocks); its four W fragments
+        // are two panels x two k-steps.  Every address is wave-uniform + lane * 16: buffer loads with the uniform part in SGPRs -- one VGPR of
+        // addressing for all six loads of a stage (64-bit per-lane pointers for each stream did not fit beside 216 data registers: hipcc spilled
+        // them and reloaded them inside the loop behind s_waitcnt vmcnt(0))
+        const int ca = wave * 2;
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(p.A), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(p.W), 0, 0x7fffffff, 0x00020000);
+        const unsigned lane16 = (unsigned)lane * 16u;
+        const unsigned a_base = (unsigned)((((size_t)(st0 * 2 + (ca >> 3)) * p.RB + mt * 8 + (ca & 7)) * 64) * 16);      // bytes (A < 2 GiB, W < 2 GiB: launcher)
+        const unsigned a_stride = (unsigned)((size_t)2 * p.RB * 64 * 16);
+        const unsigned w_base0 = (unsigned)(((size_t)(nt * 8 + wc * 2) * p.PS + (size_t)(st0 * 2) * 64) * 16);
+        const unsigned w_base1 = w_base0 + (unsigned)(p.PS * 16);
+        const unsigned adst0 = (unsigned)ca * 64u;
+        auto ldb = [&](const __amdgpu_buffer_rsrc_t& r, unsigned soff) -> u32x4 {
+            return __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane16, (int)soff, 0);
+        };
+        auto fetch_a = [&](auto SET, int st) {
+            constexpr int Q = decltype(SET)::value;
+            const unsigned o = a_base + (unsigned)min(st, nst - 1) * a_stride;
+            sa[Q][0] = ldb(ra, o);
+            sa[Q][1] = ldb(ra, o + 1024u);
+        };
+        auto fetch_w = [&](auto SET, int st) {
+            constexpr int Q = decltype(SET)::value;
+            const unsigned o = (unsigned)min(st, nst - 1) * 2048u;
+            wr_[Q][0][0] = ldb(rw, w_base0 + o); wr_[Q][0][1] = ldb(rw, w_base1 + o);
+            wr_[Q][1][0] = ldb(rw, w_base0 + o + 1024u); wr_[Q][1][1] = ldb(rw, w_base1 + o + 1024u);
+        };
+        auto park_a = [&](auto SET, int st) {                // stage st's two chunks of this wave -> slot st & 3 (16 KiB slots: A only)
+            constexpr int Q = decltype(SET)::value;
+            u32x4* const w = ldsw + (size_t)(st & (TS_SLOTS - 1)) * (16 * 64) + adst0 + lane;
+            w[0] = sa[Q][0];
+            w[64] = sa[Q][1];
+        };
+        // LOAD(j), j % 3 == Q: A fragments of stage j, then stage j + 1 (set (Q + 1) % 3) into its slot
+        auto load3 = [&](auto SET, int jj) {
+            constexpr int Q = decltype(SET)::value;
+            const u32x4* a = lds + (size_t)(jj & (TS_SLOTS - 1)) * (16 * 64) + lane;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) af[ks][m] = a[(ks * 8 + (wr * 4 + m)) * 64];
+            park_a(std::integral_constant<int, (Q + 1) % 3>{}, jj + 1);
+        };
+        // MFMA(j), j % 3 == QA, j % 2 == QW: 16 MFMAs on wr_[QW]; the A loads of stage j + 3 (set QA, parked since LOAD(j - 1)) behind the first
+        // two MFMA pairs; the W loads of stage j + 2 into the SAME set, each behind the last MFMA that reads the register it overwrites
+        // (k-step 0 after pair 3, k-step 1 after pair 7): two W sets are enough and a stage is ~3.5 half-steps ahead
+        auto mfma3 = [&](auto SETA, auto SETW, int jj) {
+            constexpr int QA = decltype(SETA)::value, QW = decltype(SETW)::value;
+            const unsigned oa = a_base + (unsigned)min(jj + 3, nst - 1) * a_stride;
+            const unsigned ow = (unsigned)min(jj + 2, nst - 1) * 2048u;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][n] = mfma32(af[ks][m], wr_[QW][ks][n], acc[m][n]);
+                    const int pr = ks * 4 + m;
+                    if (pr < 2) sa[QA][pr] = ldb(ra, oa + pr * 1024u);
+                    else if (pr == 4) wr_[QW][0][0] = ldb(rw, w_base0 + ow);
+                    else if (pr == 5) wr_[QW][0][1] = ldb(rw, w_base1 + ow);
+                    else if (pr == 7) {
+                        wr_[QW][1][0] = ldb(rw, w_base0 + ow + 1024u);
+                        wr_[QW][1][1] = ldb(rw, w_base1 + ow + 1024u);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+#define TILE_LD(QA, jj) do { __syncthreads(); load3(QA{}, jj); } while (0)
+#define TILE_MF(QA, QW, jj) do { __syncthreads(); mfma3(QA{}, QW{}, jj); } while (0)
+        fetch_a(I0{}, 0); fetch_w(I0{}, 0); fetch_a(I1{}, 1); fetch_w(I1{}, 1); fetch_a(I2{}, 2);
+        park_a(I0{}, 0);
+        if (isX) {
+            int j = 0;
+            for (; j + 5 < nst; j += 6) {
+                TILE_LD(I0, j); TILE_MF(I0, I0, j);         TILE_LD(I1, j + 1); TILE_MF(I1, I1, j + 1); TILE_LD(I2, j + 2); TILE_MF(I2, I0, j + 2);
+                TILE_LD(I0, j + 3); TILE_MF(I0, I1, j + 3); TILE_LD(I1, j + 4); TILE_MF(I1, I0, j + 4); TILE_LD(I2, j + 5); TILE_MF(I2, I1, j + 5);
+            }
+            if (j < nst) { TILE_LD(I0, j); TILE_MF(I0, I0, j); }
+            if (j + 1 < nst) { TILE_LD(I1, j + 1); TILE_MF(I1, I1, j + 1); }
+            if (j + 2 < nst) { TILE_LD(I2, j + 2); TILE_MF(I2, I0, j + 2); }
+            if (j + 3 < nst) { TILE_LD(I0, j + 3); TILE_MF(I0, I1, j + 3); }
+            if (j + 4 < nst) { TILE_LD(I1, j + 4); TILE_MF(I1, I0, j + 4); }
+            __syncthreads();                                    // Y has read its last fragments: LDS is free for the epilogue
+            BD_MFMA_DRAIN();
+        } else {
+            __syncthreads();
+            TILE_LD(I0, 0);
+            int j = 0;
+            for (; j + 6 < nst; j += 6) {
+                TILE_MF(I0, I0, j);     TILE_LD(I1, j + 1); TILE_MF(I1, I1, j + 1); TILE_LD(I2, j + 2); TILE_MF(I2, I0, j + 2); TILE_LD(I0, j + 3);
+                TILE_MF(I0, I1, j + 3); TILE_LD(I1, j + 4); TILE_MF(I1, I0, j + 4); TILE_LD(I2, j + 5); TILE_MF(I2, I1, j + 5); TILE_LD(I0, j + 6);
+            }
+            TILE_MF(I0, I0, j);                                 // 1-6 stages left, the fragments of stage j are loaded
+            if (j + 1 < nst) {
+                TILE_LD(I1, j + 1); TILE_MF(I1, I1, j + 1);
+                if (j + 2 < nst) {
+                    TILE_LD(I2, j + 2); TILE_MF(I2, I0, j + 2);
+                    if (j + 3 < nst) {
+                        TILE_LD(I0, j + 3); TILE_MF(I0, I1, j + 3);
+                        if (j + 4 < nst) {
+                            TILE_LD(I1, j + 4); TILE_MF(I1, I0, j + 4);
+                            if (j + 5 < nst) { TILE_LD(I2, j + 5); TILE_MF(I2, I1, j + 5); }
+                        }
+                    }
+                }
+            }
+            BD_MFMA_DRAIN();
+        }
+    } else if constexpr (STG == 1) {
         // REGISTER-STAGED operand fetch (tile option 2): the wave's 4 chunks of a stage come in by plain 16 B global loads, three stages
         // ahead, into one of three register sets (set = stage % 3), and are written to their LDS slot in the LOAD segment one stage
         // before they are read.  An LDS-DMA piece costs the issuing wave 60-185 cycles beside ds_reads or between MFMAs (MI355X_MICROARCH
@@ -338,10 +465,11 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(GemmP p, int dbg) {
 
 // RB % 8 == 0 (256-row tiles), N % 256 == 0, K % 32 == 0, panel-major weights; S > 1 only with fp32 slabs (BD_EPI_PARTIAL)
 static int g_tile_dbg = 0;                                       // measurement only: 1 = no MFMA work, 2 = no DMA after the prologue
+static int g_tile_wreg = 0;                                      // by-shape choice: 1 = the W-in-registers form ("tile" = 1 keeps the by-shape rule)
 static int g_tile_stg = -1;                                      // operand fetch: 1 register-staged, 0 LDS-DMA, -1 by shape (option "tile" = 2 / 3 / 1)
 void bdk_gemm_tile_debug(int v) { g_tile_dbg = v; }
 void bdk_gemm_tile_stg(int v) { g_tile_stg = v; }
-template <int EPI, bool STG>
+template <int EPI, int STG>
 static int launch_tile(const GemmP& p, int blocks, hipStream_t st) {
     constexpr int lds = TS_SLOTS * TS_STAGE_UNITS * 16;            // 128 KiB: one workgroup per CU
     static unsigned long long optin = 0;
@@ -357,13 +485,19 @@ int bdk_gemm_tile(const GemmP& p, int epi, hipStream_t st) {
     const int nR = ((RT + 7) / 8) * ((NTS + 3) / 4);
     const int blocks = ((nR + 7) / 8) * 8 * 32;
     // measured (profiles/r04_gemm_tile_regstaged.log): adaLN x8 665 vs 707 us, x16 1218 vs 1236, x52 4506 vs 4579; ImageNet w1 (K = 768) 94.0 vs 92.7
-    const bool stg = g_tile_stg < 0 ? (nst_total / p.S >= 64) : (g_tile_stg == 1);
-    if (stg) {
-        if (epi == BD_EPI_PARTIAL) return launch_tile<BD_EPI_PARTIAL, true>(p, blocks, st);
-        if (epi == BD_EPI_BF16) return launch_tile<BD_EPI_BF16, true>(p, blocks, st);
-        return launch_tile<BD_EPI_SWIGLU, true>(p, blocks, st);
+    // operand fetch: 2 = W straight into registers (round 6), 1 = both operands register-staged through LDS, 0 = LDS-DMA
+    const int stg = g_tile_stg < 0 ? (g_tile_wreg ? 2 : (nst_total / p.S >= 64 ? 1 : 0)) : g_tile_stg;
+    if (stg == 2) {
+        if (epi == BD_EPI_PARTIAL) return launch_tile<BD_EPI_PARTIAL, 2>(p, blocks, st);
+        if (epi == BD_EPI_BF16) return launch_tile<BD_EPI_BF16, 2>(p, blocks, st);
+        return launch_tile<BD_EPI_SWIGLU, 2>(p, blocks, st);
     }
-    if (epi == BD_EPI_PARTIAL) return launch_tile<BD_EPI_PARTIAL, false>(p, blocks, st);
-    if (epi == BD_EPI_BF16) return launch_tile<BD_EPI_BF16, false>(p, blocks, st);
-    return launch_tile<BD_EPI_SWIGLU, false>(p, blocks, st);
+    if (stg == 1) {
+        if (epi == BD_EPI_PARTIAL) return launch_tile<BD_EPI_PARTIAL, 1>(p, blocks, st);
+        if (epi == BD_EPI_BF16) return launch_tile<BD_EPI_BF16, 1>(p, blocks, st);
+        return launch_tile<BD_EPI_SWIGLU, 1>(p, blocks, st);
+    }
+    if (epi == BD_EPI_PARTIAL) return launch_tile<BD_EPI_PARTIAL, 0>(p, blocks, st);
+    if (epi == BD_EPI_BF16) return launch_tile<BD_EPI_BF16, 0>(p, blocks, st);
+    return launch_tile<BD_EPI_SWIGLU, 0>(p, blocks, st);
 }

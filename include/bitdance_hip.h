@@ -34,8 +34,9 @@ int bd_set_weight_layout(int stage_major);
 /* process-wide A/B switches of the GEMM kernels, for measurement (tools/, bench.py --gemm-opt); every setting computes the same
  * values.  "wide.ring" 2|3 = weight stages a wave of the 256-row kernel keeps in flight; "wide.xcd" -1|0|1 = row tiles of one
  * weight slice on one XCD (by shape / off / on); "wide.keep" -1|0|1 = default-policy instead of non-temporal weight loads when
- * several row tiles read a slice; "tile" 0|1|2|3 = from 1024 rows on N >= 4096: the 256-row kernel / the LDS-tiled 256 x 256
- * kernel with its operand fetch chosen by shape / register-staged fetch forced / LDS-DMA fetch forced (bd_gemm_tile.hip);
+ * several row tiles read a slice; "tile" 0|1|2|3|4 = from 1024 rows on N >= 4096: the 256-row kernel / the LDS-tiled 256 x 256
+ * kernel with its operand fetch chosen by shape / register-staged fetch forced / LDS-DMA fetch forced / W straight into registers
+ * forced (bd_gemm_tile.hip);
  * "tile.minrb" 8, 16, ... = row blocks from which the tiled kernel takes over (default 32 = 1024 rows);
  * "red.first" 0|1 = two-slice in-launch reduction with the ticket taken first (1, default: only the first arriver parks its
  * accumulators) or both slices parking (0); "rows.ln_occ" 4|5 = ln_mod's register bound (one / two 640-thread workgroups per CU,

@@ -150,7 +150,8 @@ def test_gemm_wide_options(eng_mod, M, N, K, S, ring, xcd):
 @pytest.mark.parametrize("K,S", [(64, 1), (128, 1), (192, 1), (448, 1), (768, 1), (1024, 1), (5120, 1), (1024, 2), (2048, 3)])
 def test_gemm_tile_kernel_both_fetch_forms(eng_mod, K, S):
     """The LDS-tiled 256 x 256 kernel (bd_gemm_tile.hip: from 1024 rows on N >= 4096) in both operand-fetch forms -- LDS-DMA
-    (option "tile" = 3) and register-staged global loads, three stages ahead in three register sets (= 2) -- against the 256-row
+    (option "tile" = 3), register-staged global loads, three stages ahead in three register sets (= 2), and W straight into registers with
+    only A through LDS (= 4, round 6) -- against the 256-row
     weight-streaming kernel (= 0): every accumulator sees its K steps in the same order through the same MFMA, so the fp32 slabs,
     the bf16(+bias) output and the fused SwiGLU operand are bit-identical; and right against fp64.  K covers 32-deep stage counts
     2 .. 160 with every residue mod 3 (the register sets rotate over whole triples; the last 1-3 stages run behind conditions)
@@ -168,7 +169,7 @@ def test_gemm_tile_kernel_both_fetch_forms(eng_mod, K, S):
     st = torch.cuda.current_stream().cuda_stream
     res = {}
     try:
-        for tile in (0, 3, 2):
+        for tile in (0, 3, 2, 4):
             check(lib().bd_set_gemm_option(b"tile", tile))
             slabs = torch.full((S, rb * 32, N), float("nan"), device=DEV)
             check(lib().bd_gemm_partial(xf.data_ptr(), rb, wp.data_ptr(), N, K, S, 8, slabs.data_ptr(), st))
@@ -183,7 +184,7 @@ def test_gemm_tile_kernel_both_fetch_forms(eng_mod, K, S):
             res[tile] = outs
     finally:
         check(lib().bd_set_gemm_option(b"tile", 1))
-    for tile in (3, 2):
+    for tile in (3, 2, 4):
         for a, c in zip(res[0], res[tile]):
             assert torch.equal(a.view(torch.int32 if a.dtype == torch.float32 else torch.int16),
                                c.view(torch.int32 if c.dtype == torch.float32 else torch.int16)), (tile, a.dtype)
