@@ -359,6 +359,11 @@ __global__ __launch_bounds__(512) void gemm_half_kernel(GemmP p) {
 
 static int g_half_form = 1;     // 1: W straight into registers (default, round 6: -0.6 .. -1.1 % per evaluation at 512 rows, same box); 0: both operands through LDS
 void bdk_gemm_half_form(int v) { g_half_form = v; }
+#undef HALF_SYNC
+#undef HALF_LOAD
+#undef HALF_LOADA
+#undef HALF_STEP
+
 template <int EPI, int FORM>
 static int launch_half_f(const GemmP& p, hipStream_t st) {
     constexpr int lds = 8 * 16384;                                 // 128 KiB: the accumulator swap (the K loop uses the first 48 / 96 KiB)

@@ -277,6 +277,8 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(GemmP p, int dbg) {
             }
             BD_MFMA_DRAIN();
         }
+#undef TILE_LD
+#undef TILE_MF
     } else if constexpr (STG == 1) {
         // REGISTER-STAGED operand fetch (tile option 2): the wave's 4 chunks of a stage come in by plain 16 B global loads, three stages
         // ahead, into one of three register sets (set = stage % 3), and are written to their LDS slot in the LOAD segment one stage
